@@ -1,0 +1,233 @@
+/*
+ * irspack_amd.h — C ABI of libirspack_amd.so, the MI355X (gfx950) native
+ * implementation of irspack's compiled hot path.
+ *
+ * Every entry point below is what the reference's FFI for this path binds
+ * (nanobind modules `irspack.recommenders._ials_core`, `._knn`,
+ * `irspack.evaluation._core_evaluator`, and `remove_diagonal` of
+ * `irspack.utils._util_cpp`); the reference interface each one replaces is
+ * cited as file:line relative to /root/reference.
+ *
+ * Conventions
+ *  - plain C: opaque handles, caller-owned host pointers + sizes, no torch or
+ *    HIP types in any signature (`void *stream` is a hipStream_t passed through
+ *    as an integer-sized pointer).
+ *  - every function returns an irs_status: 0 ok, 1 invalid argument (the
+ *    reference throws std::invalid_argument -> Python ValueError), 2 runtime
+ *    error (std::runtime_error -> RuntimeError).  irs_last_error() returns the
+ *    message of the last failing call on the calling thread.
+ *  - calls are synchronous: on return device work is complete and outputs are
+ *    host-visible, unless the function name ends in `_async`.
+ *  - inputs are copied before return; the library never keeps a caller pointer.
+ *  - CSR inputs: indptr int64[rows+1], indices int32[nnz] (sorted within a
+ *    row), data float32 (iALS) or float64 (kNN / evaluator).
+ *  - handles are not thread-safe (neither are the reference's objects).
+ */
+#ifndef IRSPACK_AMD_H
+#define IRSPACK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t irs_status;
+#define IRS_OK 0
+#define IRS_INVALID_ARGUMENT 1
+#define IRS_RUNTIME_ERROR 2
+
+const char *irs_last_error(void);
+/* Library / device probe.  irs_device_count() returns 0 when no GPU is visible. */
+int32_t irs_abi_version(void);
+int32_t irs_device_count(void);
+
+/* ------------------------------------------------------------------ iALS
+ * enums: cpp_source/als/IALSLearningConfig.hpp:11-12, als/wrapper.cpp:25-40 */
+#define IRS_LOSS_ORIGINAL 0
+#define IRS_LOSS_IALSPP 1
+#define IRS_SOLVER_CHOLESKY 0
+#define IRS_SOLVER_CG 1
+#define IRS_SOLVER_IALSPP 2
+
+/* IALSModelConfig, IALSLearningConfig.hpp:15-31 (als/wrapper.cpp:42-71) */
+typedef struct irs_ials_model_config {
+  uint64_t K;
+  float alpha0;
+  float reg;
+  float nu;
+  float init_stdev;
+  int32_t random_seed;
+  int32_t loss_type;
+  float lambda_user_feature;  /* feature-aware iALS is out of scope; */
+  float lambda_item_feature;  /* carried for pickle compatibility only.           */
+  uint64_t feature_warmup_epochs;
+} irs_ials_model_config;
+
+/* SolverConfig, IALSLearningConfig.hpp:97-112 (als/wrapper.cpp:92-115) */
+typedef struct irs_ials_solver_config {
+  uint64_t n_threads;   /* validated (> 0) like the reference; no effect on the GPU */
+  int32_t solver_type;
+  uint64_t max_cg_steps;
+  uint64_t ialspp_subspace_dimension;
+  uint64_t ialspp_iteration;
+} irs_ials_solver_config;
+
+typedef struct irs_ials_trainer irs_ials_trainer;
+
+/* Row shard of a multi-GPU run: this handle solves users [user_begin,user_end)
+ * and items [item_begin,item_end) and keeps full replicas of both factor
+ * matrices.  {0,n_users,0,n_items} is the single-GPU case. */
+typedef struct irs_ials_shard {
+  int64_t user_begin, user_end, item_begin, item_end;
+} irs_ials_shard;
+
+/* IALSTrainer(config, X): IALSTrainer.hpp:710-720, als/wrapper.cpp:131-132.
+ * Copies X (CSR f32), builds X^T, initialises both factor matrices from the same
+ * seed (hpp:64-76, 718-719).  `shard` may be NULL. */
+irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
+                           int64_t n_items, const int64_t *indptr,
+                           const int32_t *indices, const float *data,
+                           int32_t device, const irs_ials_shard *shard,
+                           irs_ials_trainer **out);
+/* Deserialising constructor IALSTrainer(config, user, item): hpp:746-756,
+ * als/wrapper.cpp:167-181.  No interaction matrix is kept. */
+irs_status irs_ials_create_from_factors(const irs_ials_model_config *config,
+                                        int64_t n_users, int64_t n_items,
+                                        const float *user, const float *item,
+                                        int32_t device, irs_ials_trainer **out);
+irs_status irs_ials_destroy(irs_ials_trainer *t);
+
+/* IALSTrainer::step, hpp:758-789: P_u, user solve, P_i, item solve. */
+irs_status irs_ials_step(irs_ials_trainer *t, const irs_ials_solver_config *sc);
+/* `.user` / `.item` read-write attributes, als/wrapper.cpp:158-159.
+ * which: 0 = user, 1 = item.  out/in are C-contiguous float32 [rows, K]. */
+irs_status irs_ials_get_factor(irs_ials_trainer *t, int32_t which, float *out);
+irs_status irs_ials_set_factor(irs_ials_trainer *t, int32_t which,
+                               const float *in, int64_t rows, int64_t cols);
+/* IALSTrainer::user_scores, hpp:942-984.  out is float32 [end-begin, n_items]. */
+irs_status irs_ials_user_scores(irs_ials_trainer *t, int64_t begin, int64_t end,
+                                const irs_ials_solver_config *sc, float *out);
+/* IALSTrainer::transform_user / transform_item, hpp:791-802 (+ X_to_vector
+ * hpp:122-141).  side 0: X is [rows, n_items] -> out [rows, K];
+ * side 1: X is [n_users, cols] -> out [cols, K]. */
+irs_status irs_ials_transform(irs_ials_trainer *t, int32_t side, int64_t rows,
+                              int64_t cols, const int64_t *indptr,
+                              const int32_t *indices, const float *data,
+                              const irs_ials_solver_config *sc, float *out);
+/* IALSTrainer::compute_loss, hpp:836-940. */
+irs_status irs_ials_compute_loss(irs_ials_trainer *t,
+                                 const irs_ials_solver_config *sc, float *out);
+
+/* -- device-level pieces of IALSTrainer::step, for the multi-GPU host loop and
+ *    the benchmark (one process per GPU; collectives run outside this library
+ *    on the buffers these calls expose). -- */
+irs_status irs_ials_set_stream(irs_ials_trainer *t, void *hip_stream);
+/* which: 0 user factors, 1 item factors (float32 [rows, ld]);
+ * 2 / 3: Gramian used by the user / item solve (float32 [ld, ld], unscaled
+ * sum over this rank's shard until irs_ials_finish_gramian is called). */
+irs_status irs_ials_device_buffer(irs_ials_trainer *t, int32_t which,
+                                  void **device_ptr, int64_t *rows, int64_t *ld);
+/* Solver::prepare_p (hpp:78-115) split in two so that an all-reduce can sit in
+ * between: partial = sum over this shard's rows of the *other* side's factors
+ * (side 0: Gramian for the user solve = item rows of this shard). */
+irs_status irs_ials_partial_gramian_async(irs_ials_trainer *t, int32_t side);
+irs_status irs_ials_finish_gramian_async(irs_ials_trainer *t, int32_t side);
+/* Solver::step (hpp:664-679) over this shard's rows of `side`. */
+irs_status irs_ials_half_step_async(irs_ials_trainer *t, int32_t side,
+                                    const irs_ials_solver_config *sc);
+/* Waits for the stream and raises what the reference would have thrown from
+ * inside the solve (hpp:317-323, 250-254). */
+irs_status irs_ials_synchronize(irs_ials_trainer *t);
+/* Per-kernel HIP-event timing (profiling aid for bench.py).  enable != 0 turns
+ * recording on and clears the counters; `names`/`ms`/`launches` receive up to
+ * `cap` entries. */
+irs_status irs_ials_profile(irs_ials_trainer *t, int32_t enable);
+irs_status irs_ials_profile_read(irs_ials_trainer *t, int32_t cap,
+                                 char (*names)[48], double *ms,
+                                 int64_t *launches, int32_t *count);
+
+/* ------------------------------------------------------------------ kNN
+ * cpp_source/knn/wrapper.cpp:11-66; KNNComputer knn.hpp:30-83 */
+#define IRS_SIM_COSINE 0
+#define IRS_SIM_ASYMMETRIC 1
+#define IRS_SIM_JACCARD 2
+#define IRS_SIM_TVERSKY 3
+#define IRS_SIM_P3ALPHA 4
+#define IRS_SIM_RP3BETA 5
+
+typedef struct irs_knn_computer irs_knn_computer;
+
+/* *SimilarityComputer(X, shrinkage, [alpha, beta, normalize], n_threads,
+ * max_chunk_size): similarities.hpp:20-28, 61-72, 96-107, 143-159, 198-222,
+ * 265-292.  X is CSR float64 [N, n_features]. */
+irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols,
+                          const int64_t *indptr, const int32_t *indices,
+                          const double *data, double shrinkage, double alpha,
+                          double beta, int32_t normalize, int64_t n_threads,
+                          int64_t max_chunk_size, int32_t device,
+                          irs_knn_computer **out);
+irs_status irs_knn_destroy(irs_knn_computer *c);
+/* compute_similarity(X, top_k) (knn.hpp:43-139) / compute_W (similarities.hpp:
+ * 224-240, 294-324; as_w != 0, result still row-major [rows, N]).  Two calls:
+ * compute runs the device work and reports nnz; fetch copies the CSR out.
+ * row_begin/row_end select a shard of target rows (multi-GPU: rows are
+ * independent, no collective). */
+irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
+                           const int64_t *indptr, const int32_t *indices,
+                           const double *data, int64_t top_k, int32_t as_w,
+                           int64_t row_begin, int64_t row_end, int64_t *nnz_out);
+irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
+                         double *data);
+/* Seconds spent in device kernels of the last irs_knn_compute (HIP events) and
+ * the number of multiply-adds it performed. */
+irs_status irs_knn_last_stats(irs_knn_computer *c, double *kernel_ms,
+                              int64_t *macs);
+/* remove_diagonal, cpp_source/util.hpp:211-226 (in place on `data`). */
+irs_status irs_remove_diagonal(int64_t rows, int64_t cols, const int64_t *indptr,
+                               const int32_t *indices, double *data);
+
+/* ------------------------------------------------------------------ evaluator
+ * cpp_source/evaluator.cpp:441-484 */
+typedef struct irs_evaluator irs_evaluator;
+
+/* Metrics accumulator state (evaluator.cpp:168-178): the caller owns
+ * item_cnt[n_items]. */
+typedef struct irs_metrics {
+  uint64_t valid_user;
+  uint64_t total_user;
+  double hit, recall, ndcg, precision, map;
+} irs_metrics;
+
+/* EvaluatorCore(ground_truth, recommendable): evaluator.cpp:183-206.
+ * Recommendable lists are ragged: rec_ptr int64[n_lists+1], rec_items int64. */
+irs_status irs_eval_create(int64_t n_users, int64_t n_items,
+                           const int64_t *indptr, const int32_t *indices,
+                           int64_t n_lists, const int64_t *rec_ptr,
+                           const int64_t *rec_items, int32_t device,
+                           irs_evaluator **out);
+irs_status irs_eval_destroy(irs_evaluator *e);
+/* get_metrics_f32 / get_metrics_f64: evaluator.cpp:256-284 (+ :292-367,
+ * Metrics::update :127-166).  scores is a host row-major [rows, n_items] block
+ * of float32 (is_f64 == 0) or float64. */
+irs_status irs_eval_get_metrics(irs_evaluator *e, int32_t is_f64,
+                                const void *scores, int64_t rows, int64_t cutoff,
+                                int64_t offset, int64_t n_threads,
+                                int32_t recall_with_cutoff, irs_metrics *out,
+                                int64_t *item_cnt);
+/* Fused device path used by the Evaluator counterpart when the model is an
+ * iALS trainer of this library: scores = user[begin:end] @ item^T (hpp:942-984)
+ * are produced, masked (evaluator.py:417-432, mask = CSR rows given here, set
+ * to -inf) and ranked on the device without leaving HBM.  mask_indptr may be
+ * NULL (no mask); it has rows+1 entries relative to `begin`. */
+irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t,
+                                     int64_t begin, int64_t end,
+                                     const int64_t *mask_indptr,
+                                     const int32_t *mask_indices, int64_t cutoff,
+                                     int64_t offset, int32_t recall_with_cutoff,
+                                     irs_metrics *out, int64_t *item_cnt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRSPACK_AMD_H */

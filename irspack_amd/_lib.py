@@ -1,0 +1,157 @@
+"""ctypes loader for ``libirspack_amd.so`` (the C ABI of include/irspack_amd.h).
+
+Loading fails loudly when the shared library has not been built; compute calls
+fail loudly (``RuntimeError``) when no HIP device is visible.  There is no
+fallback implementation.
+"""
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libirspack_amd.so")
+
+
+class ModelConfigStruct(C.Structure):
+    _fields_ = [
+        ("K", C.c_uint64),
+        ("alpha0", C.c_float),
+        ("reg", C.c_float),
+        ("nu", C.c_float),
+        ("init_stdev", C.c_float),
+        ("random_seed", C.c_int32),
+        ("loss_type", C.c_int32),
+        ("lambda_user_feature", C.c_float),
+        ("lambda_item_feature", C.c_float),
+        ("feature_warmup_epochs", C.c_uint64),
+    ]
+
+
+class SolverConfigStruct(C.Structure):
+    _fields_ = [
+        ("n_threads", C.c_uint64),
+        ("solver_type", C.c_int32),
+        ("max_cg_steps", C.c_uint64),
+        ("ialspp_subspace_dimension", C.c_uint64),
+        ("ialspp_iteration", C.c_uint64),
+    ]
+
+
+class ShardStruct(C.Structure):
+    _fields_ = [
+        ("user_begin", C.c_int64),
+        ("user_end", C.c_int64),
+        ("item_begin", C.c_int64),
+        ("item_end", C.c_int64),
+    ]
+
+
+class MetricsStruct(C.Structure):
+    _fields_ = [
+        ("valid_user", C.c_uint64),
+        ("total_user", C.c_uint64),
+        ("hit", C.c_double),
+        ("recall", C.c_double),
+        ("ndcg", C.c_double),
+        ("precision", C.c_double),
+        ("map", C.c_double),
+    ]
+
+
+# every symbol include/irspack_amd.h declares
+EXPORTED_SYMBOLS = [
+    "irs_last_error",
+    "irs_abi_version",
+    "irs_device_count",
+    "irs_ials_create",
+    "irs_ials_create_from_factors",
+    "irs_ials_destroy",
+    "irs_ials_step",
+    "irs_ials_get_factor",
+    "irs_ials_set_factor",
+    "irs_ials_user_scores",
+    "irs_ials_transform",
+    "irs_ials_compute_loss",
+    "irs_ials_set_stream",
+    "irs_ials_device_buffer",
+    "irs_ials_partial_gramian_async",
+    "irs_ials_finish_gramian_async",
+    "irs_ials_half_step_async",
+    "irs_ials_synchronize",
+    "irs_ials_profile",
+    "irs_ials_profile_read",
+    "irs_knn_create",
+    "irs_knn_destroy",
+    "irs_knn_compute",
+    "irs_knn_fetch",
+    "irs_knn_last_stats",
+    "irs_remove_diagonal",
+    "irs_eval_create",
+    "irs_eval_destroy",
+    "irs_eval_get_metrics",
+    "irs_eval_get_metrics_ials",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C irspack_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "irspack_amd has no fallback implementation."
+            )
+        _lib = C.CDLL(LIB_PATH)
+        _lib.irs_last_error.restype = C.c_char_p
+        _lib.irs_abi_version.restype = C.c_int32
+        _lib.irs_device_count.restype = C.c_int32
+    return _lib
+
+
+def check(status: int) -> None:
+    """Map an irs_status to the exception the reference raises."""
+    if status == 0:
+        return
+    msg = lib().irs_last_error().decode("utf-8", "replace")
+    if status == 1:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def device_count() -> int:
+    return int(lib().irs_device_count())
+
+
+def default_device() -> int:
+    """LOCAL_RANK when launched one process per GPU, else IRSPACK_AMD_DEVICE or 0."""
+    for key in ("IRSPACK_AMD_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v is not None:
+            try:
+                return int(v)
+            except ValueError:
+                pass
+    return 0
+
+
+def csr_arrays(X, dtype):
+    """scipy sparse -> (csr, indptr int64, indices int32, data dtype) with sorted indices."""
+    import scipy.sparse as sps
+
+    X = sps.csr_matrix(X)
+    if not X.has_sorted_indices:
+        X = X.sorted_indices()
+    indptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+    data = np.ascontiguousarray(X.data, dtype=dtype)
+    return X, indptr, indices, data

@@ -1,0 +1,80 @@
+// Shared host-side helpers of libirspack_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/irspack_amd.h"
+
+namespace irs {
+
+std::string &last_error();
+
+// The reference signals errors with std::invalid_argument (-> ValueError) and
+// std::runtime_error (-> RuntimeError), cpp_source/argcheck.hpp:7-35.
+template <class F> irs_status guard(F &&f) {
+  try {
+    f();
+    return IRS_OK;
+  } catch (const std::invalid_argument &e) {
+    last_error() = e.what();
+    return IRS_INVALID_ARGUMENT;
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return IRS_RUNTIME_ERROR;
+  }
+}
+
+inline void check_arg(bool cond, const std::string &msg) {
+  if (!cond) throw std::invalid_argument(msg);
+}
+
+#define IRS_HIP(expr)                                                          \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess)                                                      \
+      throw std::runtime_error(std::string("HIP error: ") +                    \
+                               hipGetErrorString(_e) + " at " + __FILE__ +     \
+                               ":" + std::to_string(__LINE__) + " (" #expr ")"); \
+  } while (0)
+
+// The product path has no CPU fallback: without a visible gfx950 device every
+// compute entry point fails loudly.
+void require_device(int device);
+
+template <class T> struct DeviceBuffer {
+  T *ptr = nullptr;
+  size_t count = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  ~DeviceBuffer() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    count = 0;
+  }
+  void alloc(size_t n) {
+    if (n <= count && ptr) return;
+    release();
+    if (n == 0) n = 1;
+    IRS_HIP(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+    count = n;
+  }
+  void upload(const T *host, size_t n, hipStream_t s) {
+    alloc(n);
+    if (n) IRS_HIP(hipMemcpyAsync(ptr, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
+  void zero(hipStream_t s) {
+    if (ptr) IRS_HIP(hipMemsetAsync(ptr, 0, count * sizeof(T), s));
+  }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace irs

@@ -1,0 +1,741 @@
+// Host side of the iALS path: trainer object, task lists, launches, C ABI.
+// Mirrors irspack::ials::IALSTrainer (/root/reference/cpp_source/als/
+// IALSTrainer.hpp:709-984) behind include/irspack_amd.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <random>
+#include <sstream>
+
+#include "common.hpp"
+#include "ials_kernels.hpp"
+
+namespace irs {
+
+std::string &last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+void require_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw std::runtime_error(
+        "irspack_amd: no HIP device is visible; the gfx950 kernels cannot run "
+        "(there is no CPU fallback).");
+  if (device < 0 || device >= n)
+    throw std::invalid_argument("irspack_amd: device index out of range.");
+  IRS_HIP(hipSetDevice(device));
+}
+
+namespace ials {
+
+static int padded_k(int64_t K) {
+  if (K <= 16) return 16;
+  if (K <= 32) return 32;
+  if (K <= 64) return 64;
+  return static_cast<int>(ceil_div(K, 64) * 64);
+}
+
+struct HostCsr {
+  int64_t rows = 0, cols = 0;
+  std::vector<int64_t> indptr;
+  std::vector<int32_t> indices;
+  std::vector<float> data;
+};
+
+static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
+                        const int32_t *indices, const float *data) {
+  check_arg(rows >= 0 && cols >= 0, "negative matrix shape.");
+  check_arg(indptr != nullptr, "indptr is null.");
+  HostCsr m;
+  m.rows = rows;
+  m.cols = cols;
+  m.indptr.assign(indptr, indptr + rows + 1);
+  const int64_t nnz = indptr[rows];
+  check_arg(indptr[0] == 0 && nnz >= 0, "malformed indptr.");
+  check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31 (32-bit CSR like Eigen's).");
+  for (int64_t r = 0; r < rows; r++) check_arg(indptr[r + 1] >= indptr[r], "malformed indptr.");
+  m.indices.assign(indices, indices + nnz);
+  m.data.assign(data, data + nnz);
+  for (int64_t p = 0; p < nnz; p++)
+    check_arg(m.indices[p] >= 0 && m.indices[p] < cols, "column index out of range.");
+  return m;
+}
+
+// X.transpose() as compressed row-major (hpp:713)
+static HostCsr transpose(const HostCsr &x) {
+  HostCsr t;
+  t.rows = x.cols;
+  t.cols = x.rows;
+  t.indptr.assign(t.rows + 1, 0);
+  const int64_t nnz = x.indptr[x.rows];
+  t.indices.resize(nnz);
+  t.data.resize(nnz);
+  for (int64_t p = 0; p < nnz; p++) t.indptr[x.indices[p] + 1]++;
+  for (int64_t c = 0; c < t.rows; c++) t.indptr[c + 1] += t.indptr[c];
+  std::vector<int64_t> cur(t.indptr.begin(), t.indptr.end() - 1);
+  for (int64_t r = 0; r < x.rows; r++)
+    for (int64_t p = x.indptr[r]; p < x.indptr[r + 1]; p++) {
+      const int64_t d = cur[x.indices[p]]++;
+      t.indices[d] = static_cast<int32_t>(r);
+      t.data[d] = x.data[p];
+    }
+  return t;
+}
+
+static int chunk_size() {
+  static int v = [] {
+    const char *e = std::getenv("IRSPACK_AMD_IALS_CHUNK");
+    int c = e ? std::atoi(e) : 1024;
+    if (c < 64) c = 64;
+    return (c + 3) & ~3;
+  }();
+  return v;
+}
+
+// One CSR orientation resident on the device, with its longest-first task list.
+struct Side {
+  int64_t n_rows = 0, n_other = 0, row_begin = 0, row_end = 0, nnz = 0;
+  DeviceBuffer<int32_t> indptr, indices;
+  DeviceBuffer<float> data, reg;
+  DeviceBuffer<Task> tasks;
+  DeviceBuffer<SplitRow> split;
+  int32_t n_tasks = 0, n_split = 0, n_slots = 0;
+
+  void build(const HostCsr &m, int64_t rb, int64_t re, const irs_ials_model_config &cfg,
+             hipStream_t s) {
+    n_rows = m.rows;
+    n_other = m.cols;
+    row_begin = rb;
+    row_end = re;
+    nnz = m.indptr[m.rows];
+    std::vector<int32_t> ip32(m.rows + 1);
+    for (int64_t r = 0; r <= m.rows; r++) ip32[r] = static_cast<int32_t>(m.indptr[r]);
+    std::vector<float> regs(m.rows);
+    for (int64_t r = 0; r < m.rows; r++) {
+      // Solver::compute_reg, hpp:117-120, evaluated in float like the reference
+      const int64_t nz = m.indptr[r + 1] - m.indptr[r];
+      regs[r] = cfg.reg * std::pow(cfg.alpha0 * m.cols + nz, cfg.nu);
+    }
+    const int CH = chunk_size();
+    std::vector<Task> tk;
+    std::vector<SplitRow> sp;
+    tk.reserve(re - rb);
+    int32_t slots = 0;
+    for (int64_t r = rb; r < re; r++) {
+      const int32_t b = ip32[r], e = ip32[r + 1], nz = e - b;
+      if (nz > CH) {
+        const int32_t nch = (nz + CH - 1) / CH;
+        const int32_t per = (((nz + nch - 1) / nch) + 3) & ~3;
+        SplitRow sr{static_cast<int32_t>(r), slots, 0, nz};
+        for (int32_t c = b; c < e; c += per) {
+          tk.push_back(Task{static_cast<int32_t>(r), c, std::min(c + per, e), slots++});
+          sr.n_slots++;
+        }
+        sp.push_back(sr);
+      } else {
+        tk.push_back(Task{static_cast<int32_t>(r), b, e, -1});
+      }
+    }
+    std::stable_sort(tk.begin(), tk.end(), [](const Task &a, const Task &b) {
+      return (a.end - a.begin) > (b.end - b.begin);
+    });
+    std::stable_sort(sp.begin(), sp.end(),
+                     [](const SplitRow &a, const SplitRow &b) { return a.n_slots > b.n_slots; });
+    n_tasks = static_cast<int32_t>(tk.size());
+    n_split = static_cast<int32_t>(sp.size());
+    n_slots = slots;
+    indptr.upload(ip32, s);
+    indices.upload(m.indices, s);
+    data.upload(m.data, s);
+    reg.upload(regs, s);
+    tasks.upload(tk, s);
+    split.upload(sp, s);
+    IRS_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+  }
+};
+
+struct Profiler {
+  struct Rec {
+    const char *name;
+    hipEvent_t a, b;
+  };
+  bool enabled = false;
+  std::vector<Rec> recs;
+  std::map<std::string, std::pair<double, int64_t>> totals;
+  void begin(const char *name, hipStream_t s) {
+    if (!enabled) return;
+    Rec r{name, nullptr, nullptr};
+    IRS_HIP(hipEventCreate(&r.a));
+    IRS_HIP(hipEventCreate(&r.b));
+    IRS_HIP(hipEventRecord(r.a, s));
+    recs.push_back(r);
+  }
+  void end(hipStream_t s) {
+    if (!enabled) return;
+    IRS_HIP(hipEventRecord(recs.back().b, s));
+  }
+  void collect() {
+    for (auto &r : recs) {
+      IRS_HIP(hipEventSynchronize(r.b));
+      float ms = 0;
+      IRS_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+      auto &t = totals[r.name];
+      t.first += ms;
+      t.second += 1;
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
+    recs.clear();
+  }
+  void clear() {
+    collect();
+    totals.clear();
+  }
+};
+
+}  // namespace ials
+}  // namespace irs
+
+using namespace irs;
+using namespace irs::ials;
+
+struct irs_ials_trainer {
+  irs_ials_model_config cfg;
+  int64_t K = 0, n_users = 0, n_items = 0;
+  int KP = 0, T = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool has_X = false;
+  irs_ials_shard shard{0, 0, 0, 0};
+  DeviceBuffer<float> factor[2];                  // 0 user, 1 item
+  Side side[2];                                   // 0: X (solve users), 1: X^T (solve items)
+  DeviceBuffer<float> P_raw[2], P[2], P_acc[2];   // [s]: Gramian used by the solve of side s
+  DeviceBuffer<float> gram_partial, split_partial, row_loss;
+  DeviceBuffer<double> loss_sum;
+  DeviceBuffer<int32_t> err_flag;
+  Profiler prof;
+
+  int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
+};
+
+namespace {
+
+#define IRS_DISPATCH_T(t, ...)                                                      \
+  switch (t) {                                                                      \
+    case 1: { constexpr int TT = 1; __VA_ARGS__; } break;                           \
+    case 2: { constexpr int TT = 2; __VA_ARGS__; } break;                           \
+    case 4: { constexpr int TT = 4; __VA_ARGS__; } break;                           \
+    default:                                                                        \
+      throw std::invalid_argument(                                                  \
+          "irspack_amd: n_components above 64 is not supported by this build.");    \
+  }
+
+void validate_config(const irs_ials_model_config &c) {
+  check_arg(c.K >= 1, "K must be positive.");
+  check_arg(c.K <= 64, "irspack_amd: n_components above 64 is not supported by this build.");
+  check_arg(c.loss_type == IRS_LOSS_ORIGINAL || c.loss_type == IRS_LOSS_IALSPP,
+            "unknown loss_type.");
+}
+
+void alloc_common(irs_ials_trainer *t) {
+  t->KP = padded_k(t->K);
+  t->T = t->KP / 16;
+  for (int w = 0; w < 2; w++) {
+    t->factor[w].alloc(static_cast<size_t>(t->rows_of(w)) * t->KP);
+    t->factor[w].zero(t->stream);
+    t->P_raw[w].alloc(t->KP * t->KP);
+    t->P[w].alloc(t->KP * t->KP);
+    t->P_acc[w].alloc(t->KP * t->KP);
+    t->P_raw[w].zero(t->stream);
+    t->P[w].zero(t->stream);
+    t->P_acc[w].zero(t->stream);
+  }
+  t->err_flag.alloc(1);
+  t->err_flag.zero(t->stream);
+  t->loss_sum.alloc(2);
+}
+
+void upload_factor(irs_ials_trainer *t, int which, const float *host) {
+  const int64_t n = t->rows_of(which);
+  t->factor[which].zero(t->stream);
+  if (n > 0)
+    IRS_HIP(hipMemcpy2DAsync(t->factor[which].ptr, t->KP * sizeof(float), host,
+                             t->K * sizeof(float), t->K * sizeof(float), n,
+                             hipMemcpyHostToDevice, t->stream));
+  IRS_HIP(hipStreamSynchronize(t->stream));
+}
+
+void download_factor(irs_ials_trainer *t, const float *dev, int64_t n, float *host) {
+  if (n > 0)
+    IRS_HIP(hipMemcpy2DAsync(host, t->K * sizeof(float), dev, t->KP * sizeof(float),
+                             t->K * sizeof(float), n, hipMemcpyDeviceToHost, t->stream));
+  IRS_HIP(hipStreamSynchronize(t->stream));
+}
+
+// Solver::initialize, hpp:64-76: libstdc++ mt19937 + normal_distribution<float>
+// on the host, so a libstdc++ build of the reference draws the same stream.
+void init_factor(irs_ials_trainer *t, int which) {
+  const int64_t n = t->rows_of(which);
+  std::vector<float> h(static_cast<size_t>(n) * t->K, 0.0f);
+  if (t->cfg.init_stdev > 0) {
+    std::mt19937 gen(t->cfg.random_seed);
+    std::normal_distribution<float> dist(
+        0.0, t->cfg.init_stdev / std::sqrt(static_cast<float>(t->K)));
+    for (int64_t i = 0; i < n; i++)
+      for (int64_t k = 0; k < t->K; k++) h[i * t->K + k] = dist(gen);
+  }  // init_stdev <= 0: the reference leaves the matrix uninitialised; we zero it
+  upload_factor(t, which, h.data());
+}
+
+// Gramian of `which` factors over rows [rb, re) into P_raw[dst] (unscaled).
+void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t re, int dst) {
+  const int64_t n = std::max<int64_t>(re - rb, 0);
+  int64_t n_waves = std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 64)));
+  n_waves = ceil_div(n_waves, 4) * 4;
+  int64_t per = ceil_div(std::max<int64_t>(n, 1), n_waves);
+  per = ceil_div(per, 4) * 4;
+  IRS_DISPATCH_T(t->T, {
+    using G = Geo<TT>;
+    t->gram_partial.alloc(static_cast<size_t>(n_waves) * G::NT * 256);
+    t->prof.begin("gramian_partial", t->stream);
+    hipLaunchKernelGGL((gramian_partial_kernel<TT>), dim3(n_waves / 4), dim3(256), 0, t->stream,
+                       t->factor[which].ptr, rb, re, per, t->gram_partial.ptr);
+    t->prof.end(t->stream);
+    t->prof.begin("gramian_reduce", t->stream);
+    hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 256)), dim3(256),
+                       0, t->stream, t->gram_partial.ptr, n_waves, t->P_raw[dst].ptr);
+    t->prof.end(t->stream);
+  });
+  IRS_HIP(hipGetLastError());
+}
+
+void launch_finish_gramian(irs_ials_trainer *t, int dst) {
+  IRS_DISPATCH_T(t->T, {
+    using G = Geo<TT>;
+    t->prof.begin("gramian_finish", t->stream);
+    hipLaunchKernelGGL((gramian_finish_kernel<TT>), dim3(ceil_div(G::KP * G::KP, 256)),
+                       dim3(256), 0, t->stream, t->P_raw[dst].ptr, t->cfg.alpha0,
+                       t->P[dst].ptr, t->P_acc[dst].ptr);
+    t->prof.end(t->stream);
+  });
+  IRS_HIP(hipGetLastError());
+}
+
+void check_solver(const irs_ials_solver_config *sc) {
+  check_arg(sc != nullptr, "solver_config is null.");
+  check_arg(sc->n_threads > 0, "n_threads must be strictly positive.");  // hpp:81-83
+  check_arg(sc->solver_type == IRS_SOLVER_CHOLESKY || sc->solver_type == IRS_SOLVER_CG ||
+                sc->solver_type == IRS_SOLVER_IALSPP,
+            "unknown solver_type.");
+  if (sc->solver_type == IRS_SOLVER_IALSPP)
+    throw std::invalid_argument(
+        "irspack_amd: the IALSPP subspace solver is not implemented on the device yet.");
+}
+
+// Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
+void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
+                  const irs_ials_solver_config *sc) {
+  SolveParams p;
+  p.tasks = sd.tasks.ptr;
+  p.n_tasks = sd.n_tasks;
+  p.split_rows = sd.split.ptr;
+  p.n_split = sd.n_split;
+  p.indices = sd.indices.ptr;
+  p.data = sd.data.ptr;
+  p.other = other;
+  p.target = target;
+  p.reg = sd.reg.ptr;
+  p.P_acc = t->P_acc[pidx].ptr;
+  p.err_flag = t->err_flag.ptr;
+  p.bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;  // hpp:190-191
+  p.K = static_cast<int32_t>(t->K);
+  p.max_cg_steps = sc->max_cg_steps == 0 ? static_cast<int32_t>(t->K)
+                                         : static_cast<int32_t>(std::min<uint64_t>(
+                                               sc->max_cg_steps, 1u << 20));
+  p.warm_start = 1;
+  const bool cg = sc->solver_type == IRS_SOLVER_CG;
+  IRS_DISPATCH_T(t->T, {
+    using G = Geo<TT>;
+    t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
+    p.partials = t->split_partial.ptr;
+    if (sd.n_tasks > 0) {
+      t->prof.begin(cg ? "ials_solve_cg" : "ials_solve_cholesky", t->stream);
+      if (cg)
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(sd.n_tasks, 4)),
+                           dim3(256), 0, t->stream, p);
+      else
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(sd.n_tasks, 4)),
+                           dim3(256), 0, t->stream, p);
+      t->prof.end(t->stream);
+    }
+    if (sd.n_split > 0) {
+      t->prof.begin(cg ? "ials_split_cg" : "ials_split_cholesky", t->stream);
+      if (cg)
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 1>), dim3(ceil_div(sd.n_split, 4)),
+                           dim3(256), 0, t->stream, p);
+      else
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 1>), dim3(ceil_div(sd.n_split, 4)),
+                           dim3(256), 0, t->stream, p);
+      t->prof.end(t->stream);
+    }
+  });
+  IRS_HIP(hipGetLastError());
+}
+
+// Raise what the reference would have thrown from inside the worker threads.
+void sync_and_check(irs_ials_trainer *t) {
+  int32_t flag = 0;
+  IRS_HIP(hipMemcpyAsync(&flag, t->err_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost, t->stream));
+  IRS_HIP(hipStreamSynchronize(t->stream));
+  if (flag) {
+    t->err_flag.zero(t->stream);
+    IRS_HIP(hipStreamSynchronize(t->stream));
+    if (flag & 1) throw std::runtime_error("Cholesky decomposition failed.");  // hpp:318
+    if (flag & 2) throw std::runtime_error("Cholesky solve failed.");          // hpp:322
+    throw std::runtime_error(
+        "Conjugate-gradient solver encountered a singular system.");  // hpp:252-253
+  }
+}
+
+void require_X(irs_ials_trainer *t) {
+  if (!t->has_X)
+    throw std::runtime_error(
+        "This IALSTrainer was restored from factors and holds no interaction matrix.");
+}
+
+void full_gramian(irs_ials_trainer *t, int side) {
+  // side 0 (user solve) sums item rows; side 1 sums user rows.
+  const int other = 1 - side;
+  launch_partial_gramian(t, other, 0, t->rows_of(other), side);
+  launch_finish_gramian(t, side);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *irs_last_error(void) { return irs::last_error().c_str(); }
+int32_t irs_abi_version(void) { return 1; }
+int32_t irs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
+                           int64_t n_items, const int64_t *indptr, const int32_t *indices,
+                           const float *data, int32_t device, const irs_ials_shard *shard,
+                           irs_ials_trainer **out) {
+  return guard([&] {
+    check_arg(config && out, "null argument.");
+    validate_config(*config);
+    HostCsr X = host_csr(n_users, n_items, indptr, indices, data);
+    require_device(device);
+    auto t = std::make_unique<irs_ials_trainer>();
+    t->cfg = *config;
+    t->K = static_cast<int64_t>(config->K);
+    t->n_users = n_users;
+    t->n_items = n_items;
+    t->device = device;
+    t->shard = shard ? *shard : irs_ials_shard{0, n_users, 0, n_items};
+    check_arg(0 <= t->shard.user_begin && t->shard.user_begin <= t->shard.user_end &&
+                  t->shard.user_end <= n_users && 0 <= t->shard.item_begin &&
+                  t->shard.item_begin <= t->shard.item_end && t->shard.item_end <= n_items,
+              "shard out of range.");
+    alloc_common(t.get());
+    t->side[0].build(X, t->shard.user_begin, t->shard.user_end, t->cfg, t->stream);
+    {
+      HostCsr Xt = transpose(X);
+      t->side[1].build(Xt, t->shard.item_begin, t->shard.item_end, t->cfg, t->stream);
+    }
+    t->has_X = true;
+    init_factor(t.get(), 0);  // hpp:718-719: both sides from the same seed
+    init_factor(t.get(), 1);
+    *out = t.release();
+  });
+}
+
+irs_status irs_ials_create_from_factors(const irs_ials_model_config *config, int64_t n_users,
+                                        int64_t n_items, const float *user, const float *item,
+                                        int32_t device, irs_ials_trainer **out) {
+  return guard([&] {
+    check_arg(config && out, "null argument.");
+    validate_config(*config);
+    require_device(device);
+    auto t = std::make_unique<irs_ials_trainer>();
+    t->cfg = *config;
+    t->K = static_cast<int64_t>(config->K);
+    t->n_users = n_users;
+    t->n_items = n_items;
+    t->device = device;
+    t->shard = irs_ials_shard{0, n_users, 0, n_items};
+    alloc_common(t.get());
+    upload_factor(t.get(), 0, user);
+    upload_factor(t.get(), 1, item);
+    full_gramian(t.get(), 0);  // hpp:754-755
+    full_gramian(t.get(), 1);
+    IRS_HIP(hipStreamSynchronize(t->stream));
+    *out = t.release();
+  });
+}
+
+irs_status irs_ials_destroy(irs_ials_trainer *t) {
+  return guard([&] {
+    if (t) {
+      (void)hipSetDevice(t->device);
+      t->prof.clear();
+      delete t;
+    }
+  });
+}
+
+irs_status irs_ials_set_stream(irs_ials_trainer *t, void *hip_stream) {
+  return guard([&] {
+    check_arg(t != nullptr, "null trainer.");
+    IRS_HIP(hipSetDevice(t->device));
+    IRS_HIP(hipStreamSynchronize(t->stream));
+    t->stream = static_cast<hipStream_t>(hip_stream);
+  });
+}
+
+irs_status irs_ials_device_buffer(irs_ials_trainer *t, int32_t which, void **device_ptr,
+                                  int64_t *rows, int64_t *ld) {
+  return guard([&] {
+    check_arg(t && device_ptr && rows && ld, "null argument.");
+    check_arg(which >= 0 && which <= 3, "which must be in 0..3.");
+    if (which < 2) {
+      *device_ptr = t->factor[which].ptr;
+      *rows = t->rows_of(which);
+    } else {
+      *device_ptr = t->P_raw[which - 2].ptr;
+      *rows = t->KP;
+    }
+    *ld = t->KP;
+  });
+}
+
+irs_status irs_ials_partial_gramian_async(irs_ials_trainer *t, int32_t side) {
+  return guard([&] {
+    check_arg(t && (side == 0 || side == 1), "bad argument.");
+    IRS_HIP(hipSetDevice(t->device));
+    const int other = 1 - side;
+    const int64_t rb = other == 0 ? t->shard.user_begin : t->shard.item_begin;
+    const int64_t re = other == 0 ? t->shard.user_end : t->shard.item_end;
+    launch_partial_gramian(t, other, rb, re, side);
+  });
+}
+
+irs_status irs_ials_finish_gramian_async(irs_ials_trainer *t, int32_t side) {
+  return guard([&] {
+    check_arg(t && (side == 0 || side == 1), "bad argument.");
+    IRS_HIP(hipSetDevice(t->device));
+    launch_finish_gramian(t, side);
+  });
+}
+
+irs_status irs_ials_half_step_async(irs_ials_trainer *t, int32_t side,
+                                    const irs_ials_solver_config *sc) {
+  return guard([&] {
+    check_arg(t && (side == 0 || side == 1), "bad argument.");
+    check_solver(sc);
+    require_X(t);
+    IRS_HIP(hipSetDevice(t->device));
+    launch_solve(t, t->side[side], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc);
+  });
+}
+
+irs_status irs_ials_synchronize(irs_ials_trainer *t) {
+  return guard([&] {
+    check_arg(t != nullptr, "null trainer.");
+    IRS_HIP(hipSetDevice(t->device));
+    sync_and_check(t);
+  });
+}
+
+// IALSTrainer::step, hpp:784-788
+irs_status irs_ials_step(irs_ials_trainer *t, const irs_ials_solver_config *sc) {
+  return guard([&] {
+    check_arg(t != nullptr, "null trainer.");
+    check_solver(sc);
+    require_X(t);
+    IRS_HIP(hipSetDevice(t->device));
+    check_arg(t->shard.user_begin == 0 && t->shard.user_end == t->n_users &&
+                  t->shard.item_begin == 0 && t->shard.item_end == t->n_items,
+              "irs_ials_step needs an unsharded trainer; sharded runs drive the half "
+              "steps from the host loop.");
+    full_gramian(t, 0);
+    launch_solve(t, t->side[0], t->factor[1].ptr, t->factor[0].ptr, 0, sc);
+    full_gramian(t, 1);
+    launch_solve(t, t->side[1], t->factor[0].ptr, t->factor[1].ptr, 1, sc);
+    sync_and_check(t);
+  });
+}
+
+irs_status irs_ials_get_factor(irs_ials_trainer *t, int32_t which, float *out) {
+  return guard([&] {
+    check_arg(t && out && (which == 0 || which == 1), "bad argument.");
+    IRS_HIP(hipSetDevice(t->device));
+    download_factor(t, t->factor[which].ptr, t->rows_of(which), out);
+  });
+}
+
+irs_status irs_ials_set_factor(irs_ials_trainer *t, int32_t which, const float *in,
+                               int64_t rows, int64_t cols) {
+  return guard([&] {
+    check_arg(t && in && (which == 0 || which == 1), "bad argument.");
+    check_arg(rows == t->rows_of(which) && cols == t->K,
+              "factor matrix shape does not match the trainer.");
+    IRS_HIP(hipSetDevice(t->device));
+    upload_factor(t, which, in);
+  });
+}
+
+irs_status irs_ials_user_scores(irs_ials_trainer *t, int64_t begin, int64_t end,
+                                const irs_ials_solver_config *sc, float *out) {
+  return guard([&] {
+    check_arg(t && sc, "null argument.");
+    check_arg(sc->n_threads > 0, "n_threads must be strictly positive.");  // hpp:944-951
+    check_arg(end >= begin, "userblock_end must be greater than or equal to userblock_begin");
+    check_arg(begin >= 0, "userblock_begin must be non-negative");
+    check_arg(t->n_users >= end, "userblock_end must be smaller than or equal to n_users");
+    const int64_t m = end - begin;
+    if (m == 0 || t->n_items == 0) return;
+    IRS_HIP(hipSetDevice(t->device));
+    DeviceBuffer<float> d;
+    d.alloc(static_cast<size_t>(m) * t->n_items);
+    const int64_t waves = ceil_div(m, 16) * ceil_div(t->n_items, 64);
+    t->prof.begin("user_scores", t->stream);
+    switch (t->KP) {
+      case 16:
+        hipLaunchKernelGGL((user_scores_kernel<16>), dim3(ceil_div(waves, 4)), dim3(256), 0,
+                           t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
+                           t->n_items, d.ptr);
+        break;
+      case 32:
+        hipLaunchKernelGGL((user_scores_kernel<32>), dim3(ceil_div(waves, 4)), dim3(256), 0,
+                           t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
+                           t->n_items, d.ptr);
+        break;
+      default:
+        hipLaunchKernelGGL((user_scores_kernel<64>), dim3(ceil_div(waves, 4)), dim3(256), 0,
+                           t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
+                           t->n_items, d.ptr);
+    }
+    t->prof.end(t->stream);
+    IRS_HIP(hipGetLastError());
+    IRS_HIP(hipMemcpyAsync(out, d.ptr, static_cast<size_t>(m) * t->n_items * sizeof(float),
+                           hipMemcpyDeviceToHost, t->stream));
+    IRS_HIP(hipStreamSynchronize(t->stream));
+  });
+}
+
+irs_status irs_ials_transform(irs_ials_trainer *t, int32_t side, int64_t rows, int64_t cols,
+                              const int64_t *indptr, const int32_t *indices, const float *data,
+                              const irs_ials_solver_config *sc, float *out) {
+  return guard([&] {
+    check_arg(t && out && (side == 0 || side == 1), "bad argument.");
+    check_solver(sc);
+    HostCsr X = host_csr(rows, cols, indptr, indices, data);
+    IRS_HIP(hipSetDevice(t->device));
+    full_gramian(t, side);  // hpp:793 / :799
+    if (side == 1) X = transpose(X);  // hpp:800
+    const int64_t n_other = t->rows_of(1 - side);
+    if (X.cols != n_other) {  // hpp:126-131
+      std::stringstream ss;
+      ss << "Shape mismatch: X.cols() = " << X.cols
+         << " but other.factor.rows() = " << n_other << ".";
+      throw std::invalid_argument(ss.str());
+    }
+    Side tmp;
+    tmp.build(X, 0, X.rows, t->cfg, t->stream);
+    DeviceBuffer<float> result;  // DenseMatrix::Zero(X.rows(), K), hpp:132
+    result.alloc(static_cast<size_t>(X.rows) * t->KP);
+    result.zero(t->stream);
+    launch_solve(t, tmp, t->factor[1 - side].ptr, result.ptr, side, sc);
+    sync_and_check(t);
+    download_factor(t, result.ptr, X.rows, out);
+  });
+}
+
+irs_status irs_ials_compute_loss(irs_ials_trainer *t, const irs_ials_solver_config *sc,
+                                 float *out) {
+  return guard([&] {
+    check_arg(t && out, "null argument.");
+    check_solver(sc);
+    require_X(t);
+    IRS_HIP(hipSetDevice(t->device));
+    full_gramian(t, 0);  // hpp:837-838
+    full_gramian(t, 1);
+    double loss = 0.0;
+    if (t->cfg.alpha0 != 0.0f) {  // hpp:840-844
+      std::vector<float> pu(t->KP * t->KP), pi(t->KP * t->KP);
+      IRS_HIP(hipMemcpyAsync(pu.data(), t->P[0].ptr, pu.size() * sizeof(float),
+                             hipMemcpyDeviceToHost, t->stream));
+      IRS_HIP(hipMemcpyAsync(pi.data(), t->P[1].ptr, pi.size() * sizeof(float),
+                             hipMemcpyDeviceToHost, t->stream));
+      IRS_HIP(hipStreamSynchronize(t->stream));
+      double s = 0.0;
+      for (size_t i = 0; i < pu.size(); i++) s += static_cast<double>(pu[i]) * pi[i];
+      loss = s / t->cfg.alpha0;
+    }
+    const float bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;
+    t->row_loss.alloc(static_cast<size_t>(std::max(t->n_users, t->n_items)));
+    double h[2] = {0.0, 0.0};
+    for (int s = 0; s < 2; s++) {
+      const int64_t n = t->rows_of(s);
+      if (n == 0) continue;
+      IRS_DISPATCH_T(t->T, {
+        t->prof.begin("loss_rows", t->stream);
+        hipLaunchKernelGGL((loss_rows_kernel<TT>), dim3(ceil_div(n, 4)), dim3(256), 0,
+                           t->stream, t->factor[s].ptr, t->factor[1 - s].ptr,
+                           t->side[s].indptr.ptr, t->side[s].indices.ptr, t->side[s].data.ptr,
+                           t->side[s].reg.ptr, n, bias, s == 0 ? 1 : 0, t->row_loss.ptr);
+        t->prof.end(t->stream);
+      });
+      hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, t->stream, t->row_loss.ptr, n,
+                         t->loss_sum.ptr + s);
+      IRS_HIP(hipGetLastError());
+      IRS_HIP(hipMemcpyAsync(&h[s], t->loss_sum.ptr + s, sizeof(double), hipMemcpyDeviceToHost,
+                             t->stream));
+      IRS_HIP(hipStreamSynchronize(t->stream));
+    }
+    *out = static_cast<float>((loss + h[0] + h[1]) / 2.0);  // hpp:939
+  });
+}
+
+irs_status irs_ials_profile(irs_ials_trainer *t, int32_t enable) {
+  return guard([&] {
+    check_arg(t != nullptr, "null trainer.");
+    IRS_HIP(hipSetDevice(t->device));
+    t->prof.clear();
+    t->prof.enabled = enable != 0;
+  });
+}
+
+irs_status irs_ials_profile_read(irs_ials_trainer *t, int32_t cap, char (*names)[48],
+                                 double *ms, int64_t *launches, int32_t *count) {
+  return guard([&] {
+    check_arg(t && names && ms && launches && count, "null argument.");
+    IRS_HIP(hipSetDevice(t->device));
+    t->prof.collect();
+    int32_t i = 0;
+    for (auto &kv : t->prof.totals) {
+      if (i >= cap) break;
+      std::strncpy(names[i], kv.first.c_str(), 47);
+      names[i][47] = 0;
+      ms[i] = kv.second.first;
+      launches[i] = kv.second.second;
+      i++;
+    }
+    *count = i;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,572 @@
+// iALS device kernels for gfx950 (CDNA4, wave64).  Hand-written HIP; no
+// portability layer.  Replaces the per-row loops of
+// /root/reference/cpp_source/als/IALSTrainer.hpp (Solver::prepare_p :78-115,
+// step_cholesky :273-331, step_cg :170-271, user_scores :942-984,
+// compute_loss :836-940).
+//
+// Data layout in HBM
+//   factors   float32 [rows, KP] row-major, KP = K rounded up to 16/32/64 (or a
+//             multiple of 64 above that); padded columns are kept at zero.
+//   CSR       int32 indices / float32 data; rows are addressed through a task
+//             list (row, begin, end, slot) sorted longest-first.
+//   Gramian   "accumulator layout": the 16x16 tiles (I <= J) of the KP x KP
+//             matrix exactly as v_mfma_f32_16x16x4_f32 leaves them in
+//             registers, so a solve wave starts from P with 10 coalesced loads.
+//
+// Dimension permutation.  A wave gathers a factor row with ONE coalesced
+// 16 B-per-lane load: lane (g = lane>>4, m = lane&15) holds dims T*m .. T*m+T-1
+// (T = KP/16) of gathered row g.  MFMA tile I therefore consists of the dims
+// {T*m + I : m = 0..15}; tile (I, J) register r of lane (g, m) is the Gramian
+// element (T*(4g+r) + I, T*m + J).  The permutation is undone when the matrix
+// is spilled to LDS for the solve.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace irs {
+namespace ials {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Task {
+  int32_t row;    // row of the solved side
+  int32_t begin;  // [begin, end) into indices / data
+  int32_t end;
+  int32_t slot;   // < 0: whole row, solve inline; >= 0: partial Gramian slot
+};
+
+struct SplitRow {
+  int32_t row;
+  int32_t first_slot;
+  int32_t n_slots;
+  int32_t nnz;
+};
+
+struct SolveParams {
+  const Task *tasks;
+  int32_t n_tasks;
+  const SplitRow *split_rows;
+  int32_t n_split;
+  const int32_t *indices;
+  const float *data;
+  const float *other;   // gathered factors [n_other, KP]
+  float *target;        // solved factors   [n_rows, KP]
+  const float *reg;     // per-row regulariser, hpp:117-120 (host powf)
+  const float *P_acc;   // alpha0 * F^T F in accumulator layout
+  float *partials;      // split-row scratch
+  int32_t *err_flag;    // bit 0: pivot <= 0, bit 1: non-finite solution, bit 2: CG singular
+  float bias;           // observation_bias, hpp:289-290
+  int32_t K;            // unpadded latent dimension
+  int32_t max_cg_steps; // already resolved (0 -> K), hpp:232-234
+  int32_t warm_start;   // CG: start from the current row (hpp:199) or from 0 (hpp:132)
+};
+
+__device__ __forceinline__ float readlane_f(float x, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int T> __device__ __forceinline__ void load_dims(const float *p, float (&v)[T]) {
+  if constexpr (T == 4) {
+    f32x4 t = *reinterpret_cast<const f32x4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (T == 2) {
+    f32x2 t = *reinterpret_cast<const f32x2 *>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+
+template <int T> struct Geo {
+  static constexpr int KP = 16 * T;
+  static constexpr int NT = T * (T + 1) / 2;  // upper-triangular 16x16 tiles
+  static constexpr int LD = KP + 4;           // LDS row stride (floats); keeps 16 B alignment,
+                                              // conflict-free for row-per-lane ds_read_b128
+  static constexpr int LDS_FLOATS = KP * LD + KP;
+  static constexpr int PARTIAL_FLOATS = NT * 256 + 64;
+};
+
+// ---------------------------------------------------------------------------
+// Gather + symmetric rank update on the matrix cores.
+// A += sum_q c_q v_q v_q^T (upper tiles), b += sum_q (bias + c_q) v_q.
+// hpp:300-308 (BatchedRankUpdater hpp:37-58 computes the same sum from
+// sqrt(c) v rows; here c is applied to one operand).
+template <int T>
+__device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
+                                            const int32_t *__restrict__ indices,
+                                            const float *__restrict__ data, int begin,
+                                            int end, float bias,
+                                            f32x4 (&acc)[Geo<T>::NT], float (&bsum)[T]) {
+  constexpr int KP = Geo<T>::KP;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const float *col_base = other + T * m;
+
+  int pos = begin + lane;
+  int nx_idx = pos < end ? indices[pos] : 0;
+  float nx_c = pos < end ? data[pos] : 0.f;
+  for (int base = begin; base < end; base += 64) {
+    const int my_idx = nx_idx;
+    const float my_c = nx_c;
+    pos = base + 64 + lane;
+    nx_idx = pos < end ? indices[pos] : 0;  // prefetch the next 64 entries
+    nx_c = pos < end ? data[pos] : 0.f;
+    const int n_here = min(64, end - base);
+    const int nsub = (n_here + 3) >> 2;  // sub-steps of 4 gathered rows
+
+    float v0[T], v1[T];
+    float c0, c1, w0, w1;
+    auto fetch = [&](int s, float (&v)[T], float &c, float &w) {
+      const int src = 4 * s + g;
+      const int idx = __shfl(my_idx, src, 64);
+      c = __shfl(my_c, src, 64);  // 0 beyond the row's end
+      w = (src < n_here) ? bias + c : 0.f;
+      load_dims<T>(col_base + static_cast<size_t>(idx) * KP, v);
+    };
+    auto consume = [&](const float (&v)[T], float c, float w) {
+      float cv[T];
+#pragma unroll
+      for (int i = 0; i < T; i++) {
+        cv[i] = c * v[i];
+        bsum[i] = fmaf(w, v[i], bsum[i]);
+      }
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < T; i++)
+#pragma unroll
+        for (int j = i; j < T; j++) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], v[j], acc[t], 0, 0, 0);
+          t++;
+        }
+    };
+    fetch(0, v0, c0, w0);
+    for (int s = 0; s < nsub; s += 2) {
+      const bool has1 = s + 1 < nsub;
+      if (has1) fetch(s + 1, v1, c1, w1);
+      consume(v0, c0, w0);
+      if (s + 2 < nsub) fetch(s + 2, v0, c0, w0);
+      if (has1) consume(v1, c1, w1);
+    }
+  }
+  // fold the four gathered-row groups: every lane ends with b[T*m + i]
+#pragma unroll
+  for (int i = 0; i < T; i++) {
+    bsum[i] += __shfl_xor(bsum[i], 16, 64);
+    bsum[i] += __shfl_xor(bsum[i], 32, 64);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Per-row solve by one wave.  The KP x KP system is spilled to this wave's LDS
+// slab in natural coordinates, then lane i owns row i in registers.
+//   SOLVER 0: Cholesky A = L L^T with forward / backward substitution
+//             (Eigen::LLT + solve, hpp:316-324)
+//   SOLVER 1: conjugate gradient on the explicit matrix (same iterates as the
+//             matrix-free loop of hpp:199-264: A x = P x + reg x + sum c (v.x) v)
+template <int T, int SOLVER>
+__device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
+                                          float reg, float *sm, float *xrow, int K,
+                                          int nnz, int max_cg_steps, int warm_start,
+                                          int32_t *err_flag) {
+  constexpr int KP = Geo<T>::KP;
+  constexpr int LD = Geo<T>::LD;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+
+  if constexpr (SOLVER == 1) {
+    if (nnz == 0) {  // hpp:207-210
+      if (lane < KP) xrow[lane] = 0.f;
+      return;
+    }
+  }
+  // diagonal: + reg (hpp:312-314); padded dims get 1 so that they decouple
+  {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (4 * g + r == m) acc[t][r] += (T * m + i < K) ? reg : 1.0f;
+      t += T - i;
+    }
+  }
+  {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < T; i++)
+#pragma unroll
+      for (int j = i; j < T; j++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = T * (4 * g + r) + i, col = T * m + j;
+          sm[row * LD + col] = acc[t][r];
+          if (i != j) sm[col * LD + row] = acc[t][r];
+        }
+        t++;
+      }
+  }
+  float *sb = sm + KP * LD;
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < T; i++) sb[T * m + i] = b4[i];
+  }
+  __threadfence_block();
+  const int li = lane < KP ? lane : KP - 1;
+  float a[KP];
+#pragma unroll
+  for (int q = 0; q < KP / 4; q++) {
+    f32x4 t = *reinterpret_cast<const f32x4 *>(sm + li * LD + 4 * q);
+    a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+  }
+  float bv = sb[li];
+
+  if constexpr (SOLVER == 0) {
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < KP; j++) {
+      const float piv = readlane_f(a[j], j);
+      bad |= !(piv > 0.f);
+      const float rinv = __builtin_amdgcn_rsqf(piv);
+      const float lj = a[j] * rinv;  // L[i][j] for lanes i > j, sqrt(piv) on lane j
+      a[j] = lj;
+#pragma unroll
+      for (int k = j + 1; k < KP; k++) a[k] = fmaf(-lj, readlane_f(lj, k), a[k]);
+      // forward substitution rides along: y_j = (b_j - sum_{t<j} L[j][t] y_t) / L[j][j]
+      const float tj = bv * rinv;
+      const float yj = readlane_f(tj, j);
+      if (lane > j) bv = fmaf(-lj, yj, bv);
+      if (lane == j) bv = yj;
+    }
+    if (bad) {
+      if (lane == 0) atomicOr(err_flag, 1);
+    }
+    // L^T x = y: lane j needs column j of L -> transpose through LDS
+    __threadfence_block();
+#pragma unroll
+    for (int q = 0; q < KP / 4; q++) {
+      f32x4 t = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+      if (lane < KP) *reinterpret_cast<f32x4 *>(sm + lane * LD + 4 * q) = t;
+    }
+    __threadfence_block();
+#pragma unroll
+    for (int i = 0; i < KP; i++) a[i] = sm[i * LD + li];  // a[i] = L[i][lane]
+    const float my_rinv = 1.0f / sm[li * LD + li];
+    float xv = 0.f;
+#pragma unroll
+    for (int i = KP - 1; i >= 0; i--) {
+      const float ti = bv * my_rinv;
+      const float xi = readlane_f(ti, i);
+      if (lane == i) xv = xi;
+      bv = fmaf(-a[i], xi, bv);
+    }
+    const bool fin = __builtin_isfinite(xv) || lane >= K;
+    if (!__all(fin)) {
+      if (lane == 0) atomicOr(err_flag, 2);
+    }
+    if (lane < KP) xrow[lane] = lane < K ? xv : 0.f;
+  } else {
+    // conjugate gradient, hpp:199-264
+    const bool act = lane < K;
+    float x = (warm_start && act) ? xrow[li] : 0.f;
+    auto matvec = [&](float vec) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < KP; k++) s = fmaf(a[k], readlane_f(vec, k), s);
+      return s;
+    };
+    float r = act ? bv - matvec(x) : 0.f;
+    float p = r;
+    bool singular = false;
+    for (int it = 0; it < max_cg_steps; it++) {
+      const float r2 = wave_sum(r * r);
+      if (r2 <= 1e-20f) break;  // hpp:238
+      const float Ap = act ? matvec(p) : 0.f;
+      const float denom = wave_sum(p * Ap);
+      if (!(denom > 0.f) || !__builtin_isfinite(denom)) {  // hpp:250-254
+        singular = true;
+        break;
+      }
+      const float alpha = r2 / denom;
+      x = fmaf(alpha, p, x);
+      r = fmaf(-alpha, Ap, r);
+      const float r2n = wave_sum(r * r);
+      if (r2n <= 1e-20f) break;  // hpp:258
+      const float beta = r2n / r2;  // hpp:261
+      p = fmaf(beta, p, r);
+    }
+    if (singular) {
+      if (lane == 0) atomicOr(err_flag, 4);
+    }
+    if (lane < KP) xrow[lane] = act ? x : 0.f;
+  }
+}
+
+// MODE 0: one wave per task.  Whole rows are solved inline; chunks of split
+//         rows store their partial Gramian / rhs.
+// MODE 1: one wave per split row: sum the partials in slot order and solve.
+template <int T, int SOLVER, int MODE>
+__global__ __launch_bounds__(256) void ials_solve_kernel(SolveParams p) {
+  using G = Geo<T>;
+  __shared__ __attribute__((aligned(16))) float lds[4 * G::LDS_FLOATS];
+  const int wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + wid;
+  float *sm = lds + wid * G::LDS_FLOATS;
+
+  f32x4 acc[G::NT];
+  float bsum[T];
+#pragma unroll
+  for (int i = 0; i < T; i++) bsum[i] = 0.f;
+  const f32x4 *Pacc = reinterpret_cast<const f32x4 *>(p.P_acc);
+
+  if constexpr (MODE == 0) {
+    if (w >= p.n_tasks) return;
+    const Task task = p.tasks[w];
+    if (task.slot < 0) {
+#pragma unroll
+      for (int t = 0; t < G::NT; t++) acc[t] = Pacc[t * 64 + lane];
+    } else {
+#pragma unroll
+      for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    syrk_gather<T>(p.other, p.indices, p.data, task.begin, task.end, p.bias, acc, bsum);
+    if (task.slot >= 0) {
+      float *dst = p.partials + static_cast<size_t>(task.slot) * G::PARTIAL_FLOATS;
+      f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
+#pragma unroll
+      for (int t = 0; t < G::NT; t++) d4[t * 64 + lane] = acc[t];
+      if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < T; i++) dst[G::NT * 256 + T * lane + i] = bsum[i];
+      }
+      return;
+    }
+    solve_row<T, SOLVER>(acc, bsum, p.reg[task.row], sm,
+                         p.target + static_cast<size_t>(task.row) * G::KP, p.K,
+                         task.end - task.begin, p.max_cg_steps, p.warm_start, p.err_flag);
+  } else {
+    if (w >= p.n_split) return;
+    const SplitRow sr = p.split_rows[w];
+#pragma unroll
+    for (int t = 0; t < G::NT; t++) acc[t] = Pacc[t * 64 + lane];
+    for (int s = 0; s < sr.n_slots; s++) {
+      const float *src = p.partials + static_cast<size_t>(sr.first_slot + s) * G::PARTIAL_FLOATS;
+      const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+      for (int t = 0; t < G::NT; t++) acc[t] += s4[t * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < T; i++) bsum[i] += src[G::NT * 256 + T * (lane & 15) + i];
+    }
+    solve_row<T, SOLVER>(acc, bsum, p.reg[sr.row], sm,
+                         p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
+                         p.max_cg_steps, p.warm_start, p.err_flag);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Dense Gramian  sum_r f_r f_r^T  over rows [row_begin, row_end) on the matrix
+// cores (Solver::prepare_p, hpp:78-115).  Each wave owns a slab of rows and all
+// upper tiles; partials are reduced in a fixed order by gramian_reduce_kernel.
+template <int T>
+__global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__restrict__ F,
+                                                              int64_t row_begin,
+                                                              int64_t row_end,
+                                                              int64_t rows_per_wave,
+                                                              float *__restrict__ partial) {
+  using G = Geo<T>;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  f32x4 acc[G::NT];
+#pragma unroll
+  for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t b = row_begin + w * rows_per_wave;
+  const int64_t e = min(b + rows_per_wave, row_end);
+  for (int64_t r = b; r < e; r += 4) {
+    float v[T];
+    if (r + g < e) {
+      load_dims<T>(F + (r + g) * G::KP + T * m, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < T; i++) v[i] = 0.f;
+    }
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < T; i++)
+#pragma unroll
+      for (int j = i; j < T; j++) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], v[j], acc[t], 0, 0, 0);
+        t++;
+      }
+  }
+  f32x4 *dst = reinterpret_cast<f32x4 *>(partial) + w * (G::NT * 64);
+#pragma unroll
+  for (int t = 0; t < G::NT; t++) dst[t * 64 + lane] = acc[t];
+}
+
+// Sum the per-wave partials in wave order and write the row-major symmetric
+// KP x KP matrix (unscaled).  One thread per accumulator element.
+template <int T>
+__global__ void gramian_reduce_kernel(const float *__restrict__ partial, int64_t n_waves,
+                                      float *__restrict__ P_raw) {
+  using G = Geo<T>;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // element of [NT][64][4]
+  if (e >= G::NT * 256) return;
+  float s = 0.f;
+  for (int64_t w = 0; w < n_waves; w++) s += partial[w * (G::NT * 256) + e];
+  const int t = e >> 8, lane = (e >> 2) & 63, r = e & 3;
+  int ti = 0, tj = 0, c = t;
+  for (int i = 0; i < T; i++) {
+    if (c < T - i) { ti = i; tj = i + c; break; }
+    c -= T - i;
+  }
+  const int gg = lane >> 4, m = lane & 15;
+  const int row = T * (4 * gg + r) + ti, col = T * m + tj;
+  P_raw[row * G::KP + col] = s;
+  if (ti != tj) P_raw[col * G::KP + row] = s;
+}
+
+// P = alpha0 * P_raw (hpp:113) in both row-major and accumulator layout.
+template <int T>
+__global__ void gramian_finish_kernel(const float *__restrict__ P_raw, float alpha0,
+                                      float *__restrict__ P, float *__restrict__ P_acc) {
+  using G = Geo<T>;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < G::KP * G::KP) P[e] = alpha0 * P_raw[e];
+  if (e < G::NT * 256) {
+    const int t = e >> 8, lane = (e >> 2) & 63, r = e & 3;
+    int ti = 0, tj = 0, c = t;
+    for (int i = 0; i < T; i++) {
+      if (c < T - i) { ti = i; tj = i + c; break; }
+      c -= T - i;
+    }
+    const int gg = lane >> 4, m = lane & 15;
+    const int row = T * (4 * gg + r) + ti, col = T * m + tj;
+    P_acc[e] = alpha0 * P_raw[row * G::KP + col];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// user_scores: out[m, n_items] = user[begin:end] @ item^T (hpp:942-984).
+// One wave per 16 users x 64 items; k runs over the latent dims 16 at a time
+// with each lane loading 16 B of its user row and of each of its 4 item rows.
+template <int KP>
+__global__ __launch_bounds__(256) void user_scores_kernel(const float *__restrict__ user,
+                                                          const float *__restrict__ item,
+                                                          int64_t begin, int64_t m_rows,
+                                                          int64_t n_items,
+                                                          float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int64_t item_tiles = (n_items + 63) / 64;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t ut = w / item_tiles, it = w % item_tiles;
+  if (ut * 16 >= m_rows) return;
+  const int64_t u = min(ut * 16 + m, m_rows - 1);
+  const float *up = user + (begin + u) * KP + 4 * g;
+  const float *ip[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int64_t i = min(it * 64 + q * 16 + m, n_items - 1);
+    ip[q] = item + i * KP + 4 * g;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int k = 0; k < KP; k += 16) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(up + k);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(ip[q] + k);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int64_t col = it * 64 + q * 16 + m;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int64_t row = ut * 16 + 4 * g + r;
+      if (row < m_rows && col < n_items) out[row * n_items + col] = acc[q][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// compute_loss pieces (hpp:845-917): per-row partial losses, summed afterwards
+// in row order.  One wave per row; 16 lanes share a gathered row.
+template <int T>
+__global__ __launch_bounds__(256) void loss_rows_kernel(const float *__restrict__ target,
+                                                        const float *__restrict__ other,
+                                                        const int32_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices,
+                                                        const float *__restrict__ data,
+                                                        const float *__restrict__ reg,
+                                                        int64_t n_rows, float bias,
+                                                        int with_observed,
+                                                        float *__restrict__ row_loss) {
+  constexpr int KP = Geo<T>::KP;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  float u[T];
+  load_dims<T>(target + row * KP + T * m, u);
+  float loss = 0.f;
+  if (with_observed) {
+    const int b = indptr[row], e = indptr[row + 1];
+    for (int q0 = b; q0 < e; q0 += 4) {  // 4 stored entries per step, one per 16-lane group
+      const int q = q0 + g;
+      const bool valid = q < e;
+      const int idx = valid ? indices[q] : 0;
+      const float c = valid ? data[q] : 0.f;
+      float v[T];
+      load_dims<T>(other + static_cast<size_t>(idx) * KP + T * m, v);
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < T; i++) d = fmaf(u[i], v[i], d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      d += __shfl_xor(d, 8, 64);
+      if (valid && m == 0) loss += c * d * d - 2.f * (c + bias) * d + c + bias;  // hpp:867-869
+    }
+  }
+  float n2 = 0.f;
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < T; i++) n2 = fmaf(u[i], u[i], n2);
+  }
+  loss += reg[row] * n2;
+  loss = wave_sum(loss);
+  if (lane == 0) row_loss[row] = loss;
+}
+
+// Deterministic sum of n floats in double, fixed tree.
+__global__ void sum_kernel(const float *__restrict__ v, int64_t n, double *__restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += static_cast<double>(v[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+}  // namespace ials
+}  // namespace irs

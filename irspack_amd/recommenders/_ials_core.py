@@ -1,0 +1,515 @@
+"""Counterpart of the reference's nanobind module ``irspack.recommenders._ials_core``
+(/root/reference/cpp_source/als/wrapper.cpp:19-182, stub
+src/irspack/recommenders/_ials_core.pyi), backed by ``libirspack_amd.so``.
+
+Same class names, argument meaning, pickle tuples and error behaviour; the
+arithmetic runs in the HIP kernels of ``irspack_amd/csrc``.
+"""
+
+import ctypes as C
+import enum
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sps
+
+from .. import _lib
+from .._lib import ModelConfigStruct, ShardStruct, SolverConfigStruct, check, lib, ptr
+
+
+class LossType(enum.Enum):  # IALSLearningConfig.hpp:11, wrapper.cpp:25-27
+    ORIGINAL = 0
+    IALSPP = 1
+
+
+class SolverType(enum.Enum):  # IALSLearningConfig.hpp:12, wrapper.cpp:29-32
+    CHOLESKY = 0
+    CG = 1
+    IALSPP = 2
+
+
+# legacy module-level aliases; IALSPP is the *SolverType* (wrapper.cpp:34-40)
+ORIGINAL = LossType.ORIGINAL
+CHOLESKY = SolverType.CHOLESKY
+CG = SolverType.CG
+IALSPP = SolverType.IALSPP
+
+
+class IALSModelConfig:  # IALSLearningConfig.hpp:15-31, wrapper.cpp:42-71
+    def __init__(
+        self,
+        K: int,
+        alpha0: float,
+        reg: float,
+        nu: float,
+        init_stdev: float,
+        random_seed: int,
+        loss_type: LossType,
+        lambda_user_feature: float = 0.0,
+        lambda_item_feature: float = 0.0,
+        feature_warmup_epochs: int = 0,
+    ) -> None:
+        if int(K) < 0 or int(feature_warmup_epochs) < 0:
+            raise TypeError("K and feature_warmup_epochs must be non-negative (size_t).")
+        self.K = int(K)
+        self.alpha0 = float(alpha0)
+        self.reg = float(reg)
+        self.nu = float(nu)
+        self.init_stdev = float(init_stdev)
+        self.random_seed = int(random_seed)
+        self.loss_type = LossType(loss_type)
+        self.lambda_user_feature = float(lambda_user_feature)
+        self.lambda_item_feature = float(lambda_item_feature)
+        self.feature_warmup_epochs = int(feature_warmup_epochs)
+
+    def __getstate__(self) -> tuple:
+        return (
+            self.K,
+            float(np.float32(self.alpha0)),
+            float(np.float32(self.reg)),
+            float(np.float32(self.nu)),
+            float(np.float32(self.init_stdev)),
+            self.random_seed,
+            self.loss_type,
+            float(np.float32(self.lambda_user_feature)),
+            float(np.float32(self.lambda_item_feature)),
+            self.feature_warmup_epochs,
+        )
+
+    def __setstate__(self, state: tuple) -> None:
+        self.__init__(*state)  # type: ignore[misc]
+
+    def _struct(self) -> ModelConfigStruct:
+        return ModelConfigStruct(
+            self.K,
+            self.alpha0,
+            self.reg,
+            self.nu,
+            self.init_stdev,
+            self.random_seed,
+            self.loss_type.value,
+            self.lambda_user_feature,
+            self.lambda_item_feature,
+            self.feature_warmup_epochs,
+        )
+
+
+class IALSModelConfigBuilder:  # IALSLearningConfig.hpp:33-94, wrapper.cpp:72-90
+    def __init__(self) -> None:
+        self.reg = 0.1
+        self.alpha0 = 0.1
+        self.nu = 1.0
+        self.init_stdev = 0.1
+        self.K = 16
+        self.random_seed = 42
+        self.loss_type = LossType.IALSPP
+        self.lambda_user_feature = 0.0
+        self.lambda_item_feature = 0.0
+        self.feature_warmup_epochs = 0
+
+    def build(self) -> IALSModelConfig:
+        return IALSModelConfig(
+            self.K,
+            self.alpha0,
+            self.reg,
+            self.nu,
+            self.init_stdev,
+            self.random_seed,
+            self.loss_type,
+            self.lambda_user_feature,
+            self.lambda_item_feature,
+            self.feature_warmup_epochs,
+        )
+
+    def set_K(self, K: int) -> "IALSModelConfigBuilder":
+        self.K = K
+        return self
+
+    def set_alpha0(self, alpha0: float) -> "IALSModelConfigBuilder":
+        self.alpha0 = alpha0
+        return self
+
+    def set_reg(self, reg: float) -> "IALSModelConfigBuilder":
+        self.reg = reg
+        return self
+
+    def set_nu(self, nu: float) -> "IALSModelConfigBuilder":
+        self.nu = nu
+        return self
+
+    def set_init_stdev(self, init_stdev: float) -> "IALSModelConfigBuilder":
+        self.init_stdev = init_stdev
+        return self
+
+    def set_random_seed(self, random_seed: int) -> "IALSModelConfigBuilder":
+        self.random_seed = random_seed
+        return self
+
+    def set_loss_type(self, loss_type: LossType) -> "IALSModelConfigBuilder":
+        self.loss_type = loss_type
+        return self
+
+    def set_lambda_user_feature(self, value: float) -> "IALSModelConfigBuilder":
+        self.lambda_user_feature = value
+        return self
+
+    def set_lambda_item_feature(self, value: float) -> "IALSModelConfigBuilder":
+        self.lambda_item_feature = value
+        return self
+
+    def set_feature_warmup_epochs(self, value: int) -> "IALSModelConfigBuilder":
+        self.feature_warmup_epochs = value
+        return self
+
+
+class IALSSolverConfig:  # IALSLearningConfig.hpp:97-112, wrapper.cpp:92-115
+    def __init__(
+        self,
+        n_threads: int,
+        solver_type: SolverType,
+        max_cg_steps: int,
+        ialspp_subspace_dimension: int,
+        ialspp_iteration: int,
+    ) -> None:
+        for v in (n_threads, max_cg_steps, ialspp_subspace_dimension, ialspp_iteration):
+            if int(v) < 0:
+                raise TypeError("size_t arguments must be non-negative.")
+        self.n_threads = int(n_threads)
+        self.solver_type = SolverType(solver_type)
+        self.max_cg_steps = int(max_cg_steps)
+        self.ialspp_subspace_dimension = int(ialspp_subspace_dimension)
+        self.ialspp_iteration = int(ialspp_iteration)
+
+    def __getstate__(self) -> tuple:
+        return (
+            self.n_threads,
+            self.solver_type,
+            self.max_cg_steps,
+            self.ialspp_subspace_dimension,
+            self.ialspp_iteration,
+        )
+
+    def __setstate__(self, state: tuple) -> None:
+        self.__init__(*state)  # type: ignore[misc]
+
+    def _struct(self) -> SolverConfigStruct:
+        return SolverConfigStruct(
+            self.n_threads,
+            self.solver_type.value,
+            self.max_cg_steps,
+            self.ialspp_subspace_dimension,
+            self.ialspp_iteration,
+        )
+
+
+class IALSSolverConfigBuilder:  # IALSLearningConfig.hpp:114-147, wrapper.cpp:117-128
+    def __init__(self) -> None:
+        self.n_threads = 1
+        self.solver_type = SolverType.CG
+        self.max_cg_steps = 3
+        self.ialspp_subspace_dimension = 64
+        self.ialspp_iteration = 1
+
+    def build(self) -> IALSSolverConfig:
+        return IALSSolverConfig(
+            self.n_threads,
+            self.solver_type,
+            self.max_cg_steps,
+            self.ialspp_subspace_dimension,
+            self.ialspp_iteration,
+        )
+
+    def set_n_threads(self, n_threads: int) -> "IALSSolverConfigBuilder":
+        self.n_threads = n_threads
+        return self
+
+    def set_solver_type(self, solver_type: SolverType) -> "IALSSolverConfigBuilder":
+        self.solver_type = solver_type
+        return self
+
+    def set_max_cg_steps(self, max_cg_steps: int) -> "IALSSolverConfigBuilder":
+        self.max_cg_steps = max_cg_steps
+        return self
+
+    def set_ialspp_subspace_dimension(self, v: int) -> "IALSSolverConfigBuilder":
+        self.ialspp_subspace_dimension = v
+        return self
+
+    def set_ialspp_iteration(self, v: int) -> "IALSSolverConfigBuilder":
+        self.ialspp_iteration = v
+        return self
+
+
+_FEATURE_MSG = (
+    "irspack_amd: feature-aware iALS (user_feature / item_feature) is outside the "
+    "accelerated hot path (SURVEY.md §8f.4) and is not implemented."
+)
+
+
+class IALSTrainer:
+    """``IALSTrainer(model_config, interaction)`` — wrapper.cpp:130-181, hpp:709-984.
+
+    Factors live on the GPU; ``.user`` / ``.item`` copy to / from the host.
+    Extra keyword-only arguments (not in the reference): ``device`` selects the
+    GPU, ``shard`` = (user_begin, user_end, item_begin, item_end) restricts the
+    rows this handle solves (multi-GPU host loop, see ``irspack_amd.sharding``).
+    """
+
+    def __init__(
+        self,
+        model_config: IALSModelConfig,
+        interaction: Any,
+        user_feature: Any = None,
+        item_feature: Any = None,
+        *,
+        device: Optional[int] = None,
+        shard: Optional[Tuple[int, int, int, int]] = None,
+    ) -> None:
+        if user_feature is not None or item_feature is not None:
+            empty = all(
+                f is None or (hasattr(f, "shape") and f.shape[1] == 0)
+                for f in (user_feature, item_feature)
+            )
+            if not empty:
+                raise NotImplementedError(_FEATURE_MSG)
+        if not sps.issparse(interaction):
+            raise TypeError("interaction must be a scipy sparse matrix.")
+        X, indptr, indices, data = _lib.csr_arrays(interaction, np.float32)
+        self._config = model_config
+        self._device = _lib.default_device() if device is None else int(device)
+        self._n_users, self._n_items = int(X.shape[0]), int(X.shape[1])
+        self._K = int(model_config.K)
+        cfg = model_config._struct()
+        h = C.c_void_p()
+        sh = None if shard is None else ShardStruct(*[int(v) for v in shard])
+        check(
+            lib().irs_ials_create(
+                C.byref(cfg),
+                C.c_int64(self._n_users),
+                C.c_int64(self._n_items),
+                ptr(indptr, C.c_int64),
+                ptr(indices, C.c_int32),
+                ptr(data, C.c_float),
+                C.c_int32(self._device),
+                None if sh is None else C.byref(sh),
+                C.byref(h),
+            )
+        )
+        self._h: Optional[C.c_void_p] = h
+        self._empty_feature_weight()
+
+    def _empty_feature_weight(self) -> None:
+        self._ufw = np.zeros((0, self._K), dtype=np.float32)
+        self._ifw = np.zeros((0, self._K), dtype=np.float32)
+
+    @classmethod
+    def _from_factors(
+        cls, config: IALSModelConfig, user: np.ndarray, item: np.ndarray, device: Optional[int] = None
+    ) -> "IALSTrainer":
+        self = cls.__new__(cls)
+        self._restore(config, user, item, device)
+        return self
+
+    def _restore(self, config, user, item, device=None) -> None:
+        user = np.ascontiguousarray(user, dtype=np.float32)
+        item = np.ascontiguousarray(item, dtype=np.float32)
+        if user.ndim != 2 or item.ndim != 2 or user.shape[1] != item.shape[1]:
+            raise RuntimeError("Invalid IALSTrainer pickle state.")
+        # the deserialising ctor takes K from the matrices (hpp:748)
+        cfgK = IALSModelConfig(user.shape[1], *config.__getstate__()[1:])
+        self._config = config
+        self._device = _lib.default_device() if device is None else int(device)
+        self._n_users, self._n_items = int(user.shape[0]), int(item.shape[0])
+        self._K = int(user.shape[1])
+        cfg = cfgK._struct()
+        h = C.c_void_p()
+        check(
+            lib().irs_ials_create_from_factors(
+                C.byref(cfg),
+                C.c_int64(self._n_users),
+                C.c_int64(self._n_items),
+                ptr(user, C.c_float),
+                ptr(item, C.c_float),
+                C.c_int32(self._device),
+                C.byref(h),
+            )
+        )
+        self._h = h
+        self._empty_feature_weight()
+
+    def __del__(self) -> None:
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().irs_ials_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- training / scoring -------------------------------------------------
+    def step(self, solver_config: IALSSolverConfig) -> None:
+        sc = solver_config._struct()
+        check(lib().irs_ials_step(self._h, C.byref(sc)))
+
+    def user_scores(self, begin: int, end: int, solver_config: IALSSolverConfig) -> np.ndarray:
+        if begin < 0 or end < 0:
+            raise TypeError("begin/end must be non-negative (size_t).")
+        sc = solver_config._struct()
+        out = np.empty((max(int(end) - int(begin), 0), self._n_items), dtype=np.float32)
+        check(
+            lib().irs_ials_user_scores(
+                self._h, C.c_int64(begin), C.c_int64(end), C.byref(sc), ptr(out, C.c_float)
+            )
+        )
+        return out
+
+    def _transform(self, side: int, interaction: Any, solver_config: IALSSolverConfig) -> np.ndarray:
+        X, indptr, indices, data = _lib.csr_arrays(interaction, np.float32)
+        m = X.shape[0] if side == 0 else X.shape[1]
+        out = np.zeros((m, self._K), dtype=np.float32)
+        sc = solver_config._struct()
+        check(
+            lib().irs_ials_transform(
+                self._h,
+                C.c_int32(side),
+                C.c_int64(X.shape[0]),
+                C.c_int64(X.shape[1]),
+                ptr(indptr, C.c_int64),
+                ptr(indices, C.c_int32),
+                ptr(data, C.c_float),
+                C.byref(sc),
+                ptr(out, C.c_float),
+            )
+        )
+        return out
+
+    def transform_user(self, interaction: Any, solver_config: IALSSolverConfig) -> np.ndarray:
+        return self._transform(0, interaction, solver_config)
+
+    def transform_item(self, interaction: Any, solver_config: IALSSolverConfig) -> np.ndarray:
+        return self._transform(1, interaction, solver_config)
+
+    def transform_user_with_feature(self, interaction, feature, solver_config):
+        raise NotImplementedError(_FEATURE_MSG)
+
+    def transform_item_with_feature(self, interaction, feature, solver_config):
+        raise NotImplementedError(_FEATURE_MSG)
+
+    def transform_user_feature(self, feature):
+        raise NotImplementedError(_FEATURE_MSG)
+
+    def transform_item_feature(self, feature):
+        raise NotImplementedError(_FEATURE_MSG)
+
+    def compute_loss(self, solver_config: IALSSolverConfig) -> float:
+        sc = solver_config._struct()
+        out = C.c_float(0.0)
+        check(lib().irs_ials_compute_loss(self._h, C.byref(sc), C.byref(out)))
+        return float(out.value)
+
+    # -- read/write attributes (wrapper.cpp:158-161) --------------------------
+    def _get(self, which: int) -> np.ndarray:
+        n = self._n_users if which == 0 else self._n_items
+        out = np.empty((n, self._K), dtype=np.float32)
+        check(lib().irs_ials_get_factor(self._h, C.c_int32(which), ptr(out, C.c_float)))
+        return out
+
+    def _set(self, which: int, value: np.ndarray) -> None:
+        v = np.ascontiguousarray(value, dtype=np.float32)
+        if v.ndim != 2:
+            raise TypeError("factor matrix must be 2-dimensional.")
+        check(
+            lib().irs_ials_set_factor(
+                self._h, C.c_int32(which), ptr(v, C.c_float), C.c_int64(v.shape[0]), C.c_int64(v.shape[1])
+            )
+        )
+
+    @property
+    def user(self) -> np.ndarray:
+        return self._get(0)
+
+    @user.setter
+    def user(self, value: np.ndarray) -> None:
+        self._set(0, value)
+
+    @property
+    def item(self) -> np.ndarray:
+        return self._get(1)
+
+    @item.setter
+    def item(self, value: np.ndarray) -> None:
+        self._set(1, value)
+
+    @property
+    def user_feature_weight(self) -> np.ndarray:
+        return self._ufw
+
+    @user_feature_weight.setter
+    def user_feature_weight(self, value: np.ndarray) -> None:
+        value = np.asarray(value, dtype=np.float32)
+        if value.size:
+            raise NotImplementedError(_FEATURE_MSG)
+        self._ufw = value.reshape(0, self._K) if value.ndim != 2 else value
+
+    @property
+    def item_feature_weight(self) -> np.ndarray:
+        return self._ifw
+
+    @item_feature_weight.setter
+    def item_feature_weight(self, value: np.ndarray) -> None:
+        value = np.asarray(value, dtype=np.float32)
+        if value.size:
+            raise NotImplementedError(_FEATURE_MSG)
+        self._ifw = value.reshape(0, self._K) if value.ndim != 2 else value
+
+    # -- pickle: (config, user, item, ufw, ifw); 3- or 5-tuples accepted
+    #    (wrapper.cpp:162-181).  The restored object has no interaction matrix.
+    def __getstate__(self) -> tuple:
+        return (self._config, self.user, self.item, self._ufw, self._ifw)
+
+    def __setstate__(self, state: tuple) -> None:
+        if len(state) not in (3, 5):
+            raise RuntimeError("Invalid IALSTrainer pickle state.")
+        self._restore(state[0], state[1], state[2])
+        if len(state) == 5:
+            self._ufw = np.asarray(state[3], dtype=np.float32)
+            self._ifw = np.asarray(state[4], dtype=np.float32)
+
+    # -- device-level access for the multi-GPU host loop and the benchmark ----
+    def set_stream(self, hip_stream: int) -> None:
+        check(lib().irs_ials_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def device_buffer(self, which: int) -> Tuple[int, int, int]:
+        p = C.c_void_p()
+        rows = C.c_int64()
+        ld = C.c_int64()
+        check(lib().irs_ials_device_buffer(self._h, C.c_int32(which), C.byref(p), C.byref(rows), C.byref(ld)))
+        return int(p.value or 0), int(rows.value), int(ld.value)
+
+    def partial_gramian_async(self, side: int) -> None:
+        check(lib().irs_ials_partial_gramian_async(self._h, C.c_int32(side)))
+
+    def finish_gramian_async(self, side: int) -> None:
+        check(lib().irs_ials_finish_gramian_async(self._h, C.c_int32(side)))
+
+    def half_step_async(self, side: int, solver_config: IALSSolverConfig) -> None:
+        sc = solver_config._struct()
+        check(lib().irs_ials_half_step_async(self._h, C.c_int32(side), C.byref(sc)))
+
+    def synchronize(self) -> None:
+        check(lib().irs_ials_synchronize(self._h))
+
+    def profile(self, enable: bool) -> None:
+        check(lib().irs_ials_profile(self._h, C.c_int32(1 if enable else 0)))
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        cap = 32
+        names = ((C.c_char * 48) * cap)()
+        ms = (C.c_double * cap)()
+        launches = (C.c_int64 * cap)()
+        count = C.c_int32(0)
+        check(lib().irs_ials_profile_read(self._h, C.c_int32(cap), names, ms, launches, C.byref(count)))
+        out: Dict[str, Dict[str, float]] = {}
+        for i in range(count.value):
+            out[names[i].value.decode()] = {"ms": float(ms[i]), "launches": int(launches[i])}
+        return out

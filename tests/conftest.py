@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available() -> bool:
+    try:
+        from irspack_amd import _lib
+
+        return _lib.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly, not skip silently;
+    # plain runs (no -m) on a CPU box skip the gpu tests.
+    markexpr = config.getoption("-m") or ""
+    if "gpu" in markexpr and "not gpu" not in markexpr:
+        return
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture()
+def X_small() -> sps.csr_matrix:
+    # the reference's fixture, tests/conftest.py:9-16 (4 x 5 with an empty row)
+    return sps.csr_matrix(
+        np.asarray(
+            [[1, 1, 2, 3, 4], [0, 1, 0, 1, 0], [0, 0, 1, 0, 0], [0, 0, 0, 0, 0]],
+            dtype=float,
+        )
+    )
+
+
+def random_csr(n_rows, n_cols, density, seed, dtype=np.float32, binary=False, empty_rows=()):
+    rng = np.random.default_rng(seed)
+    M = sps.random(n_rows, n_cols, density=density, format="csr", random_state=rng, dtype=np.float64)
+    if binary:
+        M.data[:] = 1.0
+    else:
+        M.data = rng.uniform(0.5, 3.0, size=M.nnz)
+    M = M.tolil()
+    for r in empty_rows:
+        M.rows[r] = []
+        M.data[r] = []
+    M = M.tocsr().astype(dtype)
+    M.sort_indices()
+    return M

@@ -1,0 +1,307 @@
+"""GPU parity tests of the iALS path: HIP kernels (through the C ABI) vs the CPU
+oracle and vs float64 closed forms.  Tolerances: 1e-4 relative on factors /
+scores (BASELINE.json north_star), written next to each assert.
+"""
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import oracle as O
+from conftest import random_csr
+from irspack_amd.recommenders._ials_core import (
+    IALSModelConfigBuilder,
+    IALSSolverConfigBuilder,
+    IALSTrainer,
+    LossType,
+    SolverType,
+)
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # relative, on factor matrices and scores
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def build(K, alpha0=0.1, reg=1e-3, nu=1.0, loss="IALSPP", init=0.1, seed=42):
+    mc = (
+        IALSModelConfigBuilder()
+        .set_K(K)
+        .set_alpha0(alpha0)
+        .set_reg(reg)
+        .set_nu(nu)
+        .set_init_stdev(init)
+        .set_random_seed(seed)
+        .set_loss_type(LossType[loss])
+        .build()
+    )
+    omc = O.model_config(K, alpha0=alpha0, reg=reg, nu=nu, init_stdev=init, random_seed=seed,
+                         loss_type=loss)
+    return mc, omc
+
+
+def solver(kind, steps=3, n_threads=2):
+    sc = (
+        IALSSolverConfigBuilder()
+        .set_n_threads(n_threads)
+        .set_solver_type(SolverType[kind])
+        .set_max_cg_steps(steps)
+        .build()
+    )
+    return sc, O.solver_config(n_threads, kind, steps)
+
+
+def closed_form_half_step(X, other, alpha0, reg_rows, bias):
+    """float64 normal equations per row (tests/recommenders/test_ials.py:185-227 style)."""
+    X = sps.csr_matrix(X).astype(np.float64)
+    other = other.astype(np.float64)
+    K = other.shape[1]
+    P = alpha0 * other.T @ other
+    out = np.zeros((X.shape[0], K))
+    for r in range(X.shape[0]):
+        sl = slice(X.indptr[r], X.indptr[r + 1])
+        V = other[X.indices[sl]]
+        c = X.data[sl]
+        A = P + (V * c[:, None]).T @ V + reg_rows[r] * np.eye(K)
+        b = ((c + bias)[:, None] * V).sum(axis=0)
+        out[r] = np.linalg.solve(A, b)
+    return out
+
+
+@pytest.mark.parametrize("K", [16, 64])
+def test_init_matches_libstdcxx_stream(K):
+    X = random_csr(37, 29, 0.2, 0)
+    mc, omc = build(K)
+    t = IALSTrainer(mc, X)
+    ref_u = O.ials_init(37, K, 0.1, 42)
+    ref_i = O.ials_init(29, K, 0.1, 42)
+    np.testing.assert_array_equal(t.user, ref_u)  # bit-exact: same engine, same stream
+    np.testing.assert_array_equal(t.item, ref_i)
+    np.testing.assert_array_equal(t.user[:29], t.item)  # hpp:718-719 same seed for both
+
+
+@pytest.mark.parametrize("K", [3, 16, 20, 31, 32, 48, 64])
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_one_epoch_matches_oracle(K, kind):
+    X = random_csr(211, 157, 0.08, 1, empty_rows=(5, 77))
+    mc, omc = build(K, alpha0=0.1, reg=1e-2)
+    sc, osc = solver(kind)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    for _ in range(2):
+        t.step(sc)
+        o.step(osc)
+    assert rel_err(t.user, o.user) < RTOL
+    assert rel_err(t.item, o.item) < RTOL
+
+
+@pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
+@pytest.mark.parametrize("K", [8, 64])
+def test_cholesky_half_step_vs_closed_form(K, loss):
+    X = random_csr(150, 120, 0.1, 2, empty_rows=(3,))
+    alpha0, reg, nu = 0.3, 0.05, 0.5
+    mc, omc = build(K, alpha0=alpha0, reg=reg, nu=nu, loss=loss)
+    sc, osc = solver("CHOLESKY")
+    t = IALSTrainer(mc, X)
+    item0 = t.item
+    t.step(sc)
+    nnz = np.diff(X.indptr)
+    reg_rows = reg * (alpha0 * X.shape[1] + nnz) ** nu
+    bias = 0.0 if loss == "IALSPP" else alpha0
+    expect = closed_form_half_step(X, item0, alpha0, reg_rows, bias)
+    got = t.user
+    o = O.IALSTrainer(omc, X)
+    o.step(osc)
+    err_gpu = rel_err(got, expect)
+    err_cpu = rel_err(o.user, expect)
+    assert err_gpu < RTOL
+    assert err_gpu < 10 * err_cpu + 1e-6  # the GPU is not materially worse than the CPU restatement
+
+
+def test_split_rows_and_long_rows():
+    # rows longer than the chunk size (1024) are split across waves and reduced
+    rng = np.random.default_rng(3)
+    n_u, n_i = 40, 6000
+    rows = []
+    for u in range(n_u):
+        d = [5000, 2500, 1025, 1024, 1023, 64, 65, 4, 1, 0][u % 10]
+        cols = np.sort(rng.choice(n_i, size=d, replace=False))
+        rows.append(cols)
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    indices = np.concatenate(rows).astype(np.int32)
+    data = rng.uniform(0.5, 2.0, size=indices.size).astype(np.float32)
+    X = sps.csr_matrix((data, indices, indptr), shape=(n_u, n_i))
+    for kind in ["CHOLESKY", "CG"]:
+        mc, omc = build(64, alpha0=0.05, reg=1e-2)
+        sc, osc = solver(kind)
+        t = IALSTrainer(mc, X)
+        o = O.IALSTrainer(omc, X)
+        t.step(sc)
+        o.step(osc)
+        assert rel_err(t.user, o.user) < RTOL
+        assert rel_err(t.item, o.item) < RTOL
+
+
+def test_cg_max_steps_zero_means_K_and_converges_to_cholesky():
+    # tests/recommenders/test_ials.py:627-661: converged CG == Cholesky
+    X = random_csr(90, 70, 0.15, 4)
+    mc, _ = build(16, alpha0=0.2, reg=0.1)
+    a = IALSTrainer(mc, X)
+    b = IALSTrainer(mc, X)
+    sa, _ = solver("CHOLESKY")
+    sb, _ = solver("CG", steps=0)
+    a.step(sa)
+    b.step(sb)
+    np.testing.assert_allclose(a.user, b.user, atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(a.item, b.item, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n_threads", [1, 4, 64])
+def test_user_scores_batching(n_threads):
+    # tests/recommenders/test_ials.py:551-570
+    rng = np.random.default_rng(0)
+    n_users, n_items, K = 513, 257, 31
+    X = sps.csr_matrix((n_users, n_items), dtype=np.float32)
+    mc = IALSModelConfigBuilder().set_K(K).build()
+    sc = IALSSolverConfigBuilder().set_n_threads(n_threads).build()
+    t = IALSTrainer(mc, X)
+    user = rng.standard_normal((n_users, K)).astype(np.float32)
+    item = rng.standard_normal((n_items, K)).astype(np.float32)
+    t.user = user
+    t.item = item
+    for begin, end in [(0, n_users), (17, 193), (n_users, n_users)]:
+        got = t.user_scores(begin, end, sc)
+        assert got.shape == (end - begin, n_items)
+        np.testing.assert_allclose(got, user[begin:end] @ item.T, rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        t.user_scores(0, n_users + 1, sc)
+    with pytest.raises(ValueError):
+        t.user_scores(5, 4, sc)
+    with pytest.raises(ValueError):
+        t.user_scores(0, 1, IALSSolverConfigBuilder().set_n_threads(0).build())
+
+
+@pytest.mark.parametrize("loss,alpha0", [("ORIGINAL", 0.1), ("IALSPP", 0.0), ("IALSPP", 0.1)])
+def test_loss_matches_bruteforce(X_small, loss, alpha0):
+    # tests/recommenders/test_ials.py:456-513
+    X = X_small.astype(np.float32)
+    mc, omc = build(2, alpha0=alpha0, reg=0.1, nu=0.0, loss=loss)
+    sc, osc = solver("CHOLESKY", n_threads=1)
+    t = IALSTrainer(mc, X)
+    for _ in range(2):
+        t.step(sc)
+    u, v = t.user.astype(np.float64), t.item.astype(np.float64)
+    ui = u @ v.T
+    row, col = X.nonzero()
+    Xd = X.toarray().astype(np.float64)
+    if loss == "ORIGINAL":
+        manual = (Xd[row, col] + alpha0) @ ((ui[row, col] - 1) ** 2)
+        ui2 = ui.copy()
+        ui2[row, col] = 0.0
+        manual += alpha0 * (ui2.ravel() @ ui2.ravel())
+    else:
+        manual = Xd[row, col] @ ((ui[row, col] - 1) ** 2)
+        manual += alpha0 * (ui.ravel() @ ui.ravel())
+    manual += 0.1 * ((u ** 2).sum() + (v ** 2).sum())
+    manual /= 2
+    assert t.compute_loss(sc) == pytest.approx(manual, rel=1e-5)
+
+
+def test_transform_and_shape_mismatch(X_small):
+    # tests/recommenders/test_ials.py:516-548 (CG, K=3)
+    X = X_small.astype(np.float32)
+    mc, omc = build(3, alpha0=100, reg=0.1, nu=0.0, loss="ORIGINAL")
+    sc, osc = solver("CG", steps=3, n_threads=1)
+    sp, osp = solver("CG", steps=5, n_threads=1)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    for _ in range(100):
+        t.step(sc)
+        o.step(osc)
+    uvec = t.transform_user(X, sp)
+    ivec = t.transform_item(X, sp)
+    Xd = X.toarray()
+    Xd[Xd.nonzero()] = 1.0
+    np.testing.assert_allclose(uvec @ ivec.T, Xd, rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(uvec, o.transform_user(X, osp), rtol=1e-3, atol=1e-4)
+    with pytest.raises(ValueError, match="Shape mismatch"):
+        t.transform_item(X.T.tocsr(), sp)
+
+
+def test_overfit_cholesky(X_small):
+    # tests/recommenders/test_ials.py:54-76
+    X = X_small.astype(np.float32)
+    mc, _ = build(4, alpha0=100, reg=0.1, nu=0.0, loss="ORIGINAL")
+    sc, _ = solver("CHOLESKY", n_threads=1)
+    t = IALSTrainer(mc, X)
+    for _ in range(100):
+        t.step(sc)
+    sp, _ = solver("CHOLESKY", steps=5, n_threads=1)
+    uvec, ivec = t.transform_user(X, sp), t.transform_item(X, sp)
+    Xd = X.toarray()
+    Xd[Xd.nonzero()] = 1.0
+    np.testing.assert_allclose(uvec @ ivec.T, Xd, rtol=1e-2, atol=1e-2)
+
+
+def test_cholesky_failure_raises(X_small):
+    # alpha0 = 0 and an empty row => A = 0 => "Cholesky decomposition failed." (hpp:317-319)
+    X = X_small.astype(np.float32)
+    mc, _ = build(4, alpha0=0.0, reg=1e-3)
+    t = IALSTrainer(mc, X)
+    sc, _ = solver("CHOLESKY")
+    with pytest.raises(RuntimeError, match="Cholesky"):
+        t.step(sc)
+    # CG zeroes the empty row instead (hpp:207-210)
+    t2 = IALSTrainer(mc, X)
+    sc2, _ = solver("CG")
+    t2.step(sc2)
+    assert np.all(t2.user[3] == 0)
+
+
+def test_n_threads_zero_is_value_error(X_small):
+    mc, _ = build(4)
+    t = IALSTrainer(mc, X_small.astype(np.float32))
+    with pytest.raises(ValueError):
+        t.step(IALSSolverConfigBuilder().set_n_threads(0).build())
+
+
+def test_pickle_round_trip(X_small):
+    # tests/recommenders/test_ials.py:317-333; the restored trainer has no X (hpp:746-756)
+    X = X_small.astype(np.float32)
+    mc, _ = build(4, alpha0=1.0, reg=0.1)
+    sc, _ = solver("CG")
+    t = IALSTrainer(mc, X)
+    t.step(sc)
+    t2 = pickle.loads(pickle.dumps(t))
+    np.testing.assert_array_equal(t.user, t2.user)
+    np.testing.assert_array_equal(t.item, t2.item)
+    np.testing.assert_allclose(t.user_scores(0, 4, sc), t2.user_scores(0, 4, sc))
+    np.testing.assert_allclose(t.transform_user(X, sc), t2.transform_user(X, sc), rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        t2.step(sc)
+    cfg2 = pickle.loads(pickle.dumps(mc))
+    assert cfg2.__getstate__() == mc.__getstate__()
+    assert pickle.loads(pickle.dumps(sc)).__getstate__() == sc.__getstate__()
+
+
+def test_ml100k_shape_parity_c1():
+    # BASELINE configs[0]: ML-100K shape, K = 16
+    from irspack_amd.synthetic import make_interactions
+
+    X = make_interactions("ml100k")
+    for kind in ["CHOLESKY", "CG"]:
+        mc, omc = build(16, alpha0=0.1, reg=1e-3)
+        sc, osc = solver(kind, n_threads=4)
+        t = IALSTrainer(mc, X)
+        o = O.IALSTrainer(omc, X)
+        for _ in range(3):
+            t.step(sc)
+            o.step(osc)
+        assert rel_err(t.user, o.user) < RTOL
+        assert rel_err(t.item, o.item) < RTOL
+        b, e = 100, 228
+        assert rel_err(t.user_scores(b, e, sc), o.user_scores(b, e, osc)) < RTOL
