@@ -152,8 +152,16 @@ struct Side {
     n_split = static_cast<int32_t>(sp.size());
     n_slots = slots;
     indptr.upload(ip32, s);
-    indices.upload(m.indices, s);
-    data.upload(m.data, s);
+    {
+      // the gather pipeline over-reads up to 2 * 8 sub-steps (64 entries) past a row
+      std::vector<int32_t> idx_pad(m.indices);
+      std::vector<float> data_pad(m.data);
+      idx_pad.resize(m.indices.size() + 128, 0);
+      data_pad.resize(m.data.size() + 128, 0.0f);
+      indices.upload(idx_pad, s);
+      data.upload(data_pad, s);
+      IRS_HIP(hipStreamSynchronize(s));
+    }
     reg.upload(regs, s);
     tasks.upload(tk, s);
     split.upload(sp, s);
@@ -303,14 +311,14 @@ void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t 
   per = ceil_div(per, 4) * 4;
   IRS_DISPATCH_T(t->T, {
     using G = Geo<TT>;
-    t->gram_partial.alloc(static_cast<size_t>(n_waves) * G::NT * 256);
+    t->gram_partial.alloc(static_cast<size_t>(n_waves / 4) * G::NT * 256);
     t->prof.begin("gramian_partial", t->stream);
     hipLaunchKernelGGL((gramian_partial_kernel<TT>), dim3(n_waves / 4), dim3(256), 0, t->stream,
                        t->factor[which].ptr, rb, re, per, t->gram_partial.ptr);
     t->prof.end(t->stream);
     t->prof.begin("gramian_reduce", t->stream);
-    hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 256)), dim3(256),
-                       0, t->stream, t->gram_partial.ptr, n_waves, t->P_raw[dst].ptr);
+    hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 64)), dim3(256),
+                       0, t->stream, t->gram_partial.ptr, n_waves / 4, t->P_raw[dst].ptr);
     t->prof.end(t->stream);
   });
   IRS_HIP(hipGetLastError());
@@ -342,6 +350,11 @@ void check_solver(const irs_ials_solver_config *sc) {
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
 void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
                   const irs_ials_solver_config *sc) {
+  static const char *kNames[2][2][2] = {
+      {{"ials_solve_cholesky_user", "ials_solve_cholesky_item"},
+       {"ials_split_cholesky_user", "ials_split_cholesky_item"}},
+      {{"ials_solve_cg_user", "ials_solve_cg_item"},
+       {"ials_split_cg_user", "ials_split_cg_item"}}};
   SolveParams p;
   p.tasks = sd.tasks.ptr;
   p.n_tasks = sd.n_tasks;
@@ -366,7 +379,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
     p.partials = t->split_partial.ptr;
     if (sd.n_tasks > 0) {
-      t->prof.begin(cg ? "ials_solve_cg" : "ials_solve_cholesky", t->stream);
+      t->prof.begin(kNames[cg][0][pidx], t->stream);
       if (cg)
         hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(sd.n_tasks, 4)),
                            dim3(256), 0, t->stream, p);
@@ -376,7 +389,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       t->prof.end(t->stream);
     }
     if (sd.n_split > 0) {
-      t->prof.begin(cg ? "ials_split_cg" : "ials_split_cholesky", t->stream);
+      t->prof.begin(kNames[cg][1][pidx], t->stream);
       if (cg)
         hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 1>), dim3(ceil_div(sd.n_split, 4)),
                            dim3(256), 0, t->stream, p);

@@ -106,56 +106,79 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
                                             int end, float bias,
                                             f32x4 (&acc)[Geo<T>::NT], float (&bsum)[T]) {
   constexpr int KP = Geo<T>::KP;
+  constexpr int D = 8;  // sub-steps per pipeline stage (a sub-step = 4 gathered rows)
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
   const float *col_base = other + T * m;
+  const int n = end - begin;
+  const int nsub = (n + 3) >> 2;
 
-  int pos = begin + lane;
-  int nx_idx = pos < end ? indices[pos] : 0;
-  float nx_c = pos < end ? data[pos] : 0.f;
-  for (int base = begin; base < end; base += 64) {
-    const int my_idx = nx_idx;
-    const float my_c = nx_c;
-    pos = base + 64 + lane;
-    nx_idx = pos < end ? indices[pos] : 0;  // prefetch the next 64 entries
-    nx_c = pos < end ? data[pos] : 0.f;
-    const int n_here = min(64, end - base);
-    const int nsub = (n_here + 3) >> 2;  // sub-steps of 4 gathered rows
-
-    float v0[T], v1[T];
-    float c0, c1, w0, w1;
-    auto fetch = [&](int s, float (&v)[T], float &c, float &w) {
-      const int src = 4 * s + g;
-      const int idx = __shfl(my_idx, src, 64);
-      c = __shfl(my_c, src, 64);  // 0 beyond the row's end
-      w = (src < n_here) ? bias + c : 0.f;
-      load_dims<T>(col_base + static_cast<size_t>(idx) * KP, v);
-    };
-    auto consume = [&](const float (&v)[T], float c, float w) {
-      float cv[T];
+  // Three-stage software pipeline over sub-steps, every load unconditional so
+  // that the loop body is one basic block and hipcc emits counted vmcnt waits:
+  //   stage A: (index, value) of sub-step s + 2D   (4 addresses per wave)
+  //   stage B: gather the factor rows of sub-step s + D (1 KiB per wave for T=4)
+  //   stage C: MFMAs of sub-step s
+  // Entries past the row's end are over-read (the CSR arrays carry 64 entries
+  // of padding) and neutralised by c = w = 0.
+  const int32_t *ip = indices + begin + g;
+  const float *dp = data + begin + g;
+  int ia[D];
+  float ca[D];
+  float v[D][T], vc[D], vw[D];
+  auto stage_a = [&](int k, int s) {
+    ia[k] = ip[4 * s];
+    ca[k] = dp[4 * s];
+  };
+  auto stage_b = [&](int k, int s) {
+    const bool valid = 4 * s + g < n;
+    vc[k] = valid ? ca[k] : 0.f;
+    vw[k] = valid ? bias + ca[k] : 0.f;
+    load_dims<T>(col_base + static_cast<size_t>(ia[k]) * KP, v[k]);
+  };
+  auto stage_c = [&](int k) {
+    float cv[T];
 #pragma unroll
-      for (int i = 0; i < T; i++) {
-        cv[i] = c * v[i];
-        bsum[i] = fmaf(w, v[i], bsum[i]);
+    for (int i = 0; i < T; i++) {
+      cv[i] = vc[k] * v[k][i];
+      bsum[i] = fmaf(vw[k], v[k][i], bsum[i]);
+    }
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < T; i++)
+#pragma unroll
+      for (int j = i; j < T; j++) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], v[k][j], acc[t], 0, 0, 0);
+        t++;
       }
-      int t = 0;
+  };
 #pragma unroll
-      for (int i = 0; i < T; i++)
+  for (int k = 0; k < D; k++) stage_a(k, k);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = i; j < T; j++) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], v[j], acc[t], 0, 0, 0);
-          t++;
-        }
-    };
-    fetch(0, v0, c0, w0);
-    for (int s = 0; s < nsub; s += 2) {
-      const bool has1 = s + 1 < nsub;
-      if (has1) fetch(s + 1, v1, c1, w1);
-      consume(v0, c0, w0);
-      if (s + 2 < nsub) fetch(s + 2, v0, c0, w0);
-      if (has1) consume(v1, c1, w1);
+  for (int k = 0; k < D; k++) {
+    // same issue order as the loop body, so that the counted waits the
+    // compiler derives for the loop hold on entry as well
+    stage_b(k, k);
+    stage_a(k, D + k);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int s0 = 0;
+  for (; s0 + D <= nsub; s0 += D) {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      // pin the stage order: without the barriers hipcc hoists the address
+      // arithmetic on a just-loaded index next to its load and waits vmcnt(0)
+      stage_c(k);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_b(k, s0 + D + k);
+      stage_a(k, s0 + 2 * D + k);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  const int rest = nsub - s0;  // 0 .. D-1 sub-steps, already gathered
+#pragma unroll
+  for (int k = 0; k < D - 1; k++)
+    if (k < rest) stage_c(k);
   // fold the four gathered-row groups: every lane ends with b[T*m + i]
 #pragma unroll
   for (int i = 0; i < T; i++) {
@@ -374,7 +397,8 @@ __global__ __launch_bounds__(256) void ials_solve_kernel(SolveParams p) {
 // ---------------------------------------------------------------------------
 // Dense Gramian  sum_r f_r f_r^T  over rows [row_begin, row_end) on the matrix
 // cores (Solver::prepare_p, hpp:78-115).  Each wave owns a slab of rows and all
-// upper tiles; partials are reduced in a fixed order by gramian_reduce_kernel.
+// upper tiles; a block folds its four waves and gramian_reduce_kernel sums the
+// per-block partials in a fixed order (bit-reproducible run to run).
 template <int T>
 __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__restrict__ F,
                                                               int64_t row_begin,
@@ -407,21 +431,39 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
         t++;
       }
   }
-  f32x4 *dst = reinterpret_cast<f32x4 *>(partial) + w * (G::NT * 64);
+  // fold the block's four waves through LDS (fixed order), one partial per block
+  __shared__ f32x4 fold[4 * G::NT * 64];
+  const int wid = threadIdx.x >> 6;
 #pragma unroll
-  for (int t = 0; t < G::NT; t++) dst[t * 64 + lane] = acc[t];
+  for (int t = 0; t < G::NT; t++) fold[(wid * G::NT + t) * 64 + lane] = acc[t];
+  __syncthreads();
+  f32x4 *dst = reinterpret_cast<f32x4 *>(partial) + static_cast<int64_t>(blockIdx.x) * (G::NT * 64);
+  for (int e = threadIdx.x; e < G::NT * 64; e += 256) {
+    f32x4 s = fold[e];
+    s += fold[G::NT * 64 + e];
+    s += fold[2 * G::NT * 64 + e];
+    s += fold[3 * G::NT * 64 + e];
+    dst[e] = s;
+  }
 }
 
-// Sum the per-wave partials in wave order and write the row-major symmetric
-// KP x KP matrix (unscaled).  One thread per accumulator element.
+// Sum the per-block partials (four interleaved chains per element, combined in
+// a fixed order) and write the row-major symmetric KP x KP matrix (unscaled).
 template <int T>
-__global__ void gramian_reduce_kernel(const float *__restrict__ partial, int64_t n_waves,
-                                      float *__restrict__ P_raw) {
+__global__ __launch_bounds__(256) void gramian_reduce_kernel(const float *__restrict__ partial,
+                                                             int64_t n_parts,
+                                                             float *__restrict__ P_raw) {
   using G = Geo<T>;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // element of [NT][64][4]
-  if (e >= G::NT * 256) return;
+  __shared__ float part[4][64];
+  const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int e = blockIdx.x * 64 + l;  // element of [NT][64][4]
   float s = 0.f;
-  for (int64_t w = 0; w < n_waves; w++) s += partial[w * (G::NT * 256) + e];
+  if (e < G::NT * 256)
+    for (int64_t w = q; w < n_parts; w += 4) s += partial[w * (G::NT * 256) + e];
+  part[q][l] = s;
+  __syncthreads();
+  if (q != 0 || e >= G::NT * 256) return;
+  s = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
   const int t = e >> 8, lane = (e >> 2) & 63, r = e & 3;
   int ti = 0, tj = 0, c = t;
   for (int i = 0; i < T; i++) {
