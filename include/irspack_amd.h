@@ -128,6 +128,14 @@ irs_status irs_ials_set_stream(irs_ials_trainer *t, void *hip_stream);
  * sum over this rank's shard until irs_ials_finish_gramian is called). */
 irs_status irs_ials_device_buffer(irs_ials_trainer *t, int32_t which,
                                   void **device_ptr, int64_t *rows, int64_t *ld);
+/* Device-to-device copy of rows [row_begin,row_end) of buffer `which` (same
+ * numbering as irs_ials_device_buffer) to (to_ext != 0) or from an external
+ * device pointer holding (row_end-row_begin) x ld floats, on the trainer's
+ * stream.  This is how the host loop stages the Gramian all-reduce and the
+ * factor all-gather through torch.distributed tensors. */
+irs_status irs_ials_copy_rows_async(irs_ials_trainer *t, int32_t which,
+                                    int64_t row_begin, int64_t row_end,
+                                    void *ext_device_ptr, int32_t to_ext);
 /* Solver::prepare_p (hpp:78-115) split in two so that an all-reduce can sit in
  * between: partial = sum over this shard's rows of the *other* side's factors
  * (side 0: Gramian for the user solve = item rows of this shard). */

@@ -77,6 +77,7 @@ EXPORTED_SYMBOLS = [
     "irs_ials_compute_loss",
     "irs_ials_set_stream",
     "irs_ials_device_buffer",
+    "irs_ials_copy_rows_async",
     "irs_ials_partial_gramian_async",
     "irs_ials_finish_gramian_async",
     "irs_ials_half_step_async",

@@ -534,6 +534,24 @@ irs_status irs_ials_device_buffer(irs_ials_trainer *t, int32_t which, void **dev
   });
 }
 
+irs_status irs_ials_copy_rows_async(irs_ials_trainer *t, int32_t which, int64_t row_begin,
+                                    int64_t row_end, void *ext, int32_t to_ext) {
+  return guard([&] {
+    check_arg(t && ext, "null argument.");
+    check_arg(which >= 0 && which <= 3, "which must be in 0..3.");
+    const int64_t rows = which < 2 ? t->rows_of(which) : t->KP;
+    check_arg(0 <= row_begin && row_begin <= row_end && row_end <= rows, "row range out of bounds.");
+    IRS_HIP(hipSetDevice(t->device));
+    float *base = which < 2 ? t->factor[which].ptr : t->P_raw[which - 2].ptr;
+    float *mine = base + row_begin * t->KP;
+    const size_t bytes = static_cast<size_t>(row_end - row_begin) * t->KP * sizeof(float);
+    if (bytes == 0) return;
+    IRS_HIP(hipMemcpyAsync(to_ext ? ext : static_cast<void *>(mine),
+                           to_ext ? static_cast<const void *>(mine) : ext, bytes,
+                           hipMemcpyDeviceToDevice, t->stream));
+  });
+}
+
 irs_status irs_ials_partial_gramian_async(irs_ials_trainer *t, int32_t side) {
   return guard([&] {
     check_arg(t && (side == 0 || side == 1), "bad argument.");

@@ -486,6 +486,14 @@ class IALSTrainer:
         check(lib().irs_ials_device_buffer(self._h, C.c_int32(which), C.byref(p), C.byref(rows), C.byref(ld)))
         return int(p.value or 0), int(rows.value), int(ld.value)
 
+    def copy_rows_async(self, which: int, row_begin: int, row_end: int, ext_ptr: int, to_ext: bool) -> None:
+        check(
+            lib().irs_ials_copy_rows_async(
+                self._h, C.c_int32(which), C.c_int64(row_begin), C.c_int64(row_end),
+                C.c_void_p(ext_ptr), C.c_int32(1 if to_ext else 0),
+            )
+        )
+
     def partial_gramian_async(self, side: int) -> None:
         check(lib().irs_ials_partial_gramian_async(self._h, C.c_int32(side)))
 

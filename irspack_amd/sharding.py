@@ -1,0 +1,188 @@
+"""Multi-GPU host loop of the iALS step: one process per GPU, rows sharded.
+
+The reference has no distributed layer; this is the natural
+sharding of ``IALSTrainer::step`` (IALSTrainer.hpp:758-789): the per-row solves
+are independent, so users (items on the alternate half-epoch) are split into
+contiguous, cost-balanced ranges; every rank keeps full replicas of both
+factor matrices and, per half-epoch, takes part in
+
+  1. an all-reduce of the K x K partial Gramian of its own rows
+     (``Solver::prepare_p``, hpp:78-115, summed over ranks), and
+  2. an all-gather of the freshly solved factor rows (each rank broadcasts its
+     contiguous shard; with RCCL over xGMI every shard leaves on its own links).
+
+Collectives go through ``torch.distributed`` (backend "nccl" = RCCL on ROCm,
+"gloo" in the CPU tests); the arithmetic is behind a small ``LocalSolver``
+interface whose product implementation (``HipLocalSolver``) drives the HIP
+library.  Results equal the single-GPU ones up to the summation order of the
+Gramian.
+"""
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sps
+
+
+def balanced_bounds(cost: np.ndarray, parts: int) -> List[int]:
+    """Contiguous partition of ``len(cost)`` rows into ``parts`` ranges of ~equal cost."""
+    n = int(cost.shape[0])
+    csum = np.concatenate([[0.0], np.cumsum(cost.astype(np.float64))])
+    total = csum[-1]
+    bounds = [0]
+    for p in range(1, parts):
+        target = total * p / parts
+        b = int(np.searchsorted(csum, target, side="left"))
+        b = min(max(b, bounds[-1]), n)
+        bounds.append(b)
+    bounds.append(n)
+    return bounds
+
+
+def row_cost(nnz: np.ndarray, K: int, solver: str) -> np.ndarray:
+    """Per-row work model: gather + rank update, plus the dense solve."""
+    nnz = nnz.astype(np.float64)
+    if solver == "CHOLESKY":
+        return nnz * (K * K + 2.0 * K) + (K ** 3) / 6.0 + 2.0 * K * K
+    return nnz * (K * K + 2.0 * K) + 8.0 * K * K
+
+
+def shard_bounds(X: sps.csr_matrix, K: int, solver: str, world: int) -> Tuple[List[int], List[int]]:
+    X = sps.csr_matrix(X)
+    user_nnz = np.diff(X.indptr)
+    item_nnz = np.bincount(X.indices, minlength=X.shape[1])
+    return (balanced_bounds(row_cost(user_nnz, K, solver), world),
+            balanced_bounds(row_cost(item_nnz, K, solver), world))
+
+
+class LocalSolver:
+    """What the host loop needs from one rank's device (or, in tests, from the oracle)."""
+
+    ld: int  # leading dimension of the factor / Gramian buffers
+
+    def new_buffer(self, rows: int):  # -> torch.Tensor [rows, ld] float32 on the solver's device
+        raise NotImplementedError
+
+    def partial_gramian(self, side: int, out) -> None:
+        """out[ld, ld] = sum over this rank's rows of the *other* side of f f^T (unscaled)."""
+        raise NotImplementedError
+
+    def set_gramian(self, side: int, total) -> None:
+        raise NotImplementedError
+
+    def half_step(self, side: int, solver_config) -> None:
+        raise NotImplementedError
+
+    def export_rows(self, which: int, begin: int, end: int, out) -> None:
+        raise NotImplementedError
+
+    def import_rows(self, which: int, begin: int, end: int, src) -> None:
+        raise NotImplementedError
+
+    def synchronize(self) -> None:
+        raise NotImplementedError
+
+
+class HipLocalSolver(LocalSolver):
+    """Product implementation: the HIP trainer of this rank's GPU, on torch's current stream."""
+
+    def __init__(self, model_config, X, shard: Tuple[int, int, int, int], device: int):
+        import torch
+
+        from .recommenders._ials_core import IALSTrainer
+
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.trainer = IALSTrainer(model_config, X, device=device, shard=shard)
+        self.trainer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        _, _, self.ld = self.trainer.device_buffer(0)
+
+    def new_buffer(self, rows: int):
+        return self.torch.empty((rows, self.ld), dtype=self.torch.float32, device=self.device)
+
+    def partial_gramian(self, side: int, out) -> None:
+        self.trainer.partial_gramian_async(side)
+        self.trainer.copy_rows_async(2 + side, 0, self.ld, out.data_ptr(), True)
+
+    def set_gramian(self, side: int, total) -> None:
+        self.trainer.copy_rows_async(2 + side, 0, self.ld, total.data_ptr(), False)
+        self.trainer.finish_gramian_async(side)
+
+    def half_step(self, side: int, solver_config) -> None:
+        self.trainer.half_step_async(side, solver_config)
+
+    def export_rows(self, which: int, begin: int, end: int, out) -> None:
+        self.trainer.copy_rows_async(which, begin, end, out.data_ptr(), True)
+
+    def import_rows(self, which: int, begin: int, end: int, src) -> None:
+        self.trainer.copy_rows_async(which, begin, end, src.data_ptr(), False)
+
+    def synchronize(self) -> None:
+        self.trainer.synchronize()
+
+
+class ShardedIALSTrainer:
+    """``IALSTrainer.step`` over ``world_size`` ranks (see the module docstring)."""
+
+    def __init__(self, local: LocalSolver, user_bounds: Sequence[int], item_bounds: Sequence[int],
+                 group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.local = local
+        if dist.is_available() and dist.is_initialized():
+            self.rank = dist.get_rank(group)
+            self.world = dist.get_world_size(group)
+        else:  # single process: no collectives are issued
+            self.rank, self.world = 0, 1
+        assert len(user_bounds) == self.world + 1 and len(item_bounds) == self.world + 1
+        self.bounds = (list(user_bounds), list(item_bounds))
+        self._gram = local.new_buffer(local.ld)
+        self._shards = [
+            [local.new_buffer(max(b[r + 1] - b[r], 1)) for r in range(self.world)]
+            for b in self.bounds
+        ]
+
+    def half_epoch(self, side: int, solver_config) -> None:
+        dist, local = self.dist, self.local
+        # (1) Gramian of the other side: own rows, then sum over ranks
+        local.partial_gramian(side, self._gram)
+        if self.world > 1:
+            dist.all_reduce(self._gram, op=dist.ReduceOp.SUM, group=self.group)
+        local.set_gramian(side, self._gram)
+        # (2) solve this rank's rows of `side`
+        local.half_step(side, solver_config)
+        # (3) every rank broadcasts its freshly solved shard to all replicas
+        if self.world > 1:
+            b = self.bounds[side]
+            works = []
+            for r in range(self.world):
+                n = b[r + 1] - b[r]
+                if n == 0:
+                    continue
+                buf = self._shards[side][r][:n]
+                if r == self.rank:
+                    local.export_rows(side, b[r], b[r + 1], buf)
+                works.append(dist.broadcast(buf, src=self._global_rank(r), group=self.group,
+                                            async_op=True))
+            for w in works:
+                w.wait()
+            for r in range(self.world):
+                n = b[r + 1] - b[r]
+                if n and r != self.rank:
+                    local.import_rows(side, b[r], b[r + 1], self._shards[side][r][:n])
+
+    def _global_rank(self, group_rank: int) -> int:
+        if self.group is None:
+            return group_rank
+        return self.dist.get_global_rank(self.group, group_rank)
+
+    def step(self, solver_config) -> None:
+        """One epoch: user half then item half (hpp:784-788)."""
+        self.half_epoch(0, solver_config)
+        self.half_epoch(1, solver_config)
+
+    def synchronize(self) -> None:
+        self.local.synchronize()
