@@ -434,6 +434,9 @@ void full_gramian(irs_ials_trainer *t, int side) {
 
 extern "C" {
 
+irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
+                                   float *device_out, void **stream_out, int32_t *device_index);
+
 const char *irs_last_error(void) { return irs::last_error().c_str(); }
 int32_t irs_abi_version(void) { return 1; }
 int32_t irs_device_count(void) {
@@ -641,29 +644,47 @@ irs_status irs_ials_user_scores(irs_ials_trainer *t, int64_t begin, int64_t end,
     IRS_HIP(hipSetDevice(t->device));
     DeviceBuffer<float> d;
     d.alloc(static_cast<size_t>(m) * t->n_items);
+    if (irs_ials_scores_device_(t, begin, end, d.ptr, nullptr, nullptr) != IRS_OK)
+      throw std::runtime_error(irs::last_error());
+    IRS_HIP(hipMemcpyAsync(out, d.ptr, static_cast<size_t>(m) * t->n_items * sizeof(float),
+                           hipMemcpyDeviceToHost, t->stream));
+    IRS_HIP(hipStreamSynchronize(t->stream));
+  });
+}
+
+// Internal hook for evaluator.hip's fused path: user[begin:end] @ item^T into a
+// device buffer on the trainer's stream (hpp:942-984).  Not part of the public ABI.
+irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
+                                   float *device_out, void **stream_out, int32_t *device_index) {
+  return guard([&] {
+    check_arg(t != nullptr, "null trainer.");
+    check_arg(0 <= begin && begin <= end && end <= t->n_users, "user block out of range.");
+    IRS_HIP(hipSetDevice(t->device));
+    if (stream_out) *stream_out = t->stream;
+    if (device_index) *device_index = t->device;
+    const int64_t m = end - begin;
+    if (m == 0 || t->n_items == 0) return;
+    check_arg(device_out != nullptr, "null output.");
     const int64_t waves = ceil_div(m, 16) * ceil_div(t->n_items, 64);
     t->prof.begin("user_scores", t->stream);
     switch (t->KP) {
       case 16:
         hipLaunchKernelGGL((user_scores_kernel<16>), dim3(ceil_div(waves, 4)), dim3(256), 0,
                            t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
-                           t->n_items, d.ptr);
+                           t->n_items, device_out);
         break;
       case 32:
         hipLaunchKernelGGL((user_scores_kernel<32>), dim3(ceil_div(waves, 4)), dim3(256), 0,
                            t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
-                           t->n_items, d.ptr);
+                           t->n_items, device_out);
         break;
       default:
         hipLaunchKernelGGL((user_scores_kernel<64>), dim3(ceil_div(waves, 4)), dim3(256), 0,
                            t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
-                           t->n_items, d.ptr);
+                           t->n_items, device_out);
     }
     t->prof.end(t->stream);
     IRS_HIP(hipGetLastError());
-    IRS_HIP(hipMemcpyAsync(out, d.ptr, static_cast<size_t>(m) * t->n_items * sizeof(float),
-                           hipMemcpyDeviceToHost, t->stream));
-    IRS_HIP(hipStreamSynchronize(t->stream));
   });
 }
 

@@ -1,0 +1,142 @@
+"""Counterpart of the reference's nanobind module ``irspack.recommenders._knn``
+(/root/reference/cpp_source/knn/wrapper.cpp:11-66), backed by ``libirspack_amd.so``
+(irspack_amd/csrc/knn.hip).  Inputs are scipy sparse float64 (CSC is accepted and
+converted, like nanobind's Eigen caster does); results are CSR float64 with sorted
+indices (``compute_similarity``) or CSC (``compute_W``).
+"""
+
+import ctypes as C
+from typing import Any, Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sps
+
+from .. import _lib
+from .._lib import check, lib, ptr
+
+_COSINE, _ASYMMETRIC, _JACCARD, _TVERSKY, _P3ALPHA, _RP3BETA = range(6)
+
+
+class _Computer:
+    _sim_type = _COSINE
+
+    def _create(self, X: Any, shrinkage: float, alpha: float, beta: float, normalize: bool,
+                n_threads: int, max_chunk_size: int, device: Optional[int]) -> None:
+        if n_threads < 0 or max_chunk_size < 0:
+            raise TypeError("n_threads / max_chunk_size must be non-negative (size_t).")
+        Xc, indptr, indices, data = _lib.csr_arrays(X, np.float64)
+        self._N, self._n_features = int(Xc.shape[0]), int(Xc.shape[1])
+        self._device = _lib.default_device() if device is None else int(device)
+        h = C.c_void_p()
+        check(
+            lib().irs_knn_create(
+                C.c_int32(self._sim_type), C.c_int64(Xc.shape[0]), C.c_int64(Xc.shape[1]),
+                ptr(indptr, C.c_int64), ptr(indices, C.c_int32), ptr(data, C.c_double),
+                C.c_double(shrinkage), C.c_double(alpha), C.c_double(beta),
+                C.c_int32(1 if normalize else 0), C.c_int64(n_threads),
+                C.c_int64(max_chunk_size), C.c_int32(self._device), C.byref(h),
+            )
+        )
+        self._h: Optional[C.c_void_p] = h
+        self.last_kernel_ms = 0.0
+        self.last_macs = 0
+
+    def __del__(self) -> None:
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().irs_knn_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _compute(self, X: Any, top_k: int, as_w: bool,
+                 rows: Optional[Tuple[int, int]] = None) -> sps.csr_matrix:
+        if top_k < 0:
+            raise TypeError("top_k must be non-negative (size_t).")
+        Xc, indptr, indices, data = _lib.csr_arrays(X, np.float64)
+        rb, re = (0, Xc.shape[0]) if rows is None else rows
+        nnz = C.c_int64(0)
+        check(
+            lib().irs_knn_compute(
+                self._h, C.c_int64(Xc.shape[0]), C.c_int64(Xc.shape[1]), ptr(indptr, C.c_int64),
+                ptr(indices, C.c_int32), ptr(data, C.c_double), C.c_int64(top_k),
+                C.c_int32(1 if as_w else 0), C.c_int64(rb), C.c_int64(re), C.byref(nnz),
+            )
+        )
+        o_ptr = np.empty(re - rb + 1, dtype=np.int64)
+        o_idx = np.empty(max(nnz.value, 1), dtype=np.int32)
+        o_val = np.empty(max(nnz.value, 1), dtype=np.float64)
+        check(lib().irs_knn_fetch(self._h, ptr(o_ptr, C.c_int64), ptr(o_idx, C.c_int32),
+                                  ptr(o_val, C.c_double)))
+        ms = C.c_double(0)
+        macs = C.c_int64(0)
+        check(lib().irs_knn_last_stats(self._h, C.byref(ms), C.byref(macs)))
+        self.last_kernel_ms, self.last_macs = float(ms.value), int(macs.value)
+        res = sps.csr_matrix((o_val[: nnz.value], o_idx[: nnz.value], o_ptr),
+                             shape=(re - rb, self._N))
+        res.has_sorted_indices = True
+        return res
+
+
+class _SimilarityComputer(_Computer):
+    def compute_similarity(self, X: Any, top_k: int, *, rows: Optional[Tuple[int, int]] = None
+                           ) -> sps.csr_matrix:
+        """knn.hpp:43-83.  ``rows`` (keyword-only, not in the reference) restricts the
+        call to a shard of target rows — rows are independent, so a multi-GPU run
+        concatenates the shards."""
+        return self._compute(X, top_k, False, rows)
+
+
+class CosineSimilarityComputer(_SimilarityComputer):  # wrapper.cpp:12-19, similarities.hpp:6-47
+    _sim_type = _COSINE
+
+    def __init__(self, X: Any, shrinkage: float, normalize: bool, n_threads: int = 1,
+                 max_chunk_size: int = 128, *, device: Optional[int] = None) -> None:
+        self._create(X, shrinkage, 0.0, 0.0, bool(normalize), n_threads, max_chunk_size, device)
+
+
+class JaccardSimilarityComputer(_SimilarityComputer):  # wrapper.cpp:21-29
+    _sim_type = _JACCARD
+
+    def __init__(self, X: Any, shrinkage: float, n_threads: int = 1, max_chunk_size: int = 128,
+                 *, device: Optional[int] = None) -> None:
+        self._create(X, shrinkage, 0.0, 0.0, False, n_threads, max_chunk_size, device)
+
+
+class TverskyIndexComputer(_SimilarityComputer):  # wrapper.cpp:31-40
+    _sim_type = _TVERSKY
+
+    def __init__(self, X: Any, shrinkage: float, alpha: float, beta: float, n_threads: int = 1,
+                 max_chunk_size: int = 128, *, device: Optional[int] = None) -> None:
+        self._create(X, shrinkage, alpha, beta, False, n_threads, max_chunk_size, device)
+
+
+class AsymmetricSimilarityComputer(_SimilarityComputer):  # wrapper.cpp:42-51
+    _sim_type = _ASYMMETRIC
+
+    def __init__(self, X: Any, shrinkage: float, alpha: float, n_threads: int = 1,
+                 max_chunk_size: int = 128, *, device: Optional[int] = None) -> None:
+        self._create(X, shrinkage, alpha, 0.0, False, n_threads, max_chunk_size, device)
+
+
+class P3alphaComputer(_Computer):  # wrapper.cpp:53-58, similarities.hpp:186-251
+    _sim_type = _P3ALPHA
+
+    def __init__(self, X: Any, alpha: float = 0, n_threads: int = 1, max_chunk_size: int = 128,
+                 *, device: Optional[int] = None) -> None:
+        self._create(X, 0.0, alpha, 0.0, False, n_threads, max_chunk_size, device)
+
+    def compute_W(self, X: Any, top_k: int) -> sps.csc_matrix:
+        return self._compute(X, top_k, True).T.tocsc()
+
+
+class RP3betaComputer(_Computer):  # wrapper.cpp:60-65, similarities.hpp:253-336
+    _sim_type = _RP3BETA
+
+    def __init__(self, X: Any, alpha: float = 0, beta: float = 0, n_threads: int = 1,
+                 max_chunk_size: int = 128, *, device: Optional[int] = None) -> None:
+        self._create(X, 0.0, alpha, beta, False, n_threads, max_chunk_size, device)
+
+    def compute_W(self, X: Any, top_k: int) -> sps.csc_matrix:
+        return self._compute(X, top_k, True).T.tocsc()

@@ -1,0 +1,189 @@
+"""GPU parity tests of the evaluator path vs the CPU oracle and the sklearn / hand-loop
+checks of the reference (tests/evaluation/test_evaluator.py:19-152, 358-398;
+tests/evaluation/test_restricted_evaluator.py:25-108).  Bar: counters and item
+histogram bit-exact; fp64 metric sums within 1e-12 relative (sum order).
+"""
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import oracle as O
+from irspack_amd.evaluation._core_evaluator import EvaluatorCore, Metrics, evaluate_list_vs_list
+
+pytestmark = pytest.mark.gpu
+
+KEYS = O.METRIC_KEYS
+
+
+def compare(m: Metrics, om: "O.Metrics"):
+    np.testing.assert_array_equal(m.item_cnt, om.item_cnt())  # bit-exact histogram
+    raw = om.raw()
+    assert m.valid_user == int(raw[0]) and m.total_user == int(raw[1])  # bit-exact counters
+    np.testing.assert_allclose([m.hit, m.recall, m.ndcg, m.precision, m.map], raw[2:], rtol=1e-12)
+    d, od = m.as_dict(), om.as_dict()
+    for k in KEYS:
+        assert d[k] == pytest.approx(od[k], rel=1e-12, abs=1e-15), k
+
+
+@pytest.mark.parametrize("U,I,dtype", [(10, 5, "float32"), (10, 30, "float64"), (3000, 5, "float32"),
+                                      (200, 1000, "float32"), (64, 5000, "float64")])
+@pytest.mark.parametrize("cutoff_kind", ["full", "small"])
+def test_random_blocks_match_oracle(U, I, dtype, cutoff_kind):
+    rns = np.random.RandomState(42)
+    scores = rns.randn(U, I).astype(dtype)
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.7).astype(np.float64))
+    cutoff = min(I, 2048) if cutoff_kind == "full" else max(1, min(I // 2, 20))
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    f = "get_metrics_f64" if dtype == "float64" else "get_metrics_f32"
+    for rwc in (False, True):
+        compare(getattr(core, f)(scores, cutoff, 0, 4, rwc), getattr(ocore, f)(scores, cutoff, 0, 4, rwc))
+
+
+def test_vs_sklearn():
+    # tests/evaluation/test_evaluator.py:19-49
+    from sklearn.metrics import average_precision_score, ndcg_score
+
+    for U, I, dtype in [(10, 5, "float32"), (10, 30, "float64"), (300, 5, "float32")]:
+        rns = np.random.RandomState(42)
+        scores = rns.randn(U, I).astype(dtype)
+        X_gt = (rns.rand(U, I) >= 0.7).astype(np.float64)
+        core = EvaluatorCore(sps.csr_matrix(X_gt), [])
+        f = core.get_metrics_f64 if dtype == "float64" else core.get_metrics_f32
+        d = f(scores, I, 0, 4).as_dict()
+        maps, ndcgs = [], []
+        for i in range(U):
+            if X_gt[i].sum() == 0:
+                continue
+            maps.append(average_precision_score(X_gt[i], scores[i]))
+            ndcgs.append(ndcg_score(X_gt[i][None, :], scores[i][None, :]))
+        assert d["map"] == pytest.approx(np.mean(maps), abs=1e-8)
+        assert d["ndcg"] == pytest.approx(np.mean(ndcgs), abs=1e-8)
+
+
+def test_ties_and_neg_inf():
+    # ties -> lower index first (evaluator.cpp:329,353-355); -inf never ranked (:328)
+    I = 300
+    scores = np.zeros((6, I), dtype=np.float32)
+    scores[0, :] = 1.0                       # all tied
+    scores[1, ::2] = 2.0                     # ties in two groups
+    scores[2, :] = -np.inf                   # nothing rankable
+    scores[2, 7] = 3.0
+    scores[3, :] = -np.inf                   # fully masked
+    scores[4, :] = np.linspace(1, 0, I)
+    scores[5, :] = -0.0
+    scores[5, 10:20] = 0.0                   # -0.0 == +0.0
+    gt = sps.csr_matrix((np.random.RandomState(1).rand(6, I) > 0.9).astype(np.float64))
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    for cutoff in (1, 5, 20, 299, 300):
+        compare(core.get_metrics_f32(scores, cutoff, 0, 1), ocore.get_metrics_f32(scores, cutoff, 0, 1))
+    # tests/evaluation/test_evaluator.py:358-368
+    one = EvaluatorCore(sps.csr_matrix(np.asarray([[1.0, 1.0, 0.0]])), [])
+    d = one.get_metrics_f64(np.asarray([[1.0, -np.inf, -np.inf]]), 3, 0, 1).as_dict()
+    assert d["precision"] == 1.0 and d["recall"] == 0.5 and d["hit"] == 1.0
+
+
+def test_offset_and_chunking():
+    # mb_size invariance (tests/evaluation/test_evaluator.py:98-106) and offset semantics
+    rns = np.random.RandomState(3)
+    U, I = 57, 400
+    scores = rns.randn(U, I)
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.6).astype(np.float64))
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    whole = core.get_metrics_f64(scores, 10, 0, 2)
+    acc, oacc = Metrics(I), O.Metrics(I)
+    for b in range(0, U, 13):
+        e = min(b + 13, U)
+        acc.merge(core.get_metrics_f64(scores[b:e], 10, b, 2))
+        oacc.merge(ocore.get_metrics_f64(scores[b:e], 10, b, 2))
+    compare(acc, oacc)
+    np.testing.assert_array_equal(acc.item_cnt, whole.item_cnt)
+    assert acc.as_dict()["ndcg"] == pytest.approx(whole.as_dict()["ndcg"], rel=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["global", "per_user"])
+def test_restricted_items(mode):
+    # tests/evaluation/test_restricted_evaluator.py:25-108
+    rns = np.random.RandomState(5)
+    U, I = 40, 120
+    scores = rns.randn(U, I).astype(np.float32)
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.8).astype(np.float64))
+    if mode == "global":
+        rec = [sorted(rns.choice(I, size=50, replace=False).tolist())[::-1]]  # unsorted input
+    else:
+        rec = [rns.choice(I, size=rns.randint(0, 40), replace=False).tolist() for _ in range(U)]
+    core, ocore = EvaluatorCore(gt, rec), O.EvaluatorCore(gt, rec)
+    for cutoff in (3, 20):
+        compare(core.get_metrics_f32(scores, cutoff, 0, 3), ocore.get_metrics_f32(scores, cutoff, 0, 3))
+
+
+def test_argument_validation():
+    # evaluator.cpp:187-205, 263-268; tests/evaluation/test_restricted_evaluator.py:130-164
+    gt = sps.csr_matrix(np.eye(4))
+    with pytest.raises(ValueError):
+        EvaluatorCore(gt, [[0], [1]])          # size not in {0, 1, U}
+    with pytest.raises(ValueError):
+        EvaluatorCore(gt, [[0, 0]])            # duplicates
+    with pytest.raises(ValueError):
+        EvaluatorCore(gt, [[4]])               # index >= n_items
+    core = EvaluatorCore(gt, [])
+    s = np.zeros((4, 4), dtype=np.float32)
+    with pytest.raises(ValueError):
+        core.get_metrics_f32(s, 0, 0, 1)       # cutoff == 0
+    with pytest.raises(ValueError):
+        core.get_metrics_f32(s, 5, 0, 1)       # cutoff > n_items
+    with pytest.raises(ValueError):
+        core.get_metrics_f32(s, 2, 4, 1)       # offset >= n_users
+    with pytest.raises(ValueError):
+        core.get_metrics_f32(s, 2, 1, 1)       # offset + rows > n_users
+    with pytest.raises(ValueError):
+        core.get_metrics_f32(s, 2, 0, 0)       # n_threads == 0
+
+
+def test_pickle_and_list_vs_list():
+    rns = np.random.RandomState(9)
+    U, I = 30, 50
+    scores = rns.randn(U, I)
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.7).astype(np.float64))
+    core = EvaluatorCore(gt, [])
+    core2 = pickle.loads(pickle.dumps(core))
+    a, b = core.get_metrics_f64(scores, 7, 0, 1), core2.get_metrics_f64(scores, 7, 0, 1)
+    assert a.as_dict() == b.as_dict()
+    # tests/evaluation/test_df_vs_df.py:50-64: list-vs-list equals the evaluator on the same ranking
+    recs = [list(np.argsort(-scores[u], kind="stable")[:7]) for u in range(U)]
+    gts = [gt[u].indices.tolist() for u in range(U)]
+    keep = [u for u in range(U) if len(gts[u]) > 0]
+    m = evaluate_list_vs_list([recs[u] for u in keep], [gts[u] for u in keep], I, 2)
+    om = O.evaluate_list_vs_list([recs[u] for u in keep], [gts[u] for u in keep], I, 2)
+    for k in ("hit", "ndcg", "recall", "map", "precision", "entropy", "gini_index"):
+        assert m.as_dict()[k] == pytest.approx(om.as_dict()[k], rel=1e-12)
+        assert m.as_dict()[k] == pytest.approx(a.as_dict()[k], rel=1e-9)
+
+
+def test_fused_ials_path_matches_block_path():
+    # score + mask + rank on the device == user_scores -> mask -> get_metrics_f32
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, IALSTrainer)
+    from irspack_amd.synthetic import holdout_split, make_interactions
+
+    X = make_interactions("small")
+    tr, te = holdout_split(X, 0.2, 7)
+    mc = IALSModelConfigBuilder().set_K(32).set_alpha0(0.1).set_reg(1e-2).build()
+    sc = IALSSolverConfigBuilder().build()
+    t = IALSTrainer(mc, tr.astype(np.float32))
+    for _ in range(2):
+        t.step(sc)
+    core = EvaluatorCore(te, [])
+    U = X.shape[0]
+    fused = core.get_metrics_ials(t, 0, U, tr, 20, 0, False)
+    acc = Metrics(X.shape[1])
+    for b in range(0, U, 500):
+        e = min(b + 500, U)
+        s = t.user_scores(b, e, sc)
+        s[tr[b:e].nonzero()] = -np.inf
+        acc.merge(core.get_metrics_f32(s, 20, b, 1))
+    np.testing.assert_array_equal(fused.item_cnt, acc.item_cnt)
+    assert fused.valid_user == acc.valid_user and fused.total_user == acc.total_user
+    for k in ("hit", "ndcg", "recall", "map", "precision"):
+        assert getattr(fused, k) == pytest.approx(getattr(acc, k), rel=1e-12)

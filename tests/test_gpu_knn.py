@@ -1,0 +1,202 @@
+"""GPU parity tests of the kNN path vs the CPU oracle and the dense numpy formulas of
+the reference's tests (tests/recommenders/test_knn.py:33-165).  Bar: top-k column
+indices bit-exact; values within 1e-12 relative (fp64; exact for binary inputs).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import oracle as O
+from irspack_amd.recommenders import _knn as K
+from irspack_amd.utils import okapi_BM_25_weight, remove_diagonal, tf_idf_weight
+
+pytestmark = pytest.mark.gpu
+
+rng = np.random.RandomState(0)
+X_small = sps.csr_matrix(
+    np.asarray([[1, 1, 2, 3, 4], [0, 1, 0, 1, 0], [0, 0, 1, 0, 0], [0, 0, 0, 0, 0]], dtype=float))
+_d = rng.rand(888, 512)
+X_many = sps.csr_matrix((_d > 0.9).astype(float))
+X_many.sort_indices()
+X_many_dense = sps.csr_matrix(rng.rand(133, 245))
+
+
+def assert_same_csr(a: sps.csr_matrix, b: sps.csr_matrix, rtol=1e-12):
+    a, b = sps.csr_matrix(a), sps.csr_matrix(b)
+    a.sort_indices()
+    b.sort_indices()
+    np.testing.assert_array_equal(a.indptr, b.indptr)
+    np.testing.assert_array_equal(a.indices, b.indices)  # bit-exact top-k indices
+    np.testing.assert_allclose(a.data, b.data, rtol=rtol, atol=0)
+
+
+CASES = [
+    ("cosine", dict(shrinkage=0.0, normalize=True)),
+    ("cosine", dict(shrinkage=0.0, normalize=False)),
+    ("cosine", dict(shrinkage=2.5, normalize=True)),
+    ("jaccard", dict(shrinkage=0.0)),
+    ("jaccard", dict(shrinkage=1.5)),
+    ("asymmetric", dict(shrinkage=1.0, alpha=0.7)),
+    ("tversky", dict(shrinkage=0.0, alpha=0.7, beta=2.0)),
+]
+
+
+def make(kind, X, **kw):
+    n_threads = kw.pop("n_threads", 1)
+    if kind == "cosine":
+        g = K.CosineSimilarityComputer(X, kw["shrinkage"], kw["normalize"], n_threads)
+    elif kind == "jaccard":
+        g = K.JaccardSimilarityComputer(X, kw["shrinkage"], n_threads)
+    elif kind == "asymmetric":
+        g = K.AsymmetricSimilarityComputer(X, kw["shrinkage"], kw["alpha"], n_threads)
+    elif kind == "tversky":
+        g = K.TverskyIndexComputer(X, kw["shrinkage"], kw["alpha"], kw["beta"], n_threads)
+    o = O.KNNComputer(kind, X, n_threads=n_threads, **kw)
+    return g, o
+
+
+@pytest.mark.parametrize("kind,kw", CASES)
+@pytest.mark.parametrize("Xname", ["small", "many", "dense"])
+@pytest.mark.parametrize("top_k", [2, 30, 100000])
+def test_matches_oracle(kind, kw, Xname, top_k):
+    X = {"small": X_small, "many": X_many, "dense": X_many_dense}[Xname]
+    Xt = sps.csr_matrix(X.T)
+    g, o = make(kind, Xt, **dict(kw))
+    top_k = min(top_k, 1024)
+    got = g.compute_similarity(Xt, top_k)
+    exp = o.compute_similarity(Xt, top_k)
+    # binary inputs give exact sums; float inputs differ by summation order only
+    assert_same_csr(got, exp, rtol=1e-12)
+
+
+@pytest.mark.parametrize("X,normalize", [(X_many, True), (X_small, False), (X_many_dense, True)])
+def test_cosine_dense_formula(X, normalize):
+    # tests/recommenders/test_knn.py:33-51
+    Xt = sps.csr_matrix(X.T)
+    g = K.CosineSimilarityComputer(Xt, 0.0, normalize, 5)
+    W = remove_diagonal(g.compute_similarity(Xt, X.shape[1])).toarray()
+    manual = X.T.toarray()
+    norm = (manual ** 2).sum(axis=1) ** 0.5
+    manual = manual.dot(manual.T)
+    if normalize:
+        manual /= norm[:, None] * norm[None, :] + 1e-6
+    np.fill_diagonal(manual, 0)
+    np.testing.assert_allclose(W, manual)
+
+
+@pytest.mark.parametrize("X", [X_many, X_small, X_many_dense])
+def test_jaccard_dense_formula(X):
+    # tests/recommenders/test_knn.py:54-70
+    Xt = sps.csr_matrix(X.T)
+    g = K.JaccardSimilarityComputer(Xt, 0.0, 1)
+    W = remove_diagonal(g.compute_similarity(Xt, X.shape[1])).toarray()
+    Xb = X.copy()
+    Xb.data[:] = 1
+    manual = Xb.T.toarray()
+    norm = manual.sum(axis=1)
+    manual = manual.dot(manual.T)
+    denom = norm[:, None] + norm[None, :] - manual + 1e-6
+    denom[denom <= 1e-10] = 1e-10
+    manual = manual / denom
+    np.fill_diagonal(manual, 0)
+    np.testing.assert_allclose(W, manual)
+
+
+def test_topk_ties_known_answer():
+    # tests/recommenders/test_knn.py:144-165
+    X = sps.csr_matrix(np.asarray(
+        [[1, 1, 1, 0, 0], [1, 1, 0, 1, 0], [1, 0, 1, 1, 0], [0, 1, 1, 1, 1]], dtype=float))
+    Xt = sps.csr_matrix(X.T)
+    c = K.CosineSimilarityComputer(Xt, 0.0, False, 1, 128)
+    full = c.compute_similarity(Xt, X.shape[1]).toarray()
+    actual = c.compute_similarity(Xt, 2).toarray()
+    expected = np.zeros_like(full)
+    for row, scores in enumerate(full):
+        cand = np.flatnonzero(scores)
+        order = np.lexsort((cand, -scores[cand]))
+        sel = cand[order[:2]]
+        expected[row, sel] = scores[sel]
+    np.testing.assert_array_equal(actual, expected)
+
+
+def test_explicit_zero_products_are_stored_entries():
+    # knn.hpp:111-118: candidates are the stored entries of the product, exact zeros included
+    X = sps.csr_matrix(np.asarray([[1.0, -1.0, 0.0], [1.0, 1.0, 2.0], [0.0, 0.0, 3.0]]))
+    Xt = sps.csr_matrix(X.T)
+    g, o = make("cosine", Xt, shrinkage=0.0, normalize=False)
+    got, exp = g.compute_similarity(Xt, 3), o.compute_similarity(Xt, 3)
+    assert_same_csr(got, exp)
+    assert got.nnz == exp.nnz and (got.data == 0).any()
+
+
+@pytest.mark.parametrize("kind,alpha,beta", [("p3alpha", 0.5, 0.0), ("p3alpha", 1.0, 0.0),
+                                             ("rp3beta", 0.7, 0.4)])
+def test_compute_w(kind, alpha, beta):
+    X = X_many_dense
+    Xt = sps.csr_matrix(X.T)
+    if kind == "p3alpha":
+        g = K.P3alphaComputer(Xt, alpha)
+        o = O.KNNComputer("p3alpha", Xt, alpha=alpha)
+    else:
+        g = K.RP3betaComputer(Xt, alpha, beta)
+        o = O.KNNComputer("rp3beta", Xt, alpha=alpha, beta=beta)
+    got = g.compute_W(Xt, 40).tocsr()
+    exp = o.compute_W(Xt, 40).tocsr()
+    got.sort_indices()
+    exp.sort_indices()
+    np.testing.assert_array_equal(got.indptr, exp.indptr)
+    np.testing.assert_array_equal(got.indices, exp.indices)
+    np.testing.assert_allclose(got.data, exp.data, rtol=1e-11)
+
+
+def test_thread_and_chunk_invariance_and_row_shards():
+    Xt = sps.csr_matrix(X_many.T)
+    a = K.CosineSimilarityComputer(Xt, 0.0, True, 1, 128).compute_similarity(Xt, 17)
+    b = K.CosineSimilarityComputer(Xt, 0.0, True, 7, 3).compute_similarity(Xt, 17)
+    assert_same_csr(a, b, rtol=0)
+    c = K.CosineSimilarityComputer(Xt, 0.0, True)
+    parts = [c.compute_similarity(Xt, 17, rows=(lo, hi)) for lo, hi in [(0, 100), (100, 101), (101, 512)]]
+    assert_same_csr(sps.vstack(parts).tocsr(), a, rtol=0)
+
+
+def test_argument_validation():
+    # tests/recommenders/test_knn.py:239-251; knn.hpp:35-45; similarities.hpp:66,148-149
+    Xt = sps.csr_matrix(X_small.T)
+    with pytest.raises(ValueError):
+        K.CosineSimilarityComputer(Xt, -1.0, False)
+    with pytest.raises(ValueError):
+        K.CosineSimilarityComputer(Xt, 0.0, False, 0)
+    with pytest.raises(ValueError):
+        K.CosineSimilarityComputer(Xt, 0.0, False, 1, 0)
+    with pytest.raises(ValueError):
+        K.AsymmetricSimilarityComputer(Xt, 0.0, 1.5)
+    with pytest.raises(ValueError):
+        K.TverskyIndexComputer(Xt, 0.0, -0.1, 0.0)
+    c = K.CosineSimilarityComputer(Xt, 0.0, False)
+    with pytest.raises(ValueError, match="illegal # of feature"):
+        c.compute_similarity(sps.csr_matrix(X_small), 2)
+    with pytest.raises(ValueError):
+        remove_diagonal(sps.csr_matrix(np.ones((2, 3))))
+
+
+def test_weighting_helpers_match_oracle():
+    for X in (X_small, X_many_dense):
+        for mine, ref in ((tf_idf_weight(X), O.tf_idf_weight(X)),
+                          (okapi_BM_25_weight(X, 1.3, 0.6), O.okapi_BM_25_weight(X, 1.3, 0.6))):
+            np.testing.assert_allclose(mine.toarray(), ref.toarray(), rtol=1e-13)
+
+
+def test_two_column_tiles():
+    # N > 16384 columns -> the product row is split over two LDS tiles and merged
+    rng2 = np.random.default_rng(5)
+    N, U = 20000, 300
+    rows = rng2.integers(0, U, size=60000)
+    cols = rng2.integers(0, N, size=60000)
+    X = sps.csr_matrix((np.ones(60000), (rows, cols)), shape=(U, N))
+    X.data[:] = 1.0
+    Xt = sps.csr_matrix(X.T)
+    g, o = make("cosine", Xt, shrinkage=0.0, normalize=False)
+    sel = (0, 3000)  # a shard of target rows keeps the CPU side quick
+    got = g.compute_similarity(Xt, 50, rows=sel)
+    exp = o.compute_similarity(Xt[sel[0]:sel[1]].tocsr() if False else Xt, 50)[sel[0]:sel[1]]
+    assert_same_csr(got, exp, rtol=0)
