@@ -1,0 +1,241 @@
+"""``IALSRecommender`` counterpart: the caller contract of the reference's
+``irspack/recommenders/ials.py:68-203, 245-562`` on top of the GPU ``IALSTrainer``.
+
+Reproduces what the reference's Python does around the native calls: float32 cast
+(:91), log confidence scaling (:437-446), the ``nu_star`` regulariser rescale
+(:232-242, 412-418), the two solver configs (training / prediction time), the
+epoch loop, scoring and fold-in.  Early stopping against a validation evaluator
+follows ``base_earlystop.py:106-149`` without the Optuna / progress-bar parts.
+"""
+
+import enum
+import pickle
+from io import BytesIO
+from typing import IO, Any, Optional
+
+import numpy as np
+import scipy.sparse as sps
+
+from .._threading import get_n_threads
+from ._ials_core import IALSModelConfigBuilder, IALSSolverConfigBuilder
+from ._ials_core import IALSTrainer as CoreTrainer
+from ._ials_core import LossType, SolverType
+from .base import BaseRecommender
+
+
+def str_to_solver_type(t: str) -> SolverType:
+    result: SolverType = getattr(SolverType, t.upper())
+    assert result in {SolverType.CG, SolverType.CHOLESKY, SolverType.IALSPP}
+    return result
+
+
+def str_to_loss_type(t: str) -> LossType:
+    result: LossType = getattr(LossType, t.upper())
+    assert result in {LossType.ORIGINAL, LossType.IALSPP}
+    return result
+
+
+class IALSTrainer:
+    """ials.py:68-203 (without the feature-aware branches)."""
+
+    def __init__(self, X: Any, n_components: int, alpha0: float, reg: float, nu: float,
+                 init_std: float, solver_type: SolverType, max_cg_steps: int,
+                 ialspp_subspace_dimension: int, loss_type: LossType, random_seed: int,
+                 n_threads: int, prediction_time_max_cg_steps: int,
+                 prediction_time_ialspp_iteration: int, device: Optional[int] = None) -> None:
+        X_train_all_f32 = X.astype(np.float32)
+        config = (
+            IALSModelConfigBuilder().set_K(n_components).set_init_stdev(init_std)
+            .set_alpha0(alpha0).set_reg(reg).set_nu(nu).set_loss_type(loss_type)
+            .set_random_seed(random_seed).build()
+        )
+        self.solver_config = (
+            IALSSolverConfigBuilder().set_n_threads(n_threads).set_solver_type(solver_type)
+            .set_max_cg_steps(max_cg_steps).set_ialspp_iteration(1)
+            .set_ialspp_subspace_dimension(ialspp_subspace_dimension).build()
+        )
+        self.core_trainer = CoreTrainer(config, X_train_all_f32, device=device)
+        self.prediction_time_solver_config = (
+            IALSSolverConfigBuilder().set_n_threads(n_threads).set_solver_type(solver_type)
+            .set_max_cg_steps(prediction_time_max_cg_steps)
+            .set_ialspp_subspace_dimension(ialspp_subspace_dimension)
+            .set_ialspp_iteration(prediction_time_ialspp_iteration).build()
+        )
+
+    def load_state(self, ifs: IO) -> None:
+        params = pickle.load(ifs)
+        self.core_trainer.user = params["user"]
+        self.core_trainer.item = params["item"]
+
+    def save_state(self, ofs: IO) -> None:
+        pickle.dump(dict(user=self.core_trainer.user, item=self.core_trainer.item), ofs,
+                    protocol=pickle.HIGHEST_PROTOCOL)
+
+    def compute_loss(self) -> float:
+        return self.core_trainer.compute_loss(self.solver_config)
+
+    def run_epoch(self) -> None:
+        self.core_trainer.step(self.solver_config)
+
+    def user_scores(self, begin: int, end: int) -> np.ndarray:
+        return self.core_trainer.user_scores(begin, end, self.solver_config)
+
+    def transform_user(self, X: Any) -> np.ndarray:
+        return self.core_trainer.transform_user(X, self.prediction_time_solver_config)
+
+    def transform_item(self, X: Any) -> np.ndarray:
+        return self.core_trainer.transform_item(X, self.prediction_time_solver_config)
+
+
+class IALSConfigScaling(enum.Enum):
+    none = enum.auto()
+    log = enum.auto()
+
+
+def compute_reg_scale(X: sps.csr_matrix, alpha0: float, nu: float) -> float:
+    # ials.py:232-242
+    X_csr = sps.csr_matrix(X)
+    U, I = X_csr.shape
+    nnz_row = np.diff(X_csr.indptr)
+    nnz_col = np.bincount(X_csr.indices, minlength=I)
+    return float(((nnz_row + alpha0 * I) ** nu).sum()) + float(((nnz_col + alpha0 * U) ** nu).sum())
+
+
+class IALSRecommender(BaseRecommender):
+    """ials.py:245-562.  Same constructor arguments and defaults (without the
+    feature-aware ones); ``device`` is an extra keyword."""
+
+    def __init__(self, X_train_all: Any, n_components: int = 20, alpha0: float = 0.0,
+                 reg: float = 1e-3, nu: float = 1.0, confidence_scaling: str = "none",
+                 epsilon: float = 1.0, init_std: float = 0.1, solver_type: str = "CG",
+                 max_cg_steps: int = 3, ialspp_subspace_dimension: int = 64,
+                 loss_type: str = "IALSPP", nu_star: Optional[float] = None,
+                 random_seed: int = 42, n_threads: Optional[int] = None, train_epochs: int = 16,
+                 prediction_time_max_cg_steps: int = 5,
+                 prediction_time_ialspp_iteration: int = 7, device: Optional[int] = None) -> None:
+        super().__init__(X_train_all)
+        self.train_epochs = train_epochs
+        self.n_components = n_components
+        self.alpha0 = alpha0
+        self.reg = reg
+        self.nu = nu
+        self.confidence_scaling = IALSConfigScaling[confidence_scaling]
+        self.epsilon = epsilon
+        self.init_std = init_std
+        self.solver_type = str_to_solver_type(solver_type)
+        self.max_cg_steps = max_cg_steps
+        self.ialspp_subspace_dimension = ialspp_subspace_dimension
+        self.random_seed = random_seed
+        self.n_threads = get_n_threads(n_threads)
+        self.loss_type = str_to_loss_type(loss_type)
+        self.nu_star = nu_star
+        self.scaled_reg = self.reg
+        if self.nu_star is not None:  # ials.py:412-418
+            self.scaled_reg = (self.reg * compute_reg_scale(self.X_train_all, alpha0, self.nu_star)
+                               / compute_reg_scale(self.X_train_all, alpha0, nu))
+        self.prediction_time_max_cg_steps = prediction_time_max_cg_steps
+        self.prediction_time_ialspp_iteration = prediction_time_ialspp_iteration
+        self.device = device
+        self.trainer: Optional[IALSTrainer] = None
+        self.best_state: Optional[bytes] = None
+        self.learnt_config = {}
+
+    @classmethod
+    def _scale_X(cls, X: sps.csr_matrix, scheme: IALSConfigScaling, epsilon: float) -> sps.csr_matrix:
+        if scheme is IALSConfigScaling.none:
+            return X
+        X_ret: sps.csr_matrix = X.copy()
+        X_ret.data = np.log(1 + X_ret.data / epsilon)  # ials.py:437-446
+        return X_ret
+
+    def _create_trainer(self) -> IALSTrainer:
+        return IALSTrainer(
+            X=self._scale_X(self.X_train_all, self.confidence_scaling, self.epsilon),
+            n_components=self.n_components, alpha0=self.alpha0, reg=self.scaled_reg, nu=self.nu,
+            init_std=self.init_std, solver_type=self.solver_type, max_cg_steps=self.max_cg_steps,
+            ialspp_subspace_dimension=self.ialspp_subspace_dimension, loss_type=self.loss_type,
+            random_seed=self.random_seed, n_threads=self.n_threads,
+            prediction_time_max_cg_steps=self.prediction_time_max_cg_steps,
+            prediction_time_ialspp_iteration=self.prediction_time_ialspp_iteration,
+            device=self.device,
+        )
+
+    # -- base_earlystop.py:80-149 ------------------------------------------
+    def start_learning(self) -> None:
+        self.trainer = self._create_trainer()
+
+    def run_epoch(self) -> None:
+        self.trainer_as_ials.run_epoch()
+
+    def save_state(self) -> None:
+        with BytesIO() as ofs:
+            self.trainer_as_ials.save_state(ofs)
+            self.best_state = ofs.getvalue()
+
+    def load_state(self) -> None:
+        if self.best_state is None:
+            raise RuntimeError("'load_state' called before achieving any results.")
+        with BytesIO(self.best_state) as ifs:
+            self.trainer_as_ials.load_state(ifs)
+
+    def _learn(self) -> None:
+        self.learn_with_evaluator(None, max_epoch=self.train_epochs)
+
+    def learn_with_evaluator(self, evaluator: Any, max_epoch: int = 128, validate_epoch: int = 5,
+                             score_degradation_max: int = 5) -> None:
+        self.start_learning()
+        best_score = -float("inf")
+        n_score_degradation = 0
+        for epoch in range(max_epoch):
+            self.run_epoch()
+            if (epoch + 1) % validate_epoch or evaluator is None:
+                continue
+            target_score = evaluator.get_target_score(self)
+            if target_score > best_score:
+                best_score = target_score
+                self.save_state()
+                self.learnt_config["train_epochs"] = epoch + 1
+                n_score_degradation = 0
+            else:
+                n_score_degradation += 1
+                if n_score_degradation >= score_degradation_max:
+                    break
+        if evaluator is not None and self.best_state is not None:
+            self.load_state()
+
+    @property
+    def trainer_as_ials(self) -> IALSTrainer:
+        if self.trainer is None:
+            raise RuntimeError("tried to fetch trainer before the training.")
+        return self.trainer
+
+    # -- scoring (ials.py:476-562) ---------------------------------------------
+    def get_score(self, user_indices: np.ndarray) -> np.ndarray:
+        return self.trainer_as_ials.core_trainer.user[user_indices].dot(self.get_item_embedding().T)
+
+    def get_score_block(self, begin: int, end: int) -> np.ndarray:
+        return self.trainer_as_ials.user_scores(begin, end)
+
+    def get_score_cold_user(self, X: Any) -> np.ndarray:
+        return self.get_score_from_user_embedding(self.compute_user_embedding(X))
+
+    def get_user_embedding(self) -> np.ndarray:
+        return self.trainer_as_ials.core_trainer.user
+
+    def get_item_embedding(self) -> np.ndarray:
+        return self.trainer_as_ials.core_trainer.item
+
+    def get_score_from_user_embedding(self, user_embedding: np.ndarray) -> np.ndarray:
+        return user_embedding.dot(self.get_item_embedding().T)
+
+    def get_score_from_item_embedding(self, user_indices: np.ndarray,
+                                      item_embedding: np.ndarray) -> np.ndarray:
+        return self.get_user_embedding()[user_indices].dot(item_embedding.T)
+
+    def compute_user_embedding(self, X: Any) -> np.ndarray:
+        return self.trainer_as_ials.transform_user(
+            self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling, self.epsilon))
+
+    def compute_item_embedding(self, X: Any) -> np.ndarray:
+        return self.trainer_as_ials.transform_item(
+            self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling, self.epsilon))

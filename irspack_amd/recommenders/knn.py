@@ -1,0 +1,146 @@
+"""Item-kNN recommenders: counterpart of the reference's ``irspack/recommenders/knn.py``
+(:35-80 ``BaseKNNRecommender._learn`` and the four concrete classes), ``p3.py`` and
+``rp3.py``, on top of the GPU similarity computers in ``_knn``.
+
+``_learn`` keeps the reference's order of operations (knn.py:67-80): optional
+feature weighting -> computer built on ``X_weighted.T`` -> ``compute_similarity``
+on the *unweighted* ``X.T`` -> ``remove_diagonal`` -> CSC.  Note that the diagonal
+competes for a top-k slot before it is zeroed.
+"""
+
+import enum
+from typing import Any, Optional
+
+from .._threading import get_n_threads
+from ..utils import okapi_BM_25_weight, remove_diagonal, tf_idf_weight
+from ._knn import (AsymmetricSimilarityComputer, CosineSimilarityComputer,
+                   JaccardSimilarityComputer, P3alphaComputer, RP3betaComputer,
+                   TverskyIndexComputer)
+from .base import BaseSimilarityRecommender
+
+
+class FeatureWeightingScheme(str, enum.Enum):
+    NONE = "NONE"
+    TF_IDF = "TF_IDF"
+    BM_25 = "BM_25"
+
+
+class BaseKNNRecommender(BaseSimilarityRecommender):
+    def __init__(self, X_train_all: Any, shrinkage: float = 0.0, top_k: int = 100,
+                 n_threads: Optional[int] = None, feature_weighting: str = "NONE",
+                 bm25_k1: float = 1.2, bm25_b: float = 0.75) -> None:
+        super().__init__(X_train_all)
+        self.shrinkage = shrinkage
+        self.top_k = top_k
+        self.feature_weighting = FeatureWeightingScheme(feature_weighting)
+        self.bm25_k1 = bm25_k1
+        self.bm25_b = bm25_b
+        self.n_threads = get_n_threads(n_threads)
+
+    def _create_computer(self, X: Any):
+        raise NotImplementedError("")
+
+    def _learn(self) -> None:
+        if self.feature_weighting == FeatureWeightingScheme.NONE:
+            X_weighted = self.X_train_all
+        elif self.feature_weighting == FeatureWeightingScheme.TF_IDF:
+            X_weighted = tf_idf_weight(self.X_train_all)
+        elif self.feature_weighting == FeatureWeightingScheme.BM_25:
+            X_weighted = okapi_BM_25_weight(self.X_train_all, self.bm25_k1, self.bm25_b)
+        else:
+            raise RuntimeError("Unknown weighting scheme.")
+        computer = self._create_computer(X_weighted.T)
+        self._W = remove_diagonal(computer.compute_similarity(self.X_train_all.T, self.top_k)).tocsc()
+
+
+class CosineKNNRecommender(BaseKNNRecommender):  # knn.py:94-161
+    def __init__(self, X_train_all: Any, shrinkage: float = 0.0, normalize: bool = False,
+                 top_k: int = 100, feature_weighting: str = "NONE", bm25_k1: float = 1.2,
+                 bm25_b: float = 0.75, n_threads: Optional[int] = None) -> None:
+        super().__init__(X_train_all, shrinkage, top_k, n_threads, feature_weighting, bm25_k1, bm25_b)
+        self.normalize = normalize
+
+    def _create_computer(self, X: Any) -> CosineSimilarityComputer:
+        return CosineSimilarityComputer(X, self.shrinkage, self.normalize, self.n_threads)
+
+
+class AsymmetricCosineKNNRecommender(BaseKNNRecommender):  # knn.py:168-235
+    def __init__(self, X_train_all: Any, shrinkage: float = 0.0, alpha: float = 0.5,
+                 top_k: int = 100, feature_weighting: str = "NONE", bm25_k1: float = 1.2,
+                 bm25_b: float = 0.75, n_threads: Optional[int] = None) -> None:
+        super().__init__(X_train_all, shrinkage, top_k, n_threads, feature_weighting, bm25_k1, bm25_b)
+        self.alpha = alpha
+
+    def _create_computer(self, X: Any) -> AsymmetricSimilarityComputer:
+        return AsymmetricSimilarityComputer(X, self.shrinkage, self.alpha, self.n_threads)
+
+
+class JaccardKNNRecommender(BaseKNNRecommender):  # knn.py:238-270
+    def __init__(self, X_train_all: Any, shrinkage: float = 0.0, top_k: int = 100,
+                 n_threads: Optional[int] = None) -> None:
+        super().__init__(X_train_all, shrinkage, top_k, n_threads)
+
+    def _create_computer(self, X: Any) -> JaccardSimilarityComputer:
+        return JaccardSimilarityComputer(X, self.shrinkage, self.n_threads)
+
+
+class TverskyIndexKNNRecommender(BaseKNNRecommender):  # knn.py:273-326
+    def __init__(self, X_train_all: Any, shrinkage: float = 0.0, alpha: float = 0.5,
+                 beta: float = 0.5, top_k: int = 100, n_threads: Optional[int] = None) -> None:
+        super().__init__(X_train_all, shrinkage, top_k, n_threads)
+        self.alpha = alpha
+        self.beta = beta
+
+    def _create_computer(self, X: Any) -> TverskyIndexComputer:
+        return TverskyIndexComputer(X, self.shrinkage, self.alpha, self.beta, self.n_threads)
+
+
+class P3alphaRecommender(BaseSimilarityRecommender):  # p3.py:44-76
+    def __init__(self, X_train_all: Any, alpha: float = 1, top_k: Optional[int] = None,
+                 normalize_weight: bool = False, n_threads: Optional[int] = None) -> None:
+        super().__init__(X_train_all)
+        self.alpha = alpha
+        self.top_k = top_k
+        self.normalize_weight = normalize_weight
+        self.n_threads = get_n_threads(n_threads)
+
+    def _learn(self) -> None:
+        import numpy as np
+        import scipy.sparse as sps
+
+        computer = P3alphaComputer(self.X_train_all.T, alpha=self.alpha, n_threads=self.n_threads)
+        top_k = self.X_train_all.shape[1] if self.top_k is None else self.top_k
+        W = computer.compute_W(self.X_train_all.T, top_k)
+        if self.normalize_weight:  # p3.py:70-75 (sklearn.preprocessing.normalize(norm="l1", axis=1))
+            W = sps.csr_matrix(W)
+            s = np.asarray(np.abs(W).sum(axis=1)).ravel()
+            s[s == 0] = 1.0
+            W = sps.diags(1.0 / s) @ W
+        self._W = W
+
+
+class RP3betaRecommender(BaseSimilarityRecommender):  # rp3.py:49-84
+    def __init__(self, X_train_all: Any, alpha: float = 1, beta: float = 0.6,
+                 top_k: Optional[int] = None, normalize_weight: bool = False,
+                 n_threads: Optional[int] = None) -> None:
+        super().__init__(X_train_all)
+        self.alpha = alpha
+        self.beta = beta
+        self.top_k = top_k
+        self.normalize_weight = normalize_weight
+        self.n_threads = get_n_threads(n_threads)
+
+    def _learn(self) -> None:
+        import numpy as np
+        import scipy.sparse as sps
+
+        computer = RP3betaComputer(self.X_train_all.T, alpha=self.alpha, beta=self.beta,
+                                   n_threads=self.n_threads)
+        top_k = self.X_train_all.shape[1] if self.top_k is None else self.top_k
+        W = computer.compute_W(self.X_train_all.T, top_k)
+        if self.normalize_weight:
+            W = sps.csr_matrix(W)
+            s = np.asarray(np.abs(W).sum(axis=1)).ravel()
+            s[s == 0] = 1.0
+            W = sps.diags(1.0 / s) @ W
+        self._W = W
