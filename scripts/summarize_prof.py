@@ -1,0 +1,80 @@
+"""Turn the rocprofv3 output of scripts/prof_bench.sh (gpurun_out/prof) into the tracked
+summaries under profiles/: the --kernel-trace --stats table, and the per-kernel HBM
+traffic from the separate FETCH_SIZE / WRITE_SIZE PMC passes.
+
+gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are in KiB;
+FETCH_SIZE counts 64 B per 128 B request of a wide coalesced stream, so it is doubled;
+WRITE_SIZE is exact for 16 B-per-lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def per_kernel(path):
+    """kernel name -> grid size -> [n, sum]"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(path)):
+        a = agg[r["Kernel_Name"]][int(r["Grid_Size"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    stats = glob.glob(os.path.join(SRC, "kt", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
+    out = {"units": "bytes per launch", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2",
+           "write_correction": "WRITE_SIZE KiB x 1024", "kernels": {}}
+    fetch = glob.glob(os.path.join(SRC, "fetch", "*", "*_counter_collection.csv"))
+    write = glob.glob(os.path.join(SRC, "write", "*", "*_counter_collection.csv"))
+    if not (fetch and write):
+        print("no PMC passes found")
+        return
+    f, w = per_kernel(fetch[0]), per_kernel(write[0])
+    traffic = {}
+    for name in f:
+        if "irs::" not in name:
+            continue
+        for grid, (n, s) in sorted(f[name].items()):
+            fb = s / n * 1024 * 2
+            wn, ws = w.get(name, {}).get(grid, [1, 0.0])
+            wb = ws / max(wn, 1) * 1024
+            out["kernels"].setdefault(name, []).append(
+                {"grid_size": grid, "launches": n, "fetch_bytes": fb, "write_bytes": wb,
+                 "hbm_bytes": fb + wb})
+    # map the two solve-kernel grids onto the library's per-side names (users = larger grid)
+    for name, rows in out["kernels"].items():
+        if "ials_solve_kernel<" in name and name.rstrip().endswith("0>(irs::ials::SolveParams)") is False:
+            pass
+    for name, rows in out["kernels"].items():
+        if "ials_solve_kernel" not in name:
+            continue
+        solver = "cg" if ", 1, " in name else "cholesky"
+        kind = "split" if name.split(",")[2].strip().startswith("1") else "solve"
+        rows = sorted(rows, key=lambda r: r["grid_size"])
+        if len(rows) >= 2:
+            # users have more rows than items => larger grid for `solve`; for `split` the item side
+            # has more split rows
+            small, large = rows[0], rows[-1]
+            user, item = (large, small) if kind == "solve" else (small, large)
+            traffic[f"ials_{kind}_{solver}_user"] = user["hbm_bytes"]
+            traffic[f"ials_{kind}_{solver}_item"] = item["hbm_bytes"]
+    json.dump(out, open(os.path.join(DST, f"{TAG}_bench_pmc_hbm.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main()
