@@ -12,7 +12,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libirspack_amd.so")
+# IRSPACK_AMD_LIB selects another build of the same ABI (kernel tuning experiments)
+LIB_PATH = os.environ.get("IRSPACK_AMD_LIB") or os.path.join(_HERE, "libirspack_amd.so")
 
 
 class ModelConfigStruct(C.Structure):

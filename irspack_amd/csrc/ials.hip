@@ -153,11 +153,11 @@ struct Side {
     n_slots = slots;
     indptr.upload(ip32, s);
     {
-      // the gather pipeline over-reads up to 2 * 8 sub-steps (64 entries) past a row
+      // the gather pipeline loads whole 64-entry blocks up to two blocks past a row's end
       std::vector<int32_t> idx_pad(m.indices);
       std::vector<float> data_pad(m.data);
-      idx_pad.resize(m.indices.size() + 128, 0);
-      data_pad.resize(m.data.size() + 128, 0.0f);
+      idx_pad.resize(m.indices.size() + 320, 0);
+      data_pad.resize(m.data.size() + 320, 0.0f);
       indices.upload(idx_pad, s);
       data.upload(data_pad, s);
       IRS_HIP(hipStreamSynchronize(s));
@@ -381,21 +381,21 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     if (sd.n_tasks > 0) {
       t->prof.begin(kNames[cg][0][pidx], t->stream);
       if (cg)
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(sd.n_tasks, 4)),
-                           dim3(256), 0, t->stream, p);
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
+                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
       else
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(sd.n_tasks, 4)),
-                           dim3(256), 0, t->stream, p);
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
+                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
       t->prof.end(t->stream);
     }
     if (sd.n_split > 0) {
       t->prof.begin(kNames[cg][1][pidx], t->stream);
       if (cg)
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 1>), dim3(ceil_div(sd.n_split, 4)),
-                           dim3(256), 0, t->stream, p);
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 1>), dim3(ceil_div(sd.n_split, SOLVE_WAVES)),
+                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
       else
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 1>), dim3(ceil_div(sd.n_split, 4)),
-                           dim3(256), 0, t->stream, p);
+        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 1>), dim3(ceil_div(sd.n_split, SOLVE_WAVES)),
+                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
       t->prof.end(t->stream);
     }
   });

@@ -304,16 +304,33 @@ def test_ml100k_shape_parity_c1():
         t = IALSTrainer(mc, X)
         o = O.IALSTrainer(omc, X)
         for _ in range(3):
-            # same factors in -> one epoch out: this is the 1e-4 contract.  (Free
-            # running from the random init the two fp32 trajectories drift apart
-            # by a few 1e-4 per epoch on this shape, GPU and CPU restatement
-            # alike; see scripts/accuracy_probe.py and DESIGN.md.)
+            # Same factors in -> one HALF-epoch out: this is the 1e-4 contract.  The item
+            # half of a step sees the freshly solved users (hpp:784-787), so feeding each
+            # half identical inputs needs the half-step API.  (Free running from the random
+            # init the two fp32 trajectories drift apart by a few 1e-4 per epoch on this
+            # shape, GPU and CPU restatement alike; scripts/accuracy_probe.py)
+            t.user, t.item = o.user, o.item
+            t.partial_gramian_async(0)
+            t.finish_gramian_async(0)
+            t.half_step_async(0, sc)
+            t.synchronize()
+            o.step(osc)  # oracle epoch; its user half used the same (user, item) as the GPU's
+            assert rel_err(t.user, o.user) < RTOL
+            t.user = o.user
+            t.partial_gramian_async(1)
+            t.finish_gramian_async(1)
+            t.half_step_async(1, sc)
+            t.synchronize()
+            assert rel_err(t.item, o.item) < RTOL
+            # a whole epoch through step(): the item half inherits the user half's
+            # rounding differences, amplified by sparsely rated items
             t.user, t.item = o.user, o.item
             t.step(sc)
             o.step(osc)
             assert rel_err(t.user, o.user) < RTOL
-            assert rel_err(t.item, o.item) < RTOL
+            assert rel_err(t.item, o.item) < 1e-3
         b, e = 100, 228
+        t.user, t.item = o.user, o.item  # scores of the SAME factors (hpp:942-984)
         assert rel_err(t.user_scores(b, e, sc), o.user_scores(b, e, osc)) < RTOL
         # free-running trajectory from the shared init: loose sanity bound
         t2 = IALSTrainer(mc, X)
