@@ -13,6 +13,7 @@
 
 #include "common.hpp"
 #include "ials_kernels.hpp"
+#include "ials_wg_kernels.hpp"
 
 namespace irs {
 
@@ -235,19 +236,39 @@ struct irs_ials_trainer {
 
 namespace {
 
+// T = KP / 16.  T <= 4: one wave per row (ials_kernels.hpp); T = 8 / 12 / 16: one
+// workgroup per row (ials_wg_kernels.hpp).
 #define IRS_DISPATCH_T(t, ...)                                                      \
   switch (t) {                                                                      \
     case 1: { constexpr int TT = 1; __VA_ARGS__; } break;                           \
     case 2: { constexpr int TT = 2; __VA_ARGS__; } break;                           \
     case 4: { constexpr int TT = 4; __VA_ARGS__; } break;                           \
     default:                                                                        \
-      throw std::invalid_argument(                                                  \
-          "irspack_amd: n_components above 64 is not supported by this build.");    \
+      throw std::invalid_argument("irspack_amd: unsupported padded latent dimension."); \
+  }
+#define IRS_DISPATCH_TW(t, ...)                                                     \
+  switch (t) {                                                                      \
+    case 8: { constexpr int TT = 8; __VA_ARGS__; } break;                           \
+    case 12: { constexpr int TT = 12; __VA_ARGS__; } break;                         \
+    case 16: { constexpr int TT = 16; __VA_ARGS__; } break;                         \
+    default:                                                                        \
+      throw std::invalid_argument("irspack_amd: unsupported padded latent dimension."); \
+  }
+#define IRS_DISPATCH_ANY(t, ...)                                                    \
+  switch (t) {                                                                      \
+    case 1: { constexpr int TT = 1; __VA_ARGS__; } break;                           \
+    case 2: { constexpr int TT = 2; __VA_ARGS__; } break;                           \
+    case 4: { constexpr int TT = 4; __VA_ARGS__; } break;                           \
+    case 8: { constexpr int TT = 8; __VA_ARGS__; } break;                           \
+    case 12: { constexpr int TT = 12; __VA_ARGS__; } break;                         \
+    case 16: { constexpr int TT = 16; __VA_ARGS__; } break;                         \
+    default:                                                                        \
+      throw std::invalid_argument("irspack_amd: unsupported padded latent dimension."); \
   }
 
 void validate_config(const irs_ials_model_config &c) {
   check_arg(c.K >= 1, "K must be positive.");
-  check_arg(c.K <= 64, "irspack_amd: n_components above 64 is not supported by this build.");
+  check_arg(c.K <= 256, "irspack_amd: n_components above 256 is not supported.");
   check_arg(c.loss_type == IRS_LOSS_ORIGINAL || c.loss_type == IRS_LOSS_IALSPP,
             "unknown loss_type.");
 }
@@ -309,23 +330,42 @@ void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t 
   n_waves = ceil_div(n_waves, 4) * 4;
   int64_t per = ceil_div(std::max<int64_t>(n, 1), n_waves);
   per = ceil_div(per, 4) * 4;
-  IRS_DISPATCH_T(t->T, {
-    using G = Geo<TT>;
-    t->gram_partial.alloc(static_cast<size_t>(n_waves / 4) * G::NT * 256);
-    t->prof.begin("gramian_partial", t->stream);
-    hipLaunchKernelGGL((gramian_partial_kernel<TT>), dim3(n_waves / 4), dim3(256), 0, t->stream,
-                       t->factor[which].ptr, rb, re, per, t->gram_partial.ptr);
-    t->prof.end(t->stream);
-    t->prof.begin("gramian_reduce", t->stream);
-    hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 64)), dim3(256),
-                       0, t->stream, t->gram_partial.ptr, n_waves / 4, t->P_raw[dst].ptr);
-    t->prof.end(t->stream);
-  });
+  if (t->T <= 4) {
+    IRS_DISPATCH_T(t->T, {
+      using G = Geo<TT>;
+      t->gram_partial.alloc(static_cast<size_t>(n_waves / 4) * G::NT * 256);
+      t->prof.begin("gramian_partial", t->stream);
+      hipLaunchKernelGGL((gramian_partial_kernel<TT>), dim3(n_waves / 4), dim3(256), 0, t->stream,
+                         t->factor[which].ptr, rb, re, per, t->gram_partial.ptr);
+      t->prof.end(t->stream);
+      t->prof.begin("gramian_reduce", t->stream);
+      hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 64)), dim3(256),
+                         0, t->stream, t->gram_partial.ptr, n_waves / 4, t->P_raw[dst].ptr);
+      t->prof.end(t->stream);
+    });
+  } else {
+    // four waves of a block share a slab of rows and split the tiles between them
+    const int64_t n_blocks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(n, 64)));
+    int64_t per_block = ceil_div(std::max<int64_t>(n, 1), n_blocks);
+    per_block = ceil_div(per_block, 4) * 4;
+    IRS_DISPATCH_TW(t->T, {
+      using G = Geo<TT>;
+      t->gram_partial.alloc(static_cast<size_t>(n_blocks) * G::NT * 256);
+      t->prof.begin("gramian_partial", t->stream);
+      hipLaunchKernelGGL((gramian_partial_wg_kernel<TT>), dim3(n_blocks), dim3(256), 0, t->stream,
+                         t->factor[which].ptr, rb, re, per_block, t->gram_partial.ptr);
+      t->prof.end(t->stream);
+      t->prof.begin("gramian_reduce", t->stream);
+      hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 64)), dim3(256),
+                         0, t->stream, t->gram_partial.ptr, n_blocks, t->P_raw[dst].ptr);
+      t->prof.end(t->stream);
+    });
+  }
   IRS_HIP(hipGetLastError());
 }
 
 void launch_finish_gramian(irs_ials_trainer *t, int dst) {
-  IRS_DISPATCH_T(t->T, {
+  IRS_DISPATCH_ANY(t->T, {
     using G = Geo<TT>;
     t->prof.begin("gramian_finish", t->stream);
     hipLaunchKernelGGL((gramian_finish_kernel<TT>), dim3(ceil_div(G::KP * G::KP, 256)),
@@ -374,31 +414,60 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                                                sc->max_cg_steps, 1u << 20));
   p.warm_start = 1;
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
-  IRS_DISPATCH_T(t->T, {
-    using G = Geo<TT>;
-    t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
-    p.partials = t->split_partial.ptr;
-    if (sd.n_tasks > 0) {
-      t->prof.begin(kNames[cg][0][pidx], t->stream);
-      if (cg)
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
-                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
-      else
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
-                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
-      t->prof.end(t->stream);
-    }
-    if (sd.n_split > 0) {
-      t->prof.begin(kNames[cg][1][pidx], t->stream);
-      if (cg)
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 1>), dim3(ceil_div(sd.n_split, SOLVE_WAVES)),
-                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
-      else
-        hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 1>), dim3(ceil_div(sd.n_split, SOLVE_WAVES)),
-                           dim3(64 * SOLVE_WAVES), 0, t->stream, p);
-      t->prof.end(t->stream);
-    }
-  });
+  if (t->T <= 4) {
+    IRS_DISPATCH_T(t->T, {
+      using G = Geo<TT>;
+      t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
+      p.partials = t->split_partial.ptr;
+      if (sd.n_tasks > 0) {
+        t->prof.begin(kNames[cg][0][pidx], t->stream);
+        if (cg)
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
+                             dim3(64 * SOLVE_WAVES), 0, t->stream, p);
+        else
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
+                             dim3(64 * SOLVE_WAVES), 0, t->stream, p);
+        t->prof.end(t->stream);
+      }
+      if (sd.n_split > 0) {
+        t->prof.begin(kNames[cg][1][pidx], t->stream);
+        if (cg)
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 1>), dim3(ceil_div(sd.n_split, SOLVE_WAVES)),
+                             dim3(64 * SOLVE_WAVES), 0, t->stream, p);
+        else
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 1>), dim3(ceil_div(sd.n_split, SOLVE_WAVES)),
+                             dim3(64 * SOLVE_WAVES), 0, t->stream, p);
+        t->prof.end(t->stream);
+      }
+    });
+  } else {
+    IRS_DISPATCH_TW(t->T, {
+      using G = Geo<TT>;
+      constexpr size_t lds = WgGeo<TT>::LDS_FLOATS * sizeof(float);
+      t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
+      p.partials = t->split_partial.ptr;
+      auto launch = [&](auto kernel, int n_items, const char *name) {
+        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        t->prof.begin(name, t->stream);
+        hipLaunchKernelGGL(kernel, dim3(n_items), dim3(256), lds, t->stream, p);
+        t->prof.end(t->stream);
+      };
+      if (sd.n_tasks > 0) {
+        if (cg)
+          launch(ials_wg_solve_kernel<TT, 1, 0>, sd.n_tasks, kNames[1][0][pidx]);
+        else
+          launch(ials_wg_solve_kernel<TT, 0, 0>, sd.n_tasks, kNames[0][0][pidx]);
+      }
+      if (sd.n_split > 0) {
+        if (cg)
+          launch(ials_wg_solve_kernel<TT, 1, 1>, sd.n_split, kNames[1][1][pidx]);
+        else
+          launch(ials_wg_solve_kernel<TT, 0, 1>, sd.n_split, kNames[0][1][pidx]);
+      }
+    });
+  }
   IRS_HIP(hipGetLastError());
 }
 
@@ -667,22 +736,11 @@ irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t e
     check_arg(device_out != nullptr, "null output.");
     const int64_t waves = ceil_div(m, 16) * ceil_div(t->n_items, 64);
     t->prof.begin("user_scores", t->stream);
-    switch (t->KP) {
-      case 16:
-        hipLaunchKernelGGL((user_scores_kernel<16>), dim3(ceil_div(waves, 4)), dim3(256), 0,
-                           t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
-                           t->n_items, device_out);
-        break;
-      case 32:
-        hipLaunchKernelGGL((user_scores_kernel<32>), dim3(ceil_div(waves, 4)), dim3(256), 0,
-                           t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
-                           t->n_items, device_out);
-        break;
-      default:
-        hipLaunchKernelGGL((user_scores_kernel<64>), dim3(ceil_div(waves, 4)), dim3(256), 0,
-                           t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m,
-                           t->n_items, device_out);
-    }
+    IRS_DISPATCH_ANY(t->T, {
+      hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
+                         t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m, t->n_items,
+                         device_out);
+    });
     t->prof.end(t->stream);
     IRS_HIP(hipGetLastError());
   });
@@ -743,7 +801,7 @@ irs_status irs_ials_compute_loss(irs_ials_trainer *t, const irs_ials_solver_conf
     for (int s = 0; s < 2; s++) {
       const int64_t n = t->rows_of(s);
       if (n == 0) continue;
-      IRS_DISPATCH_T(t->T, {
+      IRS_DISPATCH_ANY(t->T, {
         t->prof.begin("loss_rows", t->stream);
         hipLaunchKernelGGL((loss_rows_kernel<TT>), dim3(ceil_div(n, 4)), dim3(256), 0,
                            t->stream, t->factor[s].ptr, t->factor[1 - s].ptr,

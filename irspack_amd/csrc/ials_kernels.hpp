@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <utility>
 
 namespace irs {
 namespace ials {
@@ -90,9 +91,28 @@ template <int T> __device__ __forceinline__ void load_dims(const float *p, float
   } else if constexpr (T == 2) {
     f32x2 t = *reinterpret_cast<const f32x2 *>(p);
     v[0] = t.x; v[1] = t.y;
-  } else {
+  } else if constexpr (T == 1) {
     v[0] = *p;
+  } else {
+    static_assert(T % 4 == 0, "latent dims per lane must be 1, 2 or a multiple of 4");
+#pragma unroll
+    for (int q = 0; q < T / 4; q++) {
+      f32x4 t = *reinterpret_cast<const f32x4 *>(p + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
   }
+}
+
+// (I, J) of the t-th upper tile in row-major order of the T x T tile grid
+template <int T> __host__ __device__ constexpr int tile_i(int t) {
+  int i = 0;
+  while (t >= T - i) { t -= T - i; i++; }
+  return i;
+}
+template <int T> __host__ __device__ constexpr int tile_j(int t) {
+  int i = 0;
+  while (t >= T - i) { t -= T - i; i++; }
+  return i + t;
 }
 
 template <int T> struct Geo {
@@ -101,22 +121,43 @@ template <int T> struct Geo {
   static constexpr int LD = KP + 4;           // LDS row stride (floats); keeps 16 B alignment,
                                               // conflict-free for row-per-lane ds_read_b128
   static constexpr int LDS_FLOATS = KP * LD + KP;
-  static constexpr int PARTIAL_FLOATS = NT * 256 + 64;
+  static constexpr int PARTIAL_FLOATS = NT * 256 + (KP > 64 ? KP : 64);  // tiles + rhs
 };
+
+// One MFMA per owned tile; the tile coordinates are compile-time constants so that
+// the operand arrays stay in registers.
+template <int T, int NW, int W, int S>
+__device__ __forceinline__ void mfma_tile(const float (&cv)[T], const float (&v)[T],
+                                          f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW]) {
+  constexpr int t = NW * S + W;
+  if constexpr (t < Geo<T>::NT)
+    acc[S] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[tile_i<T>(t)], v[tile_j<T>(t)], acc[S], 0, 0, 0);
+}
+template <int T, int NW, int W, int... S>
+__device__ __forceinline__ void mfma_tiles(const float (&cv)[T], const float (&v)[T],
+                                           f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW],
+                                           std::integer_sequence<int, S...>) {
+  (mfma_tile<T, NW, W, S>(cv, v, acc), ...);
+}
 
 // ---------------------------------------------------------------------------
 // Gather + symmetric rank update on the matrix cores.
 // A += sum_q c_q v_q v_q^T (upper tiles), b += sum_q (bias + c_q) v_q.
 // hpp:300-308 (BatchedRankUpdater hpp:37-58 computes the same sum from
 // sqrt(c) v rows; here c is applied to one operand).
-template <int T>
+// NW > 1: the tiles are dealt round-robin to NW waves of a workgroup that all walk
+// the same row (tile t belongs to wave t % NW, local slot t / NW); D = gathered
+// sub-steps kept in flight (a sub-step = 4 stored entries).
+template <int T, int NW = 1, int W = 0, int D = 8>
 __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
                                             const int32_t *__restrict__ indices,
                                             const float *__restrict__ data, int begin,
                                             int end, float bias,
-                                            f32x4 (&acc)[Geo<T>::NT], float (&bsum)[T]) {
+                                            f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW],
+                                            float (&bsum)[T]) {
   constexpr int KP = Geo<T>::KP;
-  constexpr int D = 8;  // gathered sub-steps in flight (a sub-step = 4 stored entries)
+  constexpr int NT = Geo<T>::NT;
+  constexpr int TPW = (NT + NW - 1) / NW;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
   const float *col_base = other + T * m;
@@ -152,14 +193,21 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
       cv[i] = vc[k] * v[k][i];
       bsum[i] = fmaf(vw[k], v[k][i], bsum[i]);
     }
-    int t = 0;
+    if constexpr (NW == 1) {
+      int t = 0;
 #pragma unroll
-    for (int i = 0; i < T; i++)
+      for (int i = 0; i < T; i++)
 #pragma unroll
-      for (int j = i; j < T; j++) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], v[k][j], acc[t], 0, 0, 0);
-        t++;
-      }
+        for (int j = i; j < T; j++) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], v[k][j], acc[t], 0, 0, 0);
+          t++;
+        }
+    } else {
+      float vk[T];
+#pragma unroll
+      for (int i = 0; i < T; i++) vk[i] = v[k][i];
+      mfma_tiles<T, NW, W>(cv, vk, acc, std::make_integer_sequence<int, TPW>{});
+    }
   };
   // Two block-register sets A / B used alternately (no loop-carried copies of a
   // loaded value: a copy would make hipcc drain the gather queue with vmcnt(0)).
@@ -171,19 +219,19 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   for (int k = 0; k < D; k++) fetch(k, a_i, a_c, k, 0);
   __builtin_amdgcn_sched_barrier(0);
   int s0 = 0;  // first sub-step of the current block
+  static_assert(16 % D == 0 && D < 16, "the gather ring must divide the 16 sub-steps of a block");
   auto block = [&](int &cur_i, float &cur_c, const int nxt_i, const float nxt_c) {
 #pragma unroll
-    for (int k = 0; k < D; k++) {  // sub-steps 0..7, fetching 8..15 of this block
-      consume(k);
-      fetch(k, cur_i, cur_c, D + k, 4 * s0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    cur_i = ip[4 * s0 + 128];  // this set is exhausted: reload it with block + 2
-    cur_c = dp[4 * s0 + 128];
-#pragma unroll
-    for (int k = 0; k < D; k++) {  // sub-steps 8..15, fetching 0..7 of the next block
-      consume(k);
-      fetch(k, nxt_i, nxt_c, k, 4 * s0 + 64);
+    for (int j = 0; j < 16; j++) {  // sub-step j of this block; its gather was issued D earlier
+      consume(j % D);
+      if (j + D < 16)
+        fetch(j % D, cur_i, cur_c, j + D, 4 * s0);
+      else
+        fetch(j % D, nxt_i, nxt_c, j + D - 16, 4 * s0 + 64);
+      if (j == 15 - D) {  // last use of this set: reload it with block + 2
+        cur_i = ip[4 * s0 + 128];
+        cur_c = dp[4 * s0 + 128];
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     s0 += 16;
@@ -199,18 +247,20 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   }
   const int cur_i = a_i;
   const float cur_c = a_c;
-  // tail: up to 15 sub-steps of the last block; the first 8 are already in flight
+  // tail: up to 15 sub-steps of the last block; the first D are already in flight
   const int rest = nsub - s0;
+  // (rounds of D: consume what is in flight, then fetch the next D together — loads
+  // under per-sub-step branches would each cost a full vmcnt(0) drain)
 #pragma unroll
-  for (int k = 0; k < D; k++)
-    if (k < rest) consume(k);
-  if (rest > D) {
+  for (int base = 0; base < 15; base += D) {
 #pragma unroll
-    for (int k = 0; k < D - 1; k++)
-      if (D + k < rest) fetch(k, cur_i, cur_c, D + k, 4 * s0);
+    for (int k = 0; k < D; k++)
+      if (base + k < rest) consume(k);
+    if (base + D < 15 && rest > base + D) {
 #pragma unroll
-    for (int k = 0; k < D - 1; k++)
-      if (D + k < rest) consume(k);
+      for (int k = 0; k < D; k++)
+        if (base + D + k < rest) fetch(k, cur_i, cur_c, base + D + k, 4 * s0);
+    }
   }
   // fold the four gathered-row groups: every lane ends with b[T*m + i]
 #pragma unroll

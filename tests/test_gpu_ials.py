@@ -339,3 +339,52 @@ def test_ml100k_shape_parity_c1():
             t2.step(sc)
             o2.step(osc)
         assert rel_err(t2.user, o2.user) < 1e-2
+
+
+@pytest.mark.parametrize("K", [65, 100, 128, 160, 192, 256])
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_large_k_matches_oracle(K, kind):
+    # 64 < K <= 256: workgroup-per-row kernels (KP = 128 / 192 / 256), BASELINE configs[3], [4]
+    X = random_csr(90, 260, 0.25, 21, empty_rows=(7,))
+    mc, omc = build(K, alpha0=0.1, reg=2e-2)
+    sc, osc = solver(kind, steps=3)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    np.testing.assert_array_equal(t.user, o.user)
+    for _ in range(2):
+        t.user, t.item = o.user, o.item
+        t.partial_gramian_async(0)
+        t.finish_gramian_async(0)
+        t.half_step_async(0, sc)
+        t.synchronize()
+        o.step(osc)
+        assert rel_err(t.user, o.user) < RTOL
+        t.user = o.user
+        t.partial_gramian_async(1)
+        t.finish_gramian_async(1)
+        t.half_step_async(1, sc)
+        t.synchronize()
+        assert rel_err(t.item, o.item) < RTOL
+    b, e = 3, 77
+    assert rel_err(t.user_scores(b, e, sc), o.user_scores(b, e, osc)) < RTOL
+    assert t.compute_loss(sc) == pytest.approx(o.compute_loss(osc), rel=1e-4)
+    assert rel_err(t.transform_user(X[:9], sc), o.transform_user(X[:9], osc)) < 1e-3
+
+
+def test_large_k_split_rows():
+    rng = np.random.default_rng(5)
+    n_u, n_i = 12, 3000
+    rows = [np.sort(rng.choice(n_i, size=d, replace=False)) for d in [2600, 1500, 1025, 1024, 300, 64, 5, 0, 1, 2, 3, 700]]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    X = sps.csr_matrix((rng.uniform(0.5, 2.0, size=indptr[-1]).astype(np.float32),
+                        np.concatenate(rows).astype(np.int32), indptr), shape=(n_u, n_i))
+    for kind in ["CHOLESKY", "CG"]:
+        mc, omc = build(128, alpha0=0.05, reg=1e-2)
+        sc, osc = solver(kind)
+        t, o = IALSTrainer(mc, X), O.IALSTrainer(omc, X)
+        t.partial_gramian_async(0)
+        t.finish_gramian_async(0)
+        t.half_step_async(0, sc)
+        t.synchronize()
+        o.step(osc)
+        assert rel_err(t.user, o.user) < RTOL
