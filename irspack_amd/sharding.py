@@ -12,13 +12,15 @@ factor matrices and, per half-epoch, takes part in
      contiguous shard; with RCCL over xGMI every shard leaves on its own links).
 
 Collectives go through ``torch.distributed`` (backend "nccl" = RCCL on ROCm,
-"gloo" in the CPU tests); the arithmetic is behind a small ``LocalSolver``
-interface whose product implementation (``HipLocalSolver``) drives the HIP
-library.  Results equal the single-GPU ones up to the summation order of the
-Gramian.
+"gloo" in the CPU tests) and run IN PLACE on torch views of the solver's own
+buffers (zero-copy: the HIP library's device memory is wrapped through
+``__cuda_array_interface__``), so no staging copies sit between the kernels and
+the wire.  The arithmetic is behind a small ``LocalSolver`` interface whose
+product implementation (``HipLocalSolver``) drives the HIP library.  Results equal
+the single-GPU ones up to the summation order of the Gramian.
 """
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 import scipy.sparse as sps
@@ -58,29 +60,37 @@ def shard_bounds(X: sps.csr_matrix, K: int, solver: str, world: int) -> Tuple[Li
 class LocalSolver:
     """What the host loop needs from one rank's device (or, in tests, from the oracle)."""
 
-    ld: int  # leading dimension of the factor / Gramian buffers
-
-    def new_buffer(self, rows: int):  # -> torch.Tensor [rows, ld] float32 on the solver's device
+    def factor_view(self, which: int):
+        """torch tensor [rows, ld] ALIASING the solver's factor matrix (0 user, 1 item)."""
         raise NotImplementedError
 
-    def partial_gramian(self, side: int, out) -> None:
-        """out[ld, ld] = sum over this rank's rows of the *other* side of f f^T (unscaled)."""
+    def gramian_view(self, side: int):
+        """torch tensor [ld, ld] aliasing the Gramian accumulator of the solve of `side`."""
         raise NotImplementedError
 
-    def set_gramian(self, side: int, total) -> None:
+    def partial_gramian(self, side: int) -> None:
+        """gramian_view(side) <- sum over this rank's rows of the *other* side of f f^T."""
+        raise NotImplementedError
+
+    def finish_gramian(self, side: int) -> None:
+        """Scale the (all-reduced) gramian_view(side) by alpha0 and make it the solve's P."""
         raise NotImplementedError
 
     def half_step(self, side: int, solver_config) -> None:
         raise NotImplementedError
 
-    def export_rows(self, which: int, begin: int, end: int, out) -> None:
-        raise NotImplementedError
-
-    def import_rows(self, which: int, begin: int, end: int, src) -> None:
-        raise NotImplementedError
-
     def synchronize(self) -> None:
         raise NotImplementedError
+
+
+class _DeviceArray:
+    """Minimal ``__cuda_array_interface__`` carrier for a float32 [rows, ld] device buffer."""
+
+    def __init__(self, ptr: int, rows: int, ld: int) -> None:
+        self.__cuda_array_interface__ = {
+            "shape": (rows, ld), "typestr": "<f4", "data": (ptr, False), "version": 2,
+            "strides": None,
+        }
 
 
 class HipLocalSolver(LocalSolver):
@@ -96,27 +106,28 @@ class HipLocalSolver(LocalSolver):
         torch.cuda.set_device(self.device)
         self.trainer = IALSTrainer(model_config, X, device=device, shard=shard)
         self.trainer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
-        _, _, self.ld = self.trainer.device_buffer(0)
+        self._views = {}
+        for which in range(4):
+            ptr, rows, ld = self.trainer.device_buffer(which)
+            if rows * ld == 0:
+                self._views[which] = torch.empty((rows, ld), dtype=torch.float32, device=self.device)
+            else:
+                self._views[which] = torch.as_tensor(_DeviceArray(ptr, rows, ld), device=self.device)
 
-    def new_buffer(self, rows: int):
-        return self.torch.empty((rows, self.ld), dtype=self.torch.float32, device=self.device)
+    def factor_view(self, which: int):
+        return self._views[which]
 
-    def partial_gramian(self, side: int, out) -> None:
+    def gramian_view(self, side: int):
+        return self._views[2 + side]
+
+    def partial_gramian(self, side: int) -> None:
         self.trainer.partial_gramian_async(side)
-        self.trainer.copy_rows_async(2 + side, 0, self.ld, out.data_ptr(), True)
 
-    def set_gramian(self, side: int, total) -> None:
-        self.trainer.copy_rows_async(2 + side, 0, self.ld, total.data_ptr(), False)
+    def finish_gramian(self, side: int) -> None:
         self.trainer.finish_gramian_async(side)
 
     def half_step(self, side: int, solver_config) -> None:
         self.trainer.half_step_async(side, solver_config)
-
-    def export_rows(self, which: int, begin: int, end: int, out) -> None:
-        self.trainer.copy_rows_async(which, begin, end, out.data_ptr(), True)
-
-    def import_rows(self, which: int, begin: int, end: int, src) -> None:
-        self.trainer.copy_rows_async(which, begin, end, src.data_ptr(), False)
 
     def synchronize(self) -> None:
         self.trainer.synchronize()
@@ -139,40 +150,28 @@ class ShardedIALSTrainer:
             self.rank, self.world = 0, 1
         assert len(user_bounds) == self.world + 1 and len(item_bounds) == self.world + 1
         self.bounds = (list(user_bounds), list(item_bounds))
-        self._gram = local.new_buffer(local.ld)
-        self._shards = [
-            [local.new_buffer(max(b[r + 1] - b[r], 1)) for r in range(self.world)]
-            for b in self.bounds
-        ]
 
     def half_epoch(self, side: int, solver_config) -> None:
         dist, local = self.dist, self.local
-        # (1) Gramian of the other side: own rows, then sum over ranks
-        local.partial_gramian(side, self._gram)
+        # (1) Gramian of the other side: own rows, then sum over ranks (K x K, latency bound)
+        local.partial_gramian(side)
         if self.world > 1:
-            dist.all_reduce(self._gram, op=dist.ReduceOp.SUM, group=self.group)
-        local.set_gramian(side, self._gram)
+            dist.all_reduce(local.gramian_view(side), op=dist.ReduceOp.SUM, group=self.group)
+        local.finish_gramian(side)
         # (2) solve this rank's rows of `side`
         local.half_step(side, solver_config)
-        # (3) every rank broadcasts its freshly solved shard to all replicas
+        # (3) all-gather with uneven shards: every rank broadcasts its freshly solved rows
+        #     straight into the replicas (in place on views of the factor matrix)
         if self.world > 1:
             b = self.bounds[side]
+            view = local.factor_view(side)
             works = []
             for r in range(self.world):
-                n = b[r + 1] - b[r]
-                if n == 0:
-                    continue
-                buf = self._shards[side][r][:n]
-                if r == self.rank:
-                    local.export_rows(side, b[r], b[r + 1], buf)
-                works.append(dist.broadcast(buf, src=self._global_rank(r), group=self.group,
-                                            async_op=True))
+                if b[r + 1] > b[r]:
+                    works.append(dist.broadcast(view[b[r]:b[r + 1]], src=self._global_rank(r),
+                                                group=self.group, async_op=True))
             for w in works:
                 w.wait()
-            for r in range(self.world):
-                n = b[r + 1] - b[r]
-                if n and r != self.rank:
-                    local.import_rows(side, b[r], b[r + 1], self._shards[side][r][:n])
 
     def _global_rank(self, group_rank: int) -> int:
         if self.group is None:

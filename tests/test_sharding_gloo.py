@@ -27,7 +27,7 @@ class OracleLocalSolver(LocalSolver):
         import torch
 
         self.O, self.torch = O, torch
-        self.mc, self.K, self.ld = omc, K, K
+        self.mc, self.K = omc, K
         self.X = [sps.csr_matrix(X, dtype=np.float32), sps.csr_matrix(X.T, dtype=np.float32)]
         for m in self.X:
             m.sort_indices()
@@ -35,34 +35,34 @@ class OracleLocalSolver(LocalSolver):
         U, I = X.shape
         self.factor = [O.ials_init(U, K, omc.init_stdev, omc.random_seed),
                        O.ials_init(I, K, omc.init_stdev, omc.random_seed)]
+        self.G = [np.zeros((K, K), np.float32), np.zeros((K, K), np.float32)]
         self.P = [np.zeros((K, K), np.float32), np.zeros((K, K), np.float32)]
+        # torch views alias the numpy buffers, like the product's device views
+        self._fv = [torch.from_numpy(f) for f in self.factor]
+        self._gv = [torch.from_numpy(g) for g in self.G]
 
     def _range(self, which):
         return (self.shard[0], self.shard[1]) if which == 0 else (self.shard[2], self.shard[3])
 
-    def new_buffer(self, rows):
-        return self.torch.zeros((rows, self.ld), dtype=self.torch.float32)
+    def factor_view(self, which):
+        return self._fv[which]
 
-    def partial_gramian(self, side, out):
+    def gramian_view(self, side):
+        return self._gv[side]
+
+    def partial_gramian(self, side):
         b, e = self._range(1 - side)
         F = self.factor[1 - side][b:e]
-        G = self.O.ials_gramian(F, 1.0, 1) if e > b else np.zeros((self.K, self.K), np.float32)
-        out.copy_(self.torch.from_numpy(G))
+        self.G[side][...] = self.O.ials_gramian(F, 1.0, 1) if e > b else 0.0
 
-    def set_gramian(self, side, total):
-        self.P[side] = (np.float32(self.mc.alpha0) * total.numpy()).astype(np.float32)
+    def finish_gramian(self, side):
+        self.P[side] = (np.float32(self.mc.alpha0) * self.G[side]).astype(np.float32)
 
     def half_step(self, side, sc):
         b, e = self._range(side)
-        self.factor[side] = self.O.ials_solver_step(self.factor[side], self.X[side],
-                                                    self.factor[1 - side], self.P[side], self.mc,
-                                                    sc, b, e)
-
-    def export_rows(self, which, begin, end, out):
-        out.copy_(self.torch.from_numpy(self.factor[which][begin:end]))
-
-    def import_rows(self, which, begin, end, src):
-        self.factor[which][begin:end] = src.numpy()
+        self.factor[side][...] = self.O.ials_solver_step(self.factor[side], self.X[side],
+                                                         self.factor[1 - side], self.P[side],
+                                                         self.mc, sc, b, e)
 
     def synchronize(self):
         pass
