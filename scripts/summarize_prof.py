@@ -35,6 +35,24 @@ def main():
     stats = glob.glob(os.path.join(SRC, "kt", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
+    # the user and the item half-step launch the SAME kernel symbol with different grids:
+    # split the trace by grid so that each average can be set against bench.py's per-side
+    # HIP-event numbers (the larger MODE-0 grid is the user side)
+    trace = glob.glob(os.path.join(SRC, "kt", "*", "*_kernel_trace.csv"))
+    if trace:
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace[0])):
+            if "irs::" in r["Kernel_Name"]:
+                by[(r["Kernel_Name"], int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]),
+                    int(r["VGPR_Count"]), int(r["LDS_Block_Size"]))].append(
+                        int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        with open(os.path.join(DST, f"{TAG}_bench_kernel_by_grid.csv"), "w", newline="") as fh:
+            wr = csv.writer(fh)
+            wr.writerow(["Name", "Grid_Size", "Workgroup_Size", "VGPRs", "LDS_Bytes", "Calls",
+                         "AverageNs", "MinNs", "MaxNs"])
+            for (name, grid, wg, vgpr, lds), d in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+                wr.writerow([name, grid, wg, vgpr, lds, len(d), round(sum(d) / len(d), 1),
+                             min(d), max(d)])
     out = {"units": "bytes per launch", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2",
            "write_correction": "WRITE_SIZE KiB x 1024", "kernels": {}}
     fetch = glob.glob(os.path.join(SRC, "fetch", "*", "*_counter_collection.csv"))
