@@ -35,8 +35,10 @@ constexpr int MERGE_CAP = 4096; // candidates a row merge can hold
 constexpr int THREADS = 1024;
 
 struct Params {
-  // X_arg^T by rows u: (column j, value x) sorted by j
-  const int64_t *xt_ptr;
+  // X_arg^T by rows u: (column j, value x) sorted by j; xt_tptr[u * (n_tiles + 1) + t]
+  // is the position of the first entry of row u with column >= t * TILE (the last one is
+  // the row end), so a (row, tile) workgroup walks exactly its own slice of every row
+  const int64_t *xt_tptr;
   const int32_t *xt_idx;
   const double *xt_val;
   const double *norms;  // per column j
@@ -62,6 +64,15 @@ struct Params {
   double *out_val;
   int32_t *out_cnt;    // [n_rows]
 };
+
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int src) {
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), src);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32), src);
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  return __longlong_as_double(readlane_i64(__double_as_longlong(v), src));
+}
 
 __device__ __forceinline__ uint64_t order_key(double s) {
   if (s != s) return 0ull;
@@ -96,16 +107,22 @@ __device__ __forceinline__ double epilogue(const Params &p, double v, double nor
   }
 }
 
+// touched-ness of a column without a bitmap atomic: accumulators start at -0.0, and
+// -0.0 + x is x for every x that is not itself -0.0, so a column stays at the bit
+// pattern of -0.0 exactly when nothing (or only -0.0 products) was added.  The host
+// selects this only when no product can be a zero (no stored zeros, no underflow);
+// otherwise the bitmap is maintained with atomics next to the sums.
+constexpr uint64_t NEG_ZERO_BITS = 0x8000000000000000ull;
+
+template <bool ONES, bool SENTINEL>
 __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *acc = reinterpret_cast<double *>(smem);                        // TILE
   uint32_t *bits = reinterpret_cast<uint32_t *>(acc + TILE);             // TILE / 32
-  uint64_t *sel_key = reinterpret_cast<uint64_t *>(bits + TILE / 32);    // TOPK_CAP
-  int32_t *sel_idx = reinterpret_cast<int32_t *>(sel_key + TOPK_CAP);    // TOPK_CAP
-  uint32_t *hist = reinterpret_cast<uint32_t *>(sel_idx + TOPK_CAP);     // 256
+  uint32_t *hist = bits + TILE / 32;                                     // 256
   int32_t *wave_cnt = reinterpret_cast<int32_t *>(hist + 256);           // 16
   __shared__ uint64_t sh_prefix;
-  __shared__ int32_t sh_need, sh_count, sh_tie_base, sh_total;
+  __shared__ int32_t sh_need, sh_count, sh_total;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NW = THREADS / 64;
@@ -114,32 +131,123 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   const int c0 = tile * TILE, c1 = min(c0 + TILE, p.N);
   const int width = c1 - c0;
 
-  for (int i = tid; i < width; i += THREADS) acc[i] = 0.0;
-  for (int i = tid; i < (width + 31) / 32; i += THREADS) bits[i] = 0u;
+  for (int i = tid; i < width; i += THREADS) acc[i] = SENTINEL ? -0.0 : 0.0;
+  for (int i = tid; i < TILE / 32; i += THREADS) bits[i] = 0u;
   __syncthreads();
 
-  // ---- 1. accumulate: one wave per stored (u, y) of the target row
-  const int64_t tb = p.t_ptr[r], te = p.t_ptr[r + 1];
-  for (int64_t q = tb + wv; q < te; q += NW) {
-    const int32_t u = p.t_idx[q];
-    const double y = p.t_val[q];
-    int64_t lo = p.xt_ptr[u], hi = p.xt_ptr[u + 1];
-    const int64_t row_end = hi;
-    if (p.n_tiles > 1) {  // lower_bound of c0 in the sorted column list
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (p.xt_idx[mid] < c0) lo = mid + 1; else hi = mid;
+  // ---- 1. accumulate.  A wave takes 16 stored (u, y) of the target row at a time: lanes
+  //      0..15 own one each.  The walk is latency bound (t_idx -> slice bounds -> columns
+  //      -> LDS atomic), so it is software pipelined two blocks deep: while block b is
+  //      multiplied, the slice bounds of block b+1 and the (u, y) of block b+2 are in
+  //      flight, and the first 64 entries of all 16 slices of a block are loaded before
+  //      the first LDS atomic is issued (most slices end there; longer ones finish in a
+  //      strip loop).  Bounds travel by v_readlane, so a strip costs an address add, a
+  //      compare, the load(s) and the atomic.
+  auto add = [&](int32_t j, double v) {
+    if (j >= 0) {
+      atomicAdd(&acc[j], v);
+      if (!SENTINEL) {
+        const uint32_t bit = 1u << (j & 31);
+        if (!(bits[j >> 5] & bit)) atomicOr(&bits[j >> 5], bit);
       }
     }
-    for (int64_t e = lo + lane; e < row_end; e += 64) {
+  };
+  const int64_t tb = p.t_ptr[r], te = p.t_ptr[r + 1];
+  const int tp_stride = p.n_tiles + 1;
+  const int64_t stride = 16 * NW;
+  // every load below is unconditional (clamped address, result masked afterwards): a load
+  // under a branch makes hipcc drain the whole vector-memory queue (s_waitcnt vmcnt(0))
+  // right behind it, which would serialise the pipeline
+  auto load_uy = [&](int64_t q0, int64_t &u, double &y, bool &v) {
+    const int64_t q = q0 + lane;
+    v = lane < 16 && q < te;
+    const int64_t qc = min(q, te - 1);  // te > tb here
+    u = p.t_idx[qc];
+    y = p.t_val[qc];
+  };
+  auto load_bounds = [&](int64_t u, bool v, int64_t &lo, int &len) {
+    const int64_t *tp = p.xt_tptr + u * tp_stride + tile;
+    lo = tp[0];
+    int64_t hi = tp[1];
+    asm volatile("" : "+v"(hi));  // keep the load out of the select below (see above)
+    len = v ? static_cast<int>(hi - lo) : 0;
+  };
+  int64_t u1 = 0, lo = 0;
+  double y = 0.0, y1 = 0.0;
+  int len = 0;
+  bool v1 = false;
+  if (te > tb) {
+    load_uy(tb + 16 * wv, u1, y, v1);
+    load_bounds(u1, v1, lo, len);
+    load_uy(tb + 16 * wv + stride, u1, y1, v1);
+  }
+  for (int64_t q0 = tb + 16 * wv; q0 < te; q0 += stride) {
+    int64_t lo_n, u2;
+    int len_n;
+    double y2;
+    bool v2;
+    load_bounds(u1, v1, lo_n, len_n);
+    load_uy(q0 + 2 * stride, u2, y2, v2);
+    int32_t jj[16];
+    double prod[ONES ? 1 : 16];
+#pragma unroll
+    for (int uu = 0; uu < 16; uu++) {  // lanes past the end of the row hold len = 0
+      const int64_t lo_u = readlane_i64(lo, uu);
+      const int len_u = __builtin_amdgcn_readlane(len, uu);
+      const int64_t e = lo_u + min(lane, max(len_u - 1, 0));  // xt_idx / xt_val are padded
       const int32_t j = p.xt_idx[e];
-      if (j >= c1) break;
-      const int jj = j - c0;
-      atomicAdd(&acc[jj], __dmul_rn(p.xt_val[e], y));
-      atomicOr(&bits[jj >> 5], 1u << (jj & 31));
+      jj[uu] = lane < len_u ? j - c0 : -1;
+      if (!ONES) prod[uu] = p.xt_val[e];
     }
+#pragma unroll
+    for (int uu = 0; uu < 16; uu++) {
+      const double y_u = readlane_f64(y, uu);
+      // ONES: x == 1 exactly, x * y == y and the value stream is never read
+      add(jj[uu], ONES ? y_u : __dmul_rn(prod[ONES ? 0 : uu], y_u));
+    }
+    if (__any(len > 64)) {
+      for (int uu = 0; uu < 16; uu++) {
+        const int len_u = __builtin_amdgcn_readlane(len, uu);
+        if (len_u <= 64) continue;
+        const int64_t lo_u = readlane_i64(lo, uu);
+        const double y_u = readlane_f64(y, uu);
+        for (int off = 64 + lane; off < len_u; off += 128) {
+          const bool ok2 = off + 64 < len_u;
+          const int off2 = min(off + 64, len_u - 1);
+          const int32_t j1 = p.xt_idx[lo_u + off] - c0;
+          int32_t j2 = p.xt_idx[lo_u + off2] - c0;
+          double w1 = y_u, w2 = y_u;
+          if (!ONES) {
+            w1 = __dmul_rn(p.xt_val[lo_u + off], y_u);
+            w2 = __dmul_rn(p.xt_val[lo_u + off2], y_u);
+          }
+          j2 = ok2 ? j2 : -1;
+          add(j1, w1);
+          add(j2, w2);
+        }
+      }
+    }
+    lo = lo_n;
+    len = len_n;
+    y = y1;
+    u1 = u2;
+    y1 = y2;
+    v1 = v2;
   }
   __syncthreads();
+  if (SENTINEL) {  // derive the bitmap from the sums (64 columns per wave step)
+    for (int base = wv * 64; base < width; base += NW * 64) {
+      const int i = base + lane;
+      const bool touched =
+          i < width && static_cast<uint64_t>(__double_as_longlong(acc[i])) != NEG_ZERO_BITS;
+      const unsigned long long bal = __ballot(touched);
+      if (lane == 0) {
+        bits[base >> 5] = static_cast<uint32_t>(bal);
+        bits[(base >> 5) + 1] = static_cast<uint32_t>(bal >> 32);
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- 2. epilogue on the stored entries; count them
   const double tstat = p.t_stat[r];
@@ -181,40 +289,87 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
       if (tid < 256) hist[tid] = 0;
       __syncthreads();
       const uint64_t hi_mask = (shift + 8 >= 64) ? 0ull : (~0ull << (shift + 8));
-      for (int i = tid; i < width; i += THREADS) {
-        if (!stored(i)) continue;
-        const uint64_t k = order_key(acc[i]);
-        if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(k >> shift) & 0xff], 1u);
+      for (int base = 0; base < width; base += THREADS) {
+        const int i = base + tid;
+        bool in = false;
+        uint32_t digit = 0;
+        if (i < width && stored(i)) {
+          const uint64_t k = order_key(acc[i]);
+          in = (k & hi_mask) == (prefix & hi_mask);
+          digit = static_cast<uint32_t>(k >> shift) & 0xffu;
+        }
+        // similarities share their leading bytes: when every candidate lane of the wave
+        // has the same digit, one lane adds the count (no same-address atomic storm);
+        // otherwise the digits are spread and per-lane atomics are cheap
+        const unsigned long long todo = __ballot(in);
+        if (todo) {
+          const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+          const uint32_t d = __builtin_amdgcn_readlane(digit, leader);
+          const unsigned long long same = __ballot(in && digit == d);
+          if (same == todo) {
+            if (lane == leader) atomicAdd(&hist[d], static_cast<uint32_t>(__popcll(same)));
+          } else if (in) {
+            atomicAdd(&hist[digit], 1u);
+          }
+        }
       }
       __syncthreads();
-      if (tid == 0) {
-        int a = 0, d = 255;
-        for (; d >= 0; d--) {
-          if (a + static_cast<int>(hist[d]) >= need) break;
-          a += hist[d];
+      // the digit d with  #(digits > d) < need <= #(digits >= d): scan the bins in
+      // descending digit order with the first four waves
+      int bin = 0, incl = 0;
+      if (tid < 256) {
+        bin = static_cast<int>(hist[255 - tid]);
+        incl = bin;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += t;
         }
-        sh_prefix = prefix | (static_cast<uint64_t>(d) << shift);
-        sh_need = need - a;
+        if (lane == 63) wave_cnt[wv] = incl;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        for (int w = 0; w < wv; w++) incl += wave_cnt[w];
+        const int excl = incl - bin;
+        if (excl < need && incl >= need) {
+          sh_prefix = prefix | (static_cast<uint64_t>(255 - tid) << shift);
+          // the whole bin is wanted: every key >= the bin's lowest possible key is taken
+          // and no further digit has to be resolved (-1 tells the loop to stop)
+          sh_need = (incl == need) ? -1 : need - excl;
+        }
       }
       __syncthreads();
       prefix = sh_prefix;
       need = sh_need;
       __syncthreads();
+      if (need < 0) break;
+    }
+    if (need < 0) {
+      if (prefix == 0) {  // lowest possible key: nothing is excluded, everything else ties
+        need = n_sel;
+      } else {
+        prefix -= 1;  // k > prefix - 1  <=>  k >= prefix
+        need = 0;
+      }
     }
   } else {
     prefix = 0;  // everything is taken: treat every key as "greater than threshold"
     need = 0;
   }
   const bool take_all = n_sel >= n_stored;
-  if (tid == 0) {
-    sh_count = 0;
-    sh_tie_base = 0;
-  }
+  if (tid == 0) sh_count = 0;
   __syncthreads();
-  for (int base = 0; base < width; base += THREADS) {
-    const int i = base + tid;
+  // wave w owns the contiguous columns [w * span, (w + 1) * span) in 64-wide steps, so
+  // (wave, step, lane) order is column order.  Sweep 1 appends every key above the
+  // threshold (any order; the merge sorts) and counts this wave's ties; sweep 2 hands the
+  // `need` lowest-index ties their slots (knn.hpp:119-136: index-ordered on equal values).
+  const int span = ((width + NW * 64 - 1) / (NW * 64)) * 64;
+  const int wbeg = wv * span, wend = min(wbeg + span, width);
+  int my_ties = 0;
+  for (int base = wbeg; base < wend; base += 64) {
+    const int i = base + lane;
     bool tie = false;
-    if (i < width && stored(i)) {
+    if (i < wend && stored(i)) {
       const uint64_t k = order_key(acc[i]);
       if (take_all || k > prefix) {
         const int pos = atomicAdd(&sh_count, 1);
@@ -224,22 +379,24 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
         tie = true;
       }
     }
+    my_ties += __popcll(__ballot(tie));
+  }
+  if (take_all) return;
+  if (lane == 0) wave_cnt[wv] = my_ties;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wv; w++) before += wave_cnt[w];
+  for (int base = wbeg; base < wend && before < need; base += 64) {
+    const int i = base + lane;
+    const bool tie = i < wend && stored(i) && order_key(acc[i]) == prefix;
     const unsigned long long bal = __ballot(tie);
-    if (lane == 0) wave_cnt[wv] = __popcll(bal);
-    __syncthreads();
-    int before_me = sh_tie_base, total = 0;
-    for (int w = 0; w < NW; w++) {
-      if (w < wv) before_me += wave_cnt[w];
-      total += wave_cnt[w];
-    }
-    const int rank = before_me + __popcll(bal & ((1ull << lane) - 1ull));
+    const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
     if (tie && rank < need) {
       const int pos = atomicAdd(&sh_count, 1);
       cidx[pos] = c0 + i;
       cval[pos] = acc[i];
     }
-    __syncthreads();
-    if (tid == 0) sh_tie_base += total;
+    before += __popcll(bal);
   }
 }
 
@@ -378,9 +535,11 @@ struct irs_knn_computer {
   double shrinkage = 0, alpha = 0, beta = 0;
   bool normalize = false;
   std::vector<int64_t> xt_row_len;  // host: stored entries per feature row (work model)
-  DeviceBuffer<int64_t> xt_ptr;
+  DeviceBuffer<int64_t> xt_tptr;  // [n_features, n_tiles + 1], see Params
   DeviceBuffer<int32_t> xt_idx;
   DeviceBuffer<double> xt_val, norms;
+  bool xt_all_ones = false;
+  bool xt_nonzero = false;  // |x| in (1e-150, 1e150) for every stored x
   // last result (host)
   std::vector<int64_t> res_ptr;
   std::vector<int32_t> res_idx;
@@ -463,9 +622,31 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     c->xt_row_len.resize(Xt.rows);
     for (int64_t u = 0; u < Xt.rows; u++) c->xt_row_len[u] = Xt.indptr[u + 1] - Xt.indptr[u];
     hipStream_t s = nullptr;
-    c->xt_ptr.upload(Xt.indptr, s);
-    c->xt_idx.upload(Xt.indices, s);
-    c->xt_val.upload(Xt.data, s);
+    {
+      const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
+      std::vector<int64_t> tptr(static_cast<size_t>(Xt.rows) * (n_tiles + 1));
+      for (int64_t u = 0; u < Xt.rows; u++) {
+        const int32_t *b = Xt.indices.data() + Xt.indptr[u], *e = Xt.indices.data() + Xt.indptr[u + 1];
+        int64_t *dst = tptr.data() + u * (n_tiles + 1);
+        for (int64_t t = 0; t < n_tiles; t++)
+          dst[t] = Xt.indptr[u] + (std::lower_bound(b, e, static_cast<int32_t>(t * TILE)) - b);
+        dst[n_tiles] = Xt.indptr[u + 1];
+      }
+      c->xt_tptr.upload(tptr, s);
+    }
+    {  // one padding entry: the accumulate loop reads position `row end` of an empty slice
+      std::vector<int32_t> idx_p(Xt.indices);
+      std::vector<double> val_p(Xt.data);
+      idx_p.push_back(0);
+      val_p.push_back(0.0);
+      c->xt_idx.upload(idx_p, s);
+      c->xt_val.upload(val_p, s);
+    }
+    c->xt_all_ones = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) { return v == 1.0; });
+    c->xt_nonzero = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) {
+      const double a = std::fabs(v);
+      return a > 1e-150 && a < 1e150;
+    });
     c->norms.upload(norms, s);
     IRS_HIP(hipStreamSynchronize(s));
     *out = c.release();
@@ -575,7 +756,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     out_val.alloc(static_cast<size_t>(n) * out_k);
     out_cnt.alloc(n);
     Params p;
-    p.xt_ptr = c->xt_ptr.ptr;
+    p.xt_tptr = c->xt_tptr.ptr;
     p.xt_idx = c->xt_idx.ptr;
     p.xt_val = c->xt_val.ptr;
     p.norms = c->norms.ptr;
@@ -600,15 +781,30 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     p.out_val = out_val.ptr;
     p.out_cnt = out_cnt.ptr;
     const size_t lds = TILE * sizeof(double) + (TILE / 32) * sizeof(uint32_t) +
-                       TOPK_CAP * (sizeof(uint64_t) + sizeof(int32_t)) + 256 * sizeof(uint32_t) +
-                       16 * sizeof(int32_t);
-    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_tile_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+                       256 * sizeof(uint32_t) + 16 * sizeof(int32_t);
+    // -0.0 sentinel instead of bitmap atomics unless some product could be a zero
+    auto safe = [](const std::vector<double> &v) {
+      return std::all_of(v.begin(), v.end(), [](double x) {
+        const double a = std::fabs(x);
+        return a > 1e-150 && a < 1e150;  // no stored zero, no underflow of x * y
+      });
+    };
+    const bool sentinel = c->xt_nonzero && safe(T.data);
+    auto launch = [&](auto kernel) {
+      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds)));
+      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(slots)), dim3(THREADS), lds, s, p);
+    };
     hipEvent_t ev0, ev1;
     IRS_HIP(hipEventCreate(&ev0));
     IRS_HIP(hipEventCreate(&ev1));
     IRS_HIP(hipEventRecord(ev0, s));
-    hipLaunchKernelGGL(knn_tile_kernel, dim3(static_cast<unsigned>(slots)), dim3(THREADS), lds, s, p);
+    if (c->xt_all_ones) {
+      if (sentinel) launch(knn_tile_kernel<true, true>); else launch(knn_tile_kernel<true, false>);
+    } else {
+      if (sentinel) launch(knn_tile_kernel<false, true>); else launch(knn_tile_kernel<false, false>);
+    }
     hipLaunchKernelGGL(knn_merge_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, s, p);
     IRS_HIP(hipEventRecord(ev1, s));
     IRS_HIP(hipGetLastError());
