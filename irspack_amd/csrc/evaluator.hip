@@ -2,7 +2,8 @@
 // get_metrics_local / Metrics::update of /root/reference/cpp_source/evaluator.cpp
 // (:256-284, :292-367, :127-166) behind include/irspack_amd.h.
 //
-// One 256-thread workgroup ranks one user row:
+// One workgroup ranks one user row (1024 threads with the row's keys cached in LDS when
+// they fit, else 256 threads re-reading the scores per pass):
 //   1. candidates = all items | global list | per-user list, score != -inf (:324-348)
 //   2. top-`cutoff` by the total order (score desc, index asc) — the order
 //      std::partial_sort gives on (-score, index) pairs (:329, :353-355):
@@ -70,17 +71,32 @@ struct EvalParams {
   unsigned long long *item_cnt;
 };
 
-template <class T>
-__global__ __launch_bounds__(256) void rank_rows_kernel(EvalParams p) {
+// key value no score maps to (it is the image of a negative NaN pattern, and NaNs are
+// canonicalised to 0): marks "not rankable" (-inf) in the cached keys
+constexpr uint64_t KEY_SKIP = 1ull;
+template <class T> struct KeyStore;
+template <> struct KeyStore<float> { using type = uint32_t; };
+template <> struct KeyStore<double> { using type = uint64_t; };
+
+// NT threads per user row.  CACHED: the row's keys are computed once into dynamic LDS
+// (one pass over the scores in HBM instead of one per radix digit and sweep); used when
+// the candidate count fits, with NT = 1024.  Otherwise every pass re-reads the scores.
+template <class T, int NT, bool CACHED>
+__global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
+  using KeyT = typename KeyStore<T>::type;
+  constexpr int NWV = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char rank_dyn[];
+  KeyT *keys = reinterpret_cast<KeyT *>(rank_dyn);
   __shared__ uint32_t hist[256];
   __shared__ uint64_t sel_key[SEL_CAP];
   __shared__ int32_t sel_idx[SEL_CAP];
   __shared__ uint8_t sel_hit[SEL_CAP];
-  __shared__ int32_t scan_buf[256];
+  __shared__ int32_t scan_buf[NWV > 4 ? NWV : 4];
   __shared__ uint64_t sh_prefix;
-  __shared__ int32_t sh_need, sh_count, sh_tie_base;
+  __shared__ int32_t sh_need, sh_count;
 
   const int tid = threadIdx.x;
+  const int wv = tid >> 6, ln = tid & 63;
   const int64_t row = blockIdx.x;
   const int64_t u = row + p.offset;
   const T *srow = static_cast<const T *>(p.scores) + row * p.n_items;
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(EvalParams p) {
   const int gb = p.gt_ptr[u], ge = p.gt_ptr[u + 1];
   const int n_gt = ge - gb;
   int32_t *rec_row = p.rec_out + row * p.cutoff;
-  for (int i = tid; i < p.cutoff; i += 256) rec_row[i] = -1;
+  for (int i = tid; i < p.cutoff; i += NT) rec_row[i] = -1;
   if (n_gt == 0) {  // counted in total_user only (:316-321)
     if (tid == 0) p.out[row] = res;
     return;
@@ -106,17 +122,38 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(EvalParams p) {
     list = p.rec_items + cb;
   }
   auto item_of = [&](int64_t j) -> int32_t { return list ? list[j] : static_cast<int32_t>(j); };
+  auto key_from_scores = [&](int64_t j) -> uint64_t {
+    const T s = srow[item_of(j)];
+    return is_neg_inf(s) ? KEY_SKIP : order_key(s);
+  };
+  auto key_at = [&](int64_t j) -> uint64_t {
+    return CACHED ? static_cast<uint64_t>(keys[j]) : key_from_scores(j);
+  };
 
-  // --- count rankable candidates
+  // --- count rankable candidates (and fill the key cache).  Eight independent loads per
+  //     thread are issued before the first use (clamped index, result masked) so the one
+  //     pass over the scores in HBM is not a chain of exposed latencies.
   int local = 0;
-  for (int64_t j = tid; j < n_cand; j += 256) local += !is_neg_inf(srow[item_of(j)]);
-  scan_buf[tid] = local;
-  __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
-    if (tid < off) scan_buf[tid] += scan_buf[tid + off];
-    __syncthreads();
+  for (int64_t base = 0; base < n_cand; base += NT * 8) {
+    T sv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) sv[q] = srow[item_of(min<int64_t>(base + q * NT + tid, n_cand - 1))];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int64_t j = base + q * NT + tid;
+      if (j < n_cand) {
+        const uint64_t k = is_neg_inf(sv[q]) ? KEY_SKIP : order_key(sv[q]);
+        if (CACHED) keys[j] = static_cast<KeyT>(k);
+        local += k != KEY_SKIP;
+      }
+    }
   }
-  const int n_rankable = scan_buf[0];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o, 64);
+  if (ln == 0) scan_buf[wv] = local;
+  __syncthreads();
+  int n_rankable = 0;
+  for (int w = 0; w < NWV; w++) n_rankable += scan_buf[w];
   __syncthreads();
   const int n_rec = min(p.cutoff, n_rankable);
   res.valid = 1;
@@ -129,81 +166,171 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(EvalParams p) {
   // --- radix select: key of the n_rec-th best candidate
   uint64_t prefix = 0;
   int need = n_rec;  // how many still to take among keys matching `prefix` so far
+  bool inclusive = false;  // true: every key >= prefix is taken and there is no tie pick
   constexpr int BITS = KeyBits<T>::value;
   for (int shift = BITS - 8; shift >= 0; shift -= 8) {
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const uint64_t hi_mask = (shift + 8 >= 64) ? 0ull : (~0ull << (shift + 8));
-    for (int64_t j = tid; j < n_cand; j += 256) {
-      const T s = srow[item_of(j)];
-      if (is_neg_inf(s)) continue;
-      const uint64_t k = order_key(s);
-      if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(k >> shift) & 0xff], 1u);
+    for (int64_t base = 0; base < n_cand; base += NT) {
+      const int64_t j = base + tid;
+      bool in = false;
+      uint32_t digit = 0;
+      if (j < n_cand) {
+        const uint64_t k = key_at(j);
+        in = k != KEY_SKIP && (k & hi_mask) == (prefix & hi_mask);
+        digit = static_cast<uint32_t>(k >> shift) & 0xffu;
+      }
+      // scores share their leading byte(s): when all candidate lanes of a wave fall into
+      // one bin a single lane adds the count (no same-address atomic storm); otherwise
+      // the digits are spread and per-lane atomics are cheap
+      const unsigned long long todo = __ballot(in);
+      if (todo) {
+        const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+        const uint32_t d = __builtin_amdgcn_readlane(digit, leader);
+        const unsigned long long same = __ballot(in && digit == d);
+        if (same == todo) {
+          if (ln == leader) atomicAdd(&hist[d], static_cast<uint32_t>(__popcll(same)));
+        } else if (in) {
+          atomicAdd(&hist[digit], 1u);
+        }
+      }
     }
     __syncthreads();
-    if (tid == 0) {
-      int acc = 0, d = 255;
-      for (; d >= 0; d--) {
-        if (acc + static_cast<int>(hist[d]) >= need) break;
-        acc += hist[d];
+    // the digit d with  #(digits > d) < need <= #(digits >= d): bins scanned in descending
+    // order by the first four waves
+    int bin = 0, incl = 0;
+    if (tid < 256) {
+      bin = static_cast<int>(hist[255 - tid]);
+      incl = bin;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (ln >= o) incl += t;
       }
-      sh_prefix = prefix | (static_cast<uint64_t>(d) << shift);
-      sh_need = need - acc;
+      if (ln == 63) scan_buf[wv] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      for (int w = 0; w < wv; w++) incl += scan_buf[w];
+      if (incl - bin < need && incl >= need) {
+        sh_prefix = prefix | (static_cast<uint64_t>(255 - tid) << shift);
+        // the whole bin is wanted: no lower digit has to be resolved (-1 stops the loop)
+        sh_need = (incl == need) ? -1 : need - (incl - bin);
+      }
     }
     __syncthreads();
     prefix = sh_prefix;
     need = sh_need;
     __syncthreads();
+    if (need < 0) {
+      inclusive = true;
+      need = 0;
+      break;
+    }
   }
   const uint64_t thr = prefix;  // threshold key; `need` ties at thr are taken, lowest index first
 
-  // --- gather winners: key > thr anywhere, key == thr in index order
-  if (tid == 0) {
-    sh_count = 0;
-    sh_tie_base = 0;
-  }
+  // --- gather winners.  Wave w owns the contiguous candidates [w * span, (w + 1) * span) in
+  //     64-wide steps, so (wave, step, lane) order is index order: sweep 1 appends the keys
+  //     above the threshold and counts the wave's ties, sweep 2 gives the `need` lowest-index
+  //     ties their slots (evaluator.cpp:329, 353-355)
+  if (tid == 0) sh_count = 0;
   __syncthreads();
-  for (int64_t base = 0; base < n_cand; base += 256) {
-    const int64_t j = base + tid;
+  const int64_t span = ((n_cand + NT - 1) / NT) * 64;
+  const int64_t wbeg = wv * span, wend = min<int64_t>(wbeg + span, n_cand);
+  int my_ties = 0;
+  for (int64_t base = wbeg; base < wend; base += 64) {
+    const int64_t j = base + ln;
     bool tie = false;
-    uint64_t k = 0;
-    int32_t it = 0;
-    if (j < n_cand) {
-      it = item_of(j);
-      const T s = srow[it];
-      if (!is_neg_inf(s)) {
-        k = order_key(s);
-        if (k > thr) {
+    if (j < wend) {
+      const uint64_t k = key_at(j);
+      if (k != KEY_SKIP) {
+        if (inclusive ? k >= thr : k > thr) {
           const int pos = atomicAdd(&sh_count, 1);
           sel_key[pos] = k;
-          sel_idx[pos] = it;
+          sel_idx[pos] = item_of(j);
         } else if (k == thr) {
           tie = true;
         }
       }
     }
-    // rank of each tie in index order: ballot inside the wave, wave totals through LDS
+    my_ties += __popcll(__ballot(tie));
+  }
+  if (ln == 0) scan_buf[wv] = my_ties;
+  __syncthreads();
+  int seen = 0;
+  for (int w = 0; w < wv; w++) seen += scan_buf[w];
+  for (int64_t base = wbeg; base < wend && seen < need; base += 64) {
+    const int64_t j = base + ln;
+    const uint64_t k = j < wend ? key_at(j) : KEY_SKIP;
+    const bool tie = k != KEY_SKIP && k == thr;
     const unsigned long long bal = __ballot(tie);
-    const int wv = tid >> 6, ln = tid & 63;
-    if (ln == 0) scan_buf[wv] = __popcll(bal);
-    __syncthreads();
-    int before_me = sh_tie_base;
-    for (int ww = 0; ww < wv; ww++) before_me += scan_buf[ww];
-    const int total = scan_buf[0] + scan_buf[1] + scan_buf[2] + scan_buf[3];
-    const int rank = before_me + __popcll(bal & ((1ull << ln) - 1ull));
+    const int rank = seen + __popcll(bal & ((1ull << ln) - 1ull));
     if (tie && rank < need) {
       const int pos = atomicAdd(&sh_count, 1);
       sel_key[pos] = k;
-      sel_idx[pos] = it;
+      sel_idx[pos] = item_of(j);
     }
-    __syncthreads();
-    if (tid == 0) sh_tie_base += total;
+    seen += __popcll(bal);
   }
   __syncthreads();
+  if (n_rec <= 64) {
+    // --- common cutoffs: one wave finishes the row without further barriers.  Lane i holds
+    //     winner i; bitonic network over the lanes (key desc, index asc), hits by binary
+    //     search, then the sequential dcg / AP recurrences of Metrics::update (:136-165).
+    if (wv != 0) return;
+    uint64_t mk = ln < n_rec ? sel_key[ln] : 0ull;
+    int32_t mi = ln < n_rec ? sel_idx[ln] : 0x7fffffff;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+      for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+        const uint64_t ok = __shfl_xor(static_cast<unsigned long long>(mk), j2, 64);
+        const int32_t oi = __shfl_xor(mi, j2, 64);
+        const bool mine_first = (mk != ok) ? mk > ok : mi < oi;
+        const bool lower = (ln & j2) == 0, up = (ln & k2) == 0;
+        const bool keep = (lower == up) ? mine_first : !mine_first;
+        mk = keep ? mk : ok;
+        mi = keep ? mi : oi;
+      }
+    }
+    bool hit = false;
+    if (ln < n_rec) {
+      rec_row[ln] = mi;
+      atomicAdd(&p.item_cnt[mi], 1ull);  // :146
+      int lo = gb, hi = ge;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (p.gt_idx[mid] < mi) lo = mid + 1; else hi = mid;
+      }
+      hit = lo < ge && p.gt_idx[lo] == mi;
+    }
+    const double disc_l = ln < n_rec ? p.disc[ln] : 0.0;
+    unsigned long long hits = __ballot(hit);
+    double dcg = 0, ap = 0;
+    int cum_hit = 0;
+    while (hits) {  // ascending rank order, like the reference's loop over the list
+      const int i = __ffsll(static_cast<long long>(hits)) - 1;
+      hits &= hits - 1;
+      dcg += __shfl(disc_l, i, 64);
+      cum_hit++;
+      ap += static_cast<double>(cum_hit) / (i + 1);
+    }
+    const double idcg = p.idcg_prefix[min(n_gt, n_rec)];
+    res.hit = cum_hit > 0 ? 1.0 : 0.0;
+    res.precision = cum_hit / static_cast<double>(n_rec);
+    res.recall = cum_hit / static_cast<double>(
+                               p.recall_with_cutoff ? (n_gt > n_rec ? n_rec : n_gt) : n_gt);
+    res.ndcg = dcg / idcg;
+    res.map = ap / n_gt;
+    if (ln == 0) p.out[row] = res;
+    return;
+  }
   // --- bitonic sort of the n_rec winners: key desc, index asc
   int n_pow = 1;
   while (n_pow < n_rec) n_pow <<= 1;
-  for (int i = n_rec + tid; i < n_pow; i += 256) {
+  for (int i = n_rec + tid; i < n_pow; i += NT) {
     sel_key[i] = 0ull;
     sel_idx[i] = 0x7fffffff;
   }
@@ -214,7 +341,7 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(EvalParams p) {
   };
   for (int k2 = 2; k2 <= n_pow; k2 <<= 1) {
     for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      for (int i = tid; i < n_pow; i += 256) {
+      for (int i = tid; i < n_pow; i += NT) {
         const int l = i ^ j2;
         if (l > i) {
           const bool up = (i & k2) == 0;
@@ -233,7 +360,7 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(EvalParams p) {
     }
   }
   // --- hits, histogram, output list
-  for (int i = tid; i < n_rec; i += 256) {
+  for (int i = tid; i < n_rec; i += NT) {
     const int32_t it = sel_idx[i];
     rec_row[i] = it;
     atomicAdd(&p.item_cnt[it], 1ull);  // :146
@@ -266,28 +393,44 @@ __global__ __launch_bounds__(256) void rank_rows_kernel(EvalParams p) {
   }
 }
 
-// sum of the per-user terms in user order (one thread; rows <= a few thousand per call)
-__global__ void reduce_rows_kernel(const RowOut *rows, int64_t n, irs_metrics *out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  irs_metrics m{0, 0, 0, 0, 0, 0, 0};
-  for (int64_t i = 0; i < n; i++) {
-    m.total_user += 1;
-    if (rows[i].valid) {
-      m.valid_user += 1;
-      m.hit += rows[i].hit;
-      m.recall += rows[i].recall;
-      m.ndcg += rows[i].ndcg;
-      m.precision += rows[i].precision;
-      m.map += rows[i].map;
+// Sum of the per-user terms of one call (one wave).  Lane l adds rows l, l + 64, ... in
+// that order and the 64 partial sums are folded by a fixed butterfly, so the fp64 result
+// is reproducible run to run; it is not the strict user order of a single-threaded
+// reference run (the reference's own order depends on n_threads, evaluator.cpp:280-312).
+__global__ __launch_bounds__(64) void reduce_rows_kernel(const RowOut *rows, int64_t n,
+                                                         irs_metrics *out) {
+  const int lane = threadIdx.x;
+  long long valid = 0;
+  double hit = 0, recall = 0, ndcg = 0, precision = 0, map = 0;
+  for (int64_t i = lane; i < n; i += 64) {
+    const RowOut r = rows[i];
+    if (r.valid) {
+      valid += 1;
+      hit += r.hit;
+      recall += r.recall;
+      ndcg += r.ndcg;
+      precision += r.precision;
+      map += r.map;
     }
   }
-  out->valid_user += m.valid_user;
-  out->total_user += m.total_user;
-  out->hit += m.hit;
-  out->recall += m.recall;
-  out->ndcg += m.ndcg;
-  out->precision += m.precision;
-  out->map += m.map;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    valid += __shfl_xor(valid, o, 64);
+    hit += __shfl_xor(hit, o, 64);
+    recall += __shfl_xor(recall, o, 64);
+    ndcg += __shfl_xor(ndcg, o, 64);
+    precision += __shfl_xor(precision, o, 64);
+    map += __shfl_xor(map, o, 64);
+  }
+  if (lane == 0) {
+    out->valid_user += valid;
+    out->total_user += n;
+    out->hit += hit;
+    out->recall += recall;
+    out->ndcg += ndcg;
+    out->precision += precision;
+    out->map += map;
+  }
 }
 
 // scores[row, col] = -inf for the stored entries of the mask rows (evaluator.py:426-432)
@@ -362,7 +505,17 @@ void rank_block(irs_evaluator *e, const void *d_scores, int64_t rows, int64_t cu
   p.out = e->row_out.ptr;
   p.rec_out = e->rec_out.ptr;
   p.item_cnt = e->item_cnt.ptr;
-  hipLaunchKernelGGL((rank_rows_kernel<T>), dim3(rows), dim3(256), 0, s, p);
+  // key cache in LDS when a row's candidates fit next to the 28 KB of static LDS
+  const size_t key_bytes = static_cast<size_t>(e->n_items) * sizeof(typename KeyStore<T>::type);
+  if (key_bytes <= 128 * 1024) {
+    auto kernel = rank_rows_kernel<T, 1024, true>;
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(key_bytes)));
+    hipLaunchKernelGGL(kernel, dim3(rows), dim3(1024), key_bytes, s, p);
+  } else {
+    hipLaunchKernelGGL((rank_rows_kernel<T, 256, false>), dim3(rows), dim3(256), 0, s, p);
+  }
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, e->row_out.ptr, rows,
                      e->metrics.ptr);
   IRS_HIP(hipGetLastError());
