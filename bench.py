@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--solver", default="CHOLESKY", choices=["CHOLESKY", "CG"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the kNN / evaluator figures reported next to the headline metric")
     return ap.parse_args()
 
 
@@ -92,6 +94,59 @@ def cpu_baseline(X, K, solver, budget_s):
                    f"matrix (row order is random), one {solver} half-step each, {dt:.1f} s, "
                    f"{cores} threads; Gramians excluded"),
     }
+
+
+def secondary_metrics(X, trainer, K):
+    """The other two pieces of the hot path at the same ML-20M shape (reported, not the
+    headline): item-kNN (cosine, top_k = 100, BASELINE.json configs[2]) and the fused
+    score + nDCG@20 evaluator.  Kernel times are HIP-event timed inside the library."""
+    import scipy.sparse as sps
+
+    from irspack_amd.evaluation._core_evaluator import EvaluatorCore
+    from irspack_amd.recommenders._knn import CosineSimilarityComputer
+
+    U, I = X.shape
+    out = {}
+    Xt = sps.csr_matrix(X.T, dtype=np.float64)
+    Xt.data[:] = 1.0
+    comp = CosineSimilarityComputer(Xt, 0.0, True)
+    comp.compute_similarity(Xt, 100, rows=(0, 64))  # warm-up
+    t0 = time.perf_counter()
+    S = comp.compute_similarity(Xt, 100)
+    wall = time.perf_counter() - t0
+    ms = comp.last_kernel_ms
+    bytes_per_mac = 4.0  # int32 column id; the all-ones value stream is not read
+    out["knn"] = {
+        "workload": f"cosine item-kNN top_k=100, {I} items x {U} users, binary interactions, fp64",
+        "kernel_ms": ms, "wall_s_incl_pcie": wall, "macs": comp.last_macs,
+        "item_pairs_per_s": I * float(I) / (ms * 1e-3),
+        "gmacs_per_s": comp.last_macs / ms / 1e6,
+        "roofline": {"bound": "hbm", "achieved": comp.last_macs * bytes_per_mac / (ms * 1e-3) / 1e9,
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": comp.last_macs * bytes_per_mac / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     "traffic": None},
+        "out_nnz": int(S.nnz),
+    }
+    # evaluator: hold out one interaction per user as ground truth, mask the rest
+    rng = np.random.default_rng(5)
+    pick = X.indptr[:-1] + (rng.random(U) * np.diff(X.indptr)).astype(np.int64)
+    gt = sps.csr_matrix((np.ones(U), (np.arange(U), X.indices[pick])), shape=X.shape)
+    ev = EvaluatorCore(gt, [])
+    keep = np.ones(X.nnz, dtype=bool)
+    keep[pick] = False
+    rows = np.repeat(np.arange(U), np.diff(X.indptr))
+    mask = sps.csr_matrix((np.ones(int(keep.sum()), dtype=np.float32),
+                           (rows[keep], X.indices[keep])), shape=X.shape)
+    ev.get_metrics_ials(trainer, 0, 2048, mask[:2048], 20, 0, False)  # warm-up
+    t0 = time.perf_counter()
+    m = ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
+    wall = time.perf_counter() - t0
+    out["evaluator"] = {
+        "workload": f"fused iALS k={K} scoring + nDCG@20 over {U} users x {I} items, fp32 scores",
+        "wall_s_incl_pcie": wall, "users_per_s": U / wall,
+        "scores_per_s": U * float(I) / wall, "ndcg@20": m.as_dict()["ndcg"],
+    }
+    return out
 
 
 def main():
@@ -214,6 +269,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(X, K, args.solver, args.cpu_seconds)
+        if world == 1 and not args.no_secondary and K <= 64:
+            result["secondary"] = secondary_metrics(X, local.trainer, K)
     if world > 1:
         dist.barrier()
     if rank == 0:
