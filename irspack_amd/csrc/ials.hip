@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "ials_kernels.hpp"
 #include "ials_wg_kernels.hpp"
+#include "ials_pp_kernels.hpp"
 
 namespace irs {
 
@@ -107,6 +108,7 @@ struct Side {
   DeviceBuffer<float> data, reg;
   DeviceBuffer<Task> tasks;
   DeviceBuffer<SplitRow> split;
+  DeviceBuffer<int32_t> rows_by_len;  // rows [row_begin, row_end) longest first (iALS++ launch order)
   int32_t n_tasks = 0, n_split = 0, n_slots = 0;
 
   void build(const HostCsr &m, int64_t rb, int64_t re, const irs_ials_model_config &cfg,
@@ -162,6 +164,14 @@ struct Side {
       indices.upload(idx_pad, s);
       data.upload(data_pad, s);
       IRS_HIP(hipStreamSynchronize(s));
+    }
+    {
+      std::vector<int32_t> order(re - rb);
+      for (int64_t r = rb; r < re; r++) order[r - rb] = static_cast<int32_t>(r);
+      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        return (ip32[a + 1] - ip32[a]) > (ip32[b + 1] - ip32[b]);
+      });
+      rows_by_len.upload(order, s);
     }
     reg.upload(regs, s);
     tasks.upload(tk, s);
@@ -229,6 +239,8 @@ struct irs_ials_trainer {
   DeviceBuffer<float> gram_partial, split_partial, row_loss;
   DeviceBuffer<double> loss_sum;
   DeviceBuffer<int32_t> err_flag;
+  DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
+  DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   Profiler prof;
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
@@ -382,9 +394,62 @@ void check_solver(const irs_ials_solver_config *sc) {
   check_arg(sc->solver_type == IRS_SOLVER_CHOLESKY || sc->solver_type == IRS_SOLVER_CG ||
                 sc->solver_type == IRS_SOLVER_IALSPP,
             "unknown solver_type.");
-  if (sc->solver_type == IRS_SOLVER_IALSPP)
+  if (sc->solver_type == IRS_SOLVER_IALSPP && sc->ialspp_subspace_dimension > 64)
     throw std::invalid_argument(
-        "irspack_amd: the IALSPP subspace solver is not implemented on the device yet.");
+        "irspack_amd: ialspp_subspace_dimension above 64 is not supported by the device solver.");
+}
+
+// Solver::step_ialspp / step_icd (hpp:516-630): `ialspp_iteration` sweeps, one wave per row.
+void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
+                   const irs_ials_solver_config *sc) {
+  static const char *kNames[2] = {"ials_ialspp_user", "ials_ialspp_item"};
+  const int32_t n_rows = static_cast<int32_t>(sd.row_end - sd.row_begin);
+  if (n_rows <= 0) return;
+  t->pp_pred.alloc(static_cast<size_t>(sd.nnz) + 320);
+  if (!t->pp_llt_sink.ptr) {
+    t->pp_llt_sink.alloc(1);
+    t->pp_llt_sink.zero(t->stream);
+  }
+  PpParams p;
+  p.indptr = sd.indptr.ptr;
+  p.indices = sd.indices.ptr;
+  p.data = sd.data.ptr;
+  p.rows = sd.rows_by_len.ptr;
+  p.n_rows = n_rows;
+  p.other = other;
+  p.target = target;
+  p.reg = sd.reg.ptr;
+  p.P = t->P[pidx].ptr;
+  p.pred = t->pp_pred.ptr;
+  p.ignored_flag = t->pp_llt_sink.ptr;
+  p.bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;  // hpp:431-432
+  p.K = static_cast<int32_t>(t->K);
+  p.KP = t->KP;
+  // a subspace dimension of 0 or 1 is the iCD branch (hpp:673-677)
+  p.sub = static_cast<int32_t>(std::max<uint64_t>(1, sc->ialspp_subspace_dimension));
+  p.zero_start = 0;
+  const int D = std::min<int>(p.sub, p.K);
+  const int TS = D <= 16 ? 1 : D <= 32 ? 2 : 4;
+  const bool aligned = p.sub % TS == 0;
+  auto launch = [&](auto kernel, size_t lds_floats) {
+    const size_t lds = 4 * lds_floats * sizeof(float);
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    for (uint64_t it = 0; it < sc->ialspp_iteration; it++) {
+      t->prof.begin(kNames[pidx], t->stream);
+      hipLaunchKernelGGL(kernel, dim3(ceil_div(n_rows, 4)), dim3(256), lds, t->stream, p);
+      t->prof.end(t->stream);
+    }
+  };
+  switch (TS * 2 + (aligned ? 1 : 0)) {
+    case 2: launch(ialspp_kernel<1, false>, PpGeo<1>::LDS_FLOATS); break;  // TS = 1 is always aligned
+    case 3: launch(ialspp_kernel<1, true>, PpGeo<1>::LDS_FLOATS); break;
+    case 4: launch(ialspp_kernel<2, false>, PpGeo<2>::LDS_FLOATS); break;
+    case 5: launch(ialspp_kernel<2, true>, PpGeo<2>::LDS_FLOATS); break;
+    case 8: launch(ialspp_kernel<4, false>, PpGeo<4>::LDS_FLOATS); break;
+    default: launch(ialspp_kernel<4, true>, PpGeo<4>::LDS_FLOATS); break;
+  }
+  IRS_HIP(hipGetLastError());
 }
 
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
@@ -395,6 +460,10 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
        {"ials_split_cholesky_user", "ials_split_cholesky_item"}},
       {{"ials_solve_cg_user", "ials_solve_cg_item"},
        {"ials_split_cg_user", "ials_split_cg_item"}}};
+  if (sc->solver_type == IRS_SOLVER_IALSPP) {
+    launch_ialspp(t, sd, other, target, pidx, sc);
+    return;
+  }
   SolveParams p;
   p.tasks = sd.tasks.ptr;
   p.n_tasks = sd.n_tasks;

@@ -1,0 +1,252 @@
+// iALS++ / iCD subspace solver on gfx950: Solver::step_ialspp / _step_dimrange /
+// _prediction / step_icd of /root/reference/cpp_source/als/IALSTrainer.hpp:387-630.
+//
+// Per row, per sweep (`ialspp_iteration`):  pred_q = x . v_q  for the row's stored entries
+// (hpp:387-421), then for every block [c0, c0 + D) of `ialspp_subspace_dimension` latent
+// dims (hpp:423-514):
+//     A = P[blk, blk] + sum_q c_q v_q[blk] v_q[blk]^T + reg I
+//     B = P[blk, :] x + reg x[blk] + sum_q (c_q (pred_q - 1) - bias) v_q[blk]
+//     delta = A^-1 B (LLT),   x[blk] -= delta,   pred_q -= delta . v_q[blk]
+// Rows are independent, so one wave owns a row for a whole sweep: the prediction cache
+// lives in a global scratch array indexed like the CSR, the D x D system lives in the
+// MFMA accumulator registers (same tile layout and the same panel Cholesky as the full
+// solve in ials_kernels.hpp, with TS = ceil(D / 16) tiles per side), the row's factor
+// vector in LDS.  Subspace dimension 1 is the iCD branch (hpp:673-677), which is the
+// D = 1 case of the same arithmetic.  The reference does not test the LLT status here
+// (hpp:495-497), so a failed factorisation propagates NaN instead of raising.
+#pragma once
+#include "ials_kernels.hpp"
+
+namespace irs {
+namespace ials {
+
+struct PpParams {
+  const int32_t *indptr;
+  const int32_t *indices;  // padded like SolveParams::indices
+  const float *data;
+  const int32_t *rows;     // rows of this launch, longest first
+  int32_t n_rows;
+  const float *other;      // gathered factors [n_other, KP]
+  float *target;           // solved factors   [n_rows, KP]
+  const float *reg;        // per-row regulariser (hpp:117-120)
+  const float *P;          // alpha0 * F^T F, row-major [KP, KP], natural coordinates
+  float *pred;             // prediction cache [nnz + padding]
+  int32_t *ignored_flag;   // sink for the LLT status bits
+  float bias;              // observation_bias (hpp:431-432)
+  int32_t K, KP;
+  int32_t sub;             // subspace dimension, >= 1
+  int32_t zero_start;      // fold-in: the row starts from 0 (hpp:132)
+};
+
+template <int TS> struct PpGeo {
+  static constexpr int DP = 16 * TS;
+  static constexpr int NT = TS * (TS + 1) / 2;
+  static constexpr int XS = 256;  // largest padded K
+  // Cholesky scratch | x (whole row) | P-part of the rhs | delta
+  static constexpr int LDS_FLOATS = CholGeo<TS>::LDS_FLOATS + XS + 2 * DP;
+};
+
+// v[t] = factor[row, c0 + off[t]]; ALIGNED: c0 and off[0] are multiples of TS and the
+// offsets are consecutive (one vector load).  Lanes whose dims lie past the block are given
+// offset 0 by the caller (their values are masked), so nothing is read past the row.
+template <int TS, bool ALIGNED>
+__device__ __forceinline__ void load_sub(const float *p, const int (&off)[TS], float (&v)[TS]) {
+  if constexpr (ALIGNED) {
+    load_dims<TS>(p + off[0], v);
+  } else {
+#pragma unroll
+    for (int t = 0; t < TS; t++) v[t] = p[off[t]];
+  }
+}
+
+// Rank update of the block: acc += sum c v v^T (MFMA, upper tiles),
+// bsum += sum (c (pred - 1) - bias) v.  Two-deep pipeline of 16-entry groups with
+// unconditional loads (the CSR arrays and the prediction cache are padded).
+template <int TS, bool ALIGNED>
+__device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int end, int c0, int D,
+                                               f32x4 (&acc)[PpGeo<TS>::NT], float (&bsum)[TS]) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const float *col_base = p.other + c0;
+  const int n = end - begin;
+  const int nit = (n + 15) >> 4;
+  const int32_t *ip = p.indices + begin + g;
+  const float *dp = p.data + begin + g;
+  const float *pp = p.pred + begin + g;
+  bool dim_ok[TS];
+  int off[TS];
+#pragma unroll
+  for (int t = 0; t < TS; t++) {
+    dim_ok[t] = TS * m + t < D;
+    off[t] = ALIGNED ? (TS * m < D ? TS * m + t : t) : (dim_ok[t] ? TS * m + t : 0);
+  }
+  int ia[4], ib[4];
+  float ca[4], cb[4], pa[4], pb[4];
+  float va[4][TS], vb[4][TS], xa[4], xb[4], wa[4], wb[4];
+  auto load_idx = [&](int it, int (&ix)[4], float (&cx)[4], float (&px)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ix[u] = ip[16 * it + 4 * u];
+      cx[u] = dp[16 * it + 4 * u];
+      px[u] = pp[16 * it + 4 * u];
+    }
+  };
+  auto gather = [&](int it, const int (&ix)[4], const float (&cx)[4], const float (&px)[4],
+                    float (&v)[4][TS], float (&vc)[4], float (&vw)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool valid = 16 * it + 4 * u + g < n;
+      vc[u] = valid ? cx[u] : 0.f;
+      vw[u] = valid ? cx[u] * (px[u] - 1.0f) - p.bias : 0.f;  // hpp:485-486
+      load_sub<TS, ALIGNED>(col_base + static_cast<size_t>(static_cast<unsigned>(ix[u])) * p.KP, off,
+                            v[u]);
+    }
+  };
+  auto consume = [&](const float (&v)[4][TS], const float (&vc)[4], const float (&vw)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      float cv[TS], vk[TS];
+#pragma unroll
+      for (int i = 0; i < TS; i++) {
+        vk[i] = dim_ok[i] ? v[u][i] : 0.f;
+        cv[i] = vc[u] * vk[i];
+        bsum[i] = fmaf(vw[u], vk[i], bsum[i]);
+      }
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < TS; i++)
+#pragma unroll
+        for (int j = i; j < TS; j++) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], vk[j], acc[t], 0, 0, 0);
+          t++;
+        }
+    }
+  };
+  load_idx(0, ia, ca, pa);
+  gather(0, ia, ca, pa, va, xa, wa);
+  load_idx(1, ia, ca, pa);
+  for (int it = 0; it < nit; it += 2) {
+    load_idx(it + 2, ib, cb, pb);
+    gather(it + 1, ia, ca, pa, vb, xb, wb);
+    consume(va, xa, wa);
+    load_idx(it + 3, ia, ca, pa);
+    gather(it + 2, ib, cb, pb, va, xa, wa);
+    consume(vb, xb, wb);  // an all-masked group when nit is odd
+  }
+#pragma unroll
+  for (int i = 0; i < TS; i++) {
+    bsum[i] += __shfl_xor(bsum[i], 16, 64);
+    bsum[i] += __shfl_xor(bsum[i], 32, 64);
+  }
+}
+
+template <int TS, bool ALIGNED>
+__global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
+  using G = PpGeo<TS>;
+  using C = CholGeo<TS>;
+  extern __shared__ __attribute__((aligned(16))) float pp_lds[];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int w = blockIdx.x * 4 + wid;
+  if (w >= p.n_rows) return;  // the kernel uses no workgroup barrier
+  float *sm = pp_lds + wid * G::LDS_FLOATS;
+  float *xs = sm + C::LDS_FLOATS;
+  float *bnat = xs + G::XS;
+  float *delta = bnat + G::DP;
+
+  const int row = p.rows[w];
+  const int begin = p.indptr[row], end = p.indptr[row + 1];
+  const float reg = p.reg[row];
+  float *xrow = p.target + static_cast<size_t>(row) * p.KP;
+  for (int i = lane; i < p.KP; i += 64) {
+    const float x0 = p.zero_start ? 0.f : xrow[i];
+    xs[i] = x0;
+    if (p.zero_start) xrow[i] = 0.f;
+  }
+  __threadfence_block();
+
+  // ---- prediction cache (hpp:387-421): lane per stored entry, x broadcast from LDS
+  for (int q = begin + lane; q < end; q += 64) {
+    const float *v = p.other + static_cast<size_t>(static_cast<unsigned>(p.indices[q])) * p.KP;
+    float s = 0.f;
+    for (int k = 0; k < p.KP; k += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(v + k);
+      const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + k);
+      s = fmaf(t.x, x4.x, s);
+      s = fmaf(t.y, x4.y, s);
+      s = fmaf(t.z, x4.z, s);
+      s = fmaf(t.w, x4.w, s);
+    }
+    p.pred[q] = s;
+  }
+  __threadfence();  // the cache is re-read through other lanes' addresses below
+
+  for (int c0 = 0; c0 < p.K; c0 += p.sub) {
+    const int D = min(p.sub, p.K - c0);
+    // ---- A <- P[blk, blk] in accumulator layout: tile (I, J) register r of lane (g, m) is
+    //      element (TS (4g + r) + I, TS m + J) of the block
+    f32x4 acc[G::NT];
+    {
+      int t = 0;
+#pragma unroll
+      for (int I = 0; I < TS; I++)
+#pragma unroll
+        for (int J = I; J < TS; J++) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int rr = TS * (4 * g + r) + I, cc = TS * m + J;
+            acc[t][r] = (rr < D && cc < D) ? p.P[(c0 + rr) * p.KP + c0 + cc] : 0.f;
+          }
+          t++;
+        }
+    }
+    // ---- B <- P[blk, :] x + reg x[blk]  (hpp:473-477); P is symmetric: column reads coalesce
+    if (lane < G::DP) {
+      float s = 0.f;
+      if (lane < D) {
+        for (int k = 0; k < p.K; k++) s = fmaf(p.P[k * p.KP + c0 + lane], xs[k], s);
+        s = fmaf(reg, xs[c0 + lane], s);
+      }
+      bnat[lane] = s;
+    }
+    float bsum[TS];
+#pragma unroll
+    for (int i = 0; i < TS; i++) bsum[i] = 0.f;
+    pp_rank_update<TS, ALIGNED>(p, begin, end, c0, D, acc, bsum);
+    __threadfence_block();
+    float b4[TS];
+#pragma unroll
+    for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bnat[TS * m + i];
+    // ---- delta = (A + reg I)^-1 B   (hpp:490-497)
+    solve_row_cholesky<TS>(acc, b4, reg, sm, delta, D, p.ignored_flag);
+    __threadfence_block();
+    if (lane < D) {  // hpp:498
+      const float nx = xs[c0 + lane] - delta[lane];
+      xs[c0 + lane] = nx;
+      xrow[c0 + lane] = nx;
+    }
+    __threadfence_block();
+    // ---- pred_q -= delta . v_q[blk]   (hpp:500-506)
+    for (int q = begin + lane; q < end; q += 64) {
+      const float *v =
+          p.other + static_cast<size_t>(static_cast<unsigned>(p.indices[q])) * p.KP + c0;
+      float s = 0.f;
+      if (ALIGNED && (D & 3) == 0 && (c0 & 3) == 0) {
+        for (int i = 0; i < D; i += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4 *>(v + i);
+          s = fmaf(delta[i], t.x, s);
+          s = fmaf(delta[i + 1], t.y, s);
+          s = fmaf(delta[i + 2], t.z, s);
+          s = fmaf(delta[i + 3], t.w, s);
+        }
+      } else {
+        for (int i = 0; i < D; i++) s = fmaf(delta[i], v[i], s);
+      }
+      p.pred[q] -= s;
+    }
+    __threadfence();
+  }
+}
+
+}  // namespace ials
+}  // namespace irs

@@ -1,0 +1,107 @@
+"""GPU parity tests of the iALS++ / iCD subspace solver (SolverType.IALSPP) against the CPU
+oracle (oracle/ials_oracle.cpp: step_ialspp / step_dimrange / prediction) and the
+reference's own convergence check (tests/recommenders/test_ials.py:573-599).
+Tolerance: 1e-4 relative on the factor matrices for the same factors in.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import oracle as O
+from conftest import random_csr
+from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder, IALSSolverConfigBuilder,
+                                                  IALSTrainer, LossType, SolverType)
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def build(K, alpha0=0.1, reg=1e-2, nu=1.0, loss="IALSPP"):
+    mc = (IALSModelConfigBuilder().set_K(K).set_alpha0(alpha0).set_reg(reg).set_nu(nu)
+          .set_init_stdev(0.1).set_random_seed(42).set_loss_type(LossType[loss]).build())
+    omc = O.model_config(K, alpha0=alpha0, reg=reg, nu=nu, init_stdev=0.1, random_seed=42,
+                         loss_type=loss)
+    return mc, omc
+
+
+def solvers(sub, iters):
+    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType.IALSPP)
+          .set_ialspp_subspace_dimension(sub).set_ialspp_iteration(iters).build())
+    return sc, O.solver_config(1, "IALSPP", 3, ialspp_subspace_dimension=sub,
+                               ialspp_iteration=iters)
+
+
+@pytest.mark.parametrize("K,sub", [(4, 1), (4, 3), (16, 16), (16, 5), (20, 8), (32, 32), (48, 16),
+                                   (64, 64), (64, 16), (64, 24), (64, 33), (40, 64), (128, 64),
+                                   (130, 32)])
+@pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
+def test_epoch_matches_oracle(K, sub, loss):
+    """Every epoch starts from the oracle's factors (teacher forcing), so the comparison is one
+    iALS++ epoch (user half then item half) for the same input."""
+    X = random_csr(150, 110, 0.1, 3, empty_rows=(7, 40))
+    mc, omc = build(K, loss=loss)
+    sc, osc = solvers(sub, 2)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    np.testing.assert_array_equal(t.user, o.user)
+    for _ in range(2):
+        t.user, t.item = o.user, o.item
+        t.step(sc)
+        o.step(osc)
+        assert rel_err(t.user, o.user) < RTOL
+        assert rel_err(t.item, o.item) < 10 * RTOL  # the item half sees the user half's rounding
+
+
+def test_long_rows_and_explicit_weights():
+    """Rows far longer than one 16-entry pipeline group, non-binary confidences."""
+    rng = np.random.default_rng(4)
+    X = random_csr(40, 900, 0.6, 9)
+    X.data[:] = rng.uniform(0.5, 3.0, size=X.nnz).astype(np.float32)
+    mc, omc = build(64, alpha0=0.05, reg=1e-2)
+    sc, osc = solvers(32, 1)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    t.step(sc)
+    o.step(osc)
+    assert rel_err(t.user, o.user) < RTOL
+    assert rel_err(t.item, o.item) < 10 * RTOL
+
+
+@pytest.mark.parametrize("sub", [1, 2, 3, 4])
+def test_overfit_ialspp(X_small, sub):
+    # tests/recommenders/test_ials.py:573-599: with a tiny regulariser the model reproduces X
+    mc = (IALSModelConfigBuilder().set_K(4).set_alpha0(100).set_reg(1.0).set_nu(0)
+          .set_loss_type(LossType.ORIGINAL).build())
+    sc = (IALSSolverConfigBuilder().set_solver_type(SolverType.IALSPP)
+          .set_ialspp_subspace_dimension(sub).build())
+    t = IALSTrainer(mc, X_small)
+    for _ in range(300):
+        t.step(sc)
+    B = sps.csr_matrix(X_small).toarray()
+    B[B > 0] = 1
+    np.testing.assert_allclose(t.user @ t.item.T, B, rtol=1e-2, atol=1e-2)
+
+
+def test_transform_with_ialspp(X_small):
+    """Fold-in with the subspace solver starts from zero (hpp:132) and matches the oracle."""
+    mc, omc = build(16, alpha0=0.1, reg=1e-1)
+    t = IALSTrainer(mc, X_small)
+    o = O.IALSTrainer(omc, X_small)
+    sc, osc = solvers(8, 3)
+    np.testing.assert_array_equal(t.item, o.item)
+    u, ou = t.transform_user(X_small, sc), o.transform_user(X_small, osc)
+    assert rel_err(u, ou) < RTOL
+
+
+def test_subspace_above_64_is_rejected(X_small):
+    mc, _ = build(128)
+    sc = (IALSSolverConfigBuilder().set_solver_type(SolverType.IALSPP)
+          .set_ialspp_subspace_dimension(128).build())
+    t = IALSTrainer(mc, X_small)
+    with pytest.raises(ValueError, match="ialspp_subspace_dimension"):
+        t.step(sc)
