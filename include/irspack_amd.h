@@ -194,6 +194,18 @@ irs_status irs_knn_last_stats(irs_knn_computer *c, double *kernel_ms,
 /* remove_diagonal, cpp_source/util.hpp:211-226 (in place on `data`). */
 irs_status irs_remove_diagonal(int64_t rows, int64_t cols, const int64_t *indptr,
                                const int32_t *indices, double *data);
+/* retrieve_recommend_from_score_{f32,f64}, cpp_source/util.hpp:426-504 (bound at
+ * util.cpp; caller utils/id_mapping.py:29-44, 312-317): top-`cutoff` candidates of every
+ * score row, best first, stopping at -inf.  scores: host row-major [rows, n_items], float32
+ * (is_f64 == 0) or float64.  Allowed lists are ragged (list_ptr int64[n_lists + 1],
+ * list_items int64; n_lists in {0, 1, rows}); ids outside [0, n_items) are dropped, order
+ * and duplicates are kept.  out_idx: int32 [rows, cutoff], -1 padded; the caller reads the
+ * scores of the winners from its own array.  Equal scores come out in candidate order (the
+ * reference's comparator leaves their order unspecified, util.hpp:483-485). */
+irs_status irs_retrieve_recommend(int32_t is_f64, const void *scores, int64_t rows,
+                                  int64_t n_items, int64_t n_lists, const int64_t *list_ptr,
+                                  const int64_t *list_items, int64_t cutoff,
+                                  int64_t n_threads, int32_t device, int32_t *out_idx);
 
 /* ------------------------------------------------------------------ evaluator
  * cpp_source/evaluator.cpp:441-484 */

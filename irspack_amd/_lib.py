@@ -91,6 +91,7 @@ EXPORTED_SYMBOLS = [
     "irs_knn_fetch",
     "irs_knn_last_stats",
     "irs_remove_diagonal",
+    "irs_retrieve_recommend",
     "irs_eval_create",
     "irs_eval_destroy",
     "irs_eval_get_metrics",

@@ -63,6 +63,7 @@ struct EvalParams {
   const int64_t *rec_ptr;
   const int32_t *rec_items;
   int32_t cutoff;
+  int32_t retrieve;          // 1: only the ranked lists are wanted (no ground truth, no metrics)
   int32_t recall_with_cutoff;
   const double *disc;        // 1 / log2(2 + i)
   const double *idcg_prefix; // sequential prefix sums of disc
@@ -101,11 +102,11 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
   const int64_t u = row + p.offset;
   const T *srow = static_cast<const T *>(p.scores) + row * p.n_items;
   RowOut res{0, 0, 0, 0, 0, 0, 0};
-  const int gb = p.gt_ptr[u], ge = p.gt_ptr[u + 1];
+  const int gb = p.retrieve ? 0 : p.gt_ptr[u], ge = p.retrieve ? 0 : p.gt_ptr[u + 1];
   const int n_gt = ge - gb;
   int32_t *rec_row = p.rec_out + row * p.cutoff;
   for (int i = tid; i < p.cutoff; i += NT) rec_row[i] = -1;
-  if (n_gt == 0) {  // counted in total_user only (:316-321)
+  if (n_gt == 0 && !p.retrieve) {  // counted in total_user only (:316-321)
     if (tid == 0) p.out[row] = res;
     return;
   }
@@ -295,6 +296,10 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
         mi = keep ? mi : oi;
       }
     }
+    if (p.retrieve) {
+      if (ln < n_rec) rec_row[ln] = mi;
+      return;
+    }
     bool hit = false;
     if (ln < n_rec) {
       rec_row[ln] = mi;
@@ -358,6 +363,10 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
       }
       __syncthreads();
     }
+  }
+  if (p.retrieve) {
+    for (int i = tid; i < n_rec; i += NT) rec_row[i] = sel_idx[i];
+    return;
   }
   // --- hits, histogram, output list
   for (int i = tid; i < n_rec; i += NT) {
@@ -482,6 +491,20 @@ void validate_call(irs_evaluator *e, int64_t rows, int64_t cutoff, int64_t offse
                                 " is not supported by the device ranking kernel.");
 }
 
+template <class T> void launch_rank(const EvalParams &p, int64_t max_cand, hipStream_t s) {
+  // key cache in LDS when a row's candidates fit next to the 28 KB of static LDS
+  const size_t key_bytes = static_cast<size_t>(std::max<int64_t>(max_cand, 1)) * sizeof(typename KeyStore<T>::type);
+  if (key_bytes <= 128 * 1024) {
+    auto kernel = rank_rows_kernel<T, 1024, true>;
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(key_bytes)));
+    hipLaunchKernelGGL(kernel, dim3(p.rows), dim3(1024), key_bytes, s, p);
+  } else {
+    hipLaunchKernelGGL((rank_rows_kernel<T, 256, false>), dim3(p.rows), dim3(256), 0, s, p);
+  }
+}
+
 // ranks `rows` rows already resident at `d_scores` and accumulates into out / item_cnt
 template <class T>
 void rank_block(irs_evaluator *e, const void *d_scores, int64_t rows, int64_t cutoff,
@@ -499,23 +522,14 @@ void rank_block(irs_evaluator *e, const void *d_scores, int64_t rows, int64_t cu
   p.rec_ptr = e->rec_ptr.ptr;
   p.rec_items = e->rec_items.ptr;
   p.cutoff = static_cast<int32_t>(cutoff);
+  p.retrieve = 0;
   p.recall_with_cutoff = rwc ? 1 : 0;
   p.disc = e->disc.ptr;
   p.idcg_prefix = e->idcg_prefix.ptr;
   p.out = e->row_out.ptr;
   p.rec_out = e->rec_out.ptr;
   p.item_cnt = e->item_cnt.ptr;
-  // key cache in LDS when a row's candidates fit next to the 28 KB of static LDS
-  const size_t key_bytes = static_cast<size_t>(e->n_items) * sizeof(typename KeyStore<T>::type);
-  if (key_bytes <= 128 * 1024) {
-    auto kernel = rank_rows_kernel<T, 1024, true>;
-    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(key_bytes)));
-    hipLaunchKernelGGL(kernel, dim3(rows), dim3(1024), key_bytes, s, p);
-  } else {
-    hipLaunchKernelGGL((rank_rows_kernel<T, 256, false>), dim3(rows), dim3(256), 0, s, p);
-  }
+  launch_rank<T>(p, e->n_items, s);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, e->row_out.ptr, rows,
                      e->metrics.ptr);
   IRS_HIP(hipGetLastError());
@@ -684,6 +698,71 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
       rank_block<float>(e, scores.ptr, m, cutoff, offset + b, recall_with_cutoff != 0, s);
     }
     finish_accumulate(e, out, item_cnt, s);
+  });
+}
+
+irs_status irs_retrieve_recommend(int32_t is_f64, const void *scores, int64_t rows,
+                                  int64_t n_items, int64_t n_lists, const int64_t *list_ptr,
+                                  const int64_t *list_items, int64_t cutoff, int64_t n_threads,
+                                  int32_t device, int32_t *out_idx) {
+  return guard([&] {
+    // util.hpp:426-439
+    check_arg(n_threads > 0, "n_threads must not be 0.");
+    check_arg(rows >= 0 && n_items >= 0, "negative shape.");
+    check_arg(n_lists == 0 || n_lists == 1 || n_lists == rows,
+              "allowed_indices, if not empty, must have a size equal to X.rows()");
+    check_arg(out_idx != nullptr && (rows == 0 || scores != nullptr), "null argument.");
+    if (rows == 0 || cutoff <= 0) return;
+    if (cutoff > SEL_CAP)
+      throw std::invalid_argument("irspack_amd: cutoff above " + std::to_string(SEL_CAP) +
+                                  " is not supported by the device ranking kernel.");
+    require_device(device);
+    hipStream_t s = nullptr;
+    // candidate lists keep their order and duplicates; out-of-range ids are dropped (:468-472)
+    std::vector<int64_t> lptr(n_lists + 1, 0);
+    std::vector<int32_t> litems;
+    int64_t max_cand = n_lists == 0 ? n_items : 0;
+    for (int64_t l = 0; l < n_lists; l++) {
+      for (int64_t q = list_ptr[l]; q < list_ptr[l + 1]; q++)
+        if (list_items[q] >= 0 && list_items[q] < n_items)
+          litems.push_back(static_cast<int32_t>(list_items[q]));
+      lptr[l + 1] = static_cast<int64_t>(litems.size());
+      max_cand = std::max(max_cand, lptr[l + 1] - lptr[l]);
+    }
+    DeviceBuffer<int64_t> d_lptr;
+    DeviceBuffer<int32_t> d_litems, d_rec;
+    DeviceBuffer<RowOut> d_rows;
+    DeviceBuffer<char> d_scores;
+    if (n_lists > 0) {
+      d_lptr.upload(lptr, s);
+      if (litems.empty()) litems.push_back(0);
+      d_litems.upload(litems, s);
+    }
+    const size_t bytes = static_cast<size_t>(rows) * n_items * (is_f64 ? 8 : 4);
+    d_scores.alloc(std::max<size_t>(bytes, 8));
+    IRS_HIP(hipMemcpyAsync(d_scores.ptr, scores, bytes, hipMemcpyHostToDevice, s));
+    d_rec.alloc(static_cast<size_t>(rows) * cutoff);
+    d_rows.alloc(rows);
+    EvalParams p{};
+    p.scores = d_scores.ptr;
+    p.rows = rows;
+    p.n_items = n_items;
+    p.offset = 0;
+    p.rec_mode = n_lists == 0 ? 0 : (n_lists == 1 ? 1 : 2);
+    p.rec_ptr = d_lptr.ptr;
+    p.rec_items = d_litems.ptr;
+    p.cutoff = static_cast<int32_t>(cutoff);
+    p.retrieve = 1;
+    p.out = d_rows.ptr;
+    p.rec_out = d_rec.ptr;
+    if (is_f64)
+      launch_rank<double>(p, max_cand, s);
+    else
+      launch_rank<float>(p, max_cand, s);
+    IRS_HIP(hipGetLastError());
+    IRS_HIP(hipMemcpyAsync(out_idx, d_rec.ptr, static_cast<size_t>(rows) * cutoff * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, s));
+    IRS_HIP(hipStreamSynchronize(s));
   });
 }
 

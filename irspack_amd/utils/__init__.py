@@ -1,10 +1,13 @@
 """The pieces of the reference's ``irspack.utils._util_cpp`` that the kNN path calls
 (/root/reference/cpp_source/util.hpp:158-226, util.cpp:14,29-32).
 
-``remove_diagonal`` goes through the C ABI; the two pre-weighting helpers are
-plain element-wise host transforms (float64 like the reference) written with
-numpy — they are data preparation, not part of the accelerated product.
+``remove_diagonal`` and the serving top-k ``retrieve_recommend_from_score`` go through the
+C ABI; the two pre-weighting helpers are plain element-wise host transforms (float64 like
+the reference) written with numpy — they are data preparation, not part of the
+accelerated product.
 """
+
+from typing import List, Optional, Sequence, Tuple
 
 import ctypes as C
 
@@ -59,3 +62,60 @@ def okapi_BM_25_weight(X, k1: float = 1.2, b: float = 0.75) -> sps.csr_matrix:
     out = Xc.copy()
     out.data = idf[out.indices] * (out.data * (k1 + 1)) / (out.data + regularizer)
     return out
+
+
+def _retrieve(score: np.ndarray, allowed_item_indices: Sequence[Sequence[int]], cutoff: int,
+              n_threads: int, device: Optional[int]) -> List[List[Tuple[int, float]]]:
+    if cutoff < 0 or n_threads < 0:
+        raise TypeError("cutoff and n_threads must be non-negative (size_t).")
+    score = np.ascontiguousarray(score)
+    if score.ndim != 2:
+        raise ValueError("score must be a 2-d array.")
+    rows, n_items = score.shape
+    lptr = np.zeros(len(allowed_item_indices) + 1, dtype=np.int64)
+    for i, l in enumerate(allowed_item_indices):
+        lptr[i + 1] = lptr[i] + len(l)
+    litems = np.zeros(max(int(lptr[-1]), 1), dtype=np.int64)
+    for i, l in enumerate(allowed_item_indices):
+        litems[lptr[i]:lptr[i + 1]] = np.asarray(l, dtype=np.int64)
+    width = max(min(int(cutoff), 2 ** 31 - 1), 0)
+    out = np.full((rows, max(width, 1)), -1, dtype=np.int32)
+    check(lib().irs_retrieve_recommend(
+        C.c_int32(1 if score.dtype == np.float64 else 0), score.ctypes.data_as(C.c_void_p),
+        C.c_int64(rows), C.c_int64(n_items), C.c_int64(len(allowed_item_indices)),
+        ptr(lptr, C.c_int64), ptr(litems, C.c_int64), C.c_int64(width), C.c_int64(n_threads),
+        C.c_int32(_lib.default_device() if device is None else device), ptr(out, C.c_int32)))
+    result: List[List[Tuple[int, float]]] = []
+    for r in range(rows):
+        idx = out[r][out[r] >= 0] if width > 0 else out[r][:0]
+        # the reference returns std::pair<int64_t, float>: scores are narrowed to float32
+        vals = score[r, idx].astype(np.float32)
+        result.append([(int(i), float(v)) for i, v in zip(idx, vals)])
+    return result
+
+
+def retrieve_recommend_from_score_f32(score, allowed_item_indices, cutoff: int, n_threads: int = 1,
+                                      *, device: Optional[int] = None):
+    """util.hpp:426-504 for float32 scores (bound as ``retrieve_recommend_from_score_f32``)."""
+    return _retrieve(np.asarray(score, dtype=np.float32), allowed_item_indices, cutoff, n_threads,
+                     device)
+
+
+def retrieve_recommend_from_score_f64(score, allowed_item_indices, cutoff: int, n_threads: int = 1,
+                                      *, device: Optional[int] = None):
+    """util.hpp:426-504 for float64 scores (bound as ``retrieve_recommend_from_score_f64``)."""
+    return _retrieve(np.asarray(score, dtype=np.float64), allowed_item_indices, cutoff, n_threads,
+                     device)
+
+
+def retrieve_recommend_from_score(score, allowed_item_indices, cutoff: int, n_threads: int = 1,
+                                  *, device: Optional[int] = None):
+    """irspack/utils/id_mapping.py:29-44: dispatch on the score dtype."""
+    score = np.asarray(score)
+    if score.dtype == np.float32:
+        return retrieve_recommend_from_score_f32(score, allowed_item_indices, cutoff, n_threads,
+                                                 device=device)
+    if score.dtype == np.float64:
+        return retrieve_recommend_from_score_f64(score, allowed_item_indices, cutoff, n_threads,
+                                                 device=device)
+    raise ValueError("Only float32 or float64 are allowed.")
