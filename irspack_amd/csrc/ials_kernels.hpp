@@ -537,6 +537,60 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
     }
   }
   __threadfence_block();
+  if constexpr (KP > 64) {
+    // KP = 128: lane l owns the virtual rows l and 64 + l.  Row 64 + l only needs the last
+    // 64 columns.  As below, whatever a row accumulates after its own step is never read.
+    static_assert(KP == 128, "two rows per lane");
+    const int rk = lane & 15, I0 = lane >> 4, I1 = 4 + (lane >> 4);
+    auto tile_of = [&](int I, int J) { return I * T - I * (I - 1) / 2 + (J - I); };
+    float row0[128], row1[64];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      const float *src = sm + tile_of(I0, j >= I0 ? j : I0) * C::TS + rk * 20;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
+        row0[16 * j + 4 * c] = v.x; row0[16 * j + 4 * c + 1] = v.y;
+        row0[16 * j + 4 * c + 2] = v.z; row0[16 * j + 4 * c + 3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int j = 4; j < T; j++) {
+      const float *src = sm + tile_of(I1, j >= I1 ? j : I1) * C::TS + rk * 20;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
+        row1[16 * (j - 4) + 4 * c] = v.x; row1[16 * (j - 4) + 4 * c + 1] = v.y;
+        row1[16 * (j - 4) + 4 * c + 2] = v.z; row1[16 * (j - 4) + 4 * c + 3] = v.w;
+      }
+    }
+    const float rinv0 = 1.0f / sm[tile_of(I0, I0) * C::TS + rk * 20 + rk];
+    const float rinv1 = 1.0f / sm[tile_of(I1, I1) * C::TS + rk * 20 + rk];
+    const float y0 = ybuf[lane], y1 = ybuf[64 + lane];
+    float p0 = 0.f, p1 = 0.f, x0 = 0.f, x1 = 0.f;
+#pragma unroll
+    for (int j = 127; j >= 64; j--) {
+      const float xj = readlane_f((y1 - p1) * rinv1, j - 64);
+      if (lane == j - 64) x1 = xj;
+      p1 = fmaf(row1[j - 64], xj, p1);
+      p0 = fmaf(row0[j], xj, p0);
+    }
+#pragma unroll
+    for (int j = 63; j >= 0; j--) {
+      const float xj = readlane_f((y0 - p0) * rinv0, j);
+      if (lane == j) x0 = xj;
+      p0 = fmaf(row0[j], xj, p0);
+    }
+    // virtual index k = 16 I + m'  <->  latent dim T m' + I
+    const int dim0 = T * rk + I0, dim1 = T * rk + I1;
+    const bool fin = (__builtin_isfinite(x0) || dim0 >= K) && (__builtin_isfinite(x1) || dim1 >= K);
+    if (!__all(fin)) {
+      if (lane == 0) atomicOr(err_flag, 2);
+    }
+    xrow[dim0] = dim0 < K ? x0 : 0.f;
+    xrow[dim1] = dim1 < K ? x1 : 0.f;
+    return;
+  }
   const int k = lane < KP ? lane : KP - 1;
   const int Ik = k >> 4, rk = k & 15;
   float rowk[KP];
@@ -574,7 +628,7 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
 //         rows store their partial Gramian / rhs.
 // MODE 1: one wave per split row: sum the partials in slot order and solve.
 template <int T, int SOLVER, int MODE>
-__global__ __launch_bounds__(64 * SOLVE_WAVES, SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
+__global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
   using G = Geo<T>;
 #ifdef IRS_EXPERIMENT_SKIP_SOLVE
   constexpr int LDS_PER_WAVE = 64;  // occupancy experiment: no solve, no LDS need
