@@ -452,8 +452,8 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
   IRS_HIP(hipGetLastError());
 }
 
-// IRSPACK_AMD_IALS_WAVE128=0 sends K in (64, 128] Cholesky to the workgroup-per-row kernels.
-static bool wave_cholesky_at_128() {
+// IRSPACK_AMD_IALS_WAVE128=0 sends K in (64, 128] to the workgroup-per-row kernels.
+static bool wave_path_at_128() {
   static bool v = [] {
     const char *e = std::getenv("IRSPACK_AMD_IALS_WAVE128");
     return e ? std::atoi(e) != 0 : true;
@@ -492,21 +492,27 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                                                sc->max_cg_steps, 1u << 20));
   p.warm_start = 1;
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
-  if (t->T == 8 && !cg && wave_cholesky_at_128()) {
-    // 64 < K <= 128, Cholesky: the 36 tiles still fit one wave's 512 registers (144 of them
-    // accumulators), so the one-wave-per-task kernel and its MFMA panel Cholesky are reused
-    // (46 KB LDS per wave for the spilled factor: three waves per CU)
+  if (t->T == 8 && wave_path_at_128()) {
+    // 64 < K <= 128: the 36 tiles still fit one wave's 512 registers (144 of them
+    // accumulators), so the one-wave-per-task kernel is reused with the MFMA panel Cholesky /
+    // a two-rows-per-lane CG (46 KB LDS per wave for the spilled tiles: three waves per CU)
     using G = Geo<8>;
     t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
     p.partials = t->split_partial.ptr;
     if (sd.n_tasks > 0) {
-      t->prof.begin(kNames[0][0][pidx], t->stream);
-      hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0>), dim3(sd.n_tasks), dim3(64), 0, t->stream, p);
+      t->prof.begin(kNames[cg][0][pidx], t->stream);
+      if (cg)
+        hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0>), dim3(sd.n_tasks), dim3(64), 0, t->stream, p);
+      else
+        hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0>), dim3(sd.n_tasks), dim3(64), 0, t->stream, p);
       t->prof.end(t->stream);
     }
     if (sd.n_split > 0) {
-      t->prof.begin(kNames[0][1][pidx], t->stream);
-      hipLaunchKernelGGL((ials_solve_kernel<8, 0, 1>), dim3(sd.n_split), dim3(64), 0, t->stream, p);
+      t->prof.begin(kNames[cg][1][pidx], t->stream);
+      if (cg)
+        hipLaunchKernelGGL((ials_solve_kernel<8, 1, 1>), dim3(sd.n_split), dim3(64), 0, t->stream, p);
+      else
+        hipLaunchKernelGGL((ials_solve_kernel<8, 0, 1>), dim3(sd.n_split), dim3(64), 0, t->stream, p);
       t->prof.end(t->stream);
     }
   } else if (t->T <= 4) {

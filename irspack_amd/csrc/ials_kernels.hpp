@@ -624,6 +624,123 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
   if (lane < KP) xrow[dim] = dim < K ? xv : 0.f;
 }
 
+// Conjugate gradient for KP = 128 (hpp:199-264) with two matrix rows per lane.  The matrix
+// is spilled once as packed upper tiles (the layout of solve_row_cholesky, 46 KB) and lane l
+// reads the virtual rows l and 64 + l back through the symmetry: tiles right of the diagonal
+// row-wise (b128), tiles left of it column-wise.  Everything runs in the virtual basis
+// k = 16 I + m'  <->  latent dim T m' + I, which is a permutation and leaves CG's iterates
+// unchanged.
+template <int T>
+__device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
+                                                float reg, float *sm, float *xrow, int K, int nnz,
+                                                int max_cg_steps, int warm_start,
+                                                int32_t *err_flag) {
+  using C = CholGeo<T>;
+  static_assert(T == 8, "two rows per lane");
+  constexpr int KP = 128;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  if (nnz == 0) {  // hpp:207-210
+    xrow[lane] = 0.f;
+    xrow[64 + lane] = 0.f;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < T; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (4 * g + r == m) acc[C::tix(i, i)][r] += (T * m + i < K) ? reg : 1.0f;
+  float *bbuf = sm + C::NT * C::TS;
+#pragma unroll
+  for (int i = 0; i < T; i++) {
+#pragma unroll
+    for (int j = i; j < T; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS + (4 * g + r) * 20 + m] = acc[C::tix(i, j)][r];
+    if (g == 0) bbuf[16 * i + m] = b4[i];
+  }
+  __threadfence_block();
+  const int rk = lane & 15;
+  const int Iq[2] = {lane >> 4, 4 + (lane >> 4)};
+  auto tile_of = [&](int I, int J) { return I * T - I * (I - 1) / 2 + (J - I); };
+  float a[2][KP];
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int J = 0; J < T; J++) {
+      if (J >= Iq[q]) {  // row rk of tile (I, J)
+        const float *src = sm + tile_of(Iq[q], J) * C::TS + rk * 20;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
+          a[q][16 * J + 4 * c] = v.x; a[q][16 * J + 4 * c + 1] = v.y;
+          a[q][16 * J + 4 * c + 2] = v.z; a[q][16 * J + 4 * c + 3] = v.w;
+        }
+      } else {  // column rk of tile (J, I)
+        const float *src = sm + tile_of(J, Iq[q]) * C::TS + rk;
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[q][16 * J + c] = src[c * 20];
+      }
+    }
+  // virtual row 16 I + rk is latent dim T rk + I
+  const int dim[2] = {T * rk + Iq[0], T * rk + Iq[1]};
+  const bool act[2] = {dim[0] < K, dim[1] < K};
+  const float bv[2] = {bbuf[lane], bbuf[64 + lane]};
+  float x[2], r[2], p[2];
+  auto matvec = [&](const float (&vec)[2], float (&out)[2]) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+      const float vk = readlane_f(vec[k >> 6], k & 63);
+      s0 = fmaf(a[0][k], vk, s0);
+      s1 = fmaf(a[1][k], vk, s1);
+    }
+    out[0] = s0;
+    out[1] = s1;
+  };
+#pragma unroll
+  for (int q = 0; q < 2; q++) x[q] = (warm_start && act[q]) ? xrow[dim[q]] : 0.f;
+  {
+    float Ax[2];
+    matvec(x, Ax);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      r[q] = act[q] ? bv[q] - Ax[q] : 0.f;
+      p[q] = r[q];
+    }
+  }
+  bool singular = false;
+  for (int it = 0; it < max_cg_steps; it++) {
+    const float r2 = wave_sum(r[0] * r[0] + r[1] * r[1]);
+    if (r2 <= 1e-20f) break;  // hpp:238
+    float Ap[2];
+    matvec(p, Ap);
+#pragma unroll
+    for (int q = 0; q < 2; q++) Ap[q] = act[q] ? Ap[q] : 0.f;
+    const float denom = wave_sum(p[0] * Ap[0] + p[1] * Ap[1]);
+    if (!(denom > 0.f) || !__builtin_isfinite(denom)) {  // hpp:250-254
+      singular = true;
+      break;
+    }
+    const float alpha = r2 / denom;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      x[q] = fmaf(alpha, p[q], x[q]);
+      r[q] = fmaf(-alpha, Ap[q], r[q]);
+    }
+    const float r2n = wave_sum(r[0] * r[0] + r[1] * r[1]);
+    if (r2n <= 1e-20f) break;  // hpp:258
+    const float beta = r2n / r2;  // hpp:261
+#pragma unroll
+    for (int q = 0; q < 2; q++) p[q] = fmaf(beta, p[q], r[q]);
+  }
+  if (singular) {
+    if (lane == 0) atomicOr(err_flag, 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) xrow[dim[q]] = act[q] ? x[q] : 0.f;
+}
+
 // MODE 0: one wave per task.  Whole rows are solved inline; chunks of split
 //         rows store their partial Gramian / rhs.
 // MODE 1: one wave per split row: sum the partials in slot order and solve.
@@ -633,7 +750,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
 #ifdef IRS_EXPERIMENT_SKIP_SOLVE
   constexpr int LDS_PER_WAVE = 64;  // occupancy experiment: no solve, no LDS need
 #else
-  constexpr int LDS_PER_WAVE = SOLVER == 0 ? CholGeo<T>::LDS_FLOATS : G::LDS_FLOATS;
+  constexpr int LDS_PER_WAVE = (SOLVER == 0 || T == 8) ? CholGeo<T>::LDS_FLOATS : G::LDS_FLOATS;
 #endif
   __shared__ __attribute__((aligned(16))) float lds[SOLVE_WAVES * LDS_PER_WAVE];
   const int wid = threadIdx.x >> 6;
@@ -682,6 +799,10 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
     if constexpr (SOLVER == 0)
       solve_row_cholesky<T>(acc, bsum, p.reg[task.row], sm,
                             p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag);
+    else if constexpr (T == 8)
+      solve_row_cg128<T>(acc, bsum, p.reg[task.row], sm,
+                         p.target + static_cast<size_t>(task.row) * G::KP, p.K,
+                         task.end - task.begin, p.max_cg_steps, p.warm_start, p.err_flag);
     else
       solve_row<T, SOLVER>(acc, bsum, p.reg[task.row], sm,
                            p.target + static_cast<size_t>(task.row) * G::KP, p.K,
@@ -705,6 +826,10 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
     if constexpr (SOLVER == 0)
       solve_row_cholesky<T>(acc, bsum, p.reg[sr.row], sm,
                             p.target + static_cast<size_t>(sr.row) * G::KP, p.K, p.err_flag);
+    else if constexpr (T == 8)
+      solve_row_cg128<T>(acc, bsum, p.reg[sr.row], sm,
+                         p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
+                         p.max_cg_steps, p.warm_start, p.err_flag);
     else
       solve_row<T, SOLVER>(acc, bsum, p.reg[sr.row], sm,
                            p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
