@@ -130,8 +130,12 @@ template <int T, int NW, int W, int S>
 __device__ __forceinline__ void mfma_tile(const float (&cv)[T], const float (&v)[T],
                                           f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW]) {
   constexpr int t = NW * S + W;
-  if constexpr (t < Geo<T>::NT)
-    acc[S] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[tile_i<T>(t)], v[tile_j<T>(t)], acc[S], 0, 0, 0);
+  if constexpr (t < Geo<T>::NT) {
+    // forced constant evaluation: left to the optimiser, the search loops of tile_i / tile_j
+    // survive for T = 16 and the operand arrays are indexed through scratch at run time
+    constexpr int ti = tile_i<T>(t), tj = tile_j<T>(t);
+    acc[S] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[ti], v[tj], acc[S], 0, 0, 0);
+  }
 }
 template <int T, int NW, int W, int... S>
 __device__ __forceinline__ void mfma_tiles(const float (&cv)[T], const float (&v)[T],

@@ -24,9 +24,27 @@ template <int T> struct WgGeo {
   static constexpr int PACKED = KP * (KP + 1) / 2;
   // matrix | b | diag | rdiag | y (also CG's p) | reduction scratch
   static constexpr int LDS_FLOATS = PACKED + 4 * KP + 16;
+  // CG: upper tiles as 16 x 16 blocks | b | p | reduction scratch
+  static constexpr int CG_LDS_FLOATS = NT * 256 + 2 * KP + 16;
 };
 
 __device__ __forceinline__ int pk(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
+
+// (I, J) of every upper tile as a constant table: indexing it with an unrolled loop
+// counter folds to constants, where calling tile_i / tile_j would leave their search loops
+// in the kernel for T = 16.
+template <int T> struct TileTab {
+  int ti[WgGeo<T>::NT], tj[WgGeo<T>::NT];
+  constexpr TileTab() : ti{}, tj{} {
+    int t = 0;
+    for (int i = 0; i < T; i++)
+      for (int j = i; j < T; j++) {
+        ti[t] = i;
+        tj[t] = j;
+        t++;
+      }
+  }
+};
 
 __device__ __forceinline__ float block_sum(float v, float *red) {
   v = wave_sum(v);
@@ -110,7 +128,7 @@ __device__ __forceinline__ void syrk_gather_wg(const float *__restrict__ other,
 
 // Rank update of this wave's tiles, then either the partial store (chunk of a split
 // row; returns false) or the dump of the tiles into the packed LDS matrix (returns true).
-template <int T, int W, int MODE>
+template <int T, int W, int MODE, bool TILES>
 __device__ __forceinline__ bool wg_accumulate(const SolveParams &p, int item, float *A, float *bvec,
                                               int &row_out, int &nnz_out) {
   using G = WgGeo<T>;
@@ -128,9 +146,13 @@ __device__ __forceinline__ bool wg_accumulate(const SolveParams &p, int item, fl
     row = task.row;
     nnz_out = task.end - task.begin;
 #pragma unroll
-    for (int s = 0; s < G::TPW; s++) {
-      const int t = G::NW * s + W;
-      acc[s] = (task.slot < 0 && t < G::NT) ? Pacc[t * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < G::TPW; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (task.slot < 0) {  // one uniform branch around all the loads (not a select per load)
+#pragma unroll
+      for (int s = 0; s < G::TPW; s++) {
+        const int t = G::NW * s + W;
+        if (t < G::NT) acc[s] = Pacc[t * 64 + lane];
+      }
     }
     syrk_gather_wg<T, W>(p.other, p.indices, p.data, task.begin, task.end, p.bias, acc, bsum);
     if (task.slot >= 0) {
@@ -171,13 +193,36 @@ __device__ __forceinline__ bool wg_accumulate(const SolveParams &p, int item, fl
     }
   }
   row_out = row;
-  // dump: tile (I, J) register r of lane (g, m) is element (T (4g+r) + I, T m + J)
   const float reg = p.reg[row];
+  constexpr TileTab<T> tab{};
+  if constexpr (TILES) {
+    // dump the tiles as they are (virtual basis k = 16 I + m' <-> latent dim T m' + I):
+    // tile t, element (4g + r, m); the diagonal gets reg, padded dims a unit diagonal
+#pragma unroll
+    for (int s = 0; s < G::TPW; s++) {
+      const int t = G::NW * s + W;
+      if (t < G::NT) {
+        const int I = tab.ti[t], J = tab.tj[t];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float val = acc[s][r];
+          if (I == J && 4 * g + r == m) val += (T * m + I < p.K) ? reg : 1.0f;
+          A[t * 256 + (4 * g + r) * 16 + m] = val;
+        }
+      }
+    }
+    if (W == 0 && g == 0) {
+#pragma unroll
+      for (int i = 0; i < T; i++) bvec[16 * i + m] = bsum[i];
+    }
+    return true;
+  }
+  // dump: tile (I, J) register r of lane (g, m) is element (T (4g+r) + I, T m + J)
 #pragma unroll
   for (int s = 0; s < G::TPW; s++) {
     const int t = G::NW * s + W;
     if (t < G::NT) {
-      const int I = tile_i<T>(t), J = tile_j<T>(t);
+      const int I = tab.ti[t], J = tab.tj[t];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int vr = 4 * g + r;
@@ -319,24 +364,104 @@ __device__ __forceinline__ void wg_cg(const float *A, const float *bvec, float *
   if (tid < KP) xrow[tid] = act ? x : 0.f;
 }
 
+// Conjugate gradient (hpp:199-264) with one matrix row per thread in registers.  The tiles
+// were dumped in the virtual basis k = 16 I + m' (a permutation of the latent dims, which
+// leaves the iterates unchanged); thread k reads its row back through the symmetry: tiles
+// right of the diagonal row-wise, tiles left of it column-wise.  A mat-vec is then KP FMAs
+// against the broadcast vector in LDS.
+template <int T>
+__device__ __forceinline__ void wg_cg_rows(const float *A, const float *bvec, float *pbuf, float *red,
+                                           int K, int nnz, int max_cg_steps, float *xrow,
+                                           int32_t *err_flag) {
+  constexpr int KP = WgGeo<T>::KP;
+  const int tid = threadIdx.x;
+  if (nnz == 0) {  // hpp:207-210
+    if (tid < KP) xrow[tid] = 0.f;
+    return;
+  }
+  const int k = tid < KP ? tid : KP - 1;
+  const int Ik = k >> 4, rk = k & 15;
+  const int dim = T * rk + Ik;
+  const bool act = tid < KP && dim < K;
+  auto tile_of = [&](int I, int J) { return I * T - I * (I - 1) / 2 + (J - I); };
+  float a[KP];
+#pragma unroll
+  for (int J = 0; J < T; J++) {
+    if (J >= Ik) {
+      const float *src = A + tile_of(Ik, J) * 256 + rk * 16;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
+        a[16 * J + 4 * c] = v.x; a[16 * J + 4 * c + 1] = v.y;
+        a[16 * J + 4 * c + 2] = v.z; a[16 * J + 4 * c + 3] = v.w;
+      }
+    } else {
+      const float *src = A + tile_of(J, Ik) * 256 + rk;
+#pragma unroll
+      for (int c = 0; c < 16; c++) a[16 * J + c] = src[c * 16];
+    }
+  }
+  auto matvec = [&](float mine) {
+    __syncthreads();
+    if (tid < KP) pbuf[tid] = mine;
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < KP / 4; q++) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(pbuf + 4 * q);
+      s0 = fmaf(a[4 * q], v.x, s0);
+      s1 = fmaf(a[4 * q + 1], v.y, s1);
+      s0 = fmaf(a[4 * q + 2], v.z, s0);
+      s1 = fmaf(a[4 * q + 3], v.w, s1);
+    }
+    return s0 + s1;
+  };
+  float x = act ? xrow[dim] : 0.f;  // warm start (hpp:199); zero for fold-in (hpp:132)
+  const float Ax = matvec(x);  // barriers inside: every thread calls it the same number of times
+  float r = act ? bvec[k] - Ax : 0.f;
+  float pv = r;
+  bool singular = false;
+  for (int it = 0; it < max_cg_steps; it++) {
+    const float r2 = block_sum(r * r, red);
+    if (r2 <= 1e-20f) break;  // hpp:238
+    const float Ap_all = matvec(pv);  // one call per thread: the barriers inside must match
+    const float Ap = act ? Ap_all : 0.f;
+    const float denom = block_sum(pv * Ap, red);
+    if (!(denom > 0.f) || !__builtin_isfinite(denom)) {  // hpp:250-254
+      singular = true;
+      break;
+    }
+    const float alpha = r2 / denom;
+    x = fmaf(alpha, pv, x);
+    r = fmaf(-alpha, Ap, r);
+    const float r2n = block_sum(r * r, red);
+    if (r2n <= 1e-20f) break;  // hpp:258
+    const float beta = r2n / r2;  // hpp:261
+    pv = fmaf(beta, pv, r);
+  }
+  if (singular && tid == 0) atomicOr(err_flag, 4);
+  if (tid < KP) xrow[dim] = act ? x : 0.f;
+}
+
 template <int T, int SOLVER, int MODE>
 __global__ __launch_bounds__(256) void ials_wg_solve_kernel(SolveParams p) {
   using G = WgGeo<T>;
   extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+  constexpr bool TILES = SOLVER == 1;
   float *A = wg_lds;
-  float *bvec = A + G::PACKED;
+  float *bvec = A + (TILES ? G::NT * 256 : G::PACKED);
   float *diag = bvec + G::KP;
   float *rdiag = diag + G::KP;
   float *ybuf = rdiag + G::KP;
-  float *red = ybuf + G::KP;
+  float *red = TILES ? diag + G::KP : ybuf + G::KP;  // CG: tiles | b | p | red
   const int item = blockIdx.x;
   int row = 0, nnz = 0;
   bool solve = false;
   switch (threadIdx.x >> 6) {  // the tile ownership is a compile-time property of the wave
-    case 0: solve = wg_accumulate<T, 0, MODE>(p, item, A, bvec, row, nnz); break;
-    case 1: solve = wg_accumulate<T, 1, MODE>(p, item, A, bvec, row, nnz); break;
-    case 2: solve = wg_accumulate<T, 2, MODE>(p, item, A, bvec, row, nnz); break;
-    default: solve = wg_accumulate<T, 3, MODE>(p, item, A, bvec, row, nnz); break;
+    case 0: solve = wg_accumulate<T, 0, MODE, TILES>(p, item, A, bvec, row, nnz); break;
+    case 1: solve = wg_accumulate<T, 1, MODE, TILES>(p, item, A, bvec, row, nnz); break;
+    case 2: solve = wg_accumulate<T, 2, MODE, TILES>(p, item, A, bvec, row, nnz); break;
+    default: solve = wg_accumulate<T, 3, MODE, TILES>(p, item, A, bvec, row, nnz); break;
   }
   if (!solve) return;  // chunk of a split row: same decision in all four waves
   __syncthreads();
@@ -344,7 +469,7 @@ __global__ __launch_bounds__(256) void ials_wg_solve_kernel(SolveParams p) {
   if constexpr (SOLVER == 0)
     wg_cholesky<T>(A, bvec, diag, rdiag, ybuf, p.K, xrow, p.err_flag);
   else
-    wg_cg<T>(A, bvec, ybuf, red, p.K, nnz, p.max_cg_steps, xrow, p.err_flag);
+    wg_cg_rows<T>(A, bvec, diag, red, p.K, nnz, p.max_cg_steps, xrow, p.err_flag);
 }
 
 // Gramian partials for T > 4: a block owns a slab of rows, its four waves own the tiles.
