@@ -544,7 +544,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   } else {
     IRS_DISPATCH_TW(t->T, {
       using G = Geo<TT>;
-      const size_t lds = (cg ? WgGeo<TT>::CG_LDS_FLOATS : WgGeo<TT>::LDS_FLOATS) * sizeof(float);
+      constexpr size_t lds = WgGeo<TT>::LDS_FLOATS * sizeof(float);
       t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
       p.partials = t->split_partial.ptr;
       auto launch = [&](auto kernel, int n_items, const char *name) {

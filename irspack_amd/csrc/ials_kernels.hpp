@@ -338,51 +338,8 @@ __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float 
   }
   float bv = sb[li];
 
-  if constexpr (SOLVER == 0) {
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < KP; j++) {
-      const float piv = readlane_f(a[j], j);
-      bad |= !(piv > 0.f);
-      const float rinv = __builtin_amdgcn_rsqf(piv);
-      const float lj = a[j] * rinv;  // L[i][j] for lanes i > j, sqrt(piv) on lane j
-      a[j] = lj;
-#pragma unroll
-      for (int k = j + 1; k < KP; k++) a[k] = fmaf(-lj, readlane_f(lj, k), a[k]);
-      // forward substitution rides along: y_j = (b_j - sum_{t<j} L[j][t] y_t) / L[j][j]
-      const float tj = bv * rinv;
-      const float yj = readlane_f(tj, j);
-      if (lane > j) bv = fmaf(-lj, yj, bv);
-      if (lane == j) bv = yj;
-    }
-    if (bad) {
-      if (lane == 0) atomicOr(err_flag, 1);
-    }
-    // L^T x = y: lane j needs column j of L -> transpose through LDS
-    __threadfence_block();
-#pragma unroll
-    for (int q = 0; q < KP / 4; q++) {
-      f32x4 t = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-      if (lane < KP) *reinterpret_cast<f32x4 *>(sm + lane * LD + 4 * q) = t;
-    }
-    __threadfence_block();
-#pragma unroll
-    for (int i = 0; i < KP; i++) a[i] = sm[i * LD + li];  // a[i] = L[i][lane]
-    const float my_rinv = 1.0f / sm[li * LD + li];
-    float xv = 0.f;
-#pragma unroll
-    for (int i = KP - 1; i >= 0; i--) {
-      const float ti = bv * my_rinv;
-      const float xi = readlane_f(ti, i);
-      if (lane == i) xv = xi;
-      bv = fmaf(-a[i], xi, bv);
-    }
-    const bool fin = __builtin_isfinite(xv) || lane >= K;
-    if (!__all(fin)) {
-      if (lane == 0) atomicOr(err_flag, 2);
-    }
-    if (lane < KP) xrow[lane] = lane < K ? xv : 0.f;
-  } else {
+  static_assert(SOLVER == 1, "Cholesky is solve_row_cholesky (accumulator layout)");
+  {
     // conjugate gradient, hpp:199-264
     const bool act = lane < K;
     float x = (warm_start && act) ? xrow[li] : 0.f;

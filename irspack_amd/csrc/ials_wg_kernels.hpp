@@ -1,15 +1,21 @@
-// iALS solve for 64 < K <= 256 (KP = 128 / 192 / 256): one 256-thread workgroup per
-// task.  Same algorithm as ials_kernels.hpp (hpp:273-331 Cholesky, hpp:170-271 CG),
-// different mapping: the KP x KP Gramian no longer fits one wave's registers, so
-//   * the upper 16x16 tiles are dealt round-robin to the four waves, which all walk
-//     the same row with the gather pipeline of syrk_gather (MFMA rank update),
-//   * the finished matrix (+ P + reg) is written to LDS as a packed lower triangle in
-//     natural coordinates (131.6 KB at K = 256) and solved there by the workgroup:
-//     right-looking Cholesky with 2 barriers per column, substitutions by one wave;
-//     or conjugate gradient on the explicit matrix (one thread per unknown).
-// This is the correctness-first path for the K = 128 / 256 configurations; the LDS
-// Cholesky is VALU-only (K^3/6 multiply-adds through LDS) and is the part to replace by
-// an MFMA-blocked factorisation next.
+// iALS solve for 128 < K <= 256 (KP = 192 / 256): one 256-thread workgroup per task.
+// (K <= 128 runs on the one-wave-per-task kernels of ials_kernels.hpp.)  Same algorithm
+// (hpp:273-331 Cholesky, hpp:170-271 CG), different mapping: the KP x KP Gramian no longer
+// fits one wave's registers, so
+//   * the upper 16x16 tiles are dealt round-robin to the four waves, which all walk the
+//     same row with a gather pipeline (MFMA rank update on the wave's own tiles);
+//   * Cholesky: the tiles stay in the accumulator registers.  Per 4-row panel the wave that
+//     owns the diagonal tile factorises the 4x4 block and publishes its 10 scalars, every
+//     wave replays the row operations on its tiles of that tile row, the panel rows go
+//     through LDS and come back as MFMA operands for the trailing rank-4 update of every
+//     tile (2 barriers per panel).  R is then dumped as 16x16 blocks and R x = y is solved
+//     by blocks of 16 (a 16-lane triangular solve + a block mat-vec, 2 barriers per block);
+//   * CG: the tiles are dumped as 16x16 blocks and every thread reads one matrix row back
+//     into registers through the symmetry; a mat-vec is KP FMAs against the broadcast
+//     vector in LDS.
+// Everything after the rank update works in the virtual basis k = 16 I + m' <-> latent dim
+// T m' + I (the basis the MFMA tiles are in), a permutation that changes neither the
+// factorisation's result nor CG's iterates.
 #pragma once
 #include "ials_kernels.hpp"
 
@@ -21,14 +27,12 @@ template <int T> struct WgGeo {
   static constexpr int NT = T * (T + 1) / 2;
   static constexpr int NW = 4;
   static constexpr int TPW = (NT + NW - 1) / NW;
-  static constexpr int PACKED = KP * (KP + 1) / 2;
-  // matrix | b | diag | rdiag | y (also CG's p) | reduction scratch
-  static constexpr int LDS_FLOATS = PACKED + 4 * KP + 16;
-  // CG: upper tiles as 16 x 16 blocks | b | p | reduction scratch
-  static constexpr int CG_LDS_FLOATS = NT * 256 + 2 * KP + 16;
+  static constexpr int PR = KP + 16;  // panel row stride: KP columns + the rhs column
+  // tiles as 16 x 16 blocks (the panel rows of the factorisation overlay their head: R is
+  // dumped only after the last panel) | b / y | p / x | 4x4 scalars + reduction scratch
+  static constexpr int LDS_FLOATS = NT * 256 + 2 * KP + 32;
+  static_assert(4 * PR <= NT * 256, "panel rows must fit the tile area");
 };
-
-__device__ __forceinline__ int pk(int r, int c) { return r * (r + 1) / 2 + c; }  // r >= c
 
 // (I, J) of every upper tile as a constant table: indexing it with an unrolled loop
 // counter folds to constants, where calling tile_i / tile_j would leave their search loops
@@ -55,7 +59,7 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 }
 
 // Gather + rank update for one wave of the workgroup (tiles t % 4 == W).  Kept small on
-// purpose (the per-wave MFMA work of a sub-step is 9 .. 34 instructions here, so a
+// purpose (the per-wave MFMA work of a sub-step is 20 .. 34 instructions here, so a
 // two-deep pipeline of 4-sub-step groups already covers the gather latency): group
 // it+1 is gathered while group it is multiplied; indices run one group further ahead.
 template <int T, int W>
@@ -126,24 +130,22 @@ __device__ __forceinline__ void syrk_gather_wg(const float *__restrict__ other,
   }
 }
 
-// Rank update of this wave's tiles, then either the partial store (chunk of a split
-// row; returns false) or the dump of the tiles into the packed LDS matrix (returns true).
-template <int T, int W, int MODE, bool TILES>
-__device__ __forceinline__ bool wg_accumulate(const SolveParams &p, int item, float *A, float *bvec,
-                                              int &row_out, int &nnz_out) {
+// Rank update of this wave's tiles.  Returns false after storing the partial of a chunk of
+// a split row (MODE 0); otherwise the wave's tiles (+ P) and, in wave 0, the rhs are left
+// in acc / bsum.
+template <int T, int W, int MODE>
+__device__ __forceinline__ bool wg_gather(const SolveParams &p, int item, f32x4 (&acc)[WgGeo<T>::TPW],
+                                          float (&bsum)[T], int &row_out, int &nnz_out) {
   using G = WgGeo<T>;
   const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, m = lane & 15;
-  f32x4 acc[G::TPW];
-  float bsum[T];
+  const int m = lane & 15;
 #pragma unroll
   for (int i = 0; i < T; i++) bsum[i] = 0.f;
   const f32x4 *Pacc = reinterpret_cast<const f32x4 *>(p.P_acc);
   constexpr int PARTIAL = Geo<T>::PARTIAL_FLOATS;
-  int row;
   if constexpr (MODE == 0) {
     const Task task = p.tasks[item];
-    row = task.row;
+    row_out = task.row;
     nnz_out = task.end - task.begin;
 #pragma unroll
     for (int s = 0; s < G::TPW; s++) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -171,7 +173,7 @@ __device__ __forceinline__ bool wg_accumulate(const SolveParams &p, int item, fl
     }
   } else {
     const SplitRow sr = p.split_rows[item];
-    row = sr.row;
+    row_out = sr.row;
     nnz_out = sr.nnz;
 #pragma unroll
     for (int s = 0; s < G::TPW; s++) {
@@ -192,183 +194,253 @@ __device__ __forceinline__ bool wg_accumulate(const SolveParams &p, int item, fl
       }
     }
   }
-  row_out = row;
-  const float reg = p.reg[row];
+  return true;
+}
+
+// + reg on the diagonal (hpp:312-314); padded dims get a unit diagonal so that they decouple
+template <int T, int W>
+__device__ __forceinline__ void wg_add_reg(f32x4 (&acc)[WgGeo<T>::TPW], float reg, int K) {
+  using G = WgGeo<T>;
   constexpr TileTab<T> tab{};
-  if constexpr (TILES) {
-    // dump the tiles as they are (virtual basis k = 16 I + m' <-> latent dim T m' + I):
-    // tile t, element (4g + r, m); the diagonal gets reg, padded dims a unit diagonal
-#pragma unroll
-    for (int s = 0; s < G::TPW; s++) {
-      const int t = G::NW * s + W;
-      if (t < G::NT) {
-        const int I = tab.ti[t], J = tab.tj[t];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          float val = acc[s][r];
-          if (I == J && 4 * g + r == m) val += (T * m + I < p.K) ? reg : 1.0f;
-          A[t * 256 + (4 * g + r) * 16 + m] = val;
-        }
-      }
-    }
-    if (W == 0 && g == 0) {
-#pragma unroll
-      for (int i = 0; i < T; i++) bvec[16 * i + m] = bsum[i];
-    }
-    return true;
-  }
-  // dump: tile (I, J) register r of lane (g, m) is element (T (4g+r) + I, T m + J)
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
 #pragma unroll
   for (int s = 0; s < G::TPW; s++) {
     const int t = G::NW * s + W;
     if (t < G::NT) {
-      const int I = tab.ti[t], J = tab.tj[t];
+      if (tab.ti[t] == tab.tj[t]) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int vr = 4 * g + r;
-        if (I == J && vr > m) continue;  // the diagonal tiles hold both triangles: keep one
-        const int dr = T * vr + I, dc = T * m + J;
-        float val = acc[s][r];
-        if (dr == dc) val += dr < p.K ? reg : 1.0f;  // hpp:312-314; padded dims decouple
-        A[dr >= dc ? pk(dr, dc) : pk(dc, dr)] = val;
+        for (int r = 0; r < 4; r++)
+          if (4 * g + r == m) acc[s][r] += (T * m + tab.ti[t] < K) ? reg : 1.0f;
       }
     }
   }
-  if (W == 0 && g == 0) {
-#pragma unroll
-    for (int i = 0; i < T; i++) bvec[T * m + i] = bsum[i];
-  }
-  return true;
 }
 
-// Cholesky A = L L^T in the packed LDS matrix + both substitutions (hpp:316-324).
-template <int T>
-__device__ __forceinline__ void wg_cholesky(float *A, float *bvec, float *diag, float *rdiag,
-                                            float *ybuf, int K, float *xrow, int32_t *err_flag) {
-  constexpr int KP = WgGeo<T>::KP;
-  const int tid = threadIdx.x;
-  const int ty = tid >> 4, tx = tid & 15;
-  bool bad = false;
-  for (int j = 0; j < K; j++) {
-    __syncthreads();  // trailing update of column j-1 is complete
-    const float d = A[pk(j, j)];
-    bad |= !(d > 0.f);
-    const float rinv = __builtin_amdgcn_rsqf(d);
-    if (tid == 0) {
-      diag[j] = d * rinv;
-      rdiag[j] = rinv;
+// tile t, element (row 4g + r, column m) -> tiles[t * 256 + row * 16 + column]
+template <int T, int W>
+__device__ __forceinline__ void wg_dump_tiles(const f32x4 (&acc)[WgGeo<T>::TPW], float *tiles) {
+  using G = WgGeo<T>;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+#pragma unroll
+  for (int s = 0; s < G::TPW; s++) {
+    const int t = G::NW * s + W;
+    if (t < G::NT) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) tiles[t * 256 + (4 * g + r) * 16 + m] = acc[s][r];
     }
-    for (int i = j + 1 + tid; i < K; i += 256) A[pk(i, j)] *= rinv;
-    __syncthreads();
-    for (int i = j + 1 + ty; i < K; i += 16) {
-      const float lij = A[pk(i, j)];
-      for (int k = j + 1 + tx; k <= i; k += 16) A[pk(i, k)] = fmaf(-lij, A[pk(k, j)], A[pk(i, k)]);
+  }
+}
+
+// Cholesky M = R^T R on the tiles in registers + both substitutions (hpp:316-324).
+// LDS: tiles | ybuf | xbuf | pan | scal.
+template <int T, int W>
+__device__ __forceinline__ void wg_cholesky_tiles(f32x4 (&acc)[WgGeo<T>::TPW], const float (&bsum)[T],
+                                                  float *tiles, float *ybuf, float *xbuf, float *pan,
+                                                  float *scal, int K, float *xrow,
+                                                  int32_t *err_flag) {
+  using G = WgGeo<T>;
+  constexpr int KP = G::KP, PR = G::PR;
+  constexpr TileTab<T> tab{};
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = lane >> 4, m = lane & 15;
+  // rhs as an extra column in accumulator layout (wave 0): row 4g + r of tile row i
+  f32x4 bacc[W == 0 ? T : 1];
+  if constexpr (W == 0) {
+#pragma unroll
+    for (int i = 0; i < T; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) bacc[i][r] = __shfl(bsum[i], 20 * g + r, 64);
+  }
+  bool bad = false;
+  for (int I = 0; I < T; I++) {
+    for (int gq = 0; gq < 4; gq++) {
+      const bool mine = g == gq;
+      // ---- (A) the owner of the diagonal tile factorises the 4 x 4 block
+#pragma unroll
+      for (int s = 0; s < G::TPW; s++) {
+        const int t = G::NW * s + W;
+        if (t < G::NT) {
+          if (tab.ti[t] == tab.tj[t] && tab.ti[t] == I) {  // uniform
+            float sc[10];
+            int n_s = 4;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const float piv = readlane_f(acc[s][r], 20 * gq + r);
+              bad |= !(piv > 0.f);
+              const float rinv = __builtin_amdgcn_rsqf(piv);
+              sc[r] = rinv;
+              acc[s][r] *= mine ? rinv : 1.0f;
+#pragma unroll
+              for (int r2 = r + 1; r2 < 4; r2++) {
+                const float sv = readlane_f(acc[s][r], 20 * gq + r2);  // R[k][k2]
+                sc[n_s++] = sv;
+                acc[s][r2] = fmaf(-(mine ? sv : 0.f), acc[s][r], acc[s][r2]);
+              }
+            }
+            if (lane == 0) {
+#pragma unroll
+              for (int q = 0; q < 10; q++) scal[q] = sc[q];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- (B) replay the row operations on the other tiles of tile row I and on the rhs
+      float sc[10];
+#pragma unroll
+      for (int q = 0; q < 10; q++) sc[q] = scal[q];
+      auto replay = [&](f32x4 &v) {
+        int n_s = 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          v[r] *= mine ? sc[r] : 1.0f;
+#pragma unroll
+          for (int r2 = r + 1; r2 < 4; r2++) {
+            v[r2] = fmaf(-(mine ? sc[n_s] : 0.f), v[r], v[r2]);
+            n_s++;
+          }
+        }
+      };
+#pragma unroll
+      for (int s = 0; s < G::TPW; s++) {
+        const int t = G::NW * s + W;
+        if (t < G::NT) {
+          if (tab.ti[t] == I && tab.tj[t] > I) replay(acc[s]);
+        }
+      }
+      if constexpr (W == 0) {
+#pragma unroll
+        for (int i = 0; i < T; i++)
+          if (i == I) replay(bacc[i]);
+      }
+      if (I == T - 1 && gq == 3) break;  // nothing below the last panel
+      // ---- (C) panel rows -> LDS
+      if (mine) {
+#pragma unroll
+        for (int s = 0; s < G::TPW; s++) {
+          const int t = G::NW * s + W;
+          if (t < G::NT) {
+            if (tab.ti[t] == I) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) pan[r * PR + 16 * tab.tj[t] + m] = acc[s][r];
+            }
+          }
+        }
+        if constexpr (W == 0) {
+          if (m == 0) {
+#pragma unroll
+            for (int i = 0; i < T; i++)
+              if (i == I) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) pan[r * PR + KP] = bacc[i][r];
+              }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- (D) trailing rank-4 update: one MFMA per tile at or below tile row I
+      float op[T];
+#pragma unroll
+      for (int j = 0; j < T; j++) op[j] = pan[g * PR + 16 * j + m];
+      const float opb = pan[g * PR + KP];
+      const bool below = m > 4 * gq + 3;  // rows up to the panel are final
+#pragma unroll
+      for (int s = 0; s < G::TPW; s++) {
+        const int t = G::NW * s + W;
+        if (t < G::NT) {
+          if (tab.ti[t] >= I) {
+            float a = op[tab.ti[t]];
+            if (tab.ti[t] == I) a = below ? a : 0.f;
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a, op[tab.tj[t]], acc[s], 0, 0, 0);
+          }
+        }
+      }
+      if constexpr (W == 0) {
+#pragma unroll
+        for (int i = 0; i < T; i++)
+          if (i >= I) {
+            float a = op[i];
+            if (i == I) a = below ? a : 0.f;
+            bacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a, opb, bacc[i], 0, 0, 0);
+          }
+      }
+      // the next (A) writes scal and the next (C) writes pan: both after a barrier that
+      // every wave reaches only when it is done with the reads above
+    }
+  }
+  if (bad) {
+    if (lane == 0) atomicOr(err_flag, 1);
+  }
+  // ---- dump R (16 x 16 blocks) and y, then R x = y by blocks of 16 rows, last block first
+  wg_dump_tiles<T, W>(acc, tiles);
+  if constexpr (W == 0) {
+    if (m == 0) {
+#pragma unroll
+      for (int i = 0; i < T; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) ybuf[16 * i + 4 * g + r] = bacc[i][r];
     }
   }
   __syncthreads();
-  if (bad && tid == 0) atomicOr(err_flag, 1);
-  // substitutions by wave 0: lane l owns unknowns l, l + 64, ...
-  if (tid < 64) {
-    constexpr int Q = KP / 64;
-    float bl[Q];
+  auto tile_of = [&](int I, int J) { return I * T - I * (I - 1) / 2 + (J - I); };
+  for (int Ib = T - 1; Ib >= 0; Ib--) {
+    if (tid < 64) {  // wave 0: lane c < 16 owns row c of the diagonal block
+      const int rk = lane & 15;
+      const float *dt = tiles + tile_of(Ib, Ib) * 256 + rk * 16;
+      float rr[16];
 #pragma unroll
-    for (int q = 0; q < Q; q++) bl[q] = (tid + 64 * q) < K ? bvec[tid + 64 * q] : 0.f;
-    // L y = b
-#pragma unroll
-    for (int q = 0; q < Q; q++) {
-      for (int jl = 0; jl < 64; jl++) {
-        const int j = 64 * q + jl;
-        if (j >= K) break;
-        const float yj = readlane_f(bl[q], jl) * rdiag[j];
-        if (tid == jl) bl[q] = yj;
-#pragma unroll
-        for (int q2 = q; q2 < Q; q2++) {
-          const int i = tid + 64 * q2;
-          if (i > j && i < K) bl[q2] = fmaf(-A[pk(i, j)], yj, bl[q2]);
-        }
+      for (int c = 0; c < 4; c++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(dt + 4 * c);
+        rr[4 * c] = v.x; rr[4 * c + 1] = v.y; rr[4 * c + 2] = v.z; rr[4 * c + 3] = v.w;
       }
-    }
-    // L^T x = y
+      const float rinv = 1.0f / dt[rk];
+      const float yv = ybuf[16 * Ib + rk];
+      float partial = 0.f, xv = 0.f;
 #pragma unroll
-    for (int q = Q - 1; q >= 0; q--) {
-      for (int jl = 63; jl >= 0; jl--) {
-        const int j = 64 * q + jl;
-        if (j >= K) continue;
-        const float xj = readlane_f(bl[q], jl) * rdiag[j];
-        if (tid == jl) bl[q] = xj;
-#pragma unroll
-        for (int q2 = 0; q2 <= q; q2++) {
-          const int i = tid + 64 * q2;
-          if (i < j) bl[q2] = fmaf(-A[pk(j, i)], xj, bl[q2]);
-        }
+      for (int c = 15; c >= 0; c--) {  // what a row accumulates after its own step is never read
+        const float xc = readlane_f((yv - partial) * rinv, c);
+        if (lane == c) xv = xc;
+        partial = fmaf(rr[c], xc, partial);
       }
+      if (lane < 16) xbuf[16 * Ib + lane] = xv;
     }
-    bool fin = true;
+    __syncthreads();
+    if (tid < 16 * Ib) {  // rows above the block: y -= R[:, block] x[block]
+      const int Ik = tid >> 4, rk = tid & 15;
+      const float *src = tiles + tile_of(Ik, Ib) * 256 + rk * 16;
+      float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
-      const int i = tid + 64 * q;
-      if (i < K) fin &= __builtin_isfinite(bl[q]) != 0;
-      xrow[i] = i < K ? bl[q] : 0.f;
+      for (int c = 0; c < 4; c++) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
+        const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xbuf + 16 * Ib + 4 * c);
+        s0 = fmaf(v.x, x4.x, s0);
+        s1 = fmaf(v.y, x4.y, s1);
+        s0 = fmaf(v.z, x4.z, s0);
+        s1 = fmaf(v.w, x4.w, s1);
+      }
+      ybuf[tid] -= s0 + s1;
     }
-    if (!__all(fin) && tid == 0) atomicOr(err_flag, 2);
+    __syncthreads();
   }
-  (void)ybuf;
+  // virtual index k = 16 I + m'  <->  latent dim T m' + I
+  bool fin = true;
+  if (tid < KP) {
+    const int dim = T * (tid & 15) + (tid >> 4);
+    const float xv = xbuf[tid];
+    fin = __builtin_isfinite(xv) || dim >= K;
+    xrow[dim] = dim < K ? xv : 0.f;
+  }
+  if (!__all(fin)) {
+    if (lane == 0) atomicOr(err_flag, 2);
+  }
 }
 
-// Conjugate gradient on the explicit packed matrix, same iterates as hpp:199-264.
-template <int T>
-__device__ __forceinline__ void wg_cg(const float *A, const float *bvec, float *pbuf, float *red,
-                                      int K, int nnz, int max_cg_steps, float *xrow,
-                                      int32_t *err_flag) {
-  constexpr int KP = WgGeo<T>::KP;
-  const int tid = threadIdx.x;
-  const bool act = tid < K;
-  if (nnz == 0) {  // hpp:207-210
-    if (tid < KP) xrow[tid] = 0.f;
-    return;
-  }
-  auto matvec = [&](float mine) {
-    __syncthreads();
-    if (tid < KP) pbuf[tid] = mine;
-    __syncthreads();
-    float s = 0.f;
-    if (act) {
-      for (int k = 0; k <= tid; k++) s = fmaf(A[pk(tid, k)], pbuf[k], s);
-      for (int k = tid + 1; k < K; k++) s = fmaf(A[pk(k, tid)], pbuf[k], s);
-    }
-    return s;
-  };
-  float x = act ? xrow[tid] : 0.f;  // warm start (hpp:199); zero for fold-in (hpp:132)
-  const float Ax = matvec(x);  // barriers inside: every thread calls it exactly once
-  float r = act ? bvec[tid] - Ax : 0.f;
-  float pv = r;
-  bool singular = false;
-  for (int it = 0; it < max_cg_steps; it++) {
-    const float r2 = block_sum(r * r, red);
-    if (r2 <= 1e-20f) break;  // hpp:238
-    const float Ap = matvec(pv);
-    const float denom = block_sum(pv * Ap, red);
-    if (!(denom > 0.f) || !__builtin_isfinite(denom)) {  // hpp:250-254
-      singular = true;
-      break;
-    }
-    const float alpha = r2 / denom;
-    x = fmaf(alpha, pv, x);
-    r = fmaf(-alpha, Ap, r);
-    const float r2n = block_sum(r * r, red);
-    if (r2n <= 1e-20f) break;  // hpp:258
-    const float beta = r2n / r2;  // hpp:261
-    pv = fmaf(beta, pv, r);
-  }
-  if (singular && tid == 0) atomicOr(err_flag, 4);
-  if (tid < KP) xrow[tid] = act ? x : 0.f;
-}
-
-// Conjugate gradient (hpp:199-264) with one matrix row per thread in registers.  The tiles
-// were dumped in the virtual basis k = 16 I + m' (a permutation of the latent dims, which
-// leaves the iterates unchanged); thread k reads its row back through the symmetry: tiles
-// right of the diagonal row-wise, tiles left of it column-wise.  A mat-vec is then KP FMAs
-// against the broadcast vector in LDS.
+// Conjugate gradient (hpp:199-264) with one matrix row per thread in registers.  Thread k
+// reads its row back from the dumped tiles through the symmetry: tiles right of the
+// diagonal row-wise, tiles left of it column-wise.  A mat-vec is then KP FMAs against the
+// broadcast vector in LDS.
 template <int T>
 __device__ __forceinline__ void wg_cg_rows(const float *A, const float *bvec, float *pbuf, float *red,
                                            int K, int nnz, int max_cg_steps, float *xrow,
@@ -443,33 +515,45 @@ __device__ __forceinline__ void wg_cg_rows(const float *A, const float *bvec, fl
   if (tid < KP) xrow[dim] = act ? x : 0.f;
 }
 
-template <int T, int SOLVER, int MODE>
-__global__ __launch_bounds__(256) void ials_wg_solve_kernel(SolveParams p) {
+// One wave's share of a task: gather, then the solve together with the other three waves.
+template <int T, int W, int SOLVER, int MODE>
+__device__ __forceinline__ void wg_row(const SolveParams &p, int item, float *lds) {
   using G = WgGeo<T>;
-  extern __shared__ __attribute__((aligned(16))) float wg_lds[];
-  constexpr bool TILES = SOLVER == 1;
-  float *A = wg_lds;
-  float *bvec = A + (TILES ? G::NT * 256 : G::PACKED);
-  float *diag = bvec + G::KP;
-  float *rdiag = diag + G::KP;
-  float *ybuf = rdiag + G::KP;
-  float *red = TILES ? diag + G::KP : ybuf + G::KP;  // CG: tiles | b | p | red
-  const int item = blockIdx.x;
+  float *tiles = lds;
+  float *ybuf = tiles + G::NT * 256;  // b (CG) / y (Cholesky)
+  float *xbuf = ybuf + G::KP;         // p (CG) / x (Cholesky)
+  float *pan = tiles;                 // overlay, see WgGeo
+  float *scal = xbuf + G::KP;         // 10 scalars of the 4 x 4 factor; red[4] at +16
+  f32x4 acc[G::TPW];
+  float bsum[T];
   int row = 0, nnz = 0;
-  bool solve = false;
-  switch (threadIdx.x >> 6) {  // the tile ownership is a compile-time property of the wave
-    case 0: solve = wg_accumulate<T, 0, MODE, TILES>(p, item, A, bvec, row, nnz); break;
-    case 1: solve = wg_accumulate<T, 1, MODE, TILES>(p, item, A, bvec, row, nnz); break;
-    case 2: solve = wg_accumulate<T, 2, MODE, TILES>(p, item, A, bvec, row, nnz); break;
-    default: solve = wg_accumulate<T, 3, MODE, TILES>(p, item, A, bvec, row, nnz); break;
-  }
-  if (!solve) return;  // chunk of a split row: same decision in all four waves
-  __syncthreads();
+  // chunk of a split row: the same decision in all four waves, nobody reaches a barrier
+  if (!wg_gather<T, W, MODE>(p, item, acc, bsum, row, nnz)) return;
   float *xrow = p.target + static_cast<size_t>(row) * G::KP;
-  if constexpr (SOLVER == 0)
-    wg_cholesky<T>(A, bvec, diag, rdiag, ybuf, p.K, xrow, p.err_flag);
-  else
-    wg_cg_rows<T>(A, bvec, diag, red, p.K, nnz, p.max_cg_steps, xrow, p.err_flag);
+  wg_add_reg<T, W>(acc, p.reg[row], p.K);
+  if constexpr (SOLVER == 0) {
+    wg_cholesky_tiles<T, W>(acc, bsum, tiles, ybuf, xbuf, pan, scal, p.K, xrow, p.err_flag);
+  } else {
+    wg_dump_tiles<T, W>(acc, tiles);
+    if (W == 0 && (threadIdx.x & 63) < 16) {
+#pragma unroll
+      for (int i = 0; i < T; i++) ybuf[16 * i + (threadIdx.x & 15)] = bsum[i];
+    }
+    __syncthreads();
+    wg_cg_rows<T>(tiles, ybuf, xbuf, scal + 16, p.K, nnz, p.max_cg_steps, xrow, p.err_flag);
+  }
+}
+
+template <int T, int SOLVER, int MODE>
+__global__ __launch_bounds__(256, T <= 12 ? 2 : 1) void ials_wg_solve_kernel(SolveParams p) {
+  extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+  const int item = blockIdx.x;
+  switch (threadIdx.x >> 6) {  // the tile ownership is a compile-time property of the wave
+    case 0: wg_row<T, 0, SOLVER, MODE>(p, item, wg_lds); break;
+    case 1: wg_row<T, 1, SOLVER, MODE>(p, item, wg_lds); break;
+    case 2: wg_row<T, 2, SOLVER, MODE>(p, item, wg_lds); break;
+    default: wg_row<T, 3, SOLVER, MODE>(p, item, wg_lds); break;
+  }
 }
 
 // Gramian partials for T > 4: a block owns a slab of rows, its four waves own the tiles.
