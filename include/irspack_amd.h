@@ -59,9 +59,9 @@ typedef struct irs_ials_model_config {
   float init_stdev;
   int32_t random_seed;
   int32_t loss_type;
-  float lambda_user_feature;  /* feature-aware iALS is out of scope; */
-  float lambda_item_feature;  /* carried for pickle compatibility only.           */
-  uint64_t feature_warmup_epochs;
+  float lambda_user_feature;  /* feature-aware iALS: used by the host-side ridge update of */
+  float lambda_item_feature;  /* the feature weights (see irs_ials_set_prior); carried    */
+  uint64_t feature_warmup_epochs; /* here for the pickle state.                            */
 } irs_ials_model_config;
 
 /* SolverConfig, IALSLearningConfig.hpp:97-112 (als/wrapper.cpp:92-115) */
@@ -115,6 +115,21 @@ irs_status irs_ials_transform(irs_ials_trainer *t, int32_t side, int64_t rows,
                               int64_t cols, const int64_t *indptr,
                               const int32_t *indices, const float *data,
                               const irs_ials_solver_config *sc, float *out);
+/* transform_user_with_feature / transform_item_with_feature (hpp:803-824,
+ * X_to_vector_with_prior hpp:143-168): as irs_ials_transform with a feature prior
+ * (host float32 [out rows, K]): the rows start from the prior and the solve adds
+ * reg_r * prior_r to the right-hand side (step_cholesky_with_prior hpp:333-385, step_cg
+ * hpp:212-215).  IALSPP is rejected like in the reference (hpp:659-661). */
+irs_status irs_ials_transform_with_prior(irs_ials_trainer *t, int32_t side, int64_t rows,
+                                         int64_t cols, const int64_t *indptr,
+                                         const int32_t *indices, const float *data,
+                                         const float *prior,
+                                         const irs_ials_solver_config *sc, float *out);
+/* Feature-aware training (IALSTrainer::step, hpp:758-789): the prior of side `which`
+ * (host float32 [rows, K] = features @ feature_weight) used by the following
+ * irs_ials_half_step_async calls of that side; NULL clears it.  The feature-weight ridge
+ * update (hpp:1052-1209) is a small F x F host solve and stays with the caller. */
+irs_status irs_ials_set_prior(irs_ials_trainer *t, int32_t which, const float *prior);
 /* IALSTrainer::compute_loss, hpp:836-940. */
 irs_status irs_ials_compute_loss(irs_ials_trainer *t,
                                  const irs_ials_solver_config *sc, float *out);

@@ -75,6 +75,8 @@ EXPORTED_SYMBOLS = [
     "irs_ials_set_factor",
     "irs_ials_user_scores",
     "irs_ials_transform",
+    "irs_ials_transform_with_prior",
+    "irs_ials_set_prior",
     "irs_ials_compute_loss",
     "irs_ials_set_stream",
     "irs_ials_device_buffer",

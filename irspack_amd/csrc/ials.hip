@@ -239,6 +239,8 @@ struct irs_ials_trainer {
   DeviceBuffer<float> gram_partial, split_partial, row_loss;
   DeviceBuffer<double> loss_sum;
   DeviceBuffer<int32_t> err_flag;
+  DeviceBuffer<float> prior[2];        // feature prior of the next half step(s), [rows, KP]
+  bool has_prior[2] = {false, false};
   DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   Profiler prof;
@@ -463,17 +465,20 @@ static bool wave_path_at_128() {
 
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
 void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
-                  const irs_ials_solver_config *sc) {
+                  const irs_ials_solver_config *sc, const float *prior = nullptr) {
   static const char *kNames[2][2][2] = {
       {{"ials_solve_cholesky_user", "ials_solve_cholesky_item"},
        {"ials_split_cholesky_user", "ials_split_cholesky_item"}},
       {{"ials_solve_cg_user", "ials_solve_cg_item"},
        {"ials_split_cg_user", "ials_split_cg_item"}}};
   if (sc->solver_type == IRS_SOLVER_IALSPP) {
+    if (prior)  // hpp:659-661
+      throw std::invalid_argument("Feature-aware iALS does not support IALSPP.");
     launch_ialspp(t, sd, other, target, pidx, sc);
     return;
   }
   SolveParams p;
+  p.prior = prior;
   p.tasks = sd.tasks.ptr;
   p.n_tasks = sd.n_tasks;
   p.split_rows = sd.split.ptr;
@@ -751,7 +756,8 @@ irs_status irs_ials_half_step_async(irs_ials_trainer *t, int32_t side,
     check_solver(sc);
     require_X(t);
     IRS_HIP(hipSetDevice(t->device));
-    launch_solve(t, t->side[side], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc);
+    launch_solve(t, t->side[side], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc,
+                 t->has_prior[side] ? t->prior[side].ptr : nullptr);
   });
 }
 
@@ -847,31 +853,83 @@ irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t e
   });
 }
 
+namespace {
+
+// X_to_vector / X_to_vector_with_prior (hpp:122-168): fold-in of new rows against the stored
+// other-side factors.  Without a prior the rows start from 0; with one they start from the
+// prior (hpp:156) and the solve adds reg_r * prior_r to the right-hand side.
+void transform_impl(irs_ials_trainer *t, int32_t side, int64_t rows, int64_t cols,
+                    const int64_t *indptr, const int32_t *indices, const float *data,
+                    const float *prior, const irs_ials_solver_config *sc, float *out) {
+  check_arg(t && out && (side == 0 || side == 1), "bad argument.");
+  check_solver(sc);
+  HostCsr X = host_csr(rows, cols, indptr, indices, data);
+  IRS_HIP(hipSetDevice(t->device));
+  full_gramian(t, side);  // hpp:793 / :799
+  if (side == 1) X = transpose(X);  // hpp:800
+  const int64_t n_other = t->rows_of(1 - side);
+  if (X.cols != n_other) {  // hpp:126-131
+    std::stringstream ss;
+    ss << "Shape mismatch: X.cols() = " << X.cols
+       << " but other.factor.rows() = " << n_other << ".";
+    throw std::invalid_argument(ss.str());
+  }
+  if (prior && sc->solver_type == IRS_SOLVER_IALSPP)
+    throw std::invalid_argument("Feature-aware iALS does not support IALSPP.");
+  Side tmp;
+  tmp.build(X, 0, X.rows, t->cfg, t->stream);
+  DeviceBuffer<float> result, d_prior;  // DenseMatrix::Zero(X.rows(), K), hpp:132
+  result.alloc(static_cast<size_t>(X.rows) * t->KP);
+  result.zero(t->stream);
+  if (prior) {
+    std::vector<float> padded(static_cast<size_t>(X.rows) * t->KP, 0.0f);
+    for (int64_t r = 0; r < X.rows; r++)
+      std::copy(prior + r * t->K, prior + (r + 1) * t->K, padded.begin() + r * t->KP);
+    d_prior.upload(padded, t->stream);
+    IRS_HIP(hipMemcpyAsync(result.ptr, d_prior.ptr, padded.size() * sizeof(float),
+                           hipMemcpyDeviceToDevice, t->stream));
+    IRS_HIP(hipStreamSynchronize(t->stream));  // `padded` goes out of scope
+  }
+  launch_solve(t, tmp, t->factor[1 - side].ptr, result.ptr, side, sc,
+               prior ? d_prior.ptr : nullptr);
+  sync_and_check(t);
+  download_factor(t, result.ptr, X.rows, out);
+}
+
+}  // namespace
+
 irs_status irs_ials_transform(irs_ials_trainer *t, int32_t side, int64_t rows, int64_t cols,
                               const int64_t *indptr, const int32_t *indices, const float *data,
                               const irs_ials_solver_config *sc, float *out) {
+  return guard([&] { transform_impl(t, side, rows, cols, indptr, indices, data, nullptr, sc, out); });
+}
+
+irs_status irs_ials_transform_with_prior(irs_ials_trainer *t, int32_t side, int64_t rows,
+                                         int64_t cols, const int64_t *indptr,
+                                         const int32_t *indices, const float *data,
+                                         const float *prior, const irs_ials_solver_config *sc,
+                                         float *out) {
   return guard([&] {
-    check_arg(t && out && (side == 0 || side == 1), "bad argument.");
-    check_solver(sc);
-    HostCsr X = host_csr(rows, cols, indptr, indices, data);
-    IRS_HIP(hipSetDevice(t->device));
-    full_gramian(t, side);  // hpp:793 / :799
-    if (side == 1) X = transpose(X);  // hpp:800
-    const int64_t n_other = t->rows_of(1 - side);
-    if (X.cols != n_other) {  // hpp:126-131
-      std::stringstream ss;
-      ss << "Shape mismatch: X.cols() = " << X.cols
-         << " but other.factor.rows() = " << n_other << ".";
-      throw std::invalid_argument(ss.str());
+    check_arg(prior != nullptr, "prior is null.");
+    transform_impl(t, side, rows, cols, indptr, indices, data, prior, sc, out);
+  });
+}
+
+irs_status irs_ials_set_prior(irs_ials_trainer *t, int32_t which, const float *prior) {
+  return guard([&] {
+    check_arg(t && (which == 0 || which == 1), "bad argument.");
+    if (prior == nullptr) {
+      t->has_prior[which] = false;
+      return;
     }
-    Side tmp;
-    tmp.build(X, 0, X.rows, t->cfg, t->stream);
-    DeviceBuffer<float> result;  // DenseMatrix::Zero(X.rows(), K), hpp:132
-    result.alloc(static_cast<size_t>(X.rows) * t->KP);
-    result.zero(t->stream);
-    launch_solve(t, tmp, t->factor[1 - side].ptr, result.ptr, side, sc);
-    sync_and_check(t);
-    download_factor(t, result.ptr, X.rows, out);
+    IRS_HIP(hipSetDevice(t->device));
+    const int64_t n = t->rows_of(which);
+    std::vector<float> padded(static_cast<size_t>(n) * t->KP, 0.0f);
+    for (int64_t r = 0; r < n; r++)
+      std::copy(prior + r * t->K, prior + (r + 1) * t->K, padded.begin() + r * t->KP);
+    t->prior[which].upload(padded, t->stream);
+    IRS_HIP(hipStreamSynchronize(t->stream));
+    t->has_prior[which] = true;
   });
 }
 

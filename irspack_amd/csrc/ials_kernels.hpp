@@ -72,6 +72,8 @@ struct SolveParams {
   int32_t K;            // unpadded latent dimension
   int32_t max_cg_steps; // already resolved (0 -> K), hpp:232-234
   int32_t warm_start;   // CG: start from the current row (hpp:199) or from 0 (hpp:132)
+  const float *prior;   // feature prior [n_rows, KP] or null: rhs += reg_r * prior_r
+                        // (step_cholesky_with_prior hpp:363, step_cg hpp:212-215)
 };
 
 __device__ __forceinline__ float readlane_f(float x, int lane) {
@@ -101,6 +103,18 @@ template <int T> __device__ __forceinline__ void load_dims(const float *p, float
       v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
     }
   }
+}
+
+// rhs += reg * prior row, in the layout of bsum (lane (g, m) holds dims T m .. T m + T - 1)
+template <int T>
+__device__ __forceinline__ void add_prior(const SolveParams &p, int row, float (&bsum)[T]) {
+  if (p.prior == nullptr) return;
+  const int m = threadIdx.x & 15;
+  const float reg = p.reg[row];
+  float pr[T];
+  load_dims<T>(p.prior + static_cast<size_t>(row) * (16 * T) + T * m, pr);
+#pragma unroll
+  for (int i = 0; i < T; i++) bsum[i] = fmaf(reg, pr[i], bsum[i]);
 }
 
 // (I, J) of the t-th upper tile in row-major order of the T x T tile grid
@@ -757,17 +771,20 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
       return;
     }
 #endif
+    add_prior<T>(p, task.row, bsum);
+    // with a prior an empty row is solved like any other (hpp:207): hide nnz == 0 from CG
+    const int nnz_cg = p.prior ? max(task.end - task.begin, 1) : task.end - task.begin;
     if constexpr (SOLVER == 0)
       solve_row_cholesky<T>(acc, bsum, p.reg[task.row], sm,
                             p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag);
     else if constexpr (T == 8)
       solve_row_cg128<T>(acc, bsum, p.reg[task.row], sm,
-                         p.target + static_cast<size_t>(task.row) * G::KP, p.K,
-                         task.end - task.begin, p.max_cg_steps, p.warm_start, p.err_flag);
+                         p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
+                         p.max_cg_steps, p.warm_start, p.err_flag);
     else
       solve_row<T, SOLVER>(acc, bsum, p.reg[task.row], sm,
-                           p.target + static_cast<size_t>(task.row) * G::KP, p.K,
-                           task.end - task.begin, p.max_cg_steps, p.warm_start, p.err_flag);
+                           p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
+                           p.max_cg_steps, p.warm_start, p.err_flag);
   } else {
     if (w >= p.n_split) return;
     const SplitRow sr = p.split_rows[w];
@@ -784,6 +801,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
 #ifdef IRS_EXPERIMENT_SKIP_SOLVE
     return;
 #endif
+    add_prior<T>(p, sr.row, bsum);
     if constexpr (SOLVER == 0)
       solve_row_cholesky<T>(acc, bsum, p.reg[sr.row], sm,
                             p.target + static_cast<size_t>(sr.row) * G::KP, p.K, p.err_flag);

@@ -531,6 +531,8 @@ __device__ __forceinline__ void wg_row(const SolveParams &p, int item, float *ld
   if (!wg_gather<T, W, MODE>(p, item, acc, bsum, row, nnz)) return;
   float *xrow = p.target + static_cast<size_t>(row) * G::KP;
   wg_add_reg<T, W>(acc, p.reg[row], p.K);
+  if constexpr (W == 0) add_prior<T>(p, row, bsum);
+  if (p.prior) nnz = max(nnz, 1);  // with a prior an empty row is solved like any other
   if constexpr (SOLVER == 0) {
     wg_cholesky_tiles<T, W>(acc, bsum, tiles, ybuf, xbuf, pan, scal, p.K, xrow, p.err_flag);
   } else {

@@ -240,10 +240,16 @@ class IALSSolverConfigBuilder:  # IALSLearningConfig.hpp:114-147, wrapper.cpp:11
         return self
 
 
-_FEATURE_MSG = (
-    "irspack_amd: feature-aware iALS (user_feature / item_feature) is outside the "
-    "accelerated hot path (SURVEY.md §8f.4) and is not implemented."
-)
+def _as_feature(f: Any, rows: int) -> Any:
+    """FeatureMatrix (dense or CSR float32, hpp:693-700); ``None`` is a zero-column matrix."""
+    if f is None:
+        return np.zeros((rows, 0), dtype=np.float32)
+    if sps.issparse(f):
+        return sps.csr_matrix(f, dtype=np.float32)
+    f = np.ascontiguousarray(f, dtype=np.float32)
+    if f.ndim != 2:
+        raise TypeError("feature matrix must be 2-dimensional.")
+    return f
 
 
 class IALSTrainer:
@@ -265,13 +271,6 @@ class IALSTrainer:
         device: Optional[int] = None,
         shard: Optional[Tuple[int, int, int, int]] = None,
     ) -> None:
-        if user_feature is not None or item_feature is not None:
-            empty = all(
-                f is None or (hasattr(f, "shape") and f.shape[1] == 0)
-                for f in (user_feature, item_feature)
-            )
-            if not empty:
-                raise NotImplementedError(_FEATURE_MSG)
         if not sps.issparse(interaction):
             raise TypeError("interaction must be a scipy sparse matrix.")
         X, indptr, indices, data = _lib.csr_arrays(interaction, np.float32)
@@ -297,10 +296,93 @@ class IALSTrainer:
         )
         self._h: Optional[C.c_void_p] = h
         self._empty_feature_weight()
+        if user_feature is not None or item_feature is not None:
+            # feature-aware constructor, hpp:722-744 + initialize_feature_aware :1001-1015
+            uf = _as_feature(user_feature, self._n_users)
+            itf = _as_feature(item_feature, self._n_items)
+            if uf.shape[0] != self._n_users or itf.shape[0] != self._n_items:
+                raise ValueError("Feature matrix row count mismatch.")
+            if (uf.shape[1] and model_config.lambda_user_feature <= 0) or (
+                    itf.shape[1] and model_config.lambda_item_feature <= 0):
+                raise ValueError("Feature weight regularization must be positive.")
+            self._feature_aware = True
+            self._features = [uf, itf]
+            self._ufw = np.zeros((uf.shape[1], self._K), dtype=np.float32)
+            self._ifw = np.zeros((itf.shape[1], self._K), dtype=np.float32)
+            Xc = sps.csr_matrix(X)
+            self._row_nnz = [np.diff(Xc.indptr), np.bincount(Xc.indices, minlength=self._n_items)]
 
     def _empty_feature_weight(self) -> None:
         self._ufw = np.zeros((0, self._K), dtype=np.float32)
         self._ifw = np.zeros((0, self._K), dtype=np.float32)
+        self._feature_aware = False
+        self._features = [None, None]
+        self._row_nnz = [None, None]
+        self._ridge_cache = [None, None]
+        self._epoch = 0
+
+    # -- feature-aware pieces (hpp:758-789, 1052-1209).  The per-row solves run on the GPU
+    #    with the prior added to the right-hand side; the F x F feature-weight ridge system
+    #    is a small host solve in float32 like the reference's.
+    def _weight(self, side: int) -> np.ndarray:
+        return self._ufw if side == 0 else self._ifw
+
+    def _row_reg(self, side: int, nnz: np.ndarray) -> np.ndarray:
+        """Solver::compute_reg (hpp:117-120) in float32 for every row."""
+        c = self._config
+        n_other = self._n_items if side == 0 else self._n_users
+        base = np.float32(c.alpha0) * np.float32(n_other) + nnz.astype(np.float32)
+        return (np.float32(c.reg) * np.power(base, np.float32(c.nu), dtype=np.float32)).astype(np.float32)
+
+    def _check_prior_defined(self, side: int, nnz: np.ndarray) -> None:
+        # step_with_prior, hpp:639-653
+        if self._config.alpha0 == 0:
+            empty_reg = self._row_reg(side, np.zeros(1, dtype=np.int64))[0]
+            if (not (empty_reg > 0) or not np.isfinite(empty_reg)) and bool((nnz == 0).any()):
+                raise ValueError(
+                    "Feature-prior embedding is not uniquely defined for an empty interaction "
+                    "row when alpha0 and its regularization are zero.")
+
+    def _set_prior(self, side: int, prior: Optional[np.ndarray]) -> None:
+        if prior is None:
+            check(lib().irs_ials_set_prior(self._h, C.c_int32(side), None))
+        else:
+            prior = np.ascontiguousarray(prior, dtype=np.float32)
+            check(lib().irs_ials_set_prior(self._h, C.c_int32(side), ptr(prior, C.c_float)))
+
+    def _stored_prior(self, side: int) -> np.ndarray:
+        return np.asarray(self._features[side] @ self._weight(side), dtype=np.float32)
+
+    def _update_feature_weight(self, side: int) -> None:
+        """update_feature_weight (hpp:1069-1209): W = (F^T D F + lambda I)^-1 F^T D factor."""
+        F = self._features[side]
+        if F.shape[1] == 0:
+            return
+        lam = self._config.lambda_user_feature if side == 0 else self._config.lambda_item_feature
+        import scipy.linalg as sla
+
+        if self._ridge_cache[side] is None:  # initialize_feature_weight_cache, hpp:1085-1132
+            w = self._row_reg(side, self._row_nnz[side])
+            sw = np.sqrt(w).astype(np.float32)
+            WF = F.multiply(sw[:, None]).tocsr() if sps.issparse(F) else F * sw[:, None]
+            gram = np.asarray((WF.T @ WF).todense() if sps.issparse(WF) else WF.T @ WF,
+                              dtype=np.float32)
+            gram[np.diag_indices_from(gram)] += np.float32(lam)
+            try:
+                chol = sla.cho_factor(gram, lower=False, check_finite=True)
+            except (sla.LinAlgError, ValueError):
+                raise RuntimeError("Feature ridge Cholesky decomposition failed.")
+            self._ridge_cache[side] = (w, chol)
+        w, chol = self._ridge_cache[side]
+        factor = self._get(side)
+        rhs = np.asarray(F.T @ (factor * w[:, None]), dtype=np.float32)  # hpp:1142-1171
+        sol = sla.cho_solve(chol, rhs, check_finite=False).astype(np.float32)
+        if not np.isfinite(sol).all():
+            raise RuntimeError("Feature ridge solve failed.")
+        if side == 0:
+            self._ufw = sol
+        else:
+            self._ifw = sol
 
     @classmethod
     def _from_factors(
@@ -349,7 +431,27 @@ class IALSTrainer:
     # -- training / scoring -------------------------------------------------
     def step(self, solver_config: IALSSolverConfig) -> None:
         sc = solver_config._struct()
-        check(lib().irs_ials_step(self._h, C.byref(sc)))
+        if self._feature_aware and solver_config.solver_type == SolverType.IALSPP:
+            raise ValueError("Feature-aware iALS does not support IALSPP.")  # hpp:759-761
+        if self._feature_aware and self._epoch >= self._config.feature_warmup_epochs:
+            for side in (0, 1):  # hpp:762-783
+                self.partial_gramian_async(side)
+                self.finish_gramian_async(side)
+                if self._weight(side).shape[0]:
+                    self._check_prior_defined(side, self._row_nnz[side])
+                    self._set_prior(side, self._stored_prior(side))
+                    try:
+                        self.half_step_async(side, solver_config)
+                        self.synchronize()
+                    finally:
+                        self._set_prior(side, None)
+                    self._update_feature_weight(side)
+                else:
+                    self.half_step_async(side, solver_config)
+            self.synchronize()
+        else:
+            check(lib().irs_ials_step(self._h, C.byref(sc)))
+        self._epoch += 1
 
     def user_scores(self, begin: int, end: int, solver_config: IALSSolverConfig) -> np.ndarray:
         if begin < 0 or end < 0:
@@ -389,23 +491,72 @@ class IALSTrainer:
     def transform_item(self, interaction: Any, solver_config: IALSSolverConfig) -> np.ndarray:
         return self._transform(1, interaction, solver_config)
 
+    def _transform_feature(self, side: int, feature: Any) -> np.ndarray:
+        # transform_user_feature / transform_item_feature, hpp:826-836 + validate_* :1017-1043
+        who = "user" if side == 0 else "item"
+        W = self._weight(side)
+        if W.ndim != 2 or W.shape[1] != self._K:
+            raise ValueError(f"{who.capitalize()} feature weights are not initialized.")
+        f = _as_feature(feature, 0)
+        if f.shape[1] != W.shape[0]:
+            raise ValueError(f"Shape mismatch: {who} feature matrix has {f.shape[1]} columns but "
+                             f"{who}_feature_weight has {W.shape[0]} rows.")
+        return np.ascontiguousarray(np.asarray(f @ W, dtype=np.float32))
+
+    def _transform_with_feature(self, side: int, interaction: Any, feature: Any,
+                                solver_config: IALSSolverConfig) -> np.ndarray:
+        # transform_*_with_feature, hpp:803-824 + X_to_vector_with_prior :143-168
+        prior = self._transform_feature(side, feature)
+        X, indptr, indices, data = _lib.csr_arrays(interaction, np.float32)
+        m = X.shape[0] if side == 0 else X.shape[1]
+        if prior.shape[0] != m:
+            raise ValueError("Feature prior shape does not match X.")
+        nnz = np.diff(X.indptr) if side == 0 else np.bincount(X.indices, minlength=X.shape[1])
+        self._check_prior_defined(side, nnz)
+        out = np.zeros((m, self._K), dtype=np.float32)
+        sc = solver_config._struct()
+        check(
+            lib().irs_ials_transform_with_prior(
+                self._h, C.c_int32(side), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]),
+                ptr(indptr, C.c_int64), ptr(indices, C.c_int32), ptr(data, C.c_float),
+                ptr(prior, C.c_float), C.byref(sc), ptr(out, C.c_float),
+            )
+        )
+        return out
+
     def transform_user_with_feature(self, interaction, feature, solver_config):
-        raise NotImplementedError(_FEATURE_MSG)
+        return self._transform_with_feature(0, interaction, feature, solver_config)
 
     def transform_item_with_feature(self, interaction, feature, solver_config):
-        raise NotImplementedError(_FEATURE_MSG)
+        return self._transform_with_feature(1, interaction, feature, solver_config)
 
     def transform_user_feature(self, feature):
-        raise NotImplementedError(_FEATURE_MSG)
+        return self._transform_feature(0, feature)
 
     def transform_item_feature(self, feature):
-        raise NotImplementedError(_FEATURE_MSG)
+        return self._transform_feature(1, feature)
 
     def compute_loss(self, solver_config: IALSSolverConfig) -> float:
         sc = solver_config._struct()
         out = C.c_float(0.0)
         check(lib().irs_ials_compute_loss(self._h, C.byref(sc), C.byref(out)))
-        return float(out.value)
+        loss = float(out.value)
+        if self._feature_aware:  # hpp:880-882, 905-907, 917-938
+            twice = 2.0 * loss
+            for side in (0, 1):
+                W = self._weight(side)
+                if not W.shape[0]:
+                    continue
+                lam = (self._config.lambda_user_feature if side == 0
+                       else self._config.lambda_item_feature)
+                w = self._row_reg(side, self._row_nnz[side]).astype(np.float64)
+                factor = self._get(side).astype(np.float64)
+                resid = factor - self._stored_prior(side).astype(np.float64)
+                twice -= float(w @ np.square(factor).sum(axis=1))
+                twice += float(w @ np.square(resid).sum(axis=1))
+                twice += float(lam) * float(np.square(W.astype(np.float64)).sum())
+            loss = twice / 2.0
+        return loss
 
     # -- read/write attributes (wrapper.cpp:158-161) --------------------------
     def _get(self, which: int) -> np.ndarray:
@@ -447,9 +598,7 @@ class IALSTrainer:
     @user_feature_weight.setter
     def user_feature_weight(self, value: np.ndarray) -> None:
         value = np.asarray(value, dtype=np.float32)
-        if value.size:
-            raise NotImplementedError(_FEATURE_MSG)
-        self._ufw = value.reshape(0, self._K) if value.ndim != 2 else value
+        self._ufw = value.reshape(0, self._K) if value.ndim != 2 else np.ascontiguousarray(value)
 
     @property
     def item_feature_weight(self) -> np.ndarray:
@@ -458,9 +607,7 @@ class IALSTrainer:
     @item_feature_weight.setter
     def item_feature_weight(self, value: np.ndarray) -> None:
         value = np.asarray(value, dtype=np.float32)
-        if value.size:
-            raise NotImplementedError(_FEATURE_MSG)
-        self._ifw = value.reshape(0, self._K) if value.ndim != 2 else value
+        self._ifw = value.reshape(0, self._K) if value.ndim != 2 else np.ascontiguousarray(value)
 
     # -- pickle: (config, user, item, ufw, ifw); 3- or 5-tuples accepted
     #    (wrapper.cpp:162-181).  The restored object has no interaction matrix.

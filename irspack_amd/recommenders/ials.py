@@ -36,25 +36,35 @@ def str_to_loss_type(t: str) -> LossType:
 
 
 class IALSTrainer:
-    """ials.py:68-203 (without the feature-aware branches)."""
+    """ials.py:68-203."""
 
     def __init__(self, X: Any, n_components: int, alpha0: float, reg: float, nu: float,
                  init_std: float, solver_type: SolverType, max_cg_steps: int,
                  ialspp_subspace_dimension: int, loss_type: LossType, random_seed: int,
                  n_threads: int, prediction_time_max_cg_steps: int,
-                 prediction_time_ialspp_iteration: int, device: Optional[int] = None) -> None:
+                 prediction_time_ialspp_iteration: int, device: Optional[int] = None,
+                 user_features: Any = None, item_features: Any = None,
+                 lambda_user_feature: float = 0.0, lambda_item_feature: float = 0.0,
+                 feature_warmup_epochs: int = 0) -> None:
         X_train_all_f32 = X.astype(np.float32)
         config = (
             IALSModelConfigBuilder().set_K(n_components).set_init_stdev(init_std)
             .set_alpha0(alpha0).set_reg(reg).set_nu(nu).set_loss_type(loss_type)
-            .set_random_seed(random_seed).build()
+            .set_random_seed(random_seed).set_lambda_user_feature(lambda_user_feature)
+            .set_lambda_item_feature(lambda_item_feature)
+            .set_feature_warmup_epochs(feature_warmup_epochs).build()
         )
+        self.feature_aware = user_features is not None or item_features is not None
         self.solver_config = (
             IALSSolverConfigBuilder().set_n_threads(n_threads).set_solver_type(solver_type)
             .set_max_cg_steps(max_cg_steps).set_ialspp_iteration(1)
             .set_ialspp_subspace_dimension(ialspp_subspace_dimension).build()
         )
-        self.core_trainer = CoreTrainer(config, X_train_all_f32, device=device)
+        if self.feature_aware:
+            self.core_trainer = CoreTrainer(config, X_train_all_f32, user_features, item_features,
+                                            device=device)
+        else:
+            self.core_trainer = CoreTrainer(config, X_train_all_f32, device=device)
         self.prediction_time_solver_config = (
             IALSSolverConfigBuilder().set_n_threads(n_threads).set_solver_type(solver_type)
             .set_max_cg_steps(prediction_time_max_cg_steps)
@@ -66,9 +76,14 @@ class IALSTrainer:
         params = pickle.load(ifs)
         self.core_trainer.user = params["user"]
         self.core_trainer.item = params["item"]
+        if "user_feature_weight" in params:
+            self.core_trainer.user_feature_weight = params["user_feature_weight"]
+            self.core_trainer.item_feature_weight = params["item_feature_weight"]
 
     def save_state(self, ofs: IO) -> None:
-        pickle.dump(dict(user=self.core_trainer.user, item=self.core_trainer.item), ofs,
+        pickle.dump(dict(user=self.core_trainer.user, item=self.core_trainer.item,
+                         user_feature_weight=self.core_trainer.user_feature_weight,
+                         item_feature_weight=self.core_trainer.item_feature_weight), ofs,
                     protocol=pickle.HIGHEST_PROTOCOL)
 
     def compute_loss(self) -> float:
@@ -86,6 +101,14 @@ class IALSTrainer:
     def transform_item(self, X: Any) -> np.ndarray:
         return self.core_trainer.transform_item(X, self.prediction_time_solver_config)
 
+    def transform_user_with_feature(self, X: Any, features: Any) -> np.ndarray:
+        return self.core_trainer.transform_user_with_feature(X, features,
+                                                             self.prediction_time_solver_config)
+
+    def transform_item_with_feature(self, X: Any, features: Any) -> np.ndarray:
+        return self.core_trainer.transform_item_with_feature(X, features,
+                                                             self.prediction_time_solver_config)
+
 
 class IALSConfigScaling(enum.Enum):
     none = enum.auto()
@@ -102,8 +125,9 @@ def compute_reg_scale(X: sps.csr_matrix, alpha0: float, nu: float) -> float:
 
 
 class IALSRecommender(BaseRecommender):
-    """ials.py:245-562.  Same constructor arguments and defaults (without the
-    feature-aware ones); ``device`` is an extra keyword."""
+    """ials.py:245-562.  Same constructor arguments and defaults; ``device`` is an extra
+    keyword.  ``user_features`` / ``item_features`` (dense or CSR, one row per user / item)
+    switch on the feature-aware model (trainer hpp:722-789)."""
 
     def __init__(self, X_train_all: Any, n_components: int = 20, alpha0: float = 0.0,
                  reg: float = 1e-3, nu: float = 1.0, confidence_scaling: str = "none",
@@ -112,8 +136,16 @@ class IALSRecommender(BaseRecommender):
                  loss_type: str = "IALSPP", nu_star: Optional[float] = None,
                  random_seed: int = 42, n_threads: Optional[int] = None, train_epochs: int = 16,
                  prediction_time_max_cg_steps: int = 5,
-                 prediction_time_ialspp_iteration: int = 7, device: Optional[int] = None) -> None:
+                 prediction_time_ialspp_iteration: int = 7, device: Optional[int] = None,
+                 user_features: Any = None, item_features: Any = None,
+                 lambda_user_feature: float = 0.0, lambda_item_feature: float = 0.0,
+                 feature_warmup_epochs: int = 0) -> None:
         super().__init__(X_train_all)
+        self.user_features = user_features
+        self.item_features = item_features
+        self.lambda_user_feature = lambda_user_feature
+        self.lambda_item_feature = lambda_item_feature
+        self.feature_warmup_epochs = feature_warmup_epochs
         self.train_epochs = train_epochs
         self.n_components = n_components
         self.alpha0 = alpha0
@@ -157,7 +189,10 @@ class IALSRecommender(BaseRecommender):
             random_seed=self.random_seed, n_threads=self.n_threads,
             prediction_time_max_cg_steps=self.prediction_time_max_cg_steps,
             prediction_time_ialspp_iteration=self.prediction_time_ialspp_iteration,
-            device=self.device,
+            device=self.device, user_features=self.user_features,
+            item_features=self.item_features, lambda_user_feature=self.lambda_user_feature,
+            lambda_item_feature=self.lambda_item_feature,
+            feature_warmup_epochs=self.feature_warmup_epochs,
         )
 
     # -- base_earlystop.py:80-149 ------------------------------------------
@@ -232,10 +267,16 @@ class IALSRecommender(BaseRecommender):
                                       item_embedding: np.ndarray) -> np.ndarray:
         return self.get_user_embedding()[user_indices].dot(item_embedding.T)
 
-    def compute_user_embedding(self, X: Any) -> np.ndarray:
-        return self.trainer_as_ials.transform_user(
-            self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling, self.epsilon))
+    def compute_user_embedding(self, X: Any, user_features: Any = None) -> np.ndarray:
+        Xs = self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling,
+                           self.epsilon)
+        if user_features is not None:
+            return self.trainer_as_ials.transform_user_with_feature(Xs, user_features)
+        return self.trainer_as_ials.transform_user(Xs)
 
-    def compute_item_embedding(self, X: Any) -> np.ndarray:
-        return self.trainer_as_ials.transform_item(
-            self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling, self.epsilon))
+    def compute_item_embedding(self, X: Any, item_features: Any = None) -> np.ndarray:
+        Xs = self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling,
+                           self.epsilon)
+        if item_features is not None:
+            return self.trainer_as_ials.transform_item_with_feature(Xs, item_features)
+        return self.trainer_as_ials.transform_item(Xs)

@@ -1,0 +1,215 @@
+"""Feature-aware iALS at the compiled-core level (IALSTrainer with user / item features):
+restates the checks of the reference's tests/recommenders/test_ials.py:79-246 (weighted ridge
+update of the feature weights, the objective compute_loss reports, exact block updates with the
+prior, local stability of the converged point) and :248-453 (feature-only API, pickle state,
+shape validation) against float64 closed forms.  Tolerances as in the reference tests.
+"""
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder, IALSSolverConfigBuilder,
+                                                  IALSTrainer, LossType, SolverType)
+
+pytestmark = pytest.mark.gpu
+
+INTERACTION = np.array([[1, 0, 2, 1], [0, 3, 0, 0], [1, 1, 0, 4]], dtype=np.float64)
+USER_F = np.array([[1, 0.2], [0.3, 1], [0.7, -0.2]], dtype=np.float32)
+ITEM_F = np.array([[1, 0, 0.1], [0, 1, 0.2], [0.5, 0.2, 1], [-0.2, 0.8, 0.4]], dtype=np.float32)
+ALPHA0, REG, NU, LAM_U, LAM_I = 0.7, 0.03, 0.6, 0.11, 0.17
+
+
+def make(solver_type, max_cg_steps, feature_type, seed=0, warmup=0):
+    mc = (IALSModelConfigBuilder().set_K(3).set_alpha0(ALPHA0).set_reg(REG).set_nu(NU)
+          .set_init_stdev(0.1).set_random_seed(seed).set_loss_type(LossType.ORIGINAL)
+          .set_lambda_user_feature(LAM_U).set_lambda_item_feature(LAM_I)
+          .set_feature_warmup_epochs(warmup).build())
+    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType[solver_type])
+          .set_max_cg_steps(max_cg_steps).build())
+    uf, itf = (USER_F, ITEM_F) if feature_type == "dense" else (sps.csr_matrix(USER_F),
+                                                                 sps.csr_matrix(ITEM_F))
+    X = sps.csr_matrix(INTERACTION.astype(np.float32))
+    return IALSTrainer(mc, X, uf, itf), sc, X
+
+
+def regs():
+    user_nnz = np.count_nonzero(INTERACTION, axis=1)
+    item_nnz = np.count_nonzero(INTERACTION, axis=0)
+    return (REG * (ALPHA0 * INTERACTION.shape[1] + user_nnz) ** NU,
+            REG * (ALPHA0 * INTERACTION.shape[0] + item_nnz) ** NU)
+
+
+def objective(values):
+    user, item, uw, iw = values
+    user_reg, item_reg = regs()
+    score = user @ item.T
+    observed = INTERACTION.astype(bool)
+    loss = ALPHA0 * np.square(score[~observed]).sum()
+    loss += np.sum((INTERACTION[observed] + ALPHA0) * np.square(score[observed] - 1))
+    loss += np.sum(user_reg[:, None] * np.square(user - USER_F.astype(np.float64) @ uw))
+    loss += np.sum(item_reg[:, None] * np.square(item - ITEM_F.astype(np.float64) @ iw))
+    loss += LAM_U * np.square(uw).sum() + LAM_I * np.square(iw).sum()
+    return float(loss / 2)
+
+
+def solve_embeddings(histories, other, prior, reg_rows):
+    out = []
+    base = ALPHA0 * other.T @ other
+    for row, prior_row, row_reg in zip(histories, prior, reg_rows):
+        lhs = base + row_reg * np.eye(other.shape[1])
+        rhs = row_reg * prior_row
+        for j, value in enumerate(row):
+            if value:
+                lhs = lhs + value * np.outer(other[j], other[j])
+                rhs = rhs + (ALPHA0 + value) * other[j]
+        out.append(np.linalg.solve(lhs, rhs))
+    return np.asarray(out)
+
+
+@pytest.mark.parametrize(("solver_type", "max_cg_steps"), [("CHOLESKY", 3), ("CG", 0)])
+@pytest.mark.parametrize("feature_type", ["dense", "sparse"])
+def test_weighted_updates_objective_and_local_stability(solver_type, max_cg_steps, feature_type):
+    t, sc, X = make(solver_type, max_cg_steps, feature_type)
+    for _ in range(500):
+        t.step(sc)
+    user, item = t.user.astype(np.float64), t.item.astype(np.float64)
+    uw, iw = t.user_feature_weight.astype(np.float64), t.item_feature_weight.astype(np.float64)
+    user_reg, item_reg = regs()
+    UF, IF = USER_F.astype(np.float64), ITEM_F.astype(np.float64)
+    exp_uw = np.linalg.solve(UF.T @ (user_reg[:, None] * UF) + LAM_U * np.eye(2),
+                             UF.T @ (user_reg[:, None] * user))
+    exp_iw = np.linalg.solve(IF.T @ (item_reg[:, None] * IF) + LAM_I * np.eye(3),
+                             IF.T @ (item_reg[:, None] * item))
+    np.testing.assert_allclose(uw, exp_uw, rtol=2e-6, atol=2e-6)  # test_ials.py:152-153
+    np.testing.assert_allclose(iw, exp_iw, rtol=2e-6, atol=2e-6)
+    params = [user, item, uw, iw]
+    optimum = objective(params)
+    np.testing.assert_allclose(t.compute_loss(sc), optimum, rtol=2e-6, atol=2e-6)  # :178-183
+    # exact block updates with the prior (:185-227), through the fold-in entry points
+    fold = (IALSSolverConfigBuilder().set_solver_type(SolverType[solver_type])
+            .set_max_cg_steps(0).build())
+    uf = USER_F if feature_type == "dense" else sps.csr_matrix(USER_F)
+    itf = ITEM_F if feature_type == "dense" else sps.csr_matrix(ITEM_F)
+    np.testing.assert_allclose(t.transform_user_with_feature(X, uf, fold),
+                               solve_embeddings(INTERACTION, item, UF @ uw, user_reg),
+                               rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(t.transform_item_with_feature(X, itf, fold),
+                               solve_embeddings(INTERACTION.T, user, IF @ iw, item_reg),
+                               rtol=2e-5, atol=2e-5)
+    rng = np.random.default_rng(1)  # local stability, :234-246
+    for radius in (1e-5, 1e-3):
+        for _ in range(128):
+            direction = [rng.standard_normal(v.shape) for v in params]
+            norm = np.sqrt(sum(np.square(v).sum() for v in direction))
+            for sign in (-1, 1):
+                moved = [v + sign * radius * d / norm for v, d in zip(params, direction)]
+                assert objective(moved) >= optimum - 5e-10
+
+
+def test_one_feature_aware_epoch_vs_closed_form():
+    """One epoch from the shared init: user block update with the (zero-weight) prior, ridge
+    update of the user weights, then the item side with the fresh users."""
+    t, sc, X = make("CHOLESKY", 3, "dense", seed=3)
+    item0 = t.item.astype(np.float64)
+    user_reg, item_reg = regs()
+    UF, IF = USER_F.astype(np.float64), ITEM_F.astype(np.float64)
+    t.step(sc)
+    user1 = solve_embeddings(INTERACTION, item0, np.zeros((3, 3)), user_reg)
+    np.testing.assert_allclose(t.user, user1, rtol=2e-5, atol=2e-6)
+    uw1 = np.linalg.solve(UF.T @ (user_reg[:, None] * UF) + LAM_U * np.eye(2),
+                          UF.T @ (user_reg[:, None] * user1))
+    np.testing.assert_allclose(t.user_feature_weight, uw1, rtol=2e-5, atol=2e-6)
+    item1 = solve_embeddings(INTERACTION.T, t.user.astype(np.float64), np.zeros((4, 3)), item_reg)
+    # float32 solve of a 3 x 3 system whose small components sit at 4e-2: 2e-5 absolute
+    np.testing.assert_allclose(t.item, item1, rtol=1e-4, atol=2e-5)
+    t.step(sc)  # second epoch: the prior is F @ W from the first
+    user2 = solve_embeddings(INTERACTION, item1, UF @ uw1, user_reg)
+    np.testing.assert_allclose(t.user, user2, rtol=2e-4, atol=5e-5)
+
+
+def test_warmup_epochs_train_without_features():
+    t, sc, X = make("CHOLESKY", 3, "dense", seed=3, warmup=2)
+    t.step(sc)
+    t.step(sc)
+    assert not t.user_feature_weight.any() and not t.item_feature_weight.any()  # hpp:762
+    t.step(sc)
+    assert t.user_feature_weight.any() and t.item_feature_weight.any()
+
+
+def test_feature_api_validation_and_pickle():
+    t, sc, X = make("CG", 0, "sparse")
+    for _ in range(5):
+        t.step(sc)
+    with pytest.raises(ValueError, match="does not support IALSPP"):
+        t.step(IALSSolverConfigBuilder().set_solver_type(SolverType.IALSPP).build())
+    with pytest.raises(ValueError, match="user feature matrix has 3 columns"):
+        t.transform_user_feature(np.zeros((2, 3), dtype=np.float32))
+    with pytest.raises(ValueError, match="Feature prior shape does not match X"):
+        t.transform_user_with_feature(X, USER_F[:2], sc)
+    np.testing.assert_allclose(t.transform_item_feature(ITEM_F), ITEM_F @ t.item_feature_weight,
+                               rtol=1e-6)
+    t2 = pickle.loads(pickle.dumps(t))  # 5-tuple state, wrapper.cpp:162-181
+    np.testing.assert_array_equal(t2.user_feature_weight, t.user_feature_weight)
+    np.testing.assert_array_equal(t2.item_feature_weight, t.item_feature_weight)
+    np.testing.assert_array_equal(t2.transform_user_feature(USER_F), t.transform_user_feature(USER_F))
+    # constructor validation, hpp:1005-1012
+    mc = IALSModelConfigBuilder().set_K(3).build()
+    with pytest.raises(ValueError, match="row count mismatch"):
+        IALSTrainer(mc, X, USER_F[:2], ITEM_F)
+    with pytest.raises(ValueError, match="must be positive"):
+        IALSTrainer(mc, X, USER_F, ITEM_F)
+
+
+def test_feature_only_embedding_rejects_singular_empty_history():
+    # test_ials.py:346-376: alpha0 = 0 and an empty row leave the embedding undefined
+    Xe = sps.csr_matrix(np.array([[1, 0], [0, 0]], dtype=np.float32))
+    mc = (IALSModelConfigBuilder().set_K(2).set_alpha0(0.0).set_reg(0.1).set_nu(1.0)
+          .set_lambda_user_feature(0.1).set_lambda_item_feature(0.1).build())
+    t = IALSTrainer(mc, Xe, np.eye(2, dtype=np.float32), np.eye(2, dtype=np.float32))
+    with pytest.raises(ValueError, match="not uniquely defined"):
+        t.step(IALSSolverConfigBuilder().set_solver_type(SolverType.CHOLESKY).build())
+
+
+def test_larger_problem_cg_with_prior_matches_cholesky_limit():
+    """K = 64 shapes: CG run to convergence (max_cg_steps = 0 -> K steps) with a prior agrees
+    with the Cholesky solve of the same system."""
+    rng = np.random.default_rng(5)
+    X = sps.random(200, 150, density=0.08, random_state=3, format="csr", dtype=np.float32)
+    X.data[:] = rng.uniform(0.5, 2.0, X.nnz).astype(np.float32)
+    UFm = rng.standard_normal((200, 7)).astype(np.float32)
+    IFm = sps.random(150, 11, density=0.3, random_state=4, format="csr", dtype=np.float32)
+    mc = (IALSModelConfigBuilder().set_K(64).set_alpha0(0.1).set_reg(0.05)
+          .set_lambda_user_feature(0.2).set_lambda_item_feature(0.3).build())
+    a, b = IALSTrainer(mc, X, UFm, IFm), IALSTrainer(mc, X, UFm, IFm)
+    chol = IALSSolverConfigBuilder().set_solver_type(SolverType.CHOLESKY).build()
+    cg = IALSSolverConfigBuilder().set_solver_type(SolverType.CG).set_max_cg_steps(0).build()
+    for _ in range(3):
+        a.step(chol)
+        b.user, b.item = a.user, a.item  # same factors in: compare one epoch at a time
+        b.user_feature_weight, b.item_feature_weight = a.user_feature_weight, a.item_feature_weight
+    a.step(chol)
+    b.step(cg)
+    assert np.abs(a.user - b.user).max() / np.abs(a.user).max() < 2e-4
+    assert np.abs(a.user_feature_weight - b.user_feature_weight).max() < 2e-4
+
+
+def test_recommender_level_features():
+    """IALSRecommender pass-through (ials.py:385-475): learn with features, hybrid fold-in."""
+    from irspack_amd.recommenders import IALSRecommender
+
+    X = sps.csr_matrix(INTERACTION.astype(np.float32))
+    rec = IALSRecommender(X, n_components=3, alpha0=ALPHA0, reg=REG, nu=NU, solver_type="CHOLESKY",
+                          loss_type="ORIGINAL", user_features=USER_F, item_features=ITEM_F,
+                          lambda_user_feature=LAM_U, lambda_item_feature=LAM_I, train_epochs=200,
+                          random_seed=0).learn()
+    core = rec.trainer_as_ials.core_trainer
+    user_reg, item_reg = regs()
+    emb = rec.compute_user_embedding(X, user_features=USER_F)
+    want = solve_embeddings(INTERACTION, core.item.astype(np.float64),
+                            USER_F.astype(np.float64) @ core.user_feature_weight.astype(np.float64),
+                            user_reg)
+    # prediction-time CG (5 steps on a 3 x 3 system) has converged
+    np.testing.assert_allclose(emb, want, rtol=2e-4, atol=2e-5)
+    assert rec.get_score_cold_user(X).shape == (3, 4)
