@@ -6,8 +6,8 @@ user half-epoch and the item half-epoch; IALSTrainer.hpp:784-788) over the
 HBM-resident matrix.  For N > 1 the driver launches one process per GPU with
 ``torch.distributed.run``; rows are sharded (``irspack_amd.sharding``) and the
 same matrix is solved by all ranks together (strong scaling), with an RCCL
-all-reduce of the K x K Gramian and a broadcast-based all-gather of the solved
-factor shards every half-epoch.
+all-reduce of the K x K Gramian and an in-place all-gather of the solved factor
+shards every half-epoch.
 
 Extra objects on the line: ``roofline`` for the dominant kernel (HIP-event timed
 inside the library on the launch stream) and ``cpu_baseline`` (the CPU oracle —
@@ -168,7 +168,7 @@ def main():
 
     from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
                                                       IALSSolverConfigBuilder, SolverType)
-    from irspack_amd.sharding import HipLocalSolver, ShardedIALSTrainer, shard_bounds
+    from irspack_amd.sharding import HipLocalSolver, ShardedIALSTrainer, equal_shard_bounds
     from irspack_amd.synthetic import describe, make_interactions
 
     X = make_interactions(args.shape)  # identical on every rank (seeded)
@@ -179,7 +179,9 @@ def main():
           .set_init_stdev(0.1).set_random_seed(42).build())
     sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType[args.solver])
           .set_max_cg_steps(3).build())
-    ub, ib = shard_bounds(X, K, args.solver, world)
+    # equal row blocks (random row order: cost-balanced to a few per cent) so that the solved
+    # rows travel in ONE in-place all-gather per half-epoch
+    ub, ib = equal_shard_bounds(X, world)
     shard = (ub[rank], ub[rank + 1], ib[rank], ib[rank + 1])
     local = HipLocalSolver(mc, X, shard, local_rank)
     trainer = ShardedIALSTrainer(local, ub, ib)

@@ -138,7 +138,9 @@ irs_status irs_ials_compute_loss(irs_ials_trainer *t,
  *    the benchmark (one process per GPU; collectives run outside this library
  *    on the buffers these calls expose). -- */
 irs_status irs_ials_set_stream(irs_ials_trainer *t, void *hip_stream);
-/* which: 0 user factors, 1 item factors (float32 [rows, ld]);
+/* which: 0 user factors, 1 item factors (float32 [rows, ld]; `rows` is the allocated row
+ * count = the matrix's rows rounded up to a multiple of 8, zero padded, so that 1 / 2 / 4 / 8
+ * equal row shards tile the buffer and one in-place all-gather can exchange them);
  * 2 / 3: Gramian used by the user / item solve (float32 [ld, ld], unscaled
  * sum over this rank's shard until irs_ials_finish_gramian is called). */
 irs_status irs_ials_device_buffer(irs_ials_trainer *t, int32_t which,

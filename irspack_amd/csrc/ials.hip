@@ -291,7 +291,9 @@ void alloc_common(irs_ials_trainer *t) {
   t->KP = padded_k(t->K);
   t->T = t->KP / 16;
   for (int w = 0; w < 2; w++) {
-    t->factor[w].alloc(static_cast<size_t>(t->rows_of(w)) * t->KP);
+    // rows padded to a multiple of 8 (zero, never solved, never gathered) so that 1 / 2 / 4 / 8
+    // equal row shards tile the buffer exactly and one in-place all-gather can move them
+    t->factor[w].alloc(static_cast<size_t>(ceil_div(t->rows_of(w), 8) * 8) * t->KP);
     t->factor[w].zero(t->stream);
     t->P_raw[w].alloc(t->KP * t->KP);
     t->P[w].alloc(t->KP * t->KP);
@@ -703,7 +705,7 @@ irs_status irs_ials_device_buffer(irs_ials_trainer *t, int32_t which, void **dev
     check_arg(which >= 0 && which <= 3, "which must be in 0..3.");
     if (which < 2) {
       *device_ptr = t->factor[which].ptr;
-      *rows = t->rows_of(which);
+      *rows = ceil_div(t->rows_of(which), 8) * 8;  // allocated rows (zero padding at the end)
     } else {
       *device_ptr = t->P_raw[which - 2].ptr;
       *rows = t->KP;

@@ -8,8 +8,11 @@ factor matrices and, per half-epoch, takes part in
 
   1. an all-reduce of the K x K partial Gramian of its own rows
      (``Solver::prepare_p``, hpp:78-115, summed over ranks), and
-  2. an all-gather of the freshly solved factor rows (each rank broadcasts its
-     contiguous shard; with RCCL over xGMI every shard leaves on its own links).
+  2. an all-gather of the freshly solved factor rows: ONE in-place
+     ``all_gather_into_tensor`` when the shards are equal row blocks of the (row padded)
+     factor buffer (``equal_bounds``; what ``bench.py`` uses - with RCCL over xGMI every
+     shard leaves on its own links), else one broadcast per rank (cost-balanced uneven
+     shards, ``shard_bounds``).
 
 Collectives go through ``torch.distributed`` (backend "nccl" = RCCL on ROCm,
 "gloo" in the CPU tests) and run IN PLACE on torch views of the solver's own
@@ -47,6 +50,21 @@ def row_cost(nnz: np.ndarray, K: int, solver: str) -> np.ndarray:
     if solver == "CHOLESKY":
         return nnz * (K * K + 2.0 * K) + (K ** 3) / 6.0 + 2.0 * K * K
     return nnz * (K * K + 2.0 * K) + 8.0 * K * K
+
+
+def equal_bounds(n: int, parts: int, multiple: int = 8) -> List[int]:
+    """``parts`` equal row blocks of the buffer padded to a multiple of ``multiple`` rows,
+    clipped to ``n``: shard r is rows [r*S, (r+1)*S) with S = padded / parts.  Row order of
+    the benchmark matrix is random, so equal blocks are cost-balanced to a few per cent."""
+    padded = -(-n // multiple) * multiple
+    if padded % parts:
+        raise ValueError("the padded row count must be divisible by the number of shards.")
+    S = padded // parts
+    return [min(r * S, n) for r in range(parts)] + [n]
+
+
+def equal_shard_bounds(X: sps.csr_matrix, world: int) -> Tuple[List[int], List[int]]:
+    return equal_bounds(X.shape[0], world), equal_bounds(X.shape[1], world)
 
 
 def shard_bounds(X: sps.csr_matrix, K: int, solver: str, world: int) -> Tuple[List[int], List[int]]:
@@ -150,6 +168,7 @@ class ShardedIALSTrainer:
             self.rank, self.world = 0, 1
         assert len(user_bounds) == self.world + 1 and len(item_bounds) == self.world + 1
         self.bounds = (list(user_bounds), list(item_bounds))
+        self._gather_ok = True
 
     def half_epoch(self, side: int, solver_config) -> None:
         dist, local = self.dist, self.local
@@ -160,11 +179,22 @@ class ShardedIALSTrainer:
         local.finish_gramian(side)
         # (2) solve this rank's rows of `side`
         local.half_step(side, solver_config)
-        # (3) all-gather with uneven shards: every rank broadcasts its freshly solved rows
-        #     straight into the replicas (in place on views of the factor matrix)
+        # (3) all-gather of the freshly solved rows, in place on the view of the factor matrix
         if self.world > 1:
             b = self.bounds[side]
             view = local.factor_view(side)
+            S = view.shape[0] // self.world
+            equal = (view.shape[0] % self.world == 0 and
+                     all(b[r] == min(r * S, b[-1]) for r in range(self.world)))
+            if equal and self._gather_ok:
+                # equal blocks of the padded buffer: one collective, input = own block of output
+                try:
+                    dist.all_gather_into_tensor(view, view[self.rank * S:(self.rank + 1) * S],
+                                                group=self.group)
+                    return
+                except (RuntimeError, NotImplementedError):
+                    self._gather_ok = False  # backend without it (gloo on device tensors)
+            # uneven shards: every rank broadcasts its rows straight into the replicas
             works = []
             for r in range(self.world):
                 if b[r + 1] > b[r]:

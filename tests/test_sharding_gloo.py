@@ -16,13 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from irspack_amd.sharding import (LocalSolver, ShardedIALSTrainer, balanced_bounds,  # noqa: E402
-                                  row_cost, shard_bounds)
+                                  equal_bounds, equal_shard_bounds, row_cost, shard_bounds)
 
 
 class OracleLocalSolver(LocalSolver):
     """LocalSolver backed by oracle/ (test double for HipLocalSolver)."""
 
-    def __init__(self, omc, X, shard, K):
+    def __init__(self, omc, X, shard, K, pad=False):
         import oracle as O
         import torch
 
@@ -33,12 +33,17 @@ class OracleLocalSolver(LocalSolver):
             m.sort_indices()
         self.shard = shard
         U, I = X.shape
-        self.factor = [O.ials_init(U, K, omc.init_stdev, omc.random_seed),
-                       O.ials_init(I, K, omc.init_stdev, omc.random_seed)]
+        init = [O.ials_init(U, K, omc.init_stdev, omc.random_seed),
+                O.ials_init(I, K, omc.init_stdev, omc.random_seed)]
+        # pad=True mirrors the device buffers: rows padded to a multiple of 8 (zeros)
+        self._buf = [np.zeros((-(-n // 8) * 8 if pad else n, K), np.float32) for n in (U, I)]
+        self.factor = [self._buf[0][:U], self._buf[1][:I]]
+        for w in range(2):
+            self.factor[w][...] = init[w]
         self.G = [np.zeros((K, K), np.float32), np.zeros((K, K), np.float32)]
         self.P = [np.zeros((K, K), np.float32), np.zeros((K, K), np.float32)]
         # torch views alias the numpy buffers, like the product's device views
-        self._fv = [torch.from_numpy(f) for f in self.factor]
+        self._fv = [torch.from_numpy(f) for f in self._buf]
         self._gv = [torch.from_numpy(g) for g in self.G]
 
     def _range(self, which):
@@ -68,7 +73,7 @@ class OracleLocalSolver(LocalSolver):
         pass
 
 
-def _worker(rank, world, port, kind, out_dir):
+def _worker(rank, world, port, kind, out_dir, equal=False):
     import torch
     import torch.distributed as dist
 
@@ -82,11 +87,14 @@ def _worker(rank, world, port, kind, out_dir):
     K = 8
     omc = O.model_config(K, alpha0=0.2, reg=0.05)
     sc = O.solver_config(1, kind, 3)
-    ub, ib = shard_bounds(X, K, kind, world)
-    local = OracleLocalSolver(omc, X, (ub[rank], ub[rank + 1], ib[rank], ib[rank + 1]), K)
+    ub, ib = equal_shard_bounds(X, world) if equal else shard_bounds(X, K, kind, world)
+    local = OracleLocalSolver(omc, X, (ub[rank], ub[rank + 1], ib[rank], ib[rank + 1]), K,
+                              pad=equal)
     tr = ShardedIALSTrainer(local, ub, ib)
     for _ in range(2):
         tr.step(sc)
+    if equal:  # the equal-block path must have used the single in-place all-gather
+        assert tr._gather_ok
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), user=local.factor[0], item=local.factor[1])
     dist.barrier()
     dist.destroy_process_group()
@@ -100,15 +108,16 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("equal", [False, True])
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
-def test_world2_matches_single_process(tmp_path, kind):
+def test_world2_matches_single_process(tmp_path, kind, equal):
     import torch.multiprocessing as mp
 
     import oracle as O
     from conftest import random_csr
 
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, kind, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path), equal), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     # replicas agree bit for bit (solved rows are broadcast; the reduced Gramian is shared)
     np.testing.assert_array_equal(r0["user"], r1["user"])
@@ -120,6 +129,15 @@ def test_world2_matches_single_process(tmp_path, kind):
         ref.step(O.solver_config(1, kind, 3))
     np.testing.assert_allclose(r0["user"], ref.user, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(r0["item"], ref.item, rtol=1e-4, atol=1e-6)
+
+
+def test_equal_bounds():
+    assert equal_bounds(97, 2) == [0, 52, 97]          # padded to 104 rows, blocks of 52
+    assert equal_bounds(61, 4) == [0, 16, 32, 48, 61]  # padded to 64
+    assert equal_bounds(5, 8) == [0, 1, 2, 3, 4, 5, 5, 5, 5]
+    assert equal_bounds(16, 1) == [0, 16]
+    with pytest.raises(ValueError):
+        equal_bounds(10, 3)
 
 
 def test_balanced_bounds_properties():
