@@ -109,7 +109,7 @@ struct Side {
   DeviceBuffer<Task> tasks;
   DeviceBuffer<SplitRow> split;
   DeviceBuffer<int32_t> rows_by_len;  // rows [row_begin, row_end) longest first (iALS++ launch order)
-  int32_t n_tasks = 0, n_split = 0, n_slots = 0;
+  int32_t n_tasks = 0, n_split = 0, n_slots = 0, n_long = 0;
 
   void build(const HostCsr &m, int64_t rb, int64_t re, const irs_ials_model_config &cfg,
              hipStream_t s) {
@@ -172,6 +172,10 @@ struct Side {
         return (ip32[a + 1] - ip32[a]) > (ip32[b + 1] - ip32[b]);
       });
       rows_by_len.upload(order, s);
+      n_long = 0;  // rows long enough for a whole workgroup (ialspp_long_kernel)
+      while (n_long < static_cast<int32_t>(order.size()) &&
+             ip32[order[n_long] + 1] - ip32[order[n_long]] > 2048)
+        n_long++;
     }
     reg.upload(regs, s);
     tasks.upload(tk, s);
@@ -435,23 +439,55 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
   const int D = std::min<int>(p.sub, p.K);
   const int TS = D <= 16 ? 1 : D <= 32 ? 2 : 4;
   const bool aligned = p.sub % TS == 0;
-  auto launch = [&](auto kernel, size_t lds_floats) {
-    const size_t lds = 4 * lds_floats * sizeof(float);
+  // rows above 2048 stored entries get a whole workgroup each (they come first in
+  // rows_by_len), the rest one wave each
+  const int32_t n_long = std::min(sd.n_long, n_rows);
+  auto launch = [&](auto long_kernel, size_t long_floats, auto kernel, size_t lds_floats) {
+    const size_t lds = 4 * lds_floats * sizeof(float), lds_long = long_floats * sizeof(float);
     IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(long_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds_long)));
     for (uint64_t it = 0; it < sc->ialspp_iteration; it++) {
       t->prof.begin(kNames[pidx], t->stream);
-      hipLaunchKernelGGL(kernel, dim3(ceil_div(n_rows, 4)), dim3(256), lds, t->stream, p);
+      if (n_long > 0) {
+        PpParams pl = p;
+        pl.n_rows = n_long;
+        hipLaunchKernelGGL(long_kernel, dim3(n_long), dim3(64 * PP_LONG_WAVES), lds_long, t->stream,
+                           pl);
+      }
+      if (n_rows > n_long) {
+        PpParams ps = p;
+        ps.rows = p.rows + n_long;
+        ps.n_rows = n_rows - n_long;
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(ps.n_rows, 4)), dim3(256), lds, t->stream, ps);
+      }
       t->prof.end(t->stream);
     }
   };
   switch (TS * 2 + (aligned ? 1 : 0)) {
-    case 2: launch(ialspp_kernel<1, false>, PpGeo<1>::LDS_FLOATS); break;  // TS = 1 is always aligned
-    case 3: launch(ialspp_kernel<1, true>, PpGeo<1>::LDS_FLOATS); break;
-    case 4: launch(ialspp_kernel<2, false>, PpGeo<2>::LDS_FLOATS); break;
-    case 5: launch(ialspp_kernel<2, true>, PpGeo<2>::LDS_FLOATS); break;
-    case 8: launch(ialspp_kernel<4, false>, PpGeo<4>::LDS_FLOATS); break;
-    default: launch(ialspp_kernel<4, true>, PpGeo<4>::LDS_FLOATS); break;
+    case 2:  // TS = 1 is always aligned
+    case 3:
+      launch(ialspp_long_kernel<1, true>, PpLongGeo<1>::LDS_FLOATS, ialspp_kernel<1, true>,
+             PpGeo<1>::LDS_FLOATS);
+      break;
+    case 4:
+      launch(ialspp_long_kernel<2, false>, PpLongGeo<2>::LDS_FLOATS, ialspp_kernel<2, false>,
+             PpGeo<2>::LDS_FLOATS);
+      break;
+    case 5:
+      launch(ialspp_long_kernel<2, true>, PpLongGeo<2>::LDS_FLOATS, ialspp_kernel<2, true>,
+             PpGeo<2>::LDS_FLOATS);
+      break;
+    case 8:
+      launch(ialspp_long_kernel<4, false>, PpLongGeo<4>::LDS_FLOATS, ialspp_kernel<4, false>,
+             PpGeo<4>::LDS_FLOATS);
+      break;
+    default:
+      launch(ialspp_long_kernel<4, true>, PpLongGeo<4>::LDS_FLOATS, ialspp_kernel<4, true>,
+             PpGeo<4>::LDS_FLOATS);
+      break;
   }
   IRS_HIP(hipGetLastError());
 }

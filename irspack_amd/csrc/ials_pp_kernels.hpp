@@ -140,13 +140,92 @@ __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int
   }
 }
 
+// pred_q = x . v_q over entries [b, e): lane per stored entry, x broadcast from LDS (hpp:387-421)
+__device__ __forceinline__ void pp_predict(const PpParams &p, const float *xs, int b, int e) {
+  const int lane = threadIdx.x & 63;
+  for (int q = b + lane; q < e; q += 64) {
+    const float *v = p.other + static_cast<size_t>(static_cast<unsigned>(p.indices[q])) * p.KP;
+    float s = 0.f;
+    for (int k = 0; k < p.KP; k += 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(v + k);
+      const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + k);
+      s = fmaf(t.x, x4.x, s);
+      s = fmaf(t.y, x4.y, s);
+      s = fmaf(t.z, x4.z, s);
+      s = fmaf(t.w, x4.w, s);
+    }
+    p.pred[q] = s;
+  }
+}
+
+// pred_q -= delta . v_q[blk] over entries [b, e)   (hpp:500-506)
+template <bool ALIGNED>
+__device__ __forceinline__ void pp_pred_update(const PpParams &p, const float *delta, int c0, int D,
+                                               int b, int e) {
+  const int lane = threadIdx.x & 63;
+  for (int q = b + lane; q < e; q += 64) {
+    const float *v =
+        p.other + static_cast<size_t>(static_cast<unsigned>(p.indices[q])) * p.KP + c0;
+    float s = 0.f;
+    if (ALIGNED && (D & 3) == 0 && (c0 & 3) == 0) {
+      for (int i = 0; i < D; i += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(v + i);
+        s = fmaf(delta[i], t.x, s);
+        s = fmaf(delta[i + 1], t.y, s);
+        s = fmaf(delta[i + 2], t.z, s);
+        s = fmaf(delta[i + 3], t.w, s);
+      }
+    } else {
+      for (int i = 0; i < D; i++) s = fmaf(delta[i], v[i], s);
+    }
+    p.pred[q] -= s;
+  }
+}
+
+// A <- P[blk, blk] in accumulator layout: tile (I, J) register r of lane (g, m) is element
+// (TS (4g + r) + I, TS m + J) of the block
+template <int TS>
+__device__ __forceinline__ void pp_block_of_p(const PpParams &p, int c0, int D,
+                                              f32x4 (&acc)[PpGeo<TS>::NT]) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  int t = 0;
+#pragma unroll
+  for (int I = 0; I < TS; I++)
+#pragma unroll
+    for (int J = I; J < TS; J++) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int rr = TS * (4 * g + r) + I, cc = TS * m + J;
+        acc[t][r] = (rr < D && cc < D) ? p.P[(c0 + rr) * p.KP + c0 + cc] : 0.f;
+      }
+      t++;
+    }
+}
+
+// B <- P[blk, :] x + reg x[blk]  (hpp:473-477); P is symmetric: column reads coalesce
+template <int TS>
+__device__ __forceinline__ void pp_rhs_of_p(const PpParams &p, const float *xs, float reg, int c0,
+                                            int D, float *bnat) {
+  const int lane = threadIdx.x & 63;
+  if (lane < PpGeo<TS>::DP) {
+    float s = 0.f;
+    if (lane < D) {
+      for (int k = 0; k < p.K; k++) s = fmaf(p.P[k * p.KP + c0 + lane], xs[k], s);
+      s = fmaf(reg, xs[c0 + lane], s);
+    }
+    bnat[lane] = s;
+  }
+}
+
+// One wave per row, four independent rows per workgroup.
 template <int TS, bool ALIGNED>
 __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
   using G = PpGeo<TS>;
   using C = CholGeo<TS>;
   extern __shared__ __attribute__((aligned(16))) float pp_lds[];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int g = lane >> 4, m = lane & 15;
+  const int m = lane & 15;
   const int w = blockIdx.x * 4 + wid;
   if (w >= p.n_rows) return;  // the kernel uses no workgroup barrier
   float *sm = pp_lds + wid * G::LDS_FLOATS;
@@ -164,51 +243,14 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
     if (p.zero_start) xrow[i] = 0.f;
   }
   __threadfence_block();
-
-  // ---- prediction cache (hpp:387-421): lane per stored entry, x broadcast from LDS
-  for (int q = begin + lane; q < end; q += 64) {
-    const float *v = p.other + static_cast<size_t>(static_cast<unsigned>(p.indices[q])) * p.KP;
-    float s = 0.f;
-    for (int k = 0; k < p.KP; k += 4) {
-      const f32x4 t = *reinterpret_cast<const f32x4 *>(v + k);
-      const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + k);
-      s = fmaf(t.x, x4.x, s);
-      s = fmaf(t.y, x4.y, s);
-      s = fmaf(t.z, x4.z, s);
-      s = fmaf(t.w, x4.w, s);
-    }
-    p.pred[q] = s;
-  }
+  pp_predict(p, xs, begin, end);
   __threadfence();  // the cache is re-read through other lanes' addresses below
 
   for (int c0 = 0; c0 < p.K; c0 += p.sub) {
     const int D = min(p.sub, p.K - c0);
-    // ---- A <- P[blk, blk] in accumulator layout: tile (I, J) register r of lane (g, m) is
-    //      element (TS (4g + r) + I, TS m + J) of the block
     f32x4 acc[G::NT];
-    {
-      int t = 0;
-#pragma unroll
-      for (int I = 0; I < TS; I++)
-#pragma unroll
-        for (int J = I; J < TS; J++) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int rr = TS * (4 * g + r) + I, cc = TS * m + J;
-            acc[t][r] = (rr < D && cc < D) ? p.P[(c0 + rr) * p.KP + c0 + cc] : 0.f;
-          }
-          t++;
-        }
-    }
-    // ---- B <- P[blk, :] x + reg x[blk]  (hpp:473-477); P is symmetric: column reads coalesce
-    if (lane < G::DP) {
-      float s = 0.f;
-      if (lane < D) {
-        for (int k = 0; k < p.K; k++) s = fmaf(p.P[k * p.KP + c0 + lane], xs[k], s);
-        s = fmaf(reg, xs[c0 + lane], s);
-      }
-      bnat[lane] = s;
-    }
+    pp_block_of_p<TS>(p, c0, D, acc);
+    pp_rhs_of_p<TS>(p, xs, reg, c0, D, bnat);
     float bsum[TS];
 #pragma unroll
     for (int i = 0; i < TS; i++) bsum[i] = 0.f;
@@ -226,25 +268,103 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
       xrow[c0 + lane] = nx;
     }
     __threadfence_block();
-    // ---- pred_q -= delta . v_q[blk]   (hpp:500-506)
-    for (int q = begin + lane; q < end; q += 64) {
-      const float *v =
-          p.other + static_cast<size_t>(static_cast<unsigned>(p.indices[q])) * p.KP + c0;
-      float s = 0.f;
-      if (ALIGNED && (D & 3) == 0 && (c0 & 3) == 0) {
-        for (int i = 0; i < D; i += 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4 *>(v + i);
-          s = fmaf(delta[i], t.x, s);
-          s = fmaf(delta[i + 1], t.y, s);
-          s = fmaf(delta[i + 2], t.z, s);
-          s = fmaf(delta[i + 3], t.w, s);
-        }
-      } else {
-        for (int i = 0; i < D; i++) s = fmaf(delta[i], v[i], s);
-      }
-      p.pred[q] -= s;
-    }
+    pp_pred_update<ALIGNED>(p, delta, c0, D, begin, end);
     __threadfence();
+  }
+}
+
+// Long rows: one workgroup of PP_LONG_WAVES waves per row.  Every pass over the row's
+// entries (prediction, rank update, cache correction) is split into equal contiguous ranges,
+// the partial D x D systems are summed through LDS and wave 0 solves.
+constexpr int PP_LONG_WAVES = 8;
+
+template <int TS> struct PpLongGeo {
+  using G = PpGeo<TS>;
+  static constexpr int PART = G::NT * 256 + 64;  // tiles + rhs of one wave
+  // Cholesky scratch | x | P-part of the rhs | delta | partials of waves 1 .. 7
+  static constexpr int LDS_FLOATS = G::LDS_FLOATS + (PP_LONG_WAVES - 1) * PART;
+};
+
+template <int TS, bool ALIGNED>
+__global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParams p) {
+  using G = PpGeo<TS>;
+  using C = CholGeo<TS>;
+  using L = PpLongGeo<TS>;
+  extern __shared__ __attribute__((aligned(16))) float pp_lds[];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = lane & 15;
+  float *sm = pp_lds;
+  float *xs = sm + C::LDS_FLOATS;
+  float *bnat = xs + G::XS;
+  float *delta = bnat + G::DP;
+  float *parts = delta + G::DP;
+
+  const int row = p.rows[blockIdx.x];
+  const int begin = p.indptr[row], end = p.indptr[row + 1];
+  const float reg = p.reg[row];
+  float *xrow = p.target + static_cast<size_t>(row) * p.KP;
+  // this wave's entries: equal ranges, multiples of 16 (the rank update's group size)
+  const int per = (((end - begin + PP_LONG_WAVES - 1) / PP_LONG_WAVES) + 15) & ~15;
+  const int wb = min(begin + wid * per, end), we = min(wb + per, end);
+  for (int i = threadIdx.x; i < p.KP; i += 64 * PP_LONG_WAVES) {
+    const float x0 = p.zero_start ? 0.f : xrow[i];
+    xs[i] = x0;
+    if (p.zero_start) xrow[i] = 0.f;
+  }
+  __syncthreads();
+  pp_predict(p, xs, wb, we);
+  __threadfence();
+  __syncthreads();
+
+  for (int c0 = 0; c0 < p.K; c0 += p.sub) {
+    const int D = min(p.sub, p.K - c0);
+    f32x4 acc[G::NT];
+    if (wid == 0) {
+      pp_block_of_p<TS>(p, c0, D, acc);
+      pp_rhs_of_p<TS>(p, xs, reg, c0, D, bnat);
+    } else {
+#pragma unroll
+      for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float bsum[TS];
+#pragma unroll
+    for (int i = 0; i < TS; i++) bsum[i] = 0.f;
+    pp_rank_update<TS, ALIGNED>(p, wb, we, c0, D, acc, bsum);
+    if (wid > 0) {
+      float *dst = parts + (wid - 1) * L::PART;
+      f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
+#pragma unroll
+      for (int t = 0; t < G::NT; t++) d4[t * 64 + lane] = acc[t];
+      if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < TS; i++) dst[G::NT * 256 + TS * lane + i] = bsum[i];
+      }
+    }
+    __syncthreads();
+    if (wid == 0) {
+      for (int w2 = 0; w2 < PP_LONG_WAVES - 1; w2++) {  // fixed order: reproducible sums
+        const float *src = parts + w2 * L::PART;
+        const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+        for (int t = 0; t < G::NT; t++) acc[t] += s4[t * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < TS; i++) bsum[i] += src[G::NT * 256 + TS * m + i];
+      }
+      float b4[TS];
+#pragma unroll
+      for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bnat[TS * m + i];
+      solve_row_cholesky<TS>(acc, b4, reg, sm, delta, D, p.ignored_flag);
+      __threadfence_block();
+      if (lane < D) {  // hpp:498
+        const float nx = xs[c0 + lane] - delta[lane];
+        xs[c0 + lane] = nx;
+        xrow[c0 + lane] = nx;
+      }
+    }
+    __syncthreads();
+    pp_pred_update<ALIGNED>(p, delta, c0, D, wb, we);
+    __threadfence();
+    __syncthreads();
   }
 }
 

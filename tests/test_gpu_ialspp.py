@@ -105,3 +105,20 @@ def test_subspace_above_64_is_rejected(X_small):
     t = IALSTrainer(mc, X_small)
     with pytest.raises(ValueError, match="ialspp_subspace_dimension"):
         t.step(sc)
+
+
+@pytest.mark.parametrize("K,sub", [(64, 64), (32, 16), (20, 7)])
+def test_rows_above_the_workgroup_threshold(K, sub):
+    """Rows with more than 2048 stored entries run on ialspp_long_kernel (8 waves per row)."""
+    rng = np.random.default_rng(8)
+    X = random_csr(24, 6000, 0.5, 13)
+    X.data[:] = rng.uniform(0.5, 2.0, size=X.nnz).astype(np.float32)
+    assert np.diff(X.indptr).max() > 2048
+    mc, omc = build(K, alpha0=0.02, reg=1e-2)
+    sc, osc = solvers(sub, 2)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    t.step(sc)
+    o.step(osc)
+    assert rel_err(t.user, o.user) < RTOL
+    assert rel_err(t.item, o.item) < 10 * RTOL
