@@ -2,17 +2,18 @@
 // get_metrics_local / Metrics::update of /root/reference/cpp_source/evaluator.cpp
 // (:256-284, :292-367, :127-166) behind include/irspack_amd.h.
 //
-// One workgroup ranks one user row (1024 threads with the row's keys cached in LDS when
-// they fit, else 256 threads re-reading the scores per pass):
+// One workgroup ranks one user row (1024 threads with the row's keys held in registers or
+// LDS after one pass over the scores, else 256 threads re-reading the scores per pass):
 //   1. candidates = all items | global list | per-user list, score != -inf (:324-348)
 //   2. top-`cutoff` by the total order (score desc, index asc) — the order
 //      std::partial_sort gives on (-score, index) pairs (:329, :353-355):
-//      MSB-first 8-bit radix select of the cutoff-th key, then an index-ordered
-//      pick of the ties at the threshold, then a bitonic sort of the winners in LDS
-//   3. hits by binary search in the (recommendable-filtered) ground-truth row,
-//      then the sequential dcg / AP recurrences of Metrics::update
-// Per-user terms are summed in user order (double), item counts with int64
-// atomics; both are order-independent up to fp64 rounding / exactly.
+//      MSB-first 8-bit radix select of the cutoff-th key (wave-aggregated histogram, early
+//      exit), then an index-ordered pick of the ties at the threshold, then a bitonic sort
+//      of the winners (a shuffle network in one wave for cutoff <= 64, else in LDS)
+//   3. hits against the (recommendable-filtered) ground-truth row, then the sequential
+//      dcg / AP recurrences of Metrics::update
+// Per-user terms are folded by a fixed-order wave reduction (double), item counts with
+// int64 atomics.  The same kernel serves retrieve_recommend_from_score (no ground truth).
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -79,13 +80,22 @@ template <class T> struct KeyStore;
 template <> struct KeyStore<float> { using type = uint32_t; };
 template <> struct KeyStore<double> { using type = uint64_t; };
 
-// NT threads per user row.  CACHED: the row's keys are computed once into dynamic LDS
-// (one pass over the scores in HBM instead of one per radix digit and sweep); used when
-// the candidate count fits, with NT = 1024.  Otherwise every pass re-reads the scores.
-template <class T, int NT, bool CACHED>
-__global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
+// NT threads per user row.  Wave w owns the contiguous candidates [w * span, (w + 1) * span) in
+// 64-wide steps: slot q of lane l is candidate w * span + 64 q + l, so (wave, slot, lane)
+// order is index order.  Where the keys live between the passes:
+//   MODE 2 (NT = 1024, float scores, <= 32 slots per lane): in registers - one pass over the
+//          scores in HBM, no LDS traffic for keys (same speed as MODE 1 today: the kernel is
+//          bound by its barrier / latency chain, and the 64-VGPR budget that a second
+//          workgroup per CU would need spills);
+//   MODE 1 (NT = 1024): in dynamic LDS - one pass over the scores, one workgroup per CU;
+//   MODE 0 (NT = 256): nowhere, every pass re-reads the scores.
+constexpr int RANK_MAXQ = 32;
+
+template <class T, int NT, int MODE, int MAXQ = RANK_MAXQ>
+__global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalParams p) {
   using KeyT = typename KeyStore<T>::type;
   constexpr int NWV = NT / 64;
+  constexpr bool CACHED = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char rank_dyn[];
   KeyT *keys = reinterpret_cast<KeyT *>(rank_dyn);
   __shared__ uint32_t hist[256];
@@ -109,6 +119,15 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
   if (n_gt == 0 && !p.retrieve) {  // counted in total_user only (:316-321)
     if (tid == 0) p.out[row] = res;
     return;
+  }
+  // what the last phase needs from HBM is requested now, so that its latency hides behind
+  // the ranking: a short ground-truth row, the discounts, the ideal dcg
+  int32_t gt_pref = -1;
+  double disc_pref = 0.0, idcg_pref = 0.0;
+  if (!p.retrieve) {
+    if (n_gt <= 64 && ln < n_gt) gt_pref = p.gt_idx[gb + ln];
+    if (ln < min(p.cutoff, 64)) disc_pref = p.disc[ln];
+    idcg_pref = p.idcg_prefix[min(n_gt, p.cutoff)];
   }
   // candidate list
   int64_t cb = 0, n_cand = p.n_items;
@@ -134,24 +153,61 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
   // --- count rankable candidates (and fill the key cache).  Eight independent loads per
   //     thread are issued before the first use (clamped index, result masked) so the one
   //     pass over the scores in HBM is not a chain of exposed latencies.
+  const int64_t span = ((n_cand + NT - 1) / NT) * 64;
+  const int64_t wbeg = wv * span, wend = min<int64_t>(wbeg + span, n_cand);
+  KeyT kreg[MODE == 2 ? MAXQ : 1];
   int local = 0;
-  for (int64_t base = 0; base < n_cand; base += NT * 8) {
-    T sv[8];
+  if constexpr (MODE == 2) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) sv[q] = srow[item_of(min<int64_t>(base + q * NT + tid, n_cand - 1))];
+    for (int qb = 0; qb < MAXQ; qb += 8) {  // eight loads in flight, small register peak
+      T sv[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int64_t j = base + q * NT + tid;
-      if (j < n_cand) {
-        const uint64_t k = is_neg_inf(sv[q]) ? KEY_SKIP : order_key(sv[q]);
-        if (CACHED) keys[j] = static_cast<KeyT>(k);
+      for (int q = 0; q < 8; q++)
+        sv[q] = srow[item_of(max<int64_t>(min<int64_t>(wbeg + 64 * (qb + q) + ln, n_cand - 1), 0))];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const bool live = wbeg + 64 * (qb + q) + ln < wend;
+        const uint64_t k = (!live || is_neg_inf(sv[q])) ? KEY_SKIP : order_key(sv[q]);
+        kreg[qb + q] = static_cast<KeyT>(k);
         local += k != KEY_SKIP;
       }
     }
+  } else {
+    for (int64_t base = 0; base < n_cand; base += NT * 8) {
+      T sv[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        sv[q] = srow[item_of(min<int64_t>(base + q * NT + tid, n_cand - 1))];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int64_t j = base + q * NT + tid;
+        if (j < n_cand) {
+          const uint64_t k = is_neg_inf(sv[q]) ? KEY_SKIP : order_key(sv[q]);
+          if (CACHED) keys[j] = static_cast<KeyT>(k);
+          local += k != KEY_SKIP;
+        }
+      }
+    }
   }
+  // visit every slot of this wave, all lanes together (f may use wave-wide ballots); f
+  // returns false to stop early (a wave-uniform decision)
+  auto for_each_slot = [&](auto &&f) {
+    if constexpr (MODE == 2) {
+      bool go = true;
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++)
+        if (go && wbeg + 64 * q < wend) go = f(wbeg + 64 * q + ln, static_cast<uint64_t>(kreg[q]));
+    } else {
+      for (int64_t base = wbeg; base < wend; base += 64) {
+        const int64_t j = base + ln;
+        if (!f(j, j < wend ? key_at(j) : KEY_SKIP)) break;
+      }
+    }
+  };
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) local += __shfl_xor(local, o, 64);
   if (ln == 0) scan_buf[wv] = local;
+  if (tid < 256) hist[tid] = 0;
   __syncthreads();
   int n_rankable = 0;
   for (int w = 0; w < NWV; w++) n_rankable += scan_buf[w];
@@ -169,19 +225,13 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
   int need = n_rec;  // how many still to take among keys matching `prefix` so far
   bool inclusive = false;  // true: every key >= prefix is taken and there is no tie pick
   constexpr int BITS = KeyBits<T>::value;
+  // hist is zero here (cleared before the count barrier) and is cleared again by the bin scan
+  // of every pass: three barriers per digit
   for (int shift = BITS - 8; shift >= 0; shift -= 8) {
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
     const uint64_t hi_mask = (shift + 8 >= 64) ? 0ull : (~0ull << (shift + 8));
-    for (int64_t base = 0; base < n_cand; base += NT) {
-      const int64_t j = base + tid;
-      bool in = false;
-      uint32_t digit = 0;
-      if (j < n_cand) {
-        const uint64_t k = key_at(j);
-        in = k != KEY_SKIP && (k & hi_mask) == (prefix & hi_mask);
-        digit = static_cast<uint32_t>(k >> shift) & 0xffu;
-      }
+    for_each_slot([&](int64_t, uint64_t k) {
+      const bool in = k != KEY_SKIP && (k & hi_mask) == (prefix & hi_mask);
+      const uint32_t digit = static_cast<uint32_t>(k >> shift) & 0xffu;
       // scores share their leading byte(s): when all candidate lanes of a wave fall into
       // one bin a single lane adds the count (no same-address atomic storm); otherwise
       // the digits are spread and per-lane atomics are cheap
@@ -196,7 +246,8 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
           atomicAdd(&hist[digit], 1u);
         }
       }
-    }
+      return true;
+    });
     __syncthreads();
     // the digit d with  #(digits > d) < need <= #(digits >= d): bins scanned in descending
     // order by the first four waves
@@ -219,11 +270,12 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
         // the whole bin is wanted: no lower digit has to be resolved (-1 stops the loop)
         sh_need = (incl == need) ? -1 : need - (incl - bin);
       }
+      hist[tid] = 0;  // every bin was read before the barrier above
     }
     __syncthreads();
+    // (the next write to sh_prefix / sh_need sits two barriers ahead: no barrier after the read)
     prefix = sh_prefix;
     need = sh_need;
-    __syncthreads();
     if (need < 0) {
       inclusive = true;
       need = 0;
@@ -232,39 +284,32 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
   }
   const uint64_t thr = prefix;  // threshold key; `need` ties at thr are taken, lowest index first
 
-  // --- gather winners.  Wave w owns the contiguous candidates [w * span, (w + 1) * span) in
-  //     64-wide steps, so (wave, step, lane) order is index order: sweep 1 appends the keys
+  // --- gather winners ((wave, slot, lane) order is index order): sweep 1 appends the keys
   //     above the threshold and counts the wave's ties, sweep 2 gives the `need` lowest-index
   //     ties their slots (evaluator.cpp:329, 353-355)
   if (tid == 0) sh_count = 0;
   __syncthreads();
-  const int64_t span = ((n_cand + NT - 1) / NT) * 64;
-  const int64_t wbeg = wv * span, wend = min<int64_t>(wbeg + span, n_cand);
   int my_ties = 0;
-  for (int64_t base = wbeg; base < wend; base += 64) {
-    const int64_t j = base + ln;
+  for_each_slot([&](int64_t j, uint64_t k) {
     bool tie = false;
-    if (j < wend) {
-      const uint64_t k = key_at(j);
-      if (k != KEY_SKIP) {
-        if (inclusive ? k >= thr : k > thr) {
-          const int pos = atomicAdd(&sh_count, 1);
-          sel_key[pos] = k;
-          sel_idx[pos] = item_of(j);
-        } else if (k == thr) {
-          tie = true;
-        }
+    if (k != KEY_SKIP) {
+      if (inclusive ? k >= thr : k > thr) {
+        const int pos = atomicAdd(&sh_count, 1);
+        sel_key[pos] = k;
+        sel_idx[pos] = item_of(j);
+      } else if (k == thr) {
+        tie = true;
       }
     }
     my_ties += __popcll(__ballot(tie));
-  }
+    return true;
+  });
   if (ln == 0) scan_buf[wv] = my_ties;
   __syncthreads();
   int seen = 0;
   for (int w = 0; w < wv; w++) seen += scan_buf[w];
-  for (int64_t base = wbeg; base < wend && seen < need; base += 64) {
-    const int64_t j = base + ln;
-    const uint64_t k = j < wend ? key_at(j) : KEY_SKIP;
+  for_each_slot([&](int64_t j, uint64_t k) {
+    if (seen >= need) return false;
     const bool tie = k != KEY_SKIP && k == thr;
     const unsigned long long bal = __ballot(tie);
     const int rank = seen + __popcll(bal & ((1ull << ln) - 1ull));
@@ -274,7 +319,8 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
       sel_idx[pos] = item_of(j);
     }
     seen += __popcll(bal);
-  }
+    return true;
+  });
   __syncthreads();
   if (n_rec <= 64) {
     // --- common cutoffs: one wave finishes the row without further barriers.  Lane i holds
@@ -304,6 +350,13 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
     if (ln < n_rec) {
       rec_row[ln] = mi;
       atomicAdd(&p.item_cnt[mi], 1ull);  // :146
+    }
+    if (n_gt <= 64) {
+      // short ground-truth row (prefetched at kernel start): compare against every entry
+      // instead of a chain of dependent loads
+      for (int c = 0; c < n_gt; c++) hit |= __builtin_amdgcn_readlane(gt_pref, c) == mi;
+      hit = hit && ln < n_rec;
+    } else if (ln < n_rec) {
       int lo = gb, hi = ge;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -311,7 +364,7 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
       }
       hit = lo < ge && p.gt_idx[lo] == mi;
     }
-    const double disc_l = ln < n_rec ? p.disc[ln] : 0.0;
+    const double disc_l = ln < n_rec ? disc_pref : 0.0;
     unsigned long long hits = __ballot(hit);
     double dcg = 0, ap = 0;
     int cum_hit = 0;
@@ -322,7 +375,9 @@ __global__ __launch_bounds__(NT) void rank_rows_kernel(EvalParams p) {
       cum_hit++;
       ap += static_cast<double>(cum_hit) / (i + 1);
     }
-    const double idcg = p.idcg_prefix[min(n_gt, n_rec)];
+    const double idcg = min(n_gt, n_rec) == min(n_gt, p.cutoff)
+                            ? idcg_pref
+                            : p.idcg_prefix[min(n_gt, n_rec)];
     res.hit = cum_hit > 0 ? 1.0 : 0.0;
     res.precision = cum_hit / static_cast<double>(n_rec);
     res.recall = cum_hit / static_cast<double>(
@@ -494,14 +549,16 @@ void validate_call(irs_evaluator *e, int64_t rows, int64_t cutoff, int64_t offse
 template <class T> void launch_rank(const EvalParams &p, int64_t max_cand, hipStream_t s) {
   // key cache in LDS when a row's candidates fit next to the 28 KB of static LDS
   const size_t key_bytes = static_cast<size_t>(std::max<int64_t>(max_cand, 1)) * sizeof(typename KeyStore<T>::type);
-  if (key_bytes <= 128 * 1024) {
-    auto kernel = rank_rows_kernel<T, 1024, true>;
+  if (std::is_same<T, float>::value && max_cand <= 1024 * RANK_MAXQ) {
+    hipLaunchKernelGGL((rank_rows_kernel<T, 1024, 2>), dim3(p.rows), dim3(1024), 0, s, p);
+  } else if (key_bytes <= 128 * 1024) {
+    auto kernel = rank_rows_kernel<T, 1024, 1>;
     IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(key_bytes)));
     hipLaunchKernelGGL(kernel, dim3(p.rows), dim3(1024), key_bytes, s, p);
   } else {
-    hipLaunchKernelGGL((rank_rows_kernel<T, 256, false>), dim3(p.rows), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((rank_rows_kernel<T, 256, 0>), dim3(p.rows), dim3(256), 0, s, p);
   }
 }
 

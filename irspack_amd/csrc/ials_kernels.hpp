@@ -34,9 +34,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int SOLVE_WAVES = 1;  // waves per solve workgroup: waves never cooperate, so LDS per
                                 // wave (not per block) sets residency
 
-#ifndef SYRK_INTERLEAVE
-#define SYRK_INTERLEAVE 1
-#endif
 #ifndef SOLVE_MIN_WAVES_PER_SIMD
 #define SOLVE_MIN_WAVES_PER_SIMD 2  // register budget hint (waves per SIMD)
 #endif
@@ -722,11 +719,7 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
 template <int T, int SOLVER, int MODE>
 __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
   using G = Geo<T>;
-#ifdef IRS_EXPERIMENT_SKIP_SOLVE
-  constexpr int LDS_PER_WAVE = 64;  // occupancy experiment: no solve, no LDS need
-#else
   constexpr int LDS_PER_WAVE = (SOLVER == 0 || T == 8) ? CholGeo<T>::LDS_FLOATS : G::LDS_FLOATS;
-#endif
   __shared__ __attribute__((aligned(16))) float lds[SOLVE_WAVES * LDS_PER_WAVE];
   const int wid = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -761,16 +754,6 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
       }
       return;
     }
-#ifdef IRS_EXPERIMENT_SKIP_SOLVE  // timing experiment only: rank update without the solve
-    {
-      f32x4 s = acc[0];
-#pragma unroll
-      for (int t = 1; t < G::NT; t++) s += acc[t];
-      const float sum = s.x + s.y + s.z + s.w + bsum[0];
-      if (lane < 16) p.target[static_cast<size_t>(task.row) * G::KP + lane] = sum == 12345.f ? 1.f : 0.01f;
-      return;
-    }
-#endif
     add_prior<T>(p, task.row, bsum);
     // with a prior an empty row is solved like any other (hpp:207): hide nnz == 0 from CG
     const int nnz_cg = p.prior ? max(task.end - task.begin, 1) : task.end - task.begin;
@@ -798,9 +781,6 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
 #pragma unroll
       for (int i = 0; i < T; i++) bsum[i] += src[G::NT * 256 + T * (lane & 15) + i];
     }
-#ifdef IRS_EXPERIMENT_SKIP_SOLVE
-    return;
-#endif
     add_prior<T>(p, sr.row, bsum);
     if constexpr (SOLVER == 0)
       solve_row_cholesky<T>(acc, bsum, p.reg[sr.row], sm,
@@ -920,8 +900,10 @@ __global__ void gramian_finish_kernel(const float *__restrict__ P_raw, float alp
 
 // ---------------------------------------------------------------------------
 // user_scores: out[m, n_items] = user[begin:end] @ item^T (hpp:942-984).
-// One wave per 16 users x 64 items; k runs over the latent dims 16 at a time
-// with each lane loading 16 B of its user row and of each of its 4 item rows.
+// One wave per 64 users x 64 items (4 x 4 MFMA tiles: every item row that is loaded feeds
+// four user tiles, which divides the L2 traffic of the 16-user version by ~2.5); k runs
+// over the latent dims 16 at a time with each lane loading 16 B of each of its 4 user rows
+// and 4 item rows.  Per (user, item) the products are added in ascending k.
 template <int KP>
 __global__ __launch_bounds__(256) void user_scores_kernel(const float *__restrict__ user,
                                                           const float *__restrict__ item,
@@ -933,39 +915,58 @@ __global__ __launch_bounds__(256) void user_scores_kernel(const float *__restric
   const int64_t item_tiles = (n_items + 63) / 64;
   const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   const int64_t ut = w / item_tiles, it = w % item_tiles;
-  if (ut * 16 >= m_rows) return;
-  const int64_t u = min(ut * 16 + m, m_rows - 1);
-  const float *up = user + (begin + u) * KP + 4 * g;
-  const float *ip[4];
+  if (ut * 64 >= m_rows) return;
+  const float *up[4], *ip[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int64_t i = min(it * 64 + q * 16 + m, n_items - 1);
+    const int64_t u = min(ut * 64 + q * 16 + m, m_rows - 1);
+    // item tile q holds the columns 4 m + q: lane m then owns 4 adjacent columns of a row
+    // across the four tiles and a row leaves as one 256 B run of 16 B stores
+    const int64_t i = min(it * 64 + 4 * m + q, n_items - 1);
+    up[q] = user + (begin + u) * KP + 4 * g;
     ip[q] = item + i * KP + 4 * g;
   }
-  f32x4 acc[4];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < KP; k += 16) {
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(up + k);
+    f32x4 a[4], b[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const f32x4 b = *reinterpret_cast<const f32x4 *>(ip[q] + k);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[q], 0, 0, 0);
+      a[q] = *reinterpret_cast<const f32x4 *>(up[q] + k);
+      b[q] = *reinterpret_cast<const f32x4 *>(ip[q] + k);
     }
-  }
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int64_t col = it * 64 + q * 16 + m;
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].x, b[q].x, acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].y, b[q].y, acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].z, b[q].z, acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].w, b[q].w, acc[p][q], 0, 0, 0);
+      }
+  }
+  const int64_t col = it * 64 + 4 * m;
+  const bool vec = (n_items & 3) == 0 && col + 3 < n_items &&
+                   (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+#pragma unroll
+  for (int p = 0; p < 4; p++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int64_t row = ut * 16 + 4 * g + r;
-      if (row < m_rows && col < n_items) out[row * n_items + col] = acc[q][r];
+      const int64_t row = ut * 64 + p * 16 + 4 * g + r;
+      if (row >= m_rows) continue;
+      float *dst = out + row * n_items + col;
+      if (vec) {
+        *reinterpret_cast<f32x4 *>(dst) =
+            f32x4{acc[p][0][r], acc[p][1][r], acc[p][2][r], acc[p][3][r]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (col + q < n_items) dst[q] = acc[p][q][r];
+      }
     }
-  }
 }
 
 // ---------------------------------------------------------------------------
