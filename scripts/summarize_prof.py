@@ -30,15 +30,21 @@ def per_kernel(path):
     return agg
 
 
+def newest(pattern):
+    """gpurun merges every run into gpurun_out/: keep the most recent match only."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
 def main():
     os.makedirs(DST, exist_ok=True)
-    stats = glob.glob(os.path.join(SRC, "kt", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(SRC, "kt", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
     # the user and the item half-step launch the SAME kernel symbol with different grids:
     # split the trace by grid so that each average can be set against bench.py's per-side
     # HIP-event numbers (the larger MODE-0 grid is the user side)
-    trace = glob.glob(os.path.join(SRC, "kt", "*", "*_kernel_trace.csv"))
+    trace = newest(os.path.join(SRC, "kt", "*", "*_kernel_trace.csv"))
     if trace:
         by = collections.defaultdict(list)
         for r in csv.DictReader(open(trace[0])):
@@ -55,8 +61,8 @@ def main():
                              min(d), max(d)])
     out = {"units": "bytes per launch", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2",
            "write_correction": "WRITE_SIZE KiB x 1024", "kernels": {}}
-    fetch = glob.glob(os.path.join(SRC, "fetch", "*", "*_counter_collection.csv"))
-    write = glob.glob(os.path.join(SRC, "write", "*", "*_counter_collection.csv"))
+    fetch = newest(os.path.join(SRC, "fetch", "*", "*_counter_collection.csv"))
+    write = newest(os.path.join(SRC, "write", "*", "*_counter_collection.csv"))
     if not (fetch and write):
         print("no PMC passes found")
         return
