@@ -134,7 +134,8 @@ struct Side {
     for (int64_t r = rb; r < re; r++) {
       const int32_t b = ip32[r], e = ip32[r + 1], nz = e - b;
       if (nz > CH) {
-        const int32_t nch = (nz + CH - 1) / CH;
+        // at most 32 chunks per row: the second kernel adds a row's partials one after the other
+        const int32_t nch = std::min<int32_t>((nz + CH - 1) / CH, 32);
         const int32_t per = (((nz + nch - 1) / nch) + 3) & ~3;
         SplitRow sr{static_cast<int32_t>(r), slots, 0, nz};
         for (int32_t c = b; c < e; c += per) {

@@ -408,7 +408,11 @@ template <int T> struct CholGeo {
   static constexpr int KP = 16 * T;
   static constexpr int NT = T * (T + 1) / 2;
   static constexpr int PR = ((16 * T + 16) % 32 == 0) ? 16 * T + 32 : 16 * T + 16;  // panel row stride
-  static constexpr int TS = 16 * 20;  // spilled tile: 16 rows, stride 20 floats (conflict-free b128 rows)
+#ifndef IRS_CHOL_ROW_STRIDE
+#define IRS_CHOL_ROW_STRIDE 20
+#endif
+  static constexpr int RS = IRS_CHOL_ROW_STRIDE;  // spilled tile row stride (20: conflict-free b128 rows)
+  static constexpr int TS = 16 * RS;  // spilled tile: 16 rows
   static constexpr int PAN_FLOATS = 4 * PR;
   static constexpr int SPILL_FLOATS = NT * TS + KP;
   static constexpr int LDS_FLOATS = PAN_FLOATS > SPILL_FLOATS ? PAN_FLOATS : SPILL_FLOATS;
@@ -502,7 +506,7 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
 #pragma unroll
     for (int j = i; j < T; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS + (4 * g + r) * 20 + m] = acc[C::tix(i, j)][r];
+      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS + (4 * g + r) * C::RS + m] = acc[C::tix(i, j)][r];
     if (m == 0) {
 #pragma unroll
       for (int r = 0; r < 4; r++) ybuf[16 * i + 4 * g + r] = bacc[i][r];
@@ -518,7 +522,7 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
     float row0[128], row1[64];
 #pragma unroll
     for (int j = 0; j < T; j++) {
-      const float *src = sm + tile_of(I0, j >= I0 ? j : I0) * C::TS + rk * 20;
+      const float *src = sm + tile_of(I0, j >= I0 ? j : I0) * C::TS + rk * C::RS;
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
@@ -528,7 +532,7 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
     }
 #pragma unroll
     for (int j = 4; j < T; j++) {
-      const float *src = sm + tile_of(I1, j >= I1 ? j : I1) * C::TS + rk * 20;
+      const float *src = sm + tile_of(I1, j >= I1 ? j : I1) * C::TS + rk * C::RS;
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
@@ -536,8 +540,8 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
         row1[16 * (j - 4) + 4 * c + 2] = v.z; row1[16 * (j - 4) + 4 * c + 3] = v.w;
       }
     }
-    const float rinv0 = 1.0f / sm[tile_of(I0, I0) * C::TS + rk * 20 + rk];
-    const float rinv1 = 1.0f / sm[tile_of(I1, I1) * C::TS + rk * 20 + rk];
+    const float rinv0 = 1.0f / sm[tile_of(I0, I0) * C::TS + rk * C::RS + rk];
+    const float rinv1 = 1.0f / sm[tile_of(I1, I1) * C::TS + rk * C::RS + rk];
     const float y0 = ybuf[lane], y1 = ybuf[64 + lane];
     float p0 = 0.f, p1 = 0.f, x0 = 0.f, x1 = 0.f;
 #pragma unroll
@@ -569,7 +573,7 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const int jj = j >= Ik ? j : Ik;  // tiles left of the diagonal are never needed
-    const float *src = sm + (Ik * T - Ik * (Ik - 1) / 2 + (jj - Ik)) * C::TS + rk * 20;
+    const float *src = sm + (Ik * T - Ik * (Ik - 1) / 2 + (jj - Ik)) * C::TS + rk * C::RS;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
@@ -577,7 +581,7 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
       rowk[16 * j + 4 * c + 2] = v.z; rowk[16 * j + 4 * c + 3] = v.w;
     }
   }
-  const float rinv_k = 1.0f / sm[(Ik * T - Ik * (Ik - 1) / 2) * C::TS + rk * 20 + rk];
+  const float rinv_k = 1.0f / sm[(Ik * T - Ik * (Ik - 1) / 2) * C::TS + rk * C::RS + rk];
   const float yk = ybuf[k];
   float partial = 0.f, xv = 0.f;
 #pragma unroll
@@ -628,7 +632,7 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
 #pragma unroll
     for (int j = i; j < T; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS + (4 * g + r) * 20 + m] = acc[C::tix(i, j)][r];
+      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS + (4 * g + r) * C::RS + m] = acc[C::tix(i, j)][r];
     if (g == 0) bbuf[16 * i + m] = b4[i];
   }
   __threadfence_block();
@@ -641,7 +645,7 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
 #pragma unroll
     for (int J = 0; J < T; J++) {
       if (J >= Iq[q]) {  // row rk of tile (I, J)
-        const float *src = sm + tile_of(Iq[q], J) * C::TS + rk * 20;
+        const float *src = sm + tile_of(Iq[q], J) * C::TS + rk * C::RS;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
@@ -651,7 +655,7 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
       } else {  // column rk of tile (J, I)
         const float *src = sm + tile_of(J, Iq[q]) * C::TS + rk;
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[q][16 * J + c] = src[c * 20];
+        for (int c = 0; c < 16; c++) a[q][16 * J + c] = src[c * C::RS];
       }
     }
   // virtual row 16 I + rk is latent dim T rk + I
@@ -773,13 +777,31 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
     const SplitRow sr = p.split_rows[w];
 #pragma unroll
     for (int t = 0; t < G::NT; t++) acc[t] = Pacc[t * 64 + lane];
-    for (int s = 0; s < sr.n_slots; s++) {
-      const float *src = p.partials + static_cast<size_t>(sr.first_slot + s) * G::PARTIAL_FLOATS;
-      const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+    // slots are added in ascending order (deterministic); U of them are loaded before the
+    // first add so that the chain is not one exposed memory latency per slot
+    constexpr int U = T <= 4 ? 4 : 1;
+    for (int s0 = 0; s0 < sr.n_slots; s0 += U) {
+      f32x4 part[U][G::NT];
+      float pb[U][T];
 #pragma unroll
-      for (int t = 0; t < G::NT; t++) acc[t] += s4[t * 64 + lane];
+      for (int u = 0; u < U; u++) {
+        const int s = min(s0 + u, sr.n_slots - 1);  // clamped: the duplicate is not added
+        const float *src = p.partials + static_cast<size_t>(sr.first_slot + s) * G::PARTIAL_FLOATS;
+        const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
-      for (int i = 0; i < T; i++) bsum[i] += src[G::NT * 256 + T * (lane & 15) + i];
+        for (int t = 0; t < G::NT; t++) part[u][t] = s4[t * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < T; i++) pb[u][i] = src[G::NT * 256 + T * (lane & 15) + i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (s0 + u < sr.n_slots) {
+#pragma unroll
+          for (int t = 0; t < G::NT; t++) acc[t] += part[u][t];
+#pragma unroll
+          for (int i = 0; i < T; i++) bsum[i] += pb[u][i];
+        }
+      }
     }
     add_prior<T>(p, sr.row, bsum);
     if constexpr (SOLVER == 0)

@@ -103,21 +103,22 @@ void initialize(float *factor, int64_t rows, int64_t K, const ModelConfig &c) {
   }
 }
 
-// Solver::prepare_p, hpp:78-115.  16-row micro batches off an atomic cursor,
-// per-thread partial sums, reduced in thread-join order, then scaled by alpha0.
+// Solver::prepare_p, hpp:78-115.  16-row micro batches, per-thread partial sums, reduced
+// in thread order, then scaled by alpha0.  The reference hands the batches out through an
+// atomic cursor, which makes its own float sums vary from run to run (up to 1e-4 relative
+// on ill-conditioned rows downstream); the checker deals them round-robin instead so that
+// it is reproducible.
 void prepare_p(const float *F, int64_t n, int64_t K, float alpha0,
                uint64_t n_threads, float *P) {
   if (n_threads == 0)
     throw std::invalid_argument("n_threads must be strictly positive.");
   const int64_t mb_size = 16;
-  std::atomic<int64_t> cursor{0};
   std::vector<std::vector<float>> partial(n_threads,
                                           std::vector<float>(K * K, 0.0f));
   auto work = [&](size_t tid) {
     float *Pl = partial[tid].data();
-    while (true) {
-      int64_t b = cursor.fetch_add(mb_size);
-      if (b >= n) break;
+    for (int64_t b = static_cast<int64_t>(tid) * mb_size; b < n;
+         b += static_cast<int64_t>(n_threads) * mb_size) {
       int64_t e = std::min<int64_t>(b + mb_size, n);
       for (int64_t r = b; r < e; r++) {
         const float *row = F + r * K;
