@@ -87,6 +87,10 @@ def test_compute_fails_loudly_without_gpu():
         K.CosineSimilarityComputer(X.astype(np.float64), 0.0, False)
     with pytest.raises(RuntimeError, match="no HIP device"):
         EvaluatorCore(X.astype(np.float64), [])
+    from irspack_amd.utils import retrieve_recommend_from_score
+
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        retrieve_recommend_from_score(np.zeros((2, 5), dtype=np.float32), [], 3, 1)
 
 
 def test_argument_errors_come_before_device_use():
@@ -98,6 +102,15 @@ def test_argument_errors_come_before_device_use():
         K.CosineSimilarityComputer(X, -1.0, False)
     with pytest.raises(ValueError):
         K.JaccardSimilarityComputer(X, 0.0, 0)
+    from irspack_amd.utils import retrieve_recommend_from_score
+
+    score = np.zeros((4, 10), dtype=np.float32)
+    with pytest.raises(ValueError, match="n_threads"):  # util.hpp:433
+        retrieve_recommend_from_score(score, [], 3, 0)
+    with pytest.raises(ValueError, match="allowed_indices"):  # util.hpp:434-438
+        retrieve_recommend_from_score(score, [[1], [2]], 3, 1)
+    with pytest.raises(ValueError, match="float32 or float64"):  # id_mapping.py:43-44
+        retrieve_recommend_from_score(score.astype(np.int64), [], 3, 1)
 
 
 def test_synthetic_shapes_are_seeded():
