@@ -211,7 +211,16 @@ __device__ __forceinline__ void pp_rhs_of_p(const PpParams &p, const float *xs, 
   if (lane < PpGeo<TS>::DP) {
     float s = 0.f;
     if (lane < D) {
-      for (int k = 0; k < p.K; k++) s = fmaf(p.P[k * p.KP + c0 + lane], xs[k], s);
+      // four independent chains: the loads of a step do not wait for the previous FMA
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      const float *col = p.P + c0 + lane;
+      int k = 0;
+      for (; k + 4 <= p.K; k += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) s4[q] = fmaf(col[(k + q) * p.KP], xs[k + q], s4[q]);
+      }
+      for (; k < p.K; k++) s4[0] = fmaf(col[k * p.KP], xs[k], s4[0]);
+      s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
       s = fmaf(reg, xs[c0 + lane], s);
     }
     bnat[lane] = s;
@@ -268,8 +277,12 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
       xrow[c0 + lane] = nx;
     }
     __threadfence_block();
-    pp_pred_update<ALIGNED>(p, delta, c0, D, begin, end);
-    __threadfence();
+    // the cache is rebuilt at the start of every sweep (hpp:521-523): the correction after
+    // the last block would never be read
+    if (c0 + p.sub < p.K) {
+      pp_pred_update<ALIGNED>(p, delta, c0, D, begin, end);
+      __threadfence();
+    }
   }
 }
 
@@ -362,9 +375,11 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
       }
     }
     __syncthreads();
-    pp_pred_update<ALIGNED>(p, delta, c0, D, wb, we);
-    __threadfence();
-    __syncthreads();
+    if (c0 + p.sub < p.K) {  // see ialspp_kernel: the last correction is never read
+      pp_pred_update<ALIGNED>(p, delta, c0, D, wb, we);
+      __threadfence();
+      __syncthreads();
+    }
   }
 }
 
