@@ -62,9 +62,13 @@ __device__ __forceinline__ void load_sub(const float *p, const int (&off)[TS], f
 // Rank update of the block: acc += sum c v v^T (MFMA, upper tiles),
 // bsum += sum (c (pred - 1) - bias) v.  Two-deep pipeline of 16-entry groups with
 // unconditional loads (the CSR arrays and the prediction cache are padded).
-template <int TS, bool ALIGNED>
+// FUSED (single block: D == K): the block is the whole row, so pred_q = x . v_q is formed
+// from the gathered row itself (16-lane butterfly) and the prediction cache is never touched;
+// xs is the row's factor vector in LDS.
+template <int TS, bool ALIGNED, bool FUSED = false>
 __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int end, int c0, int D,
-                                               f32x4 (&acc)[PpGeo<TS>::NT], float (&bsum)[TS]) {
+                                               f32x4 (&acc)[PpGeo<TS>::NT], float (&bsum)[TS],
+                                               const float *xs = nullptr) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
   const float *col_base = p.other + c0;
@@ -80,6 +84,9 @@ __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int
     dim_ok[t] = TS * m + t < D;
     off[t] = ALIGNED ? (TS * m < D ? TS * m + t : t) : (dim_ok[t] ? TS * m + t : 0);
   }
+  float xloc[TS];
+#pragma unroll
+  for (int t = 0; t < TS; t++) xloc[t] = (FUSED && dim_ok[t]) ? xs[c0 + TS * m + t] : 0.f;
   int ia[4], ib[4];
   float ca[4], cb[4], pa[4], pb[4];
   float va[4][TS], vb[4][TS], xa[4], xb[4], wa[4], wb[4];
@@ -88,7 +95,7 @@ __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int
     for (int u = 0; u < 4; u++) {
       ix[u] = ip[16 * it + 4 * u];
       cx[u] = dp[16 * it + 4 * u];
-      px[u] = pp[16 * it + 4 * u];
+      px[u] = FUSED ? 0.f : pp[16 * it + 4 * u];
     }
   };
   auto gather = [&](int it, const int (&ix)[4], const float (&cx)[4], const float (&px)[4],
@@ -97,7 +104,9 @@ __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int
     for (int u = 0; u < 4; u++) {
       const bool valid = 16 * it + 4 * u + g < n;
       vc[u] = valid ? cx[u] : 0.f;
-      vw[u] = valid ? cx[u] * (px[u] - 1.0f) - p.bias : 0.f;  // hpp:485-486
+      // hpp:485-486; FUSED: the entry's validity travels in vw and the residual is formed in
+      // consume() once the row is there
+      vw[u] = FUSED ? (valid ? 1.f : 0.f) : (valid ? cx[u] * (px[u] - 1.0f) - p.bias : 0.f);
       load_sub<TS, ALIGNED>(col_base + static_cast<size_t>(static_cast<unsigned>(ix[u])) * p.KP, off,
                             v[u]);
     }
@@ -107,10 +116,22 @@ __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int
     for (int u = 0; u < 4; u++) {
       float cv[TS], vk[TS];
 #pragma unroll
+      for (int i = 0; i < TS; i++) vk[i] = dim_ok[i] ? v[u][i] : 0.f;
+      float w = vw[u];
+      if constexpr (FUSED) {
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < TS; i++) dot = fmaf(vk[i], xloc[i], dot);
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        dot += __shfl_xor(dot, 8, 64);
+        w = vw[u] != 0.f ? vc[u] * (dot - 1.0f) - p.bias : 0.f;
+      }
+#pragma unroll
       for (int i = 0; i < TS; i++) {
-        vk[i] = dim_ok[i] ? v[u][i] : 0.f;
         cv[i] = vc[u] * vk[i];
-        bsum[i] = fmaf(vw[u], vk[i], bsum[i]);
+        bsum[i] = fmaf(w, vk[i], bsum[i]);
       }
       int t = 0;
 #pragma unroll
@@ -252,8 +273,11 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
     if (p.zero_start) xrow[i] = 0.f;
   }
   __threadfence_block();
-  pp_predict(p, xs, begin, end);
-  __threadfence();  // the cache is re-read through other lanes' addresses below
+  const bool single = p.sub >= p.K;  // one block = the whole row: no prediction cache needed
+  if (!single) {
+    pp_predict(p, xs, begin, end);
+    __threadfence();  // the cache is re-read through other lanes' addresses below
+  }
 
   for (int c0 = 0; c0 < p.K; c0 += p.sub) {
     const int D = min(p.sub, p.K - c0);
@@ -263,7 +287,10 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
     float bsum[TS];
 #pragma unroll
     for (int i = 0; i < TS; i++) bsum[i] = 0.f;
-    pp_rank_update<TS, ALIGNED>(p, begin, end, c0, D, acc, bsum);
+    if (single)
+      pp_rank_update<TS, ALIGNED, true>(p, begin, end, c0, D, acc, bsum, xs);
+    else
+      pp_rank_update<TS, ALIGNED>(p, begin, end, c0, D, acc, bsum);
     __threadfence_block();
     float b4[TS];
 #pragma unroll
@@ -325,9 +352,12 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
     if (p.zero_start) xrow[i] = 0.f;
   }
   __syncthreads();
-  pp_predict(p, xs, wb, we);
-  __threadfence();
-  __syncthreads();
+  const bool single = p.sub >= p.K;  // see ialspp_kernel
+  if (!single) {
+    pp_predict(p, xs, wb, we);
+    __threadfence();
+    __syncthreads();
+  }
 
   for (int c0 = 0; c0 < p.K; c0 += p.sub) {
     const int D = min(p.sub, p.K - c0);
@@ -342,7 +372,10 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
     float bsum[TS];
 #pragma unroll
     for (int i = 0; i < TS; i++) bsum[i] = 0.f;
-    pp_rank_update<TS, ALIGNED>(p, wb, we, c0, D, acc, bsum);
+    if (single)
+      pp_rank_update<TS, ALIGNED, true>(p, wb, we, c0, D, acc, bsum, xs);
+    else
+      pp_rank_update<TS, ALIGNED>(p, wb, we, c0, D, acc, bsum);
     if (wid > 0) {
       float *dst = parts + (wid - 1) * L::PART;
       f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
