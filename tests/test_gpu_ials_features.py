@@ -213,3 +213,36 @@ def test_recommender_level_features():
     # prediction-time CG (5 steps on a 3 x 3 system) has converged
     np.testing.assert_allclose(emb, want, rtol=2e-4, atol=2e-5)
     assert rec.get_score_cold_user(X).shape == (3, 4)
+
+
+@pytest.mark.parametrize("K", [100, 200])
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_prior_on_the_large_k_kernels(K, kind):
+    """K in (64, 128] runs on the one-wave kernel with 36 tiles, K > 128 on the workgroup
+    kernels: the prior must reach their right-hand sides too (closed form, float64)."""
+    rng = np.random.default_rng(K)
+    Xd = (rng.random((30, 25)) < 0.3) * rng.uniform(0.5, 2.0, (30, 25))
+    X = sps.csr_matrix(Xd.astype(np.float32))
+    Fu = rng.standard_normal((30, 4)).astype(np.float32)
+    a0, reg, lam = 0.2, 0.5, 0.3
+    mc = (IALSModelConfigBuilder().set_K(K).set_alpha0(a0).set_reg(reg).set_nu(0.0)
+          .set_loss_type(LossType.ORIGINAL).set_lambda_user_feature(lam)
+          .set_lambda_item_feature(lam).build())
+    sc = (IALSSolverConfigBuilder().set_solver_type(SolverType[kind]).set_max_cg_steps(0).build())
+    t = IALSTrainer(mc, X, Fu, None)
+    W = rng.standard_normal((4, K)).astype(np.float32) * 0.1
+    t.user_feature_weight = W
+    item = t.item.astype(np.float64)
+    prior = Fu.astype(np.float64) @ W.astype(np.float64)
+    t.step(sc)  # user half with the prior F @ W, then the ridge update and the item half
+    base = a0 * item.T @ item
+    want = np.zeros((30, K))
+    for u in range(30):
+        lhs = base + reg * np.eye(K)
+        rhs = reg * prior[u]
+        for j in np.nonzero(Xd[u])[0]:
+            lhs = lhs + Xd[u, j] * np.outer(item[j], item[j])
+            rhs = rhs + (a0 + Xd[u, j]) * item[j]
+        want[u] = np.linalg.solve(lhs, rhs)
+    got = t.user.astype(np.float64)
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-3  # CG: K steps in float32
