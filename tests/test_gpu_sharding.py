@@ -55,8 +55,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("equal", [False, True])
-@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+@pytest.mark.parametrize("kind,equal", [("CHOLESKY", False), ("CHOLESKY", True), ("CG", False),
+                                        ("CG", True), ("IALSPP", True)])
 def test_two_ranks_match_single_gpu(tmp_path, kind, equal):
     import torch.multiprocessing as mp
 
