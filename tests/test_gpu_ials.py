@@ -388,3 +388,27 @@ def test_large_k_split_rows():
         t.synchronize()
         o.step(osc)
         assert rel_err(t.user, o.user) < RTOL
+
+
+@pytest.mark.parametrize("K", [20, 100, 200])
+def test_loss_user_scores_transform_at_every_kernel_family(K):
+    """compute_loss / user_scores / transform on the K <= 64, K <= 128 and K <= 256 code paths
+    against float64 numpy on the same factors."""
+    X = random_csr(60, 45, 0.2, 21, empty_rows=(3,))
+    alpha0, reg = 0.1, 0.2
+    mc, omc = build(K, alpha0=alpha0, reg=reg, nu=0.0, loss="ORIGINAL")
+    sc, osc = solver("CHOLESKY", n_threads=1)
+    t = IALSTrainer(mc, X)
+    t.step(sc)
+    u, v = t.user.astype(np.float64), t.item.astype(np.float64)
+    ui = u @ v.T
+    Xd = X.toarray().astype(np.float64)
+    obs = Xd != 0
+    manual = ((Xd[obs] + alpha0) * (ui[obs] - 1) ** 2).sum() + alpha0 * (ui[~obs] ** 2).sum()
+    manual += reg * ((u ** 2).sum() + (v ** 2).sum())
+    assert t.compute_loss(sc) == pytest.approx(manual / 2, rel=2e-5)
+    np.testing.assert_allclose(t.user_scores(5, 37, sc), ui[5:37], rtol=1e-4, atol=1e-5)
+    o = O.IALSTrainer(omc, X)
+    o.user, o.item = t.user, t.item
+    Xn = random_csr(17, 45, 0.3, 5)
+    assert rel_err(t.transform_user(Xn, sc), o.transform_user(Xn, osc)) < RTOL
