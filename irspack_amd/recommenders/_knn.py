@@ -50,12 +50,29 @@ class _Computer:
                 pass
             self._h = None
 
+    # candidate slots (target rows x column tiles x top_k) one device call may hold: 64 M
+    # (~0.8 GB of scratch); larger requests are cut into row batches
+    _MAX_SLOT_ENTRIES = 1 << 26
+
     def _compute(self, X: Any, top_k: int, as_w: bool,
                  rows: Optional[Tuple[int, int]] = None) -> sps.csr_matrix:
         if top_k < 0:
             raise TypeError("top_k must be non-negative (size_t).")
         Xc, indptr, indices, data = _lib.csr_arrays(X, np.float64)
         rb, re = (0, Xc.shape[0]) if rows is None else rows
+        n_tiles = max(1, -(-self._N // 16384))
+        per_row = max(1, n_tiles * min(max(int(top_k), 1), self._N))
+        batch = max(1, self._MAX_SLOT_ENTRIES // per_row)
+        if re - rb > batch:  # rows are independent: stitch the batches
+            parts, ms, macs = [], 0.0, 0
+            for b in range(rb, re, batch):
+                parts.append(self._compute(Xc, top_k, as_w, (b, min(b + batch, re))))
+                ms += self.last_kernel_ms
+                macs += self.last_macs
+            self.last_kernel_ms, self.last_macs = ms, macs
+            res = sps.vstack(parts, format="csr")
+            res.has_sorted_indices = True
+            return res
         nnz = C.c_int64(0)
         check(
             lib().irs_knn_compute(

@@ -200,3 +200,19 @@ def test_two_column_tiles():
     got = g.compute_similarity(Xt, 50, rows=sel)
     exp = o.compute_similarity(Xt[sel[0]:sel[1]].tocsr() if False else Xt, 50)[sel[0]:sel[1]]
     assert_same_csr(got, exp, rtol=0)
+
+
+def test_row_batching_is_transparent(monkeypatch):
+    """Requests whose candidate scratch would be too large are cut into row batches."""
+    from conftest import random_csr
+
+    X = random_csr(300, 120, 0.1, 17, dtype=np.float64)
+    comp = K.CosineSimilarityComputer(X, 0.5, True)
+    whole = comp.compute_similarity(X, 7)
+    monkeypatch.setattr(K._Computer, "_MAX_SLOT_ENTRIES", 7 * 37)  # 37 rows per call
+    cut = comp.compute_similarity(X, 7)
+    # indices are bit-exact; real-valued sums may differ in the last bit between two runs
+    # (fp64 LDS atomics), batched or not
+    assert np.array_equal(whole.indptr, cut.indptr) and np.array_equal(whole.indices, cut.indices)
+    np.testing.assert_allclose(whole.data, cut.data, rtol=1e-12)
+    assert comp.last_macs > 0
