@@ -30,7 +30,7 @@ namespace irs {
 namespace knn {
 
 constexpr int TILE = 16384;     // columns per workgroup (128 KB of fp64 accumulators)
-constexpr int TOPK_CAP = 1024;  // largest top_k ranked in LDS next to the accumulators
+constexpr int TOPK_CAP = 2048;  // largest top_k: two candidate sets must fit one merge round
 constexpr int MERGE_CAP = 4096; // candidates a row merge can hold
 constexpr int THREADS = 1024;
 
@@ -402,58 +402,66 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
 
 // One 256-thread workgroup per target row: union of the tile winners, keep the
 // top_k by (value desc, column asc), emit them sorted by column (knn.hpp:119-136).
+// The tiles are merged in rounds: as many tiles as fit next to the best-so-far are appended,
+// the buffer is sorted and cut back to top_k (any number of tiles, top_k <= MERGE_CAP / 2).
 __global__ __launch_bounds__(256) void knn_merge_kernel(Params p) {
   __shared__ uint64_t key[MERGE_CAP];
   __shared__ double val[MERGE_CAP];
   __shared__ int32_t idx[MERGE_CAP];
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
-  int n = 0;
-  for (int t = 0; t < p.n_tiles; t++) {
-    const int b = slot * p.n_tiles + t;
-    const int c = p.cand_cnt[b];
-    for (int i = tid; i < c; i += 256) {
-      const double v = p.cand_val[static_cast<size_t>(b) * p.top_k + i];
-      val[n + i] = v;
-      key[n + i] = order_key(v);
-      idx[n + i] = p.cand_idx[static_cast<size_t>(b) * p.top_k + i];
-    }
-    n += c;
-  }
-  int n_pow = 1;
-  while (n_pow < n) n_pow <<= 1;
-  for (int i = n + tid; i < n_pow; i += 256) {
-    key[i] = 0ull;
-    val[i] = 0.0;
-    idx[i] = 0x7fffffff;
-  }
-  __syncthreads();
   auto swap_el = [&](int a, int b) {
     const uint64_t tk = key[a]; key[a] = key[b]; key[b] = tk;
     const double tv = val[a]; val[a] = val[b]; val[b] = tv;
     const int32_t ti = idx[a]; idx[a] = idx[b]; idx[b] = ti;
   };
-  // pass 1: (value desc, column asc); padding (column = INT_MAX) sorts last among equal keys
-  for (int k2 = 2; k2 <= n_pow; k2 <<= 1)
-    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      for (int i = tid; i < n_pow; i += 256) {
-        const int l = i ^ j2;
-        if (l > i) {
-          const bool up = (i & k2) == 0;
-          const bool l_first = (key[l] != key[i]) ? key[l] > key[i] : idx[l] < idx[i];
-          const bool i_first = (key[l] != key[i]) ? key[i] > key[l] : idx[i] < idx[l];
-          if (up ? l_first : i_first) swap_el(i, l);
-        }
+  int n = 0;  // entries currently in the buffer (the best so far after a round)
+  int t = 0;
+  do {
+    // append tiles while they fit (cand_cnt <= top_k <= MERGE_CAP / 2: at least one fits)
+    while (t < p.n_tiles) {
+      const int b = slot * p.n_tiles + t;
+      const int c = p.cand_cnt[b];
+      if (n + c > MERGE_CAP) break;
+      for (int i = tid; i < c; i += 256) {
+        const double v = p.cand_val[static_cast<size_t>(b) * p.top_k + i];
+        val[n + i] = v;
+        key[n + i] = order_key(v);
+        idx[n + i] = p.cand_idx[static_cast<size_t>(b) * p.top_k + i];
       }
-      __syncthreads();
+      n += c;
+      t++;
     }
-  // real entries with key 0 (NaN / padding ties) cannot outrank padding by key; they do by column
-  const int keep = min(n, p.top_k);
+    int n_pow = 1;
+    while (n_pow < n) n_pow <<= 1;
+    for (int i = n + tid; i < n_pow; i += 256) {
+      key[i] = 0ull;
+      val[i] = 0.0;
+      idx[i] = 0x7fffffff;
+    }
+    __syncthreads();
+    // (value desc, column asc); padding (column = INT_MAX) sorts last among equal keys
+    for (int k2 = 2; k2 <= n_pow; k2 <<= 1)
+      for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+        for (int i = tid; i < n_pow; i += 256) {
+          const int l = i ^ j2;
+          if (l > i) {
+            const bool up = (i & k2) == 0;
+            const bool l_first = (key[l] != key[i]) ? key[l] > key[i] : idx[l] < idx[i];
+            const bool i_first = (key[l] != key[i]) ? key[i] > key[l] : idx[i] < idx[l];
+            if (up ? l_first : i_first) swap_el(i, l);
+          }
+        }
+        __syncthreads();
+      }
+    n = min(n, p.top_k);  // real entries with key 0 (NaN) outrank padding by column
+  } while (t < p.n_tiles);
+  const int keep = n;
   int k_pow = 1;
   while (k_pow < keep) k_pow <<= 1;
   for (int i = keep + tid; i < k_pow; i += 256) idx[i] = 0x7fffffff;
   __syncthreads();
-  // pass 2: the kept entries by column
+  // the kept entries by column
   for (int k2 = 2; k2 <= k_pow; k2 <<= 1)
     for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
       for (int i = tid; i < k_pow; i += 256) {
@@ -722,8 +730,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     if (out_k > TOPK_CAP)
       throw std::invalid_argument("irspack_amd: top_k above " + std::to_string(TOPK_CAP) +
                                   " is not supported by the device kNN kernel.");
-    if (static_cast<int64_t>(n_tiles) * out_k > MERGE_CAP)
-      throw std::invalid_argument("irspack_amd: top_k * column tiles exceeds the merge capacity.");
     IRS_HIP(hipSetDevice(c->device));
     hipStream_t s = nullptr;
     // work per target row = multiply-adds of its product row; longest first

@@ -216,3 +216,19 @@ def test_row_batching_is_transparent(monkeypatch):
     assert np.array_equal(whole.indptr, cut.indptr) and np.array_equal(whole.indices, cut.indices)
     np.testing.assert_allclose(whole.data, cut.data, rtol=1e-12)
     assert comp.last_macs > 0
+
+
+def test_many_tiles_and_large_top_k_merge_in_rounds():
+    """3 column tiles x top_k = 1500 candidates exceed one merge buffer (4096): the row merge
+    runs in rounds.  Indices bit-exact against the oracle."""
+    from conftest import random_csr
+
+    X = random_csr(33000, 40, 0.05, 23, dtype=np.float64, binary=True)
+    comp = K.CosineSimilarityComputer(X, 0.0, True)
+    ref = O.KNNComputer("cosine", X, 0.0, normalize=True, n_threads=8)
+    rows = (100, 164)
+    got = comp.compute_similarity(X, 1500, rows=rows)
+    want = ref.compute_similarity(X, 1500)[rows[0]:rows[1]]
+    assert np.diff(want.indptr).max() == 1500  # the cut is exercised
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    np.testing.assert_allclose(got.data, want.data, rtol=1e-12)
