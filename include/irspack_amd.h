@@ -130,6 +130,20 @@ irs_status irs_ials_transform_with_prior(irs_ials_trainer *t, int32_t side, int6
  * irs_ials_half_step_async calls of that side; NULL clears it.  The feature-weight ridge
  * update (hpp:1052-1209) is a small F x F host solve and stays with the caller. */
 irs_status irs_ials_set_prior(irs_ials_trainer *t, int32_t which, const float *prior);
+/* The two feature products of feature-aware training on the device, so that the factor
+ * matrices never leave HBM during an epoch.  irs_ials_set_features stores the feature
+ * matrix of side `which` (CSR float32 [rows, n_feat]; a dense matrix is passed as a full
+ * CSR; FeatureMatrix, hpp:693-700).  irs_ials_apply_feature_prior computes
+ * prior = features @ weight (host float32 [n_feat, K]; feature_times_weight hpp:702-708)
+ * and installs it like irs_ials_set_prior.  irs_ials_feature_rhs returns
+ * features^T (reg_r * factor_r) as host float32 [n_feat, K], the right-hand side of the
+ * feature-weight ridge system (solve_feature_weight hpp:1134-1171). */
+irs_status irs_ials_set_features(irs_ials_trainer *t, int32_t which, int64_t rows,
+                                 int64_t n_feat, const int64_t *indptr,
+                                 const int32_t *indices, const float *data);
+irs_status irs_ials_apply_feature_prior(irs_ials_trainer *t, int32_t which,
+                                        const float *weight);
+irs_status irs_ials_feature_rhs(irs_ials_trainer *t, int32_t which, float *out);
 /* IALSTrainer::compute_loss, hpp:836-940. */
 irs_status irs_ials_compute_loss(irs_ials_trainer *t,
                                  const irs_ials_solver_config *sc, float *out);

@@ -77,6 +77,9 @@ EXPORTED_SYMBOLS = [
     "irs_ials_transform",
     "irs_ials_transform_with_prior",
     "irs_ials_set_prior",
+    "irs_ials_set_features",
+    "irs_ials_apply_feature_prior",
+    "irs_ials_feature_rhs",
     "irs_ials_compute_loss",
     "irs_ials_set_stream",
     "irs_ials_device_buffer",

@@ -15,6 +15,7 @@
 #include "ials_kernels.hpp"
 #include "ials_wg_kernels.hpp"
 #include "ials_pp_kernels.hpp"
+#include "ials_feature_kernels.hpp"
 
 namespace irs {
 
@@ -249,6 +250,11 @@ struct irs_ials_trainer {
   DeviceBuffer<int32_t> err_flag;
   DeviceBuffer<float> prior[2];        // feature prior of the next half step(s), [rows, KP]
   bool has_prior[2] = {false, false};
+  // feature matrices (CSR and CSR of the transpose), weights and ridge right-hand sides
+  int64_t n_feat[2] = {0, 0};
+  DeviceBuffer<int32_t> f_indptr[2], f_indices[2], ft_indptr[2], ft_indices[2];
+  DeviceBuffer<float> f_data[2], ft_data[2], f_W[2], f_rhs[2], f_part[2];
+  int f_chunks[2] = {1, 1};  // feature_rhs_kernel: chunks of FEATURE_RHS_CHUNK stored rows per feature
   DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   Profiler prof;
@@ -972,6 +978,89 @@ irs_status irs_ials_set_prior(irs_ials_trainer *t, int32_t which, const float *p
     t->prior[which].upload(padded, t->stream);
     IRS_HIP(hipStreamSynchronize(t->stream));
     t->has_prior[which] = true;
+  });
+}
+
+constexpr int64_t FEATURE_RHS_CHUNK = 2048;
+
+irs_status irs_ials_set_features(irs_ials_trainer *t, int32_t which, int64_t rows, int64_t n_feat,
+                                 const int64_t *indptr, const int32_t *indices,
+                                 const float *data) {
+  return guard([&] {
+    check_arg(t && (which == 0 || which == 1), "bad argument.");
+    if (rows != t->rows_of(which))  // initialize_feature_aware, hpp:1005-1007
+      throw std::invalid_argument("Feature matrix row count mismatch.");
+    HostCsr F = host_csr(rows, n_feat, indptr, indices, data);
+    HostCsr Ft = transpose(F);
+    IRS_HIP(hipSetDevice(t->device));
+    auto to32 = [](const std::vector<int64_t> &v) {
+      std::vector<int32_t> o(v.size());
+      for (size_t i = 0; i < v.size(); i++) o[i] = static_cast<int32_t>(v[i]);
+      return o;
+    };
+    hipStream_t s = t->stream;
+    t->f_indptr[which].upload(to32(F.indptr), s);
+    t->f_indices[which].upload(F.indices, s);
+    t->f_data[which].upload(F.data, s);
+    t->ft_indptr[which].upload(to32(Ft.indptr), s);
+    t->ft_indices[which].upload(Ft.indices, s);
+    t->ft_data[which].upload(Ft.data, s);
+    t->f_W[which].alloc(static_cast<size_t>(std::max<int64_t>(n_feat, 1)) * t->KP);
+    t->f_rhs[which].alloc(static_cast<size_t>(std::max<int64_t>(n_feat, 1)) * t->KP);
+    int64_t longest = 1;
+    for (int64_t f = 0; f < n_feat; f++) longest = std::max(longest, Ft.indptr[f + 1] - Ft.indptr[f]);
+    t->f_chunks[which] = static_cast<int>(ceil_div(longest, FEATURE_RHS_CHUNK));
+    t->f_part[which].alloc(static_cast<size_t>(t->f_chunks[which]) * std::max<int64_t>(n_feat, 1) *
+                           t->KP);
+    IRS_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+    t->n_feat[which] = n_feat;
+  });
+}
+
+irs_status irs_ials_apply_feature_prior(irs_ials_trainer *t, int32_t which, const float *weight) {
+  return guard([&] {
+    check_arg(t && weight && (which == 0 || which == 1), "bad argument.");
+    check_arg(t->n_feat[which] > 0, "no feature matrix was set for this side.");
+    IRS_HIP(hipSetDevice(t->device));
+    const int64_t F = t->n_feat[which], n = t->rows_of(which);
+    std::vector<float> padded(static_cast<size_t>(F) * t->KP, 0.0f);
+    for (int64_t f = 0; f < F; f++)
+      std::copy(weight + f * t->K, weight + (f + 1) * t->K, padded.begin() + f * t->KP);
+    t->f_W[which].upload(padded, t->stream);
+    t->prior[which].alloc(static_cast<size_t>(ceil_div(n, 8) * 8) * t->KP);
+    t->prof.begin(which == 0 ? "feature_prior_user" : "feature_prior_item", t->stream);
+    hipLaunchKernelGGL(feature_prior_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, t->stream,
+                       t->f_indptr[which].ptr, t->f_indices[which].ptr, t->f_data[which].ptr,
+                       t->f_W[which].ptr, n, t->KP, t->prior[which].ptr);
+    t->prof.end(t->stream);
+    IRS_HIP(hipGetLastError());
+    IRS_HIP(hipStreamSynchronize(t->stream));  // `padded` goes out of scope
+    t->has_prior[which] = true;
+  });
+}
+
+irs_status irs_ials_feature_rhs(irs_ials_trainer *t, int32_t which, float *out) {
+  return guard([&] {
+    check_arg(t && out && (which == 0 || which == 1), "bad argument.");
+    check_arg(t->n_feat[which] > 0, "no feature matrix was set for this side.");
+    require_X(t);
+    IRS_HIP(hipSetDevice(t->device));
+    const int64_t F = t->n_feat[which];
+    t->prof.begin(which == 0 ? "feature_rhs_user" : "feature_rhs_item", t->stream);
+    const int nc = t->f_chunks[which];
+    hipLaunchKernelGGL(feature_rhs_kernel, dim3(F, nc), dim3(256), 0, t->stream,
+                       t->ft_indptr[which].ptr, t->ft_indices[which].ptr, t->ft_data[which].ptr,
+                       t->side[which].reg.ptr, t->factor[which].ptr, t->KP,
+                       static_cast<int>(FEATURE_RHS_CHUNK), static_cast<int>(F),
+                       t->f_part[which].ptr);
+    hipLaunchKernelGGL(feature_rhs_reduce_kernel, dim3(ceil_div(F * t->KP, 256)), dim3(256), 0,
+                       t->stream, t->f_part[which].ptr, nc, F * t->KP, t->f_rhs[which].ptr);
+    t->prof.end(t->stream);
+    IRS_HIP(hipGetLastError());
+    IRS_HIP(hipMemcpy2DAsync(out, t->K * sizeof(float), t->f_rhs[which].ptr,
+                             t->KP * sizeof(float), t->K * sizeof(float), F,
+                             hipMemcpyDeviceToHost, t->stream));
+    IRS_HIP(hipStreamSynchronize(t->stream));
   });
 }
 

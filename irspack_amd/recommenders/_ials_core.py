@@ -252,6 +252,26 @@ def _as_feature(f: Any, rows: int) -> Any:
     return f
 
 
+_BLAS_CONTROLLER: Any = None
+
+
+def _single_blas_thread() -> Any:
+    """Context manager that keeps the host BLAS on one thread (no-op without threadpoolctl)."""
+    global _BLAS_CONTROLLER
+    if _BLAS_CONTROLLER is None:
+        try:
+            from threadpoolctl import ThreadpoolController
+
+            _BLAS_CONTROLLER = ThreadpoolController()
+        except Exception:  # pragma: no cover - threadpoolctl is optional
+            _BLAS_CONTROLLER = False
+    if _BLAS_CONTROLLER is False:
+        import contextlib
+
+        return contextlib.nullcontext()
+    return _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
+
+
 class IALSTrainer:
     """``IALSTrainer(model_config, interaction)`` — wrapper.cpp:130-181, hpp:709-984.
 
@@ -311,6 +331,14 @@ class IALSTrainer:
             self._ifw = np.zeros((itf.shape[1], self._K), dtype=np.float32)
             Xc = sps.csr_matrix(X)
             self._row_nnz = [np.diff(Xc.indptr), np.bincount(Xc.indices, minlength=self._n_items)]
+            for side, F in enumerate(self._features):  # the products with F run on the device
+                if F.shape[1]:
+                    Fc, fp, fi, fd = _lib.csr_arrays(sps.csr_matrix(F), np.float32)
+                    if fi.size == 0:
+                        fi, fd = np.zeros(1, np.int32), np.zeros(1, np.float32)
+                    check(lib().irs_ials_set_features(
+                        self._h, C.c_int32(side), C.c_int64(Fc.shape[0]), C.c_int64(Fc.shape[1]),
+                        ptr(fp, C.c_int64), ptr(fi, C.c_int32), ptr(fd, C.c_float)))
 
     def _empty_feature_weight(self) -> None:
         self._ufw = np.zeros((0, self._K), dtype=np.float32)
@@ -374,9 +402,10 @@ class IALSTrainer:
                 raise RuntimeError("Feature ridge Cholesky decomposition failed.")
             self._ridge_cache[side] = (w, chol)
         w, chol = self._ridge_cache[side]
-        factor = self._get(side)
-        rhs = np.asarray(F.T @ (factor * w[:, None]), dtype=np.float32)  # hpp:1142-1171
-        sol = sla.cho_solve(chol, rhs, check_finite=False).astype(np.float32)
+        rhs = np.empty((F.shape[1], self._K), dtype=np.float32)  # F^T (D factor), hpp:1142-1171
+        check(lib().irs_ials_feature_rhs(self._h, C.c_int32(side), ptr(rhs, C.c_float)))
+        with _single_blas_thread():  # an F x F solve: a BLAS thread team costs more than it saves
+            sol = sla.cho_solve(chol, rhs, check_finite=False).astype(np.float32)
         if not np.isfinite(sol).all():
             raise RuntimeError("Feature ridge solve failed.")
         if side == 0:
@@ -439,7 +468,9 @@ class IALSTrainer:
                 self.finish_gramian_async(side)
                 if self._weight(side).shape[0]:
                     self._check_prior_defined(side, self._row_nnz[side])
-                    self._set_prior(side, self._stored_prior(side))
+                    W = np.ascontiguousarray(self._weight(side), dtype=np.float32)
+                    check(lib().irs_ials_apply_feature_prior(self._h, C.c_int32(side),
+                                                             ptr(W, C.c_float)))
                     try:
                         self.half_step_async(side, solver_config)
                         self.synchronize()
