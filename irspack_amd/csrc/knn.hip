@@ -38,8 +38,8 @@ struct Params {
   // X_arg^T by rows u: (column j, value x) sorted by j; xt_tptr[u * (n_tiles + 1) + t]
   // is the position of the first entry of row u with column >= t * TILE (the last one is
   // the row end), so a (row, tile) workgroup walks exactly its own slice of every row
-  const int64_t *xt_tptr;
-  const int32_t *xt_idx;
+  const uint32_t *xt_tptr;
+  const uint32_t *xt_idx16;  // tile-relative columns, 16 bits each, two per dword
   const double *xt_val;
   const double *norms;  // per column j
   // target rows
@@ -63,6 +63,9 @@ struct Params {
   int32_t *out_idx;    // [n_rows * top_k]
   double *out_val;
   int32_t *out_cnt;    // [n_rows]
+  // persistent launch: workgroups draw (row slot, tile) pairs from this counter
+  int32_t *cursor;
+  int32_t n_slots;     // n_rows * n_tiles
 };
 
 __device__ __forceinline__ int64_t readlane_i64(int64_t v, int src) {
@@ -114,40 +117,82 @@ __device__ __forceinline__ double epilogue(const Params &p, double v, double nor
 // otherwise the bitmap is maintained with atomics next to the sums.
 constexpr uint64_t NEG_ZERO_BITS = 0x8000000000000000ull;
 
-template <bool ONES, bool SENTINEL>
+#ifdef IRS_KNN_PHASES
+__device__ unsigned long long knn_phase_clk[8];
+#define PHASE_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&knn_phase_clk[i], t_ - ph_t); ph_t = t_; } } while (0)
+#else
+#define PHASE_MARK(i)
+#endif
+
+// ACC32 (every stored value of both operands is exactly 1, so every product is 1): the sums
+// are counts, accumulated with 32-bit LDS atomics (one bank per lane instead of two: 1.5x the
+// fp64 atomic rate) in the upper half of the accumulator block and widened to fp64 in place
+// afterwards - the same values as the fp64 sums, which are exact for integers.
+template <bool ONES, bool SENTINEL, bool ACC32 = false>
 __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
+  static_assert(!ACC32 || (ONES && SENTINEL), "counts need all-ones operands");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *acc = reinterpret_cast<double *>(smem);                        // TILE
   uint32_t *bits = reinterpret_cast<uint32_t *>(acc + TILE);             // TILE / 32
   uint32_t *hist = bits + TILE / 32;                                     // 256
   int32_t *wave_cnt = reinterpret_cast<int32_t *>(hist + 256);           // 16
+  // one sink per lane for the lanes of a strip that lie outside their slice: the atomic is
+  // issued without a branch (ACC32 uses the idle upper half of the accumulator block)
+  constexpr uint32_t SINK_BYTES = TILE * 8 + (TILE / 32) * 4 + 256 * 4 + 16 * 4;
   __shared__ uint64_t sh_prefix;
   __shared__ int32_t sh_need, sh_count, sh_total;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int NW = THREADS / 64;
-  const int slot = blockIdx.x / p.n_tiles, tile = blockIdx.x % p.n_tiles;
+  __shared__ int32_t sh_slot;
+  // One workgroup per CU stays resident and draws (row slot, tile) pairs, heaviest rows
+  // first, from a global counter: a 1024-thread / 130 KB workgroup costs ~20 us to launch
+  // and retire, as much as the whole accumulation of a light row.  The draw for the next
+  // pair is issued before the current one is processed, so its latency is hidden.
+  int32_t next_slot = 0;
+  if (tid == 0) next_slot = atomicAdd(p.cursor, 1);
+  for (;;) {
+  __syncthreads();  // the previous pair is finished by every wave (LDS and sh_* reuse)
+  if (tid == 0) {
+    sh_slot = next_slot;
+    next_slot = atomicAdd(p.cursor, 1);
+  }
+  __syncthreads();
+  const int bid = sh_slot;
+  if (bid >= p.n_slots) break;
+  const int slot = bid / p.n_tiles, tile = bid % p.n_tiles;
   const int r = p.row_order[slot];
   const int c0 = tile * TILE, c1 = min(c0 + TILE, p.N);
   const int width = c1 - c0;
+#ifdef IRS_KNN_PHASES
+  unsigned long long ph_t = wall_clock64();
+#endif
 
-  for (int i = tid; i < width; i += THREADS) acc[i] = SENTINEL ? -0.0 : 0.0;
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(acc);  // ACC32: TILE counters
+  if (ACC32) {
+    for (int i = tid; i < width; i += THREADS) cnt[i] = 0u;
+  } else {
+    for (int i = tid; i < width; i += THREADS) acc[i] = SENTINEL ? -0.0 : 0.0;
+  }
   for (int i = tid; i < TILE / 32; i += THREADS) bits[i] = 0u;
   __syncthreads();
+  PHASE_MARK(0);
 
   // ---- 1. accumulate.  A wave takes 16 stored (u, y) of the target row at a time: lanes
-  //      0..15 own one each.  The walk is latency bound (t_idx -> slice bounds -> columns
-  //      -> LDS atomic), so it is software pipelined two blocks deep: while block b is
-  //      multiplied, the slice bounds of block b+1 and the (u, y) of block b+2 are in
-  //      flight, and the first 64 entries of all 16 slices of a block are loaded before
-  //      the first LDS atomic is issued (most slices end there; longer ones finish in a
-  //      strip loop).  Bounds travel by v_readlane, so a strip costs an address add, a
-  //      compare, the load(s) and the atomic.
-  auto add = [&](int32_t j, double v) {
-    if (j >= 0) {
-      atomicAdd(&acc[j], v);
-      if (!SENTINEL) {
-        const uint32_t bit = 1u << (j & 31);
+  //      0..15 own one each.  The walk is a chain of dependent loads (t_idx -> slice bounds
+  //      -> columns -> LDS atomic), software pipelined three blocks deep; per slice the wave
+  //      spends ~16 instructions: positions are 32-bit (nnz < 2^31), bounds travel by
+  //      v_readlane, the column fields are stored as LDS byte offsets (column * 4) and the
+  //      atomic is issued by every lane (lanes outside the slice add to their sink).
+  auto add = [&](uint32_t off4, bool ok, double v) {
+    if (ACC32) {
+      const uint32_t a = ok ? off4 : TILE * 4 + 4 * lane;
+      atomicAdd(reinterpret_cast<uint32_t *>(smem + a), 1u);
+    } else {
+      const uint32_t a = ok ? 2 * off4 : SINK_BYTES + 8 * lane;
+      atomicAdd(reinterpret_cast<double *>(smem + a), v);
+      if (!SENTINEL && ok) {
+        const uint32_t j = off4 >> 2, bit = 1u << (j & 31);
         if (!(bits[j >> 5] & bit)) atomicOr(&bits[j >> 5], bit);
       }
     }
@@ -165,76 +210,124 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
     u = p.t_idx[qc];
     y = p.t_val[qc];
   };
-  auto load_bounds = [&](int64_t u, bool v, int64_t &lo, int &len) {
-    const int64_t *tp = p.xt_tptr + u * tp_stride + tile;
+  auto load_bounds = [&](int64_t u, bool v, uint32_t &lo, int &len) {
+    const uint32_t *tp = p.xt_tptr + u * tp_stride + tile;
     lo = tp[0];
-    int64_t hi = tp[1];
+    uint32_t hi = tp[1];
     asm volatile("" : "+v"(hi));  // keep the load out of the select below (see above)
     len = v ? static_cast<int>(hi - lo) : 0;
   };
-  int64_t u1 = 0, lo = 0;
-  double y = 0.0, y1 = 0.0;
-  int len = 0;
-  bool v1 = false;
-  if (te > tb) {
-    load_uy(tb + 16 * wv, u1, y, v1);
-    load_bounds(u1, v1, lo, len);
-    load_uy(tb + 16 * wv + stride, u1, y1, v1);
-  }
-  for (int64_t q0 = tb + 16 * wv; q0 < te; q0 += stride) {
-    int64_t lo_n, u2;
-    int len_n;
-    double y2;
-    bool v2;
-    load_bounds(u1, v1, lo_n, len_n);
-    load_uy(q0 + 2 * stride, u2, y2, v2);
-    int32_t jj[16];
-    double prod[ONES ? 1 : 16];
-#pragma unroll
-    for (int uu = 0; uu < 16; uu++) {  // lanes past the end of the row hold len = 0
-      const int64_t lo_u = readlane_i64(lo, uu);
-      const int len_u = __builtin_amdgcn_readlane(len, uu);
-      const int64_t e = lo_u + min(lane, max(len_u - 1, 0));  // xt_idx / xt_val are padded
-      const int32_t j = p.xt_idx[e];
-      jj[uu] = lane < len_u ? j - c0 : -1;
-      if (!ONES) prod[uu] = p.xt_val[e];
-    }
+  // Columns are stored tile-relative in 16 bits, two per dword: lane l of a strip takes the
+  // entries a + 2l and a + 2l + 1 (a = slice start rounded down to even), so one 256-byte
+  // wave load covers 128 entries of a slice (most slices end there).
+  auto issue_idx = [&](uint32_t lo_v, uint32_t (&w)[16]) {
 #pragma unroll
     for (int uu = 0; uu < 16; uu++) {
-      const double y_u = readlane_f64(y, uu);
-      // ONES: x == 1 exactly, x * y == y and the value stream is never read
-      add(jj[uu], ONES ? y_u : __dmul_rn(prod[ONES ? 0 : uu], y_u));
+      const uint32_t lo_u = __builtin_amdgcn_readlane(lo_v, uu);
+      w[uu] = p.xt_idx16[(lo_u >> 1) + static_cast<uint32_t>(lane)];  // padded arrays
     }
-    if (__any(len > 64)) {
+  };
+  auto accumulate = [&](uint32_t lo_v, int len_v, double y_v, const uint32_t (&w)[16]) {
+    constexpr int SUB = ONES ? 16 : 8;  // the value stream costs 4 registers per slice
+#pragma unroll
+    for (int h = 0; h < 16; h += SUB) {
+      double xa[ONES ? 1 : SUB], xb[ONES ? 1 : SUB];
+      if (!ONES) {
+#pragma unroll
+        for (int uu = 0; uu < SUB; uu++) {
+          const uint32_t lo_u = __builtin_amdgcn_readlane(lo_v, h + uu);
+          const double2 xv = *reinterpret_cast<const double2 *>(
+              p.xt_val + ((lo_u & ~1u) + 2u * static_cast<uint32_t>(lane)));
+          xa[uu] = xv.x;
+          xb[uu] = xv.y;
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < SUB; uu++) {  // lanes past the end of the row hold len = 0
+        const uint32_t odd = __builtin_amdgcn_readlane(lo_v, h + uu) & 1u;
+        const int len_u = __builtin_amdgcn_readlane(len_v, h + uu);
+        const int o = 2 * lane - static_cast<int>(odd);  // offset of entry A in the slice
+        const uint32_t wd = w[h + uu];
+        const bool oka = static_cast<uint32_t>(o) < static_cast<uint32_t>(len_u);
+        const bool okb = o < len_u - 1;
+        // ONES: x == 1 exactly, x * y == y and the value stream is never read
+        const double y_u = ACC32 ? 1.0 : readlane_f64(y_v, h + uu);
+        add(wd & 0xffffu, oka, ONES ? y_u : __dmul_rn(xa[ONES ? 0 : uu], y_u));
+        add(wd >> 16, okb, ONES ? y_u : __dmul_rn(xb[ONES ? 0 : uu], y_u));
+      }
+    }
+    if (__any(len_v > 127)) {  // slices that continue past their first strip (rare)
       for (int uu = 0; uu < 16; uu++) {
-        const int len_u = __builtin_amdgcn_readlane(len, uu);
-        if (len_u <= 64) continue;
-        const int64_t lo_u = readlane_i64(lo, uu);
-        const double y_u = readlane_f64(y, uu);
-        for (int off = 64 + lane; off < len_u; off += 128) {
-          const bool ok2 = off + 64 < len_u;
-          const int off2 = min(off + 64, len_u - 1);
-          const int32_t j1 = p.xt_idx[lo_u + off] - c0;
-          int32_t j2 = p.xt_idx[lo_u + off2] - c0;
+        const int len_u = __builtin_amdgcn_readlane(len_v, uu);
+        if (len_u <= 127) continue;
+        const uint32_t lo_u = __builtin_amdgcn_readlane(lo_v, uu);
+        const double y_u = readlane_f64(y_v, uu);
+        const int odd = static_cast<int>(lo_u & 1u);
+        for (int off = 128; off < len_u + odd; off += 128) {
+          const uint32_t e0 = (lo_u & ~1u) + off + 2 * lane;
+          const uint32_t wd = p.xt_idx16[e0 >> 1];
+          const int o = off + 2 * lane - odd;
           double w1 = y_u, w2 = y_u;
           if (!ONES) {
-            w1 = __dmul_rn(p.xt_val[lo_u + off], y_u);
-            w2 = __dmul_rn(p.xt_val[lo_u + off2], y_u);
+            const double2 xv = *reinterpret_cast<const double2 *>(p.xt_val + e0);
+            w1 = __dmul_rn(xv.x, y_u);
+            w2 = __dmul_rn(xv.y, y_u);
           }
-          j2 = ok2 ? j2 : -1;
-          add(j1, w1);
-          add(j2, w2);
+          add(wd & 0xffffu, o < len_u, w1);
+          add(wd >> 16, o + 1 < len_u, w2);
         }
       }
     }
-    lo = lo_n;
-    len = len_n;
-    y = y1;
-    u1 = u2;
-    y1 = y2;
-    v1 = v2;
+  };
+  // Three blocks deep: while block k is added, the column words of block k + 1, the slice
+  // bounds of block k + 2 and the (u, y) of block k + 3 are in flight.
+  const int64_t q00 = tb + 16 * wv;
+  if (q00 < te) {
+    int64_t uA, uB, uC;
+    uint32_t loA, loB;
+    double yA, yB, yC;
+    bool vA, vB, vC;
+    int lenA, lenB;
+    load_uy(q00, uA, yA, vA);
+    load_uy(q00 + stride, uB, yB, vB);
+    load_uy(q00 + 2 * stride, uC, yC, vC);
+    load_bounds(uA, vA, loA, lenA);
+    load_bounds(uB, vB, loB, lenB);
+    uint32_t wc[16], wn[16];
+    issue_idx(loA, wc);
+    for (int64_t q0 = q00; q0 < te; q0 += stride) {
+      int64_t uD;
+      uint32_t loC;
+      int lenC;
+      double yD;
+      bool vD;
+      load_bounds(uC, vC, loC, lenC);
+      load_uy(q0 + 3 * stride, uD, yD, vD);
+      issue_idx(loB, wn);
+      accumulate(loA, lenA, yA, wc);
+#pragma unroll
+      for (int uu = 0; uu < 16; uu++) wc[uu] = wn[uu];
+      loA = loB; lenA = lenB; yA = yB;
+      loB = loC; lenB = lenC; yB = yC;
+      uC = uD; yC = yD; vC = vD;
+    }
   }
   __syncthreads();
+  PHASE_MARK(1);
+  if (ACC32) {
+    // widen in place: count i sits in the bytes of acc[i / 2], so every count is read before
+    // any sum is written
+    uint32_t mine[TILE / THREADS];
+#pragma unroll
+    for (int k = 0; k < TILE / THREADS; k++) mine[k] = cnt[min(tid + k * THREADS, TILE - 1)];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TILE / THREADS; k++) {
+      const int i = tid + k * THREADS;
+      if (i < width) acc[i] = mine[k] ? static_cast<double>(mine[k]) : -0.0;
+    }
+    __syncthreads();
+  }
   if (SENTINEL) {  // derive the bitmap from the sums (64 columns per wave step)
     for (int base = wv * 64; base < width; base += NW * 64) {
       const int i = base + lane;
@@ -249,6 +342,7 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
     __syncthreads();
   }
 
+  PHASE_MARK(2);
   // ---- 2. epilogue on the stored entries; count them
   const double tstat = p.t_stat[r];
   int local = 0;
@@ -274,10 +368,11 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   __syncthreads();
   const int n_stored = sh_total;
   const int n_sel = min(p.top_k, n_stored);
-  int32_t *cidx = p.cand_idx + static_cast<size_t>(blockIdx.x) * p.top_k;
-  double *cval = p.cand_val + static_cast<size_t>(blockIdx.x) * p.top_k;
-  if (tid == 0) p.cand_cnt[blockIdx.x] = n_sel;
-  if (n_sel == 0) return;
+  int32_t *cidx = p.cand_idx + static_cast<size_t>(bid) * p.top_k;
+  double *cval = p.cand_val + static_cast<size_t>(bid) * p.top_k;
+  if (tid == 0) p.cand_cnt[bid] = n_sel;
+  if (n_sel == 0) continue;
+  PHASE_MARK(3);
 
   auto stored = [&](int i) { return (bits[i >> 5] >> (i & 31)) & 1u; };
 
@@ -359,6 +454,7 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   const bool take_all = n_sel >= n_stored;
   if (tid == 0) sh_count = 0;
   __syncthreads();
+  PHASE_MARK(4);
   // wave w owns the contiguous columns [w * span, (w + 1) * span) in 64-wide steps, so
   // (wave, step, lane) order is column order.  Sweep 1 appends every key above the
   // threshold (any order; the merge sorts) and counts this wave's ties; sweep 2 hands the
@@ -381,7 +477,7 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
     }
     my_ties += __popcll(__ballot(tie));
   }
-  if (take_all) return;
+  if (take_all) continue;
   if (lane == 0) wave_cnt[wv] = my_ties;
   __syncthreads();
   int before = 0;
@@ -398,6 +494,8 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
     }
     before += __popcll(bal);
   }
+  PHASE_MARK(5);
+  }  // persistent loop
 }
 
 // One 256-thread workgroup per target row: union of the tile winners, keep the
@@ -543,8 +641,8 @@ struct irs_knn_computer {
   double shrinkage = 0, alpha = 0, beta = 0;
   bool normalize = false;
   std::vector<int64_t> xt_row_len;  // host: stored entries per feature row (work model)
-  DeviceBuffer<int64_t> xt_tptr;  // [n_features, n_tiles + 1], see Params
-  DeviceBuffer<int32_t> xt_idx;
+  DeviceBuffer<uint32_t> xt_tptr;  // [n_features, n_tiles + 1], see Params
+  DeviceBuffer<uint32_t> xt_idx16;
   DeviceBuffer<double> xt_val, norms;
   bool xt_all_ones = false;
   bool xt_nonzero = false;  // |x| in (1e-150, 1e150) for every stored x
@@ -632,22 +730,29 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     hipStream_t s = nullptr;
     {
       const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
-      std::vector<int64_t> tptr(static_cast<size_t>(Xt.rows) * (n_tiles + 1));
+      check_arg(Xt.indptr[Xt.rows] < (int64_t(1) << 31) - 1024, "nnz must be below 2^31.");
+      std::vector<uint32_t> tptr(static_cast<size_t>(Xt.rows) * (n_tiles + 1));
       for (int64_t u = 0; u < Xt.rows; u++) {
         const int32_t *b = Xt.indices.data() + Xt.indptr[u], *e = Xt.indices.data() + Xt.indptr[u + 1];
-        int64_t *dst = tptr.data() + u * (n_tiles + 1);
+        uint32_t *dst = tptr.data() + u * (n_tiles + 1);
         for (int64_t t = 0; t < n_tiles; t++)
-          dst[t] = Xt.indptr[u] + (std::lower_bound(b, e, static_cast<int32_t>(t * TILE)) - b);
-        dst[n_tiles] = Xt.indptr[u + 1];
+          dst[t] = static_cast<uint32_t>(Xt.indptr[u] +
+                                         (std::lower_bound(b, e, static_cast<int32_t>(t * TILE)) - b));
+        dst[n_tiles] = static_cast<uint32_t>(Xt.indptr[u + 1]);
       }
       c->xt_tptr.upload(tptr, s);
     }
-    {  // one padding entry: the accumulate loop reads position `row end` of an empty slice
-      std::vector<int32_t> idx_p(Xt.indices);
+    {  // columns relative to their tile as 16-bit LDS byte offsets (column * 4), two per
+       // dword; 256 padding entries: the accumulate loop reads whole 128-entry strips from
+       // the (even) start of a slice
+      static_assert(TILE * 4 <= 65536, "tile-relative column offsets are stored in 16 bits");
+      const size_t nnz = Xt.indices.size(), padded = (nnz + 256 + 1) & ~size_t(1);
+      std::vector<uint32_t> idx_p(padded / 2, 0u);
+      for (size_t e = 0; e < nnz; e++)
+        idx_p[e >> 1] |= static_cast<uint32_t>((Xt.indices[e] % TILE) * 4) << (16 * (e & 1));
       std::vector<double> val_p(Xt.data);
-      idx_p.push_back(0);
-      val_p.push_back(0.0);
-      c->xt_idx.upload(idx_p, s);
+      val_p.resize(padded, 0.0);
+      c->xt_idx16.upload(idx_p, s);
       c->xt_val.upload(val_p, s);
     }
     c->xt_all_ones = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) { return v == 1.0; });
@@ -763,7 +868,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     out_cnt.alloc(n);
     Params p;
     p.xt_tptr = c->xt_tptr.ptr;
-    p.xt_idx = c->xt_idx.ptr;
+    p.xt_idx16 = c->xt_idx16.ptr;
     p.xt_val = c->xt_val.ptr;
     p.norms = c->norms.ptr;
     p.t_ptr = t_ptr.ptr;
@@ -787,7 +892,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     p.out_val = out_val.ptr;
     p.out_cnt = out_cnt.ptr;
     const size_t lds = TILE * sizeof(double) + (TILE / 32) * sizeof(uint32_t) +
-                       256 * sizeof(uint32_t) + 16 * sizeof(int32_t);
+                       256 * sizeof(uint32_t) + 16 * sizeof(int32_t) + 64 * sizeof(double);
     // -0.0 sentinel instead of bitmap atomics unless some product could be a zero
     auto safe = [](const std::vector<double> &v) {
       return std::all_of(v.begin(), v.end(), [](double x) {
@@ -796,18 +901,32 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       });
     };
     const bool sentinel = c->xt_nonzero && safe(T.data);
+    const bool t_all_ones =  // with xt_all_ones: every product is 1 (ACC32)
+        std::all_of(T.data.begin() + T.indptr[row_begin], T.data.begin() + T.indptr[row_begin + n],
+                    [](double x) { return x == 1.0; });
+    // persistent launch: one resident workgroup per CU (its LDS footprint allows no second)
+    int n_cu = 0;
+    IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+    DeviceBuffer<int32_t> cursor;
+    cursor.alloc(1);
+    IRS_HIP(hipMemsetAsync(cursor.ptr, 0, sizeof(int32_t), s));
+    p.cursor = cursor.ptr;
+    p.n_slots = static_cast<int32_t>(slots);
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>(slots, static_cast<size_t>(std::max(n_cu, 1))));
     auto launch = [&](auto kernel) {
       IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds)));
-      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(slots)), dim3(THREADS), lds, s, p);
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(THREADS), lds, s, p);
     };
     hipEvent_t ev0, ev1;
     IRS_HIP(hipEventCreate(&ev0));
     IRS_HIP(hipEventCreate(&ev1));
     IRS_HIP(hipEventRecord(ev0, s));
     if (c->xt_all_ones) {
-      if (sentinel) launch(knn_tile_kernel<true, true>); else launch(knn_tile_kernel<true, false>);
+      if (sentinel && t_all_ones) launch(knn_tile_kernel<true, true, true>);
+      else if (sentinel) launch(knn_tile_kernel<true, true>);
+      else launch(knn_tile_kernel<true, false>);
     } else {
       if (sentinel) launch(knn_tile_kernel<false, true>); else launch(knn_tile_kernel<false, false>);
     }
@@ -827,6 +946,15 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     c->last_ms = ms;
+#ifdef IRS_KNN_PHASES
+    {
+      unsigned long long h[8] = {0}, z[8] = {0};
+      IRS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(knn_phase_clk), sizeof(h)));
+      IRS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(knn_phase_clk), z, sizeof(z)));
+      fprintf(stderr, "knn phases (10 ns ticks, sum over %lld WGs): init %llu acc %llu bitmap %llu epi %llu select %llu write %llu\n",
+              static_cast<long long>(slots), h[0], h[1], h[2], h[3], h[4], h[5]);
+    }
+#endif
     // assemble the CSR in target-row order (slots are work-ordered)
     std::vector<int32_t> slot_of(n);
     for (int64_t sl = 0; sl < n; sl++) slot_of[order[sl] - row_begin] = static_cast<int32_t>(sl);

@@ -16,3 +16,14 @@ for name, i in [("heaviest", order[0]), ("2nd", order[1]), ("10th", order[9]), (
     print(json.dumps({"row": name, "users": int(Xt.indptr[i+1]-Xt.indptr[i]), "macs": int(work[i]), "kernel_ms": round(comp.last_kernel_ms, 3),
                       "gmacs_per_s": round(work[i]/comp.last_kernel_ms/1e6, 2)}))
 print("total macs", int(work.sum()), "top10 share", float(work[order[:10]].sum()/work.sum()), "top100 share", float(work[order[:100]].sum()/work.sum()), "top1000", float(work[order[:1000]].sum()/work.sum()))
+
+# kernel time by work quantile: target rows sorted heaviest first, timed in contiguous ranges
+Xs = sps.csr_matrix(Xt[order])
+edges = [0, 100, 1000, 3000, 8000, 16000, Xs.shape[0]]
+for a, b in zip(edges[:-1], edges[1:]):
+    comp.compute_similarity(Xs, 100, rows=(a, b))
+    w = int(work[order[a:b]].sum())
+    print(json.dumps({"rows": [a, b], "macs": w, "share": round(w / work.sum(), 4),
+                      "kernel_ms": round(comp.last_kernel_ms, 3),
+                      "us_per_row": round(1e3 * comp.last_kernel_ms / (b - a), 2),
+                      "gmacs_per_s": round(w / comp.last_kernel_ms / 1e6, 1)}))
