@@ -219,97 +219,147 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   };
   // Columns are stored tile-relative in 16 bits, two per dword: lane l of a strip takes the
   // entries a + 2l and a + 2l + 1 (a = slice start rounded down to even), so one 256-byte
-  // wave load covers 128 entries of a slice (most slices end there).
-  auto issue_idx = [&](uint32_t lo_v, uint32_t (&w)[16]) {
+  // wave load covers 128 entries of a slice.  The 16 slices of a block are cut into such
+  // strips and the strips are processed in batches of 16 (16 loads in flight, then 32
+  // atomics), whatever slice they belong to: lanes 0..15 each describe one strip of the
+  // batch (first dword, offset of its first entry in the slice, slice length, y) by a
+  // binary search in the running strip count of the block.
+  struct Block {   // per-lane (0..15) state of one block of 16 stored (u, y)
+    uint32_t lo;   // slice start in xt_idx16 / xt_val (entries)
+    int len;       // slice length, 0 past the end of the row
+    double y;
+    int pin;       // inclusive prefix of the strip counts over lanes 0..15
+    int total, nb; // strips, batches (wave-uniform)
+  };
+  auto count_strips = [&](Block &bk) {
+    const int ns = bk.len > 0 ? (bk.len + static_cast<int>(bk.lo & 1u) + 127) >> 7 : 0;
+    int pin = lane < 16 ? ns : 0;
 #pragma unroll
-    for (int uu = 0; uu < 16; uu++) {
-      const uint32_t lo_u = __builtin_amdgcn_readlane(lo_v, uu);
-      w[uu] = p.xt_idx16[(lo_u >> 1) + static_cast<uint32_t>(lane)];  // padded arrays
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(pin, o, 64);
+      if (lane >= o) pin += t;
+    }
+    bk.pin = pin;
+    bk.total = __builtin_amdgcn_readlane(pin, 15);
+    bk.nb = max(1, (bk.total + 15) >> 4);
+  };
+  struct Batch {  // per-lane (0..15): one strip
+    uint32_t dw;  // first dword of the strip in xt_idx16
+    int o0;       // slice offset of the strip's first entry (-1: the slice starts odd)
+    int ln;       // slice length (0: no strip)
+    double y;
+  };
+  auto make_batch = [&](uint32_t lo, int len, double y, int pin, int total, int j) {
+    const int m = 16 * j + (lane & 15);
+    int u = 0;  // smallest slice with pin[u] > m
+#pragma unroll
+    for (int step = 8; step >= 1; step >>= 1) {
+      const int t = __shfl(pin, u + step - 1, 64);
+      if (t <= m) u += step;
+    }
+    u = min(u, 15);
+    const int before = __shfl(pin, max(u - 1, 0), 64);
+    const int sidx = m - (u > 0 ? before : 0);
+    const uint32_t lo_u = __shfl(lo, u, 64);
+    Batch bt;
+    bt.dw = (lo_u >> 1) + 64u * static_cast<uint32_t>(sidx);
+    bt.o0 = 128 * sidx - static_cast<int>(lo_u & 1u);
+    // (shuffles stay outside conditionals: ds_bpermute returns 0 from an inactive source lane)
+    const int len_u = __shfl(len, u, 64);
+    bt.ln = m < total ? len_u : 0;
+    bt.y = ACC32 ? 1.0 : __shfl(y, u, 64);
+    if (!(m < total)) bt.dw = lo_u >> 1;  // a valid address for the (ignored) load
+    return bt;
+  };
+  auto issue_idx = [&](const Batch &bt, uint32_t (&w)[16]) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const uint32_t dw = __builtin_amdgcn_readlane(bt.dw, t);
+      w[t] = p.xt_idx16[dw + static_cast<uint32_t>(lane)];  // padded arrays
     }
   };
-  auto accumulate = [&](uint32_t lo_v, int len_v, double y_v, const uint32_t (&w)[16]) {
-    constexpr int SUB = ONES ? 16 : 8;  // the value stream costs 4 registers per slice
+  auto accumulate = [&](const Batch &bt, const uint32_t (&w)[16]) {
+    constexpr int SUB = ONES ? 16 : 8;  // the value stream costs 4 registers per strip
 #pragma unroll
     for (int h = 0; h < 16; h += SUB) {
       double xa[ONES ? 1 : SUB], xb[ONES ? 1 : SUB];
       if (!ONES) {
 #pragma unroll
-        for (int uu = 0; uu < SUB; uu++) {
-          const uint32_t lo_u = __builtin_amdgcn_readlane(lo_v, h + uu);
+        for (int t = 0; t < SUB; t++) {
+          const uint32_t dw = __builtin_amdgcn_readlane(bt.dw, h + t);
           const double2 xv = *reinterpret_cast<const double2 *>(
-              p.xt_val + ((lo_u & ~1u) + 2u * static_cast<uint32_t>(lane)));
-          xa[uu] = xv.x;
-          xb[uu] = xv.y;
+              p.xt_val + 2u * (dw + static_cast<uint32_t>(lane)));
+          xa[t] = xv.x;
+          xb[t] = xv.y;
         }
       }
 #pragma unroll
-      for (int uu = 0; uu < SUB; uu++) {  // lanes past the end of the row hold len = 0
-        const uint32_t odd = __builtin_amdgcn_readlane(lo_v, h + uu) & 1u;
-        const int len_u = __builtin_amdgcn_readlane(len_v, h + uu);
-        const int o = 2 * lane - static_cast<int>(odd);  // offset of entry A in the slice
-        const uint32_t wd = w[h + uu];
-        const bool oka = static_cast<uint32_t>(o) < static_cast<uint32_t>(len_u);
-        const bool okb = o < len_u - 1;
+      for (int t = 0; t < SUB; t++) {
+        const int o = 2 * lane + __builtin_amdgcn_readlane(bt.o0, h + t);
+        const int ln = __builtin_amdgcn_readlane(bt.ln, h + t);
+        const uint32_t wd = w[h + t];
+        const bool oka = static_cast<uint32_t>(o) < static_cast<uint32_t>(ln);
+        const bool okb = o < ln - 1;
         // ONES: x == 1 exactly, x * y == y and the value stream is never read
-        const double y_u = ACC32 ? 1.0 : readlane_f64(y_v, h + uu);
-        add(wd & 0xffffu, oka, ONES ? y_u : __dmul_rn(xa[ONES ? 0 : uu], y_u));
-        add(wd >> 16, okb, ONES ? y_u : __dmul_rn(xb[ONES ? 0 : uu], y_u));
-      }
-    }
-    if (__any(len_v > 127)) {  // slices that continue past their first strip (rare)
-      for (int uu = 0; uu < 16; uu++) {
-        const int len_u = __builtin_amdgcn_readlane(len_v, uu);
-        if (len_u <= 127) continue;
-        const uint32_t lo_u = __builtin_amdgcn_readlane(lo_v, uu);
-        const double y_u = readlane_f64(y_v, uu);
-        const int odd = static_cast<int>(lo_u & 1u);
-        for (int off = 128; off < len_u + odd; off += 128) {
-          const uint32_t e0 = (lo_u & ~1u) + off + 2 * lane;
-          const uint32_t wd = p.xt_idx16[e0 >> 1];
-          const int o = off + 2 * lane - odd;
-          double w1 = y_u, w2 = y_u;
-          if (!ONES) {
-            const double2 xv = *reinterpret_cast<const double2 *>(p.xt_val + e0);
-            w1 = __dmul_rn(xv.x, y_u);
-            w2 = __dmul_rn(xv.y, y_u);
-          }
-          add(wd & 0xffffu, o < len_u, w1);
-          add(wd >> 16, o + 1 < len_u, w2);
-        }
+        const double y_t = ACC32 ? 1.0 : readlane_f64(bt.y, h + t);
+        add(wd & 0xffffu, oka, ONES ? y_t : __dmul_rn(xa[ONES ? 0 : t], y_t));
+        add(wd >> 16, okb, ONES ? y_t : __dmul_rn(xb[ONES ? 0 : t], y_t));
       }
     }
   };
-  // Three blocks deep: while block k is added, the column words of block k + 1, the slice
-  // bounds of block k + 2 and the (u, y) of block k + 3 are in flight.
+  // Pipeline: while batch b is added, the column words of batch b + 1 are in flight, and so
+  // are the slice bounds of block k + 2 and the (u, y) of block k + 3.  The block-level
+  // loads are issued with every batch (their results are used when the block advances): a
+  // load under a branch would make hipcc drain the queue.
   const int64_t q00 = tb + 16 * wv;
   if (q00 < te) {
+    Block A, B;
     int64_t uA, uB, uC;
-    uint32_t loA, loB;
-    double yA, yB, yC;
+    double yC;
     bool vA, vB, vC;
-    int lenA, lenB;
-    load_uy(q00, uA, yA, vA);
-    load_uy(q00 + stride, uB, yB, vB);
+    load_uy(q00, uA, A.y, vA);
+    load_uy(q00 + stride, uB, B.y, vB);
     load_uy(q00 + 2 * stride, uC, yC, vC);
-    load_bounds(uA, vA, loA, lenA);
-    load_bounds(uB, vB, loB, lenB);
+    load_bounds(uA, vA, A.lo, A.len);
+    load_bounds(uB, vB, B.lo, B.len);
+    count_strips(A);
+    count_strips(B);
+    Batch cur = make_batch(A.lo, A.len, A.y, A.pin, A.total, 0);
     uint32_t wc[16], wn[16];
-    issue_idx(loA, wc);
-    for (int64_t q0 = q00; q0 < te; q0 += stride) {
+    issue_idx(cur, wc);
+    int j = 0;
+    int64_t q0 = q00;
+    for (;;) {
+      const bool adv = j + 1 >= A.nb;  // wave-uniform
+      uint32_t loN;
+      int lenN;
       int64_t uD;
-      uint32_t loC;
-      int lenC;
       double yD;
       bool vD;
-      load_bounds(uC, vC, loC, lenC);
+      load_bounds(uC, vC, loN, lenN);
       load_uy(q0 + 3 * stride, uD, yD, vD);
-      issue_idx(loB, wn);
-      accumulate(loA, lenA, yA, wc);
+      asm volatile("" : "+v"(loN), "+v"(lenN), "+v"(uD), "+v"(yD));  // keep them out of `if (adv)`
+      const int jn = adv ? 0 : j + 1;
+      const Batch nxt = make_batch(adv ? B.lo : A.lo, adv ? B.len : A.len, adv ? B.y : A.y,
+                                   adv ? B.pin : A.pin, adv ? B.total : A.total, jn);
+      issue_idx(nxt, wn);
+      accumulate(cur, wc);
+      if (adv) {
+        A = B;
+        B.lo = loN;
+        B.len = lenN;
+        B.y = yC;
+        count_strips(B);
+        uC = uD;
+        yC = yD;
+        vC = vD;
+        q0 += stride;
+        if (q0 >= te) break;
+      }
+      j = jn;
+      cur = nxt;
 #pragma unroll
-      for (int uu = 0; uu < 16; uu++) wc[uu] = wn[uu];
-      loA = loB; lenA = lenB; yA = yB;
-      loB = loC; lenB = lenC; yB = yC;
-      uC = uD; yC = yD; vC = vD;
+      for (int t = 0; t < 16; t++) wc[t] = wn[t];
     }
   }
   __syncthreads();

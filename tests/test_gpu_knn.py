@@ -232,3 +232,25 @@ def test_many_tiles_and_large_top_k_merge_in_rounds():
     assert np.diff(want.indptr).max() == 1500  # the cut is exercised
     assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
     np.testing.assert_allclose(got.data, want.data, rtol=1e-12)
+
+
+@pytest.mark.parametrize("values", ["ones", "weighted_target", "weighted_both"])
+def test_long_slices_many_strips_per_block(values):
+    """Target rows with ~600 stored users (several 16-user blocks per wave) whose slices span
+    two 128-entry strips: more than 16 strips per block, i.e. several load batches per block,
+    on each accumulator variant (32-bit counts, fp64 sums of y, fp64 sums of x * y)."""
+    rng2 = np.random.default_rng(11)
+    X = sps.random(1500, 600, density=0.4, random_state=rng2, format="csr", dtype=np.float64)
+    X.data[:] = 1.0
+    Xt = sps.csr_matrix(X.T)  # 600 target rows x 1500 features
+    arg = Xt.copy()
+    tgt = Xt.copy()
+    if values != "ones":  # small integers: every sum is exact in fp64, so rtol = 0 holds
+        tgt.data[:] = rng2.integers(1, 4, size=tgt.nnz).astype(np.float64)
+    if values == "weighted_both":
+        arg.data[:] = rng2.integers(1, 4, size=arg.nnz).astype(np.float64)
+    comp = K.CosineSimilarityComputer(arg, 0.0, False)
+    ref = O.KNNComputer("cosine", arg, 0.0, normalize=False, n_threads=8)
+    got = comp.compute_similarity(tgt, 40)
+    want = ref.compute_similarity(tgt, 40)
+    assert_same_csr(got, want, rtol=0)
