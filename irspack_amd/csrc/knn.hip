@@ -362,61 +362,94 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
       for (int t = 0; t < 16; t++) wc[t] = wn[t];
     }
   }
+  // (the column norms of this thread's first eight columns are fetched while the slower
+  // waves finish accumulating)
+  constexpr int PER = TILE / THREADS;  // 16
+  const int cbase = wv * (PER * 64) + lane;
+  double nrm0[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) nrm0[k] = p.norms[c0 + min(cbase + 64 * k, width - 1)];
   __syncthreads();
   PHASE_MARK(1);
+
+  // ---- 2. epilogue.  Thread (wave w, lane l) owns the columns w * 1024 + 64 k + l,
+  //      k = 0..15, so (wave, k, lane) order is column order.  The similarity of every stored
+  //      entry is written back (the winners' values are read from there) and its
+  //      order-preserving key stays in registers: the selection below never reads LDS keys.
+  static_assert(PER == 16 && THREADS / 64 * PER * 64 == TILE, "column ownership");
+  const double tstat = p.t_stat[r];
+  uint64_t key[PER];
+  uint32_t have = 0;  // bit k: column k of this thread is a stored entry of the product row
+  uint32_t cv[ACC32 ? PER : 1];
   if (ACC32) {
-    // widen in place: count i sits in the bytes of acc[i / 2], so every count is read before
-    // any sum is written
-    uint32_t mine[TILE / THREADS];
+    // count i sits in the bytes of acc[i / 2]: every count is read before any sum is written
 #pragma unroll
-    for (int k = 0; k < TILE / THREADS; k++) mine[k] = cnt[min(tid + k * THREADS, TILE - 1)];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < TILE / THREADS; k++) {
-      const int i = tid + k * THREADS;
-      if (i < width) acc[i] = mine[k] ? static_cast<double>(mine[k]) : -0.0;
+    for (int k = 0; k < PER; k++) {
+      const int i = cbase + 64 * k;
+      cv[k] = cnt[min(i, TILE - 1)];
+      if (i < width && cv[k] != 0u) have |= 1u << k;
     }
     __syncthreads();
   }
-  if (SENTINEL) {  // derive the bitmap from the sums (64 columns per wave step)
-    for (int base = wv * 64; base < width; base += NW * 64) {
-      const int i = base + lane;
-      const bool touched =
-          i < width && static_cast<uint64_t>(__double_as_longlong(acc[i])) != NEG_ZERO_BITS;
-      const unsigned long long bal = __ballot(touched);
-      if (lane == 0) {
-        bits[base >> 5] = static_cast<uint32_t>(bal);
-        bits[(base >> 5) + 1] = static_cast<uint32_t>(bal >> 32);
+#pragma unroll
+  for (int h = 0; h < PER; h += 8) {  // eight columns at a time (register budget)
+    double nrm[8], raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      nrm[k] = h == 0 ? nrm0[k] : p.norms[c0 + min(cbase + 64 * (h + k), width - 1)];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = cbase + 64 * (h + k);
+      if (ACC32) {
+        raw[k] = static_cast<double>(cv[ACC32 ? h + k : 0]);
+      } else {
+        raw[k] = acc[min(i, TILE - 1)];
+        const bool st = SENTINEL ? static_cast<uint64_t>(__double_as_longlong(raw[k])) != NEG_ZERO_BITS
+                                 : ((bits[min(i, TILE - 1) >> 5] >> (i & 31)) & 1u) != 0u;
+        if (i < width && st) have |= 1u << (h + k);
       }
     }
-    __syncthreads();
-  }
-
-  PHASE_MARK(2);
-  // ---- 2. epilogue on the stored entries; count them
-  const double tstat = p.t_stat[r];
-  int local = 0;
-  for (int i = tid; i < width; i += THREADS) {
-    if (bits[i >> 5] & (1u << (i & 31))) {
-      acc[i] = epilogue(p, acc[i], p.norms[c0 + i], tstat);
-      local++;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const double sv = epilogue(p, raw[k], nrm[k], tstat);
+      key[h + k] = order_key(sv);
+      if ((have >> (h + k)) & 1u) acc[cbase + 64 * (h + k)] = sv;
     }
   }
-  local += __shfl_xor(local, 32, 64);
-  local += __shfl_xor(local, 16, 64);
-  local += __shfl_xor(local, 8, 64);
-  local += __shfl_xor(local, 4, 64);
-  local += __shfl_xor(local, 2, 64);
-  local += __shfl_xor(local, 1, 64);
-  if (lane == 0) wave_cnt[wv] = local;
-  __syncthreads();
-  if (tid == 0) {
-    int s = 0;
-    for (int w = 0; w < NW; w++) s += wave_cnt[w];
-    sh_total = s;
+  // stored entries of the tile, and the bits in which their keys differ (the radix select
+  // starts at the first digit that is not common to all of them)
+  uint64_t k_and = ~0ull, k_or = 0ull;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    if ((have >> k) & 1u) {
+      k_and &= key[k];
+      k_or |= key[k];
+    }
+  }
+  int local = __popc(have);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    local += __shfl_xor(local, o, 64);
+    k_and &= __shfl_xor(k_and, o, 64);
+    k_or |= __shfl_xor(k_or, o, 64);
+  }
+  uint64_t *red = reinterpret_cast<uint64_t *>(hist);  // 16 x (and, or) + counts behind
+  if (lane == 0) {
+    red[2 * wv] = k_and;
+    red[2 * wv + 1] = k_or;
+    wave_cnt[wv] = local;
   }
   __syncthreads();
-  const int n_stored = sh_total;
+  int n_stored = 0;
+  k_and = ~0ull;
+  k_or = 0ull;
+#pragma unroll
+  for (int w = 0; w < NW; w++) {
+    n_stored += wave_cnt[w];
+    k_and &= red[2 * w];
+    k_or |= red[2 * w + 1];
+  }
+  __syncthreads();  // red / wave_cnt are reused below
   const int n_sel = min(p.top_k, n_stored);
   int32_t *cidx = p.cand_idx + static_cast<size_t>(bid) * p.top_k;
   double *cval = p.cand_val + static_cast<size_t>(bid) * p.top_k;
@@ -424,123 +457,147 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   if (n_sel == 0) continue;
   PHASE_MARK(3);
 
-  auto stored = [&](int i) { return (bits[i >> 5] >> (i & 31)) & 1u; };
-
-  // ---- 3. radix select of the n_sel-th largest key (value desc, column asc on ties)
+  // ---- 3. radix select of the n_sel-th largest key (value desc, column asc on ties):
+  //      `prefix` becomes that key and `need` the number of its ties that are taken.
   uint64_t prefix = 0;
   int need = n_sel;
-  if (n_sel < n_stored) {
-    for (int shift = 56; shift >= 0; shift -= 8) {
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
-      const uint64_t hi_mask = (shift + 8 >= 64) ? 0ull : (~0ull << (shift + 8));
-      for (int base = 0; base < width; base += THREADS) {
-        const int i = base + tid;
-        bool in = false;
-        uint32_t digit = 0;
-        if (i < width && stored(i)) {
-          const uint64_t k = order_key(acc[i]);
-          in = (k & hi_mask) == (prefix & hi_mask);
-          digit = static_cast<uint32_t>(k >> shift) & 0xffu;
-        }
-        // similarities share their leading bytes: when every candidate lane of the wave
-        // has the same digit, one lane adds the count (no same-address atomic storm);
-        // otherwise the digits are spread and per-lane atomics are cheap
-        const unsigned long long todo = __ballot(in);
-        if (todo) {
-          const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-          const uint32_t d = __builtin_amdgcn_readlane(digit, leader);
-          const unsigned long long same = __ballot(in && digit == d);
-          if (same == todo) {
-            if (lane == leader) atomicAdd(&hist[d], static_cast<uint32_t>(__popcll(same)));
-          } else if (in) {
-            atomicAdd(&hist[digit], 1u);
+  const bool take_all = n_sel >= n_stored;
+  if (!take_all) {
+    const uint64_t diff = k_and ^ k_or;
+    if (diff == 0) {
+      prefix = k_and;  // all stored keys are equal: everything ties
+    } else {
+      int shift = ((63 - __clzll(static_cast<long long>(diff))) >> 3) << 3;
+      prefix = shift + 8 >= 64 ? 0ull : k_and & (~0ull << (shift + 8));
+      for (; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint64_t hi_mask = (shift + 8 >= 64) ? 0ull : (~0ull << (shift + 8));
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+          const bool in = ((have >> k) & 1u) && (key[k] & hi_mask) == prefix;
+          const uint32_t digit = static_cast<uint32_t>(key[k] >> shift) & 0xffu;
+          // similarities share their leading bytes: when every candidate lane of the wave
+          // has the same digit, one lane adds the count (no same-address atomic storm);
+          // otherwise the digits are spread and per-lane atomics are cheap
+          const unsigned long long todo = __ballot(in);
+          if (todo) {
+            const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+            const uint32_t d = __builtin_amdgcn_readlane(digit, leader);
+            const unsigned long long same = __ballot(in && digit == d);
+            if (same == todo) {
+              if (lane == leader) atomicAdd(&hist[d], static_cast<uint32_t>(__popcll(same)));
+            } else if (in) {
+              atomicAdd(&hist[digit], 1u);
+            }
           }
         }
-      }
-      __syncthreads();
-      // the digit d with  #(digits > d) < need <= #(digits >= d): scan the bins in
-      // descending digit order with the first four waves
-      int bin = 0, incl = 0;
-      if (tid < 256) {
-        bin = static_cast<int>(hist[255 - tid]);
-        incl = bin;
+        __syncthreads();
+        // the digit d with  #(digits > d) < need <= #(digits >= d): scan the bins in
+        // descending digit order with the first four waves
+        int bin = 0, incl = 0;
+        if (tid < 256) {
+          bin = static_cast<int>(hist[255 - tid]);
+          incl = bin;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int t = __shfl_up(incl, o, 64);
-          if (lane >= o) incl += t;
+          for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+          }
+          if (lane == 63) wave_cnt[wv] = incl;
         }
-        if (lane == 63) wave_cnt[wv] = incl;
-      }
-      __syncthreads();
-      if (tid < 256) {
-        for (int w = 0; w < wv; w++) incl += wave_cnt[w];
-        const int excl = incl - bin;
-        if (excl < need && incl >= need) {
-          sh_prefix = prefix | (static_cast<uint64_t>(255 - tid) << shift);
-          // the whole bin is wanted: every key >= the bin's lowest possible key is taken
-          // and no further digit has to be resolved (-1 tells the loop to stop)
-          sh_need = (incl == need) ? -1 : need - excl;
+        __syncthreads();
+        if (tid < 256) {
+          for (int w = 0; w < wv; w++) incl += wave_cnt[w];
+          const int excl = incl - bin;
+          if (excl < need && incl >= need) {
+            sh_prefix = prefix | (static_cast<uint64_t>(255 - tid) << shift);
+            // the whole bin is wanted: every key >= the bin's lowest possible key is taken
+            // and no further digit has to be resolved (-1 tells the loop to stop)
+            sh_need = (incl == need) ? -1 : need - excl;
+            sh_total = bin;
+          }
+        }
+        __syncthreads();
+        prefix = sh_prefix;
+        need = sh_need;
+        const int in_bin = sh_total;
+        __syncthreads();
+        if (need < 0 || shift == 0) break;
+        if (in_bin <= 64) {
+          // few candidates left: one wave ranks them instead of more digit passes
+          const uint64_t lo_mask = ~0ull << shift;
+          if (tid == 0) sh_count = 0;
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < PER; k++)
+            if (((have >> k) & 1u) && (key[k] & lo_mask) == prefix)
+              red[atomicAdd(&sh_count, 1)] = key[k];
+          __syncthreads();
+          if (wv == 0) {
+            const uint64_t mine = lane < in_bin ? red[lane] : 0ull;
+            int gt = 0, ge = 0;
+            for (int q = 0; q < in_bin; q++) {
+              const uint64_t other = red[q];
+              gt += other > mine;
+              ge += other >= mine;
+            }
+            if (lane < in_bin && gt < need && need <= ge) {  // equal keys write equal values
+              sh_prefix = mine;
+              sh_need = need - gt;
+            }
+          }
+          __syncthreads();
+          prefix = sh_prefix;
+          need = sh_need;
+          __syncthreads();
+          break;
         }
       }
-      __syncthreads();
-      prefix = sh_prefix;
-      need = sh_need;
-      __syncthreads();
-      if (need < 0) break;
-    }
-    if (need < 0) {
-      if (prefix == 0) {  // lowest possible key: nothing is excluded, everything else ties
-        need = n_sel;
-      } else {
-        prefix -= 1;  // k > prefix - 1  <=>  k >= prefix
-        need = 0;
+      if (need < 0) {
+        if (prefix == 0) {  // lowest possible key: nothing is excluded, everything else ties
+          need = n_sel;
+        } else {
+          prefix -= 1;  // k > prefix - 1  <=>  k >= prefix
+          need = 0;
+        }
       }
     }
   } else {
-    prefix = 0;  // everything is taken: treat every key as "greater than threshold"
-    need = 0;
+    need = 0;  // everything is taken
   }
-  const bool take_all = n_sel >= n_stored;
   if (tid == 0) sh_count = 0;
   __syncthreads();
   PHASE_MARK(4);
-  // wave w owns the contiguous columns [w * span, (w + 1) * span) in 64-wide steps, so
-  // (wave, step, lane) order is column order.  Sweep 1 appends every key above the
-  // threshold (any order; the merge sorts) and counts this wave's ties; sweep 2 hands the
-  // `need` lowest-index ties their slots (knn.hpp:119-136: index-ordered on equal values).
-  const int span = ((width + NW * 64 - 1) / (NW * 64)) * 64;
-  const int wbeg = wv * span, wend = min(wbeg + span, width);
+  // Sweep 1 appends every key above the threshold (any order; the merge sorts) and counts
+  // this wave's ties; sweep 2 hands the `need` lowest-column ties their slots (knn.hpp:119-136:
+  // index-ordered on equal values).
   int my_ties = 0;
-  for (int base = wbeg; base < wend; base += 64) {
-    const int i = base + lane;
-    bool tie = false;
-    if (i < wend && stored(i)) {
-      const uint64_t k = order_key(acc[i]);
-      if (take_all || k > prefix) {
-        const int pos = atomicAdd(&sh_count, 1);
-        cidx[pos] = c0 + i;
-        cval[pos] = acc[i];
-      } else if (k == prefix) {
-        tie = true;
-      }
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const bool st = (have >> k) & 1u;
+    const bool win = st && (take_all || key[k] > prefix);
+    if (win) {
+      const int pos = atomicAdd(&sh_count, 1);
+      cidx[pos] = c0 + cbase + 64 * k;
+      cval[pos] = acc[cbase + 64 * k];
     }
-    my_ties += __popcll(__ballot(tie));
+    my_ties += __popcll(__ballot(st && !take_all && key[k] == prefix));
   }
-  if (take_all) continue;
+  if (take_all || need == 0) continue;
   if (lane == 0) wave_cnt[wv] = my_ties;
   __syncthreads();
   int before = 0;
   for (int w = 0; w < wv; w++) before += wave_cnt[w];
-  for (int base = wbeg; base < wend && before < need; base += 64) {
-    const int i = base + lane;
-    const bool tie = i < wend && stored(i) && order_key(acc[i]) == prefix;
+#pragma unroll
+  for (int k = 0; k < PER; k++) {
+    const bool tie = ((have >> k) & 1u) && key[k] == prefix;
     const unsigned long long bal = __ballot(tie);
     const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
     if (tie && rank < need) {
       const int pos = atomicAdd(&sh_count, 1);
-      cidx[pos] = c0 + i;
-      cval[pos] = acc[i];
+      cidx[pos] = c0 + cbase + 64 * k;
+      cval[pos] = acc[cbase + 64 * k];
     }
     before += __popcll(bal);
   }
