@@ -66,6 +66,7 @@ struct Params {
   // persistent launch: workgroups draw (row slot, tile) pairs from this counter
   int32_t *cursor;
   int32_t n_slots;     // n_rows * n_tiles
+  int32_t merge_cap;   // entries of the merge buffer: power of two, >= 2 * top_k
 };
 
 __device__ __forceinline__ int64_t readlane_i64(int64_t v, int src) {
@@ -610,9 +611,11 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
 // The tiles are merged in rounds: as many tiles as fit next to the best-so-far are appended,
 // the buffer is sorted and cut back to top_k (any number of tiles, top_k <= MERGE_CAP / 2).
 __global__ __launch_bounds__(256) void knn_merge_kernel(Params p) {
-  __shared__ uint64_t key[MERGE_CAP];
-  __shared__ double val[MERGE_CAP];
-  __shared__ int32_t idx[MERGE_CAP];
+  // merge_cap entries (a power of two sized to the request, at most MERGE_CAP): 20 B each
+  extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
+  uint64_t *key = reinterpret_cast<uint64_t *>(merge_smem);
+  double *val = reinterpret_cast<double *>(key + p.merge_cap);
+  int32_t *idx = reinterpret_cast<int32_t *>(val + p.merge_cap);
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
   auto swap_el = [&](int a, int b) {
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(Params p) {
     while (t < p.n_tiles) {
       const int b = slot * p.n_tiles + t;
       const int c = p.cand_cnt[b];
-      if (n + c > MERGE_CAP) break;
+      if (n + c > p.merge_cap) break;
       for (int i = tid; i < c; i += 256) {
         const double v = p.cand_val[static_cast<size_t>(b) * p.top_k + i];
         val[n + i] = v;
@@ -1018,6 +1021,12 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     cursor.alloc(1);
     IRS_HIP(hipMemsetAsync(cursor.ptr, 0, sizeof(int32_t), s));
     p.cursor = cursor.ptr;
+    {  // merge buffer: all tiles' candidates at once when they fit, else rounds of MERGE_CAP
+      int64_t want = std::max<int64_t>(2 * out_k, std::min<int64_t>(int64_t(n_tiles) * out_k, MERGE_CAP));
+      int cap = 64;
+      while (cap < want) cap <<= 1;
+      p.merge_cap = std::min(cap, MERGE_CAP);
+    }
     p.n_slots = static_cast<int32_t>(slots);
     const unsigned grid = static_cast<unsigned>(std::min<size_t>(slots, static_cast<size_t>(std::max(n_cu, 1))));
     auto launch = [&](auto kernel) {
@@ -1037,7 +1046,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     } else {
       if (sentinel) launch(knn_tile_kernel<false, true>); else launch(knn_tile_kernel<false, false>);
     }
-    hipLaunchKernelGGL(knn_merge_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, s, p);
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_CAP * 20));
+    hipLaunchKernelGGL(knn_merge_kernel, dim3(static_cast<unsigned>(n)), dim3(256),
+                       static_cast<size_t>(p.merge_cap) * 20, s, p);
     IRS_HIP(hipEventRecord(ev1, s));
     IRS_HIP(hipGetLastError());
     std::vector<int32_t> h_cnt(n), h_idx(static_cast<size_t>(n) * out_k);
