@@ -157,6 +157,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
   const int64_t wbeg = wv * span, wend = min<int64_t>(wbeg + span, n_cand);
   KeyT kreg[MODE == 2 ? MAXQ : 1];
   int local = 0;
+  uint64_t tmax = 0;  // best rankable key of this thread (0: none)
   if constexpr (MODE == 2) {
 #pragma unroll
     for (int qb = 0; qb < MAXQ; qb += 8) {  // eight loads in flight, small register peak
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
         const uint64_t k = (!live || is_neg_inf(sv[q])) ? KEY_SKIP : order_key(sv[q]);
         kreg[qb + q] = static_cast<KeyT>(k);
         local += k != KEY_SKIP;
+        tmax = (k != KEY_SKIP && k > tmax) ? k : tmax;
       }
     }
   } else {
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
           const uint64_t k = is_neg_inf(sv[q]) ? KEY_SKIP : order_key(sv[q]);
           if (CACHED) keys[j] = static_cast<KeyT>(k);
           local += k != KEY_SKIP;
+          tmax = (k != KEY_SKIP && k > tmax) ? k : tmax;
         }
       }
     }
@@ -220,11 +223,83 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
     return;
   }
 
+  // --- short lists (the usual cutoffs): the n_rec-th largest of the per-thread maxima is a
+  //     lower bound L of the n_rec-th largest key (those maxima are n_rec different keys
+  //     >= L).  L costs a radix select over ONE key per thread, and the keys >= L - the
+  //     n_rec winners, all their ties and a few more - are gathered in one sweep and
+  //     sorted exactly by (key desc, index asc) below.  Rows where that list does not fit
+  //     (e.g. thousands of equal scores) take the general selection.
+  constexpr int BITS = KeyBits<T>::value;
+  int n_sel = n_rec;  // entries in sel_key / sel_idx; the best n_rec of them are the result
+  bool fast = n_rec <= NT;
+  if (fast) {
+    uint64_t lpre = 0;
+    int lneed = n_rec;
+    for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+      const uint64_t hi_mask = (shift + 8 >= 64) ? 0ull : (~0ull << (shift + 8));
+      const bool in = (tmax & hi_mask) == (lpre & hi_mask);
+      const uint32_t digit = static_cast<uint32_t>(tmax >> shift) & 0xffu;
+      const unsigned long long todo = __ballot(in);
+      if (todo) {
+        const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+        const uint32_t d = __builtin_amdgcn_readlane(digit, leader);
+        const unsigned long long same = __ballot(in && digit == d);
+        if (same == todo) {
+          if (ln == leader) atomicAdd(&hist[d], static_cast<uint32_t>(__popcll(same)));
+        } else if (in) {
+          atomicAdd(&hist[digit], 1u);
+        }
+      }
+      __syncthreads();
+      int bin = 0, incl = 0;
+      if (tid < 256) {
+        bin = static_cast<int>(hist[255 - tid]);
+        incl = bin;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o, 64);
+          if (ln >= o) incl += t;
+        }
+        if (ln == 63) scan_buf[wv] = incl;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        for (int w = 0; w < wv && w < 4; w++) incl += scan_buf[w];
+        if (incl - bin < lneed && incl >= lneed) {
+          sh_prefix = lpre | (static_cast<uint64_t>(255 - tid) << shift);
+          sh_need = (incl == lneed) ? -1 : lneed - (incl - bin);
+        }
+        hist[tid] = 0;
+      }
+      __syncthreads();
+      lpre = sh_prefix;
+      lneed = sh_need;
+      if (lneed < 0) break;  // the whole bin is wanted: its lowest possible key bounds L
+    }
+    const uint64_t L = lpre;
+    if (tid == 0) sh_count = 0;
+    __syncthreads();
+    for_each_slot([&](int64_t j, uint64_t k) {
+      if (k != KEY_SKIP && k >= L) {
+        const int pos = atomicAdd(&sh_count, 1);
+        if (pos < SEL_CAP) {
+          sel_key[pos] = k;
+          sel_idx[pos] = item_of(j);
+        }
+      }
+      return true;
+    });
+    __syncthreads();
+    n_sel = sh_count;
+    fast = n_sel <= SEL_CAP;
+    __syncthreads();  // sh_count is reset by the general selection
+  }
+  if (!fast) {
+  n_sel = n_rec;
   // --- radix select: key of the n_rec-th best candidate
   uint64_t prefix = 0;
   int need = n_rec;  // how many still to take among keys matching `prefix` so far
   bool inclusive = false;  // true: every key >= prefix is taken and there is no tie pick
-  constexpr int BITS = KeyBits<T>::value;
   // hist is zero here (cleared before the count barrier) and is cleared again by the bin scan
   // of every pass: three barriers per digit
   for (int shift = BITS - 8; shift >= 0; shift -= 8) {
@@ -322,13 +397,15 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
     return true;
   });
   __syncthreads();
-  if (n_rec <= 64) {
+  }  // general selection
+  if (n_sel <= 64) {
     // --- common cutoffs: one wave finishes the row without further barriers.  Lane i holds
-    //     winner i; bitonic network over the lanes (key desc, index asc), hits by binary
-    //     search, then the sequential dcg / AP recurrences of Metrics::update (:136-165).
+    //     candidate i (the best n_rec of the n_sel gathered ones are the list); bitonic network
+    //     over the lanes (key desc, index asc), hits by binary search, then the sequential
+    //     dcg / AP recurrences of Metrics::update (:136-165).
     if (wv != 0) return;
-    uint64_t mk = ln < n_rec ? sel_key[ln] : 0ull;
-    int32_t mi = ln < n_rec ? sel_idx[ln] : 0x7fffffff;
+    uint64_t mk = ln < n_sel ? sel_key[ln] : 0ull;
+    int32_t mi = ln < n_sel ? sel_idx[ln] : 0x7fffffff;
 #pragma unroll
     for (int k2 = 2; k2 <= 64; k2 <<= 1) {
 #pragma unroll
@@ -387,10 +464,10 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
     if (ln == 0) p.out[row] = res;
     return;
   }
-  // --- bitonic sort of the n_rec winners: key desc, index asc
+  // --- bitonic sort of the n_sel gathered candidates: key desc, index asc
   int n_pow = 1;
-  while (n_pow < n_rec) n_pow <<= 1;
-  for (int i = n_rec + tid; i < n_pow; i += NT) {
+  while (n_pow < n_sel) n_pow <<= 1;
+  for (int i = n_sel + tid; i < n_pow; i += NT) {
     sel_key[i] = 0ull;
     sel_idx[i] = 0x7fffffff;
   }
