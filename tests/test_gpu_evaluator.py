@@ -187,3 +187,21 @@ def test_fused_ials_path_matches_block_path():
     assert fused.valid_user == acc.valid_user and fused.total_user == acc.total_user
     for k in ("hit", "ndcg", "recall", "map", "precision"):
         assert getattr(fused, k) == pytest.approx(getattr(acc, k), rel=1e-12)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("levels,cutoff", [(1, 10), (3, 20), (40, 64), (3, 700), (100000, 1500)])
+def test_many_ties_short_list_and_general_selection(dtype, levels, cutoff):
+    """Rows whose scores take few distinct values: thousands of keys tie at the cutoff, so the
+    short-list ranking overflows and the general selection (ties by lowest index) runs; with
+    many levels the short list is used, also for cutoffs above one wave."""
+    rns = np.random.RandomState(7)
+    U, I = 48, 6000
+    scores = rns.randint(0, levels, size=(U, I)).astype(dtype) / 7.0
+    scores[rns.rand(U, I) < 0.05] = -np.inf
+    scores[1, :] = -np.inf  # nothing rankable
+    scores[2, :5990] = -np.inf  # fewer rankable items than the cutoff
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.97).astype(np.float64))
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    f = "get_metrics_f64" if dtype == "float64" else "get_metrics_f32"
+    compare(getattr(core, f)(scores, cutoff, 0, 4, False), getattr(ocore, f)(scores, cutoff, 0, 4, False))
