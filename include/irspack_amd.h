@@ -270,13 +270,20 @@ irs_status irs_eval_get_metrics(irs_evaluator *e, int32_t is_f64,
  * iALS trainer of this library: scores = user[begin:end] @ item^T (hpp:942-984)
  * are produced, masked (evaluator.py:417-432, mask = CSR rows given here, set
  * to -inf) and ranked on the device without leaving HBM.  mask_indptr may be
- * NULL (no mask); it has rows+1 entries relative to `begin`. */
+ * NULL (no mask, or the mask cached by irs_eval_cache_mask); it has rows+1 entries
+ * relative to `begin`. */
 irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t,
                                      int64_t begin, int64_t end,
                                      const int64_t *mask_indptr,
                                      const int32_t *mask_indices, int64_t cutoff,
                                      int64_t offset, int32_t recall_with_cutoff,
                                      irs_metrics *out, int64_t *item_cnt);
+/* Keeps the mask of the fused path on the device between calls: the same CSR rows
+ * irs_eval_get_metrics_ials takes (rows + 1 entries of indptr relative to its `begin`).
+ * While a mask of `rows` rows is cached, a call of irs_eval_get_metrics_ials over that many
+ * users with mask_indptr == NULL applies it; rows <= 0 or mask_indptr == NULL drops it. */
+irs_status irs_eval_cache_mask(irs_evaluator *e, int64_t rows, const int64_t *mask_indptr,
+                               const int32_t *mask_indices);
 
 #ifdef __cplusplus
 }

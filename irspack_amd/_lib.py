@@ -101,6 +101,7 @@ EXPORTED_SYMBOLS = [
     "irs_eval_destroy",
     "irs_eval_get_metrics",
     "irs_eval_get_metrics_ials",
+    "irs_eval_cache_mask",
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -71,6 +71,7 @@ struct EvalParams {
   RowOut *out;
   int32_t *rec_out;          // [rows, cutoff] recommended items (-1 padded)
   unsigned long long *item_cnt;
+  int32_t *todo;             // per row: 1 = left to rank_rows_kernel by rank_wave_kernel (or null)
 };
 
 // key value no score maps to (it is the image of a negative NaN pattern, and NaNs are
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
   const int tid = threadIdx.x;
   const int wv = tid >> 6, ln = tid & 63;
   const int64_t row = blockIdx.x;
+  if (p.todo != nullptr && p.todo[row] == 0) return;  // ranked by rank_wave_kernel
   const int64_t u = row + p.offset;
   const T *srow = static_cast<const T *>(p.scores) + row * p.n_items;
   RowOut res{0, 0, 0, 0, 0, 0, 0};
@@ -534,16 +536,176 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
   }
 }
 
-// Sum of the per-user terms of one call (one wave).  Lane l adds rows l, l + 64, ... in
-// that order and the 64 partial sums are folded by a fixed butterfly, so the fp64 result
-// is reproducible run to run; it is not the strict user order of a single-threaded
-// reference run (the reference's own order depends on n_threads, evaluator.cpp:280-312).
-__global__ __launch_bounds__(64) void reduce_rows_kernel(const RowOut *rows, int64_t n,
-                                                         irs_metrics *out) {
-  const int lane = threadIdx.x;
+// ---------------------------------------------------------------------------
+// One WAVE per user row, one pass over the scores, no barrier and no LDS: the usual case
+// (every item is a candidate, cutoff <= 64).  Lane l streams the scores l, l + 64, ... with
+// U loads in flight and keeps its own M best (key, index) pairs sorted in registers.  The
+// list is then drawn from the 64 heads: a wave-wide arg-max of (key desc, index asc) per
+// rank, the winning lane popping its head; lane i ends up with rank i, exactly the state the
+// single-wave finish of rank_rows_kernel starts from.  A lane that runs dry although it saw
+// more than M rankable scores may hide a better candidate: the row is then flagged in p.todo
+// and ranked by rank_rows_kernel (for cutoff 20 and M = 4 about one row in a thousand).
+// 8 waves per SIMD are resident, so the loads of some rows overlap the drawing of others.
+template <class T, int M>
+__global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
+  using KT = typename KeyStore<T>::type;  // keys + 1 (0 = empty slot); no key reaches the type's maximum
+  constexpr int U = 16;
+  const int ln = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int64_t u = row + p.offset;
+  const T *srow = static_cast<const T *>(p.scores) + row * p.n_items;
+  RowOut res{0, 0, 0, 0, 0, 0, 0};
+  const int gb = p.retrieve ? 0 : p.gt_ptr[u], ge = p.retrieve ? 0 : p.gt_ptr[u + 1];
+  const int n_gt = ge - gb;
+  int32_t *rec_row = p.rec_out + row * p.cutoff;
+  if (ln < p.cutoff) rec_row[ln] = -1;  // cutoff <= 64
+  if (ln == 0) p.todo[row] = 0;
+  if (n_gt == 0 && !p.retrieve) {  // counted in total_user only (:316-321)
+    if (ln == 0) p.out[row] = res;
+    return;
+  }
+  int32_t gt_pref = -1;
+  double disc_pref = 0.0, idcg_pref = 0.0;
+  if (!p.retrieve) {
+    if (n_gt <= 64 && ln < n_gt) gt_pref = p.gt_idx[gb + ln];
+    if (ln < p.cutoff) disc_pref = p.disc[ln];
+    idcg_pref = p.idcg_prefix[min(n_gt, p.cutoff)];
+  }
+  KT bk[M];
+  int32_t bi[M];
+#pragma unroll
+  for (int t = 0; t < M; t++) {
+    bk[t] = 0;
+    bi[t] = 0x7fffffff;
+  }
+  int seen = 0;
+  const int32_t n = static_cast<int32_t>(p.n_items);
+  for (int32_t base = 0; base < n; base += 64 * U) {
+    T sv[U];
+#pragma unroll
+    for (int q = 0; q < U; q++) sv[q] = srow[min(base + 64 * q + ln, n - 1)];
+#pragma unroll
+    for (int q = 0; q < U; q++) {
+      const int32_t j = base + 64 * q + ln;
+      const bool ok = j < n && !is_neg_inf(sv[q]);
+      KT ck = ok ? static_cast<KT>(order_key(sv[q])) + 1 : 0;
+      int32_t ci = j;
+      seen += ok;
+      if (__any(ck > bk[M - 1])) {  // insertion keeps equal keys in index order (strict >)
+#pragma unroll
+        for (int t = 0; t < M; t++) {
+          const bool gt = ck > bk[t];
+          const KT tk = bk[t];
+          const int32_t ti = bi[t];
+          bk[t] = gt ? ck : tk;
+          bi[t] = gt ? ci : ti;
+          ck = gt ? tk : ck;
+          ci = gt ? ti : ci;
+        }
+      }
+    }
+  }
+  int n_rankable = seen;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) n_rankable += __shfl_xor(n_rankable, o, 64);
+  const int n_rec = min(p.cutoff, n_rankable);
+  res.valid = 1;
+  res.n_rec = n_rec;
+  if (n_rec == 0) {  // :132-135
+    if (ln == 0) p.out[row] = res;
+    return;
+  }
+  // --- draw the list: rank `it` is the best head
+  int32_t mi = 0x7fffffff;
+  int popped = 0;
+  for (int it = 0; it < n_rec; it++) {
+    KT wk = bk[0];
+    int32_t wi = bi[0];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      KT ok_;
+      if constexpr (sizeof(KT) == 8) ok_ = __shfl_xor(static_cast<unsigned long long>(wk), o, 64);
+      else ok_ = __shfl_xor(wk, o, 64);
+      const int32_t oi = __shfl_xor(wi, o, 64);
+      const bool better = ok_ > wk || (ok_ == wk && oi < wi);
+      wk = better ? ok_ : wk;
+      wi = better ? oi : wi;
+    }
+    if (ln == it) mi = wi;
+    const bool mine = bk[0] == wk && bi[0] == wi;  // indices are unique: one lane
+    if (mine) {
+#pragma unroll
+      for (int t = 0; t + 1 < M; t++) {
+        bk[t] = bk[t + 1];
+        bi[t] = bi[t + 1];
+      }
+      bk[M - 1] = 0;
+      bi[M - 1] = 0x7fffffff;
+      popped++;
+    }
+    // a lane that ran dry but saw more than it kept may hide the next best candidate
+    if (it + 1 < n_rec && __any(popped == M && seen > M)) {
+      if (ln == 0) p.todo[row] = 1;
+      return;
+    }
+  }
+  if (p.retrieve) {
+    if (ln < n_rec) rec_row[ln] = mi;
+    return;
+  }
+  bool hit = false;
+  if (ln < n_rec) {
+    rec_row[ln] = mi;
+    atomicAdd(&p.item_cnt[mi], 1ull);  // :146
+  }
+  if (n_gt <= 64) {
+    for (int c = 0; c < n_gt; c++) hit |= __builtin_amdgcn_readlane(gt_pref, c) == mi;
+    hit = hit && ln < n_rec;
+  } else if (ln < n_rec) {
+    int lo = gb, hi = ge;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (p.gt_idx[mid] < mi) lo = mid + 1; else hi = mid;
+    }
+    hit = lo < ge && p.gt_idx[lo] == mi;
+  }
+  const double disc_l = ln < n_rec ? disc_pref : 0.0;
+  unsigned long long hits = __ballot(hit);
+  double dcg = 0, ap = 0;
+  int cum_hit = 0;
+  while (hits) {  // ascending rank order, like the reference's loop over the list (:136-165)
+    const int i = __ffsll(static_cast<long long>(hits)) - 1;
+    hits &= hits - 1;
+    dcg += __shfl(disc_l, i, 64);
+    cum_hit++;
+    ap += static_cast<double>(cum_hit) / (i + 1);
+  }
+  const double idcg = min(n_gt, n_rec) == min(n_gt, p.cutoff) ? idcg_pref
+                                                              : p.idcg_prefix[min(n_gt, n_rec)];
+  res.hit = cum_hit > 0 ? 1.0 : 0.0;
+  res.precision = cum_hit / static_cast<double>(n_rec);
+  res.recall = cum_hit / static_cast<double>(
+                             p.recall_with_cutoff ? (n_gt > n_rec ? n_rec : n_gt) : n_gt);
+  res.ndcg = dcg / idcg;
+  res.map = ap / n_gt;
+  if (ln == 0) p.out[row] = res;
+}
+
+// Sum of the per-user terms of one call (one 1024-thread workgroup) in a fixed order, so the
+// fp64 result is reproducible run to run; it is not the strict user order of a
+// single-threaded reference run (the reference's own order depends on n_threads,
+// evaluator.cpp:280-312).
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const RowOut *rows, int64_t n,
+                                                           irs_metrics *out) {
+  // thread t adds rows t, t + 1024, ... in that order; the 64 lanes of a wave fold by a fixed
+  // butterfly and wave 0 adds the 16 wave sums in wave order
+  __shared__ double part[16][5];
+  __shared__ long long part_valid[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   long long valid = 0;
   double hit = 0, recall = 0, ndcg = 0, precision = 0, map = 0;
-  for (int64_t i = lane; i < n; i += 64) {
+  for (int64_t i = tid; i < n; i += 1024) {
     const RowOut r = rows[i];
     if (r.valid) {
       valid += 1;
@@ -564,13 +726,28 @@ __global__ __launch_bounds__(64) void reduce_rows_kernel(const RowOut *rows, int
     map += __shfl_xor(map, o, 64);
   }
   if (lane == 0) {
-    out->valid_user += valid;
+    part_valid[wv] = valid;
+    part[wv][0] = hit;
+    part[wv][1] = recall;
+    part[wv][2] = ndcg;
+    part[wv][3] = precision;
+    part[wv][4] = map;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    long long v = 0;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 16; w++) {
+      v += part_valid[w];
+      for (int c = 0; c < 5; c++) acc[c] += part[w][c];
+    }
+    out->valid_user += v;
     out->total_user += n;
-    out->hit += hit;
-    out->recall += recall;
-    out->ndcg += ndcg;
-    out->precision += precision;
-    out->map += map;
+    out->hit += acc[0];
+    out->recall += acc[1];
+    out->ndcg += acc[2];
+    out->precision += acc[3];
+    out->map += acc[4];
   }
 }
 
@@ -602,10 +779,15 @@ struct irs_evaluator {
   DeviceBuffer<int64_t> rec_ptr;
   DeviceBuffer<double> disc, idcg_prefix;
   DeviceBuffer<RowOut> row_out;
-  DeviceBuffer<int32_t> rec_out;
+  DeviceBuffer<int32_t> rec_out, todo;
   DeviceBuffer<unsigned long long> item_cnt;
   DeviceBuffer<irs_metrics> metrics;
   DeviceBuffer<char> score_buf;
+  // mask of the fused path kept on the device between calls (irs_eval_cache_mask)
+  DeviceBuffer<int64_t> mask_ptr;
+  DeviceBuffer<int32_t> mask_idx;
+  int64_t mask_rows = -1;
+  DeviceBuffer<float> fused_scores;  // score block of the fused path, kept between calls
 };
 
 namespace {
@@ -623,7 +805,19 @@ void validate_call(irs_evaluator *e, int64_t rows, int64_t cutoff, int64_t offse
                                 " is not supported by the device ranking kernel.");
 }
 
-template <class T> void launch_rank(const EvalParams &p, int64_t max_cand, hipStream_t s) {
+template <class T> void launch_rank(EvalParams p, int64_t max_cand, hipStream_t s, int32_t *todo) {
+  // the usual case first (all items are candidates, cutoff <= 64): one wave per row; the
+  // rows it flags (and every row otherwise) go through the general kernel
+  p.todo = nullptr;
+  if (p.rec_mode == 0 && p.cutoff <= 64 && p.n_items < (int64_t(1) << 31) - 64 * 16 &&
+      todo != nullptr) {
+    p.todo = todo;
+    const dim3 grid(static_cast<unsigned>((p.rows + 3) / 4));
+    if (p.cutoff <= 24)
+      hipLaunchKernelGGL((rank_wave_kernel<T, 4>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((rank_wave_kernel<T, 8>), grid, dim3(256), 0, s, p);
+  }
   // key cache in LDS when a row's candidates fit next to the 28 KB of static LDS
   const size_t key_bytes = static_cast<size_t>(std::max<int64_t>(max_cand, 1)) * sizeof(typename KeyStore<T>::type);
   if (std::is_same<T, float>::value && max_cand <= 1024 * RANK_MAXQ) {
@@ -645,6 +839,7 @@ void rank_block(irs_evaluator *e, const void *d_scores, int64_t rows, int64_t cu
                 int64_t offset, bool rwc, hipStream_t s) {
   e->row_out.alloc(rows);
   e->rec_out.alloc(rows * cutoff);
+  e->todo.alloc(rows);
   EvalParams p;
   p.scores = d_scores;
   p.rows = rows;
@@ -663,8 +858,8 @@ void rank_block(irs_evaluator *e, const void *d_scores, int64_t rows, int64_t cu
   p.out = e->row_out.ptr;
   p.rec_out = e->rec_out.ptr;
   p.item_cnt = e->item_cnt.ptr;
-  launch_rank<T>(p, e->n_items, s);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, e->row_out.ptr, rows,
+  launch_rank<T>(p, e->n_items, s, e->todo.ptr);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
                      e->metrics.ptr);
   IRS_HIP(hipGetLastError());
 }
@@ -803,8 +998,11 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
     const int64_t rows = end - begin;
     validate_call(e, rows, cutoff, offset, 1);
     IRS_HIP(hipSetDevice(e->device));
-    const int64_t BLOCK = 1024;  // users scored and ranked per pass
-    DeviceBuffer<float> scores;
+    // users scored and ranked per pass: enough rows to fill the device with one wave per row
+    // (32 waves x 256 CUs), within a 2 GiB score block
+    const int64_t fit = (int64_t(1) << 31) / (std::max<int64_t>(e->n_items, 1) * 4);
+    const int64_t BLOCK = std::min<int64_t>(16384, std::max<int64_t>(1024, fit / 1024 * 1024));
+    DeviceBuffer<float> &scores = e->fused_scores;
     scores.alloc(static_cast<size_t>(std::min(BLOCK, std::max<int64_t>(rows, 1))) * e->n_items);
     DeviceBuffer<int64_t> mptr;
     DeviceBuffer<int32_t> midx;
@@ -816,22 +1014,48 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
     check_arg(dev == e->device, "evaluator and trainer live on different devices.");
     hipStream_t s = static_cast<hipStream_t>(sv);
     begin_accumulate(e, s);
+    const int64_t *d_mptr = nullptr;
+    const int32_t *d_midx = nullptr;
     if (mask_indptr) {
       std::vector<int64_t> mp(mask_indptr, mask_indptr + rows + 1);
       mptr.upload(mp, s);
       midx.upload(mask_indices, static_cast<size_t>(mask_indptr[rows]), s);
       IRS_HIP(hipStreamSynchronize(s));
+      d_mptr = mptr.ptr;
+      d_midx = midx.ptr;
+    } else if (e->mask_rows == rows) {  // the cached mask (irs_eval_cache_mask)
+      d_mptr = e->mask_ptr.ptr;
+      d_midx = e->mask_idx.ptr;
     }
     for (int64_t b = 0; b < rows; b += BLOCK) {
       const int64_t m = std::min(BLOCK, rows - b);
       if (irs_ials_scores_device_(t, begin + b, begin + b + m, scores.ptr, &sv, &dev) != IRS_OK)
         throw std::runtime_error(irs_last_error());
-      if (mask_indptr)
+      if (d_mptr)
         hipLaunchKernelGGL(mask_rows_kernel, dim3(m), dim3(64), 0, s, scores.ptr, m, e->n_items,
-                           mptr.ptr + b, midx.ptr);
+                           d_mptr + b, d_midx);
       rank_block<float>(e, scores.ptr, m, cutoff, offset + b, recall_with_cutoff != 0, s);
     }
     finish_accumulate(e, out, item_cnt, s);
+  });
+}
+
+irs_status irs_eval_cache_mask(irs_evaluator *e, int64_t rows, const int64_t *mask_indptr,
+                               const int32_t *mask_indices) {
+  return guard([&] {
+    check_arg(e != nullptr, "null argument.");
+    if (mask_indptr == nullptr || rows <= 0) {  // drop the cached mask
+      e->mask_rows = -1;
+      return;
+    }
+    check_arg(mask_indices != nullptr && mask_indptr[0] == 0, "malformed mask.");
+    IRS_HIP(hipSetDevice(e->device));
+    hipStream_t s = nullptr;
+    std::vector<int64_t> mp(mask_indptr, mask_indptr + rows + 1);
+    e->mask_ptr.upload(mp, s);
+    e->mask_idx.upload(mask_indices, static_cast<size_t>(std::max<int64_t>(mask_indptr[rows], 1)), s);
+    IRS_HIP(hipStreamSynchronize(s));
+    e->mask_rows = rows;
   });
 }
 
@@ -877,6 +1101,8 @@ irs_status irs_retrieve_recommend(int32_t is_f64, const void *scores, int64_t ro
     IRS_HIP(hipMemcpyAsync(d_scores.ptr, scores, bytes, hipMemcpyHostToDevice, s));
     d_rec.alloc(static_cast<size_t>(rows) * cutoff);
     d_rows.alloc(rows);
+    DeviceBuffer<int32_t> d_todo;
+    d_todo.alloc(rows);
     EvalParams p{};
     p.scores = d_scores.ptr;
     p.rows = rows;
@@ -890,9 +1116,9 @@ irs_status irs_retrieve_recommend(int32_t is_f64, const void *scores, int64_t ro
     p.out = d_rows.ptr;
     p.rec_out = d_rec.ptr;
     if (is_f64)
-      launch_rank<double>(p, max_cand, s);
+      launch_rank<double>(p, max_cand, s, d_todo.ptr);
     else
-      launch_rank<float>(p, max_cand, s);
+      launch_rank<float>(p, max_cand, s, d_todo.ptr);
     IRS_HIP(hipGetLastError());
     IRS_HIP(hipMemcpyAsync(out_idx, d_rec.ptr, static_cast<size_t>(rows) * cutoff * sizeof(int32_t),
                            hipMemcpyDeviceToHost, s));

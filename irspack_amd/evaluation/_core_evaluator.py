@@ -197,15 +197,24 @@ class EvaluatorCore:
         [begin, end) of an ``irspack_amd`` IALSTrainer without leaving HBM."""
         st = MetricsStruct()
         cnt = np.zeros(self.n_items, dtype=np.int64)
-        if mask is not None:
-            M, mp, mi, _ = _lib.csr_arrays(mask, np.float32)
-            if M.shape != (end - begin, self.n_items):
-                raise ValueError("mask must have shape (end - begin, n_items).")
-            if mi.size == 0:
-                mi = np.zeros(1, dtype=np.int32)
-            mp_arg, mi_arg = ptr(mp, C.c_int64), ptr(mi, C.c_int32)
-        else:
-            mp_arg, mi_arg = None, None
+        # The mask (usually the training interactions) is converted and uploaded once and stays
+        # on the device while calls keep passing the same matrix object over the same users
+        # (a tuning loop evaluates hundreds of times against one mask).  The object is held
+        # here so that its identity stays valid; a mask edited in place needs a new object.
+        key = None if mask is None else (id(mask), mask.shape, mask.nnz, begin, end)
+        if key != getattr(self, "_mask_key", None):
+            if mask is not None:
+                M, mp, mi, _ = _lib.csr_arrays(mask, np.float32)
+                if M.shape != (end - begin, self.n_items):
+                    raise ValueError("mask must have shape (end - begin, n_items).")
+                if mi.size == 0:
+                    mi = np.zeros(1, dtype=np.int32)
+                check(lib().irs_eval_cache_mask(self._h, C.c_int64(end - begin),
+                                                ptr(mp, C.c_int64), ptr(mi, C.c_int32)))
+            else:
+                check(lib().irs_eval_cache_mask(self._h, C.c_int64(0), None, None))
+            self._mask_key, self._mask_ref = key, mask
+        mp_arg, mi_arg = None, None
         check(
             lib().irs_eval_get_metrics_ials(
                 self._h, trainer._h, C.c_int64(begin), C.c_int64(end), mp_arg, mi_arg,

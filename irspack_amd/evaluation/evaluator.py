@@ -130,10 +130,12 @@ class Evaluator:
         block_start, block_end = self.offset, self.offset + self.n_users
         trainer = self._fused_trainer(model)
         if trainer is not None:
-            if self.masked_interactions is None:
-                mask = model.X_train_all[block_start:block_end]
-            else:
+            if self.masked_interactions is not None:
                 mask = self.masked_interactions
+            elif block_start == 0 and block_end == model.X_train_all.shape[0]:
+                mask = model.X_train_all  # the whole matrix: no copy, and the device copy is reused
+            else:
+                mask = model.X_train_all[block_start:block_end]
             for i, c in enumerate(cutoffs):
                 metrics[i].merge(self.core.get_metrics_ials(trainer, block_start, block_end, mask, c,
                                                             0, self.recall_with_cutoff))

@@ -187,6 +187,29 @@ def test_fused_ials_path_matches_block_path():
     assert fused.valid_user == acc.valid_user and fused.total_user == acc.total_user
     for k in ("hit", "ndcg", "recall", "map", "precision"):
         assert getattr(fused, k) == pytest.approx(getattr(acc, k), rel=1e-12)
+    # the device copy of the mask is reused for the same object, replaced for another one and
+    # dropped for None
+    again = core.get_metrics_ials(t, 0, U, tr, 20, 0, False)
+    np.testing.assert_array_equal(again.item_cnt, fused.item_cnt)
+    assert again.ndcg == fused.ndcg
+    other = sps.csr_matrix(tr.shape, dtype=np.float32)  # empty mask: training items are ranked too
+    unmasked = core.get_metrics_ials(t, 0, U, other, 20, 0, False)
+    nomask = core.get_metrics_ials(t, 0, U, None, 20, 0, False)
+    np.testing.assert_array_equal(unmasked.item_cnt, nomask.item_cnt)
+    assert unmasked.ndcg == nomask.ndcg and (nomask.item_cnt != fused.item_cnt).any()
+    back = core.get_metrics_ials(t, 0, U, tr, 20, 0, False)
+    np.testing.assert_array_equal(back.item_cnt, fused.item_cnt)
+    # cutoffs on the wave-per-row kernel with 8 entries per lane, and on the general kernel
+    for cutoff in (50, 64, 100):
+        f2 = core.get_metrics_ials(t, 0, U, tr, cutoff, 0, True)
+        a2 = Metrics(X.shape[1])
+        for b in range(0, U, 500):
+            e = min(b + 500, U)
+            s = t.user_scores(b, e, sc)
+            s[tr[b:e].nonzero()] = -np.inf
+            a2.merge(core.get_metrics_f32(s, cutoff, b, 1, True))
+        np.testing.assert_array_equal(f2.item_cnt, a2.item_cnt)
+        assert f2.ndcg == pytest.approx(a2.ndcg, rel=1e-12) and f2.recall == pytest.approx(a2.recall, rel=1e-12)
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
