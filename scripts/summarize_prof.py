@@ -59,6 +59,31 @@ def main():
             for (name, grid, wg, vgpr, lds), d in sorted(by.items(), key=lambda kv: -sum(kv[1])):
                 wr.writerow([name, grid, wg, vgpr, lds, len(d), round(sum(d) / len(d), 1),
                              min(d), max(d)])
+    # secondary paths (scripts/prof_secondary.sh): kNN + evaluator trace, iALS++ trace, SQ counters
+    for src, dst in (("sec_kt", "knn_eval"), ("pp_kt", "ialspp")):
+        st = newest(os.path.join(SRC, src, "*", "*_kernel_stats.csv"))
+        if st:
+            shutil.copy(st[0], os.path.join(DST, f"{TAG}_{dst}_kernel_stats.csv"))
+    pmc = newest(os.path.join(SRC, "sec_pmc", "*", "*_counter_collection.csv"))
+    if pmc:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        launches = collections.defaultdict(set)
+        for r in csv.DictReader(open(pmc[0])):
+            if "irs::" not in r["Kernel_Name"]:
+                continue
+            agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[r["Kernel_Name"]].add(r["Dispatch_Id"])
+        sq = {}
+        for name, c in agg.items():
+            n = max(len(launches[name]), 1)
+            d = {k: v / n for k, v in sorted(c.items())}
+            d["launches"] = n
+            if d.get("GRBM_GUI_ACTIVE"):
+                # SQ counters are summed over 32 shader engines (8 XCDs x 4)
+                d["valu_busy_frac"] = d.get("SQ_ACTIVE_INST_VALU", 0.0) / (32 * d["GRBM_GUI_ACTIVE"])
+                d["lds_inst_busy_frac"] = d.get("SQ_ACTIVE_INST_LDS", 0.0) / (32 * d["GRBM_GUI_ACTIVE"])
+            sq[name] = d
+        json.dump(sq, open(os.path.join(DST, f"{TAG}_knn_eval_pmc_sq.json"), "w"), indent=1)
     out = {"units": "bytes per launch", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2",
            "write_correction": "WRITE_SIZE KiB x 1024", "kernels": {}}
     fetch = newest(os.path.join(SRC, "fetch", "*", "*_counter_collection.csv"))
