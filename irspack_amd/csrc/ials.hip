@@ -1125,6 +1125,16 @@ irs_status irs_ials_profile_read(irs_ials_trainer *t, int32_t cap, char (*names)
     check_arg(t && names && ms && launches && count, "null argument.");
     IRS_HIP(hipSetDevice(t->device));
     t->prof.collect();
+#ifdef IRS_IALS_PHASES
+    {
+      std::vector<unsigned long long> h(2 * 4096), z(2 * 4096, 0);
+      IRS_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(ials_phase_clk), h.size() * 8));
+      IRS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ials_phase_clk), z.data(), z.size() * 8));
+      unsigned long long a = 0, b = 0;
+      for (int i = 0; i < 4096; i++) { a += h[i]; b += h[4096 + i]; }
+      fprintf(stderr, "ials phases (10 ns ticks, summed over waves): gather+syrk %llu solve %llu\n", a, b);
+    }
+#endif
     int32_t i = 0;
     for (auto &kv : t->prof.totals) {
       if (i >= cap) break;

@@ -720,6 +720,13 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
 // MODE 0: one wave per task.  Whole rows are solved inline; chunks of split
 //         rows store their partial Gramian / rhs.
 // MODE 1: one wave per split row: sum the partials in slot order and solve.
+#ifdef IRS_IALS_PHASES
+__device__ unsigned long long ials_phase_clk[2 * 4096];  // development: device-clock phase sums
+#define IPHASE(i) do { if ((threadIdx.x & 63) == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&ials_phase_clk[(i) * 4096 + (blockIdx.x & 4095)], t_ - ph_t); ph_t = t_; } } while (0)
+#else
+#define IPHASE(i)
+#endif
+
 template <int T, int SOLVER, int MODE>
 __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
   using G = Geo<T>;
@@ -736,6 +743,9 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
   for (int i = 0; i < T; i++) bsum[i] = 0.f;
   const f32x4 *Pacc = reinterpret_cast<const f32x4 *>(p.P_acc);
 
+#ifdef IRS_IALS_PHASES
+  unsigned long long ph_t = wall_clock64();
+#endif
   if constexpr (MODE == 0) {
     if (w >= p.n_tasks) return;
     const Task task = p.tasks[w];
@@ -747,6 +757,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
       for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     syrk_gather<T>(p.other, p.indices, p.data, task.begin, task.end, p.bias, acc, bsum);
+    IPHASE(0);
     if (task.slot >= 0) {
       float *dst = p.partials + static_cast<size_t>(task.slot) * G::PARTIAL_FLOATS;
       f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
@@ -772,6 +783,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
       solve_row<T, SOLVER>(acc, bsum, p.reg[task.row], sm,
                            p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
                            p.max_cg_steps, p.warm_start, p.err_flag);
+    IPHASE(1);
   } else {
     if (w >= p.n_split) return;
     const SplitRow sr = p.split_rows[w];
