@@ -16,6 +16,7 @@
 #include "ials_wg_kernels.hpp"
 #include "ials_pp_kernels.hpp"
 #include "ials_feature_kernels.hpp"
+#include "ials_short_kernels.hpp"
 
 namespace irs {
 
@@ -111,6 +112,8 @@ struct Side {
   DeviceBuffer<SplitRow> split;
   DeviceBuffer<int32_t> rows_by_len;  // rows [row_begin, row_end) longest first (iALS++ launch order)
   int32_t n_tasks = 0, n_split = 0, n_slots = 0, n_long = 0;
+  // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
+  int32_t n_short = 0, n_short16 = 0;
 
   void build(const HostCsr &m, int64_t rb, int64_t re, const irs_ials_model_config &cfg,
              hipStream_t s) {
@@ -158,6 +161,12 @@ struct Side {
                      [](const SplitRow &a, const SplitRow &b) { return a.n_slots > b.n_slots; });
     n_tasks = static_cast<int32_t>(tk.size());
     n_split = static_cast<int32_t>(sp.size());
+    n_short = n_short16 = 0;
+    while (n_short < n_tasks && tk[n_tasks - 1 - n_short].slot < 0 &&
+           tk[n_tasks - 1 - n_short].end - tk[n_tasks - 1 - n_short].begin <= SHORT_MAX) {
+      if (tk[n_tasks - 1 - n_short].end - tk[n_tasks - 1 - n_short].begin <= 16) n_short16++;
+      n_short++;
+    }
     n_slots = slots;
     indptr.upload(ip32, s);
     {
@@ -271,6 +280,15 @@ namespace {
     case 1: { constexpr int TT = 1; __VA_ARGS__; } break;                           \
     case 2: { constexpr int TT = 2; __VA_ARGS__; } break;                           \
     case 4: { constexpr int TT = 4; __VA_ARGS__; } break;                           \
+    default:                                                                        \
+      throw std::invalid_argument("irspack_amd: unsupported padded latent dimension."); \
+  }
+#define IRS_DISPATCH_T8(t, ...)                                                     \
+  switch (t) {                                                                      \
+    case 1: { constexpr int TT = 1; __VA_ARGS__; } break;                           \
+    case 2: { constexpr int TT = 2; __VA_ARGS__; } break;                           \
+    case 4: { constexpr int TT = 4; __VA_ARGS__; } break;                           \
+    case 8: { constexpr int TT = 8; __VA_ARGS__; } break;                           \
     default:                                                                        \
       throw std::invalid_argument("irspack_amd: unsupported padded latent dimension."); \
   }
@@ -511,6 +529,15 @@ static bool wave_path_at_128() {
   return v;
 }
 
+// IRSPACK_AMD_IALS_SHORT=0 sends the short rows of a CG step through the general kernels too.
+static bool short_rows_enabled() {
+  static bool v = [] {
+    const char *e = std::getenv("IRSPACK_AMD_IALS_SHORT");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  return v;
+}
+
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
 void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
                   const irs_ials_solver_config *sc, const float *prior = nullptr) {
@@ -545,6 +572,33 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                                                sc->max_cg_steps, 1u << 20));
   p.warm_start = 1;
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
+  // CG, short rows: the matrix-free kernel takes the tail of the longest-first task list
+  int n_regular = sd.n_tasks;
+  if (cg && prior == nullptr && sd.n_short > 0 && (t->T <= 4 || t->T == 8) && short_rows_enabled()) {
+    n_regular = sd.n_tasks - sd.n_short;
+    int n_cu = 0;
+    IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device));
+    t->prof.begin(pidx == 0 ? "ials_short_cg_user" : "ials_short_cg_item", t->stream);
+    IRS_DISPATCH_T8(t->T, {
+      constexpr int KPP = 16 * TT;
+      const size_t lds = ShortGeo<KPP>::LDS_BYTES;
+      auto launch = [&](auto kernel, int first, int count) {
+        if (count <= 0) return;
+        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        const int grid = static_cast<int>(
+            std::min<int64_t>(ceil_div(count, SHORT_WAVES), 2 * std::max(n_cu, 1)));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * SHORT_WAVES), lds, t->stream, p,
+                           t->P[pidx].ptr, first, count);
+      };
+      // the list is longest first: [general | 17..32 entries | <= 16 entries]
+      launch(ials_cg_short_kernel<KPP, 32>, n_regular, sd.n_short - sd.n_short16);
+      launch(ials_cg_short_kernel<KPP, 16>, sd.n_tasks - sd.n_short16, sd.n_short16);
+    });
+    t->prof.end(t->stream);
+    p.n_tasks = n_regular;
+  }
   if (t->T == 8 && wave_path_at_128()) {
     // 64 < K <= 128: the 36 tiles still fit one wave's 512 registers (144 of them
     // accumulators), so the one-wave-per-task kernel is reused with the MFMA panel Cholesky /
@@ -552,12 +606,12 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     using G = Geo<8>;
     t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
     p.partials = t->split_partial.ptr;
-    if (sd.n_tasks > 0) {
+    if (n_regular > 0) {
       t->prof.begin(kNames[cg][0][pidx], t->stream);
       if (cg)
-        hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0>), dim3(sd.n_tasks), dim3(64), 0, t->stream, p);
+        hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0>), dim3(n_regular), dim3(64), 0, t->stream, p);
       else
-        hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0>), dim3(sd.n_tasks), dim3(64), 0, t->stream, p);
+        hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0>), dim3(n_regular), dim3(64), 0, t->stream, p);
       t->prof.end(t->stream);
     }
     if (sd.n_split > 0) {
@@ -573,13 +627,13 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       using G = Geo<TT>;
       t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
       p.partials = t->split_partial.ptr;
-      if (sd.n_tasks > 0) {
+      if (n_regular > 0) {
         t->prof.begin(kNames[cg][0][pidx], t->stream);
         if (cg)
-          hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(n_regular, SOLVE_WAVES)),
                              dim3(64 * SOLVE_WAVES), 0, t->stream, p);
         else
-          hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(sd.n_tasks, SOLVE_WAVES)),
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(n_regular, SOLVE_WAVES)),
                              dim3(64 * SOLVE_WAVES), 0, t->stream, p);
         t->prof.end(t->stream);
       }
@@ -608,11 +662,11 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         hipLaunchKernelGGL(kernel, dim3(n_items), dim3(256), lds, t->stream, p);
         t->prof.end(t->stream);
       };
-      if (sd.n_tasks > 0) {
+      if (n_regular > 0) {
         if (cg)
-          launch(ials_wg_solve_kernel<TT, 1, 0>, sd.n_tasks, kNames[1][0][pidx]);
+          launch(ials_wg_solve_kernel<TT, 1, 0>, n_regular, kNames[1][0][pidx]);
         else
-          launch(ials_wg_solve_kernel<TT, 0, 0>, sd.n_tasks, kNames[0][0][pidx]);
+          launch(ials_wg_solve_kernel<TT, 0, 0>, n_regular, kNames[0][0][pidx]);
       }
       if (sd.n_split > 0) {
         if (cg)

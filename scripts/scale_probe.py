@@ -48,11 +48,15 @@ def main():
     tr = IALSTrainer(mc, X)
     print("create", f"{time.time() - t0:.1f}s", flush=True)
     times = []
+    tr.step(sc)
+    tr.profile(True)
     for _ in range(3):
         t1 = time.perf_counter()
         tr.step(sc)
         times.append(time.perf_counter() - t1)
     u = tr.user
+    prof = tr.profile_read()
+    print(json.dumps({k: round(v["ms"] / v["launches"], 3) for k, v in prof.items()}))
     print(json.dumps({"shape": list(X.shape), "nnz": int(X.nnz), "K": args.K, "solver": args.solver,
                       "epoch_ms": [round(t * 1e3, 1) for t in times],
                       "updates_per_s": round(sum(X.shape) / min(times), 1),

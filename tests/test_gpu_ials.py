@@ -412,3 +412,29 @@ def test_loss_user_scores_transform_at_every_kernel_family(K):
     o.user, o.item = t.user, t.item
     Xn = random_csr(17, 45, 0.3, 5)
     assert rel_err(t.transform_user(Xn, sc), o.transform_user(Xn, osc)) < RTOL
+
+
+@pytest.mark.parametrize("K", [8, 24, 40, 64, 100, 128])
+@pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
+def test_cg_short_and_general_rows_mixed(K, loss):
+    """CG over rows of 0..60 stored entries: rows up to 16 and up to 32 entries take the two
+    matrix-free short-row kernels, the rest the general kernel; two epochs (the second one
+    warm-started), non-binary confidences."""
+    rng = np.random.default_rng(3)
+    U, I = 700, 500
+    deg = rng.integers(0, 61, size=U)
+    deg[:5] = [0, 1, 16, 17, 32]
+    rows = np.repeat(np.arange(U), deg)
+    cols = np.concatenate([rng.choice(I, size=d, replace=False) for d in deg]) if deg.sum() else []
+    vals = rng.integers(1, 3, size=rows.shape[0]).astype(np.float32)
+    X = sps.csr_matrix((vals, (rows, cols)), shape=(U, I), dtype=np.float32)
+    mc, omc = build(K, reg=1e-2, loss=loss)  # (as test_one_epoch_matches_oracle)
+    sc, osc = solver("CG", steps=3)
+    t, o = IALSTrainer(mc, X), O.IALSTrainer(omc, X)
+    for _ in range(2):
+        t.step(sc)
+        o.step(osc)
+    assert rel_err(t.user, o.user) < RTOL and rel_err(t.item, o.item) < RTOL
+    # fold-in of short and long rows (zero start, hpp:132)
+    got, want = t.transform_user(X[:50], sc), o.transform_user(X[:50], osc)
+    assert rel_err(got, want) < RTOL
