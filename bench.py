@@ -103,7 +103,7 @@ def secondary_metrics(X, trainer, K):
     import scipy.sparse as sps
 
     from irspack_amd.evaluation._core_evaluator import EvaluatorCore
-    from irspack_amd.recommenders._knn import CosineSimilarityComputer
+    from irspack_amd.recommenders._knn import CosineSimilarityComputer, JaccardSimilarityComputer
 
     U, I = X.shape
     out = {}
@@ -127,6 +127,15 @@ def secondary_metrics(X, trainer, K):
                      "traffic": None},
         "out_nnz": int(S.nnz),
     }
+    # the other two SURVEY 8(d) variants, kernel time only
+    variants = {}
+    for name, other in (("cosine_normalize_false", CosineSimilarityComputer(Xt, 0.0, False)),
+                        ("jaccard", JaccardSimilarityComputer(Xt, 0.0))):
+        other.compute_similarity(Xt, 100)
+        variants[name] = {"kernel_ms": other.last_kernel_ms,
+                          "item_pairs_per_s": I * float(I) / (other.last_kernel_ms * 1e-3)}
+        del other
+    out["knn"]["variants"] = variants
     # evaluator: hold out one interaction per user as ground truth, mask the rest
     rng = np.random.default_rng(5)
     pick = X.indptr[:-1] + (rng.random(U) * np.diff(X.indptr)).astype(np.int64)
@@ -140,9 +149,13 @@ def secondary_metrics(X, trainer, K):
     ev.get_metrics_ials(trainer, 0, 2048, mask[:2048], 20, 0, False)  # warm-up
     t0 = time.perf_counter()
     m = ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
-    wall = time.perf_counter() - t0
+    wall_first = time.perf_counter() - t0  # converts and uploads the mask (80 MB)
+    t0 = time.perf_counter()
+    m = ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
+    wall = time.perf_counter() - t0        # the mask is resident, as in a tuning loop
     out["evaluator"] = {
         "workload": f"fused iALS k={K} scoring + nDCG@20 over {U} users x {I} items, fp32 scores",
+        "wall_s_first_call_incl_mask_upload": wall_first,
         "wall_s_incl_pcie": wall, "users_per_s": U / wall,
         "scores_per_s": U * float(I) / wall, "ndcg@20": m.as_dict()["ndcg"],
     }

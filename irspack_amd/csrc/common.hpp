@@ -29,6 +29,11 @@ template <class F> irs_status guard(F &&f) {
   }
 }
 
+// (the literal overload matters: a std::string parameter would be constructed - and heap
+// allocated - on every call, 160 ms for a per-entry check over 20 M entries)
+inline void check_arg(bool cond, const char *msg) {
+  if (!cond) throw std::invalid_argument(msg);
+}
 inline void check_arg(bool cond, const std::string &msg) {
   if (!cond) throw std::invalid_argument(msg);
 }

@@ -20,6 +20,9 @@
 // run-dependent; for integer-valued inputs (binary interactions) all sums are
 // exact and the result is bit-reproducible.
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <chrono>
 #include <cmath>
 #include <memory>
 #include <numeric>
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
     v = lane < 16 && q < te;
     const int64_t qc = min(q, te - 1);  // te > tb here
     u = p.t_idx[qc];
-    y = p.t_val[qc];
+    y = ACC32 ? 1.0 : p.t_val[qc];  // ACC32: the value stream is not uploaded
   };
   auto load_bounds = [&](int64_t u, bool v, uint32_t &lo, int &len) {
     const uint32_t *tp = p.xt_tptr + u * tp_stride + tile;
@@ -885,6 +888,19 @@ irs_status irs_knn_destroy(irs_knn_computer *c) {
   });
 }
 
+// IRSPACK_AMD_KNN_TIMING=1 prints the host phases of a compute call to stderr
+struct PhaseTimer {
+  bool on = std::getenv("IRSPACK_AMD_KNN_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char *what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "knn host phase %-18s %8.2f ms\n", what,
+            std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            const int64_t *indptr, const int32_t *indices, const double *data,
                            int64_t top_k, int32_t as_w, int64_t row_begin, int64_t row_end,
@@ -893,11 +909,19 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     check_arg(c && nnz_out, "null argument.");
     if (cols != c->n_features) throw std::invalid_argument("illegal # of feature.");  // knn.hpp:44-45
     check_arg(top_k >= 0, "top_k must be non-negative.");
-    HostCsrD T = host_csr(rows, cols, indptr, indices, data);
+    PhaseTimer pt;
+    check_arg(rows >= 0 && cols >= 0 && indptr && indptr[0] == 0, "bad matrix.");
     check_arg(0 <= row_begin && row_begin <= row_end && row_end <= rows, "row range out of bounds.");
     const int64_t n = row_end - row_begin;
-    // --- target preparation (host; mirrors the prologues of compute_similarity_imple / compute_W)
+    // --- target preparation (host; mirrors the prologues of compute_similarity_imple / compute_W).
+    // Only compute_W transforms the values (a private copy); otherwise the caller's arrays are
+    // read in place, and only the rows of this call are looked at.
+    HostCsrD T;  // as_w only
+    const int64_t *ip = indptr;
+    const int32_t *ix = indices;
+    const double *dv = data;
     if (as_w) {  // similarities.hpp:224-240, 294-324
+      T = host_csr(rows, cols, indptr, indices, data);
       std::vector<double> norm_temp(cols, 0.0), pop(rows, 0.0);
       if (c->sim_type == IRS_SIM_RP3BETA) {
         for (int64_t i = 0; i < rows; i++)
@@ -915,24 +939,71 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
           else
             T.data[q] /= norm_temp[T.indices[q]];
         }
+      ip = T.indptr.data();
+      ix = T.indices.data();
+      dv = T.data.data();
     }
+    pt.mark("compute_W prologue");
     const bool binarise = c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
-    std::vector<double> tstat(rows, 0.0);
-    for (int64_t i = 0; i < rows; i++) {
-      double s = 0;
-      for (int64_t q = T.indptr[i]; q < T.indptr[i + 1]; q++) s += T.data[q] * T.data[q];
-      switch (c->sim_type) {
-        case IRS_SIM_COSINE: tstat[i] = std::sqrt(s); break;                  // :39
-        case IRS_SIM_ASYMMETRIC: tstat[i] = std::pow(s, c->alpha); break;      // :78-79
-        case IRS_SIM_JACCARD:
-        case IRS_SIM_TVERSKY:
-          tstat[i] = static_cast<double>(T.indptr[i + 1] - T.indptr[i]);      // :122, :174
-          break;
-        default: break;
-      }
+    // One pass over the rows of the call, on several threads: index check, the per-row
+    // statistic of the epilogue, the multiply-add count that orders the launch, and whether the
+    // values are all ones / free of zeros (which accumulator the kernel may use).
+    std::vector<double> tstat(std::max<int64_t>(n, 1), 0.0);
+    std::vector<int64_t> work(std::max<int64_t>(n, 1), 0);
+    const int64_t e_begin = ip[row_begin], e_end = ip[row_end];
+    check_arg(e_begin >= 0 && e_end >= e_begin, "malformed indptr.");
+    check_arg(e_end < (int64_t(1) << 31), "nnz must be below 2^31.");
+    std::atomic<int> bad_index(0), not_ones(0), unsafe(0);
+    {
+      const int n_thr = static_cast<int>(std::max<int64_t>(
+          1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                                (e_end - e_begin) / 200000 + 1})));
+      auto body = [&](int th) {
+        // contiguous row chunks of about equal entry counts
+        const int64_t lo_e = e_begin + (e_end - e_begin) * th / n_thr;
+        const int64_t hi_e = e_begin + (e_end - e_begin) * (th + 1) / n_thr;
+        int64_t r0 = std::lower_bound(ip + row_begin, ip + row_end, lo_e) - ip;
+        int64_t r1 = th + 1 == n_thr ? row_end : std::lower_bound(ip + row_begin, ip + row_end, hi_e) - ip;
+        if (th == 0) r0 = row_begin;
+        bool bad = false, ones = true, safe = true;
+        for (int64_t i = r0; i < r1; i++) {
+          if (ip[i + 1] < ip[i]) { bad = true; break; }
+          double ss = 0;
+          int64_t w = 0;
+          for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
+            const int32_t j = ix[q];
+            if (j < 0 || j >= cols) { bad = true; break; }
+            const double x = binarise ? 1.0 : dv[q];  // similarities.hpp:113-118, 165-170
+            ss += x * x;
+            w += c->xt_row_len[j];
+            ones &= x == 1.0;
+            const double ax = std::fabs(x);
+            safe &= ax > 1e-150 && ax < 1e150;  // no stored zero, no underflow of x * y
+          }
+          if (bad) break;
+          switch (c->sim_type) {
+            case IRS_SIM_COSINE: tstat[i - row_begin] = std::sqrt(ss); break;             // :39
+            case IRS_SIM_ASYMMETRIC: tstat[i - row_begin] = std::pow(ss, c->alpha); break; // :78-79
+            case IRS_SIM_JACCARD:
+            case IRS_SIM_TVERSKY:
+              tstat[i - row_begin] = static_cast<double>(ip[i + 1] - ip[i]);            // :122, :174
+              break;
+            default: break;
+          }
+          work[i - row_begin] = w;
+        }
+        if (bad) bad_index.store(1);
+        if (!ones) not_ones.store(1);
+        if (!safe) unsafe.store(1);
+      };
+      std::vector<std::thread> th;
+      for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+      body(0);
+      for (auto &t : th) t.join();
     }
-    if (binarise)
-      for (auto &v : T.data) v = 1;  // similarities.hpp:113-118, 165-170
+    check_arg(bad_index.load() == 0, "malformed matrix: column index out of range or indptr not monotone.");
+    const bool t_all_ones = not_ones.load() == 0, t_safe = unsafe.load() == 0;
+    pt.mark("target pass");
     const int64_t out_k = std::min<int64_t>(top_k, c->N);
     c->res_ptr.assign(n + 1, 0);
     c->res_idx.clear();
@@ -947,27 +1018,38 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                                   " is not supported by the device kNN kernel.");
     IRS_HIP(hipSetDevice(c->device));
     hipStream_t s = nullptr;
-    // work per target row = multiply-adds of its product row; longest first
-    std::vector<int64_t> work(n, 0);
-    for (int64_t i = 0; i < n; i++) {
-      int64_t w = 0;
-      for (int64_t q = T.indptr[row_begin + i]; q < T.indptr[row_begin + i + 1]; q++)
-        w += c->xt_row_len[T.indices[q]];
-      work[i] = w;
-      c->last_macs += w;
-    }
+    // rows of the call, heaviest product row first (ids relative to row_begin)
+    for (int64_t i = 0; i < n; i++) c->last_macs += work[i];
     std::vector<int32_t> order(n);
-    for (int64_t i = 0; i < n; i++) order[i] = static_cast<int32_t>(row_begin + i);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-      return work[a - row_begin] > work[b - row_begin];
-    });
+    for (int64_t i = 0; i < n; i++) order[i] = static_cast<int32_t>(i);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return work[a] > work[b]; });
+    pt.mark("work + order");
     DeviceBuffer<int64_t> t_ptr;
     DeviceBuffer<int32_t> t_idx, d_order, cand_idx, cand_cnt, out_idx, out_cnt;
     DeviceBuffer<double> t_val, t_stat, cand_val, out_val;
-    t_ptr.upload(T.indptr, s);
-    t_idx.upload(T.indices, s);
-    t_val.upload(T.data, s);
-    t_stat.upload(tstat, s);
+    // which accumulator: 32-bit counts when every product is 1, else fp64 sums with the -0.0
+    // sentinel unless some product could be a zero
+    const bool sentinel = c->xt_nonzero && t_safe;
+    const bool acc32 = c->xt_all_ones && sentinel && t_all_ones;
+    {  // only the rows of the call travel; the values only if the kernel reads them
+      std::vector<int64_t> rel(n + 1);
+      for (int64_t i = 0; i <= n; i++) rel[i] = ip[row_begin + i] - e_begin;
+      t_ptr.upload(rel, s);
+      const size_t ne = static_cast<size_t>(e_end - e_begin);
+      t_idx.upload(ix + e_begin, std::max<size_t>(ne, 1), s);
+      if (acc32) {
+        t_val.alloc(1);
+      } else if (binarise) {
+        std::vector<double> ones(std::max<size_t>(ne, 1), 1.0);
+        t_val.upload(ones, s);
+        IRS_HIP(hipStreamSynchronize(s));
+      } else {
+        t_val.upload(dv + e_begin, std::max<size_t>(ne, 1), s);
+      }
+      t_stat.upload(tstat, s);
+      IRS_HIP(hipStreamSynchronize(s));  // `rel` goes out of scope
+    }
     d_order.upload(order, s);
     const size_t slots = static_cast<size_t>(n) * n_tiles;
     cand_idx.alloc(slots * out_k);
@@ -1003,17 +1085,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     p.out_cnt = out_cnt.ptr;
     const size_t lds = TILE * sizeof(double) + (TILE / 32) * sizeof(uint32_t) +
                        256 * sizeof(uint32_t) + 16 * sizeof(int32_t) + 64 * sizeof(double);
-    // -0.0 sentinel instead of bitmap atomics unless some product could be a zero
-    auto safe = [](const std::vector<double> &v) {
-      return std::all_of(v.begin(), v.end(), [](double x) {
-        const double a = std::fabs(x);
-        return a > 1e-150 && a < 1e150;  // no stored zero, no underflow of x * y
-      });
-    };
-    const bool sentinel = c->xt_nonzero && safe(T.data);
-    const bool t_all_ones =  // with xt_all_ones: every product is 1 (ACC32)
-        std::all_of(T.data.begin() + T.indptr[row_begin], T.data.begin() + T.indptr[row_begin + n],
-                    [](double x) { return x == 1.0; });
     // persistent launch: one resident workgroup per CU (its LDS footprint allows no second)
     int n_cu = 0;
     IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -1035,12 +1106,13 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                                   static_cast<int>(lds)));
       hipLaunchKernelGGL(kernel, dim3(grid), dim3(THREADS), lds, s, p);
     };
+    pt.mark("uploads + flags");
     hipEvent_t ev0, ev1;
     IRS_HIP(hipEventCreate(&ev0));
     IRS_HIP(hipEventCreate(&ev1));
     IRS_HIP(hipEventRecord(ev0, s));
     if (c->xt_all_ones) {
-      if (sentinel && t_all_ones) launch(knn_tile_kernel<true, true, true>);
+      if (acc32) launch(knn_tile_kernel<true, true, true>);
       else if (sentinel) launch(knn_tile_kernel<true, true>);
       else launch(knn_tile_kernel<true, false>);
     } else {
@@ -1065,6 +1137,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     c->last_ms = ms;
+    pt.mark("kernels + D2H");
 #ifdef IRS_KNN_PHASES
     {
       unsigned long long h[8] = {0}, z[8] = {0};
@@ -1076,7 +1149,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
 #endif
     // assemble the CSR in target-row order (slots are work-ordered)
     std::vector<int32_t> slot_of(n);
-    for (int64_t sl = 0; sl < n; sl++) slot_of[order[sl] - row_begin] = static_cast<int32_t>(sl);
+    for (int64_t sl = 0; sl < n; sl++) slot_of[order[sl]] = static_cast<int32_t>(sl);
     for (int64_t i = 0; i < n; i++) c->res_ptr[i + 1] = c->res_ptr[i] + h_cnt[slot_of[i]];
     c->res_idx.resize(c->res_ptr[n]);
     c->res_val.resize(c->res_ptr[n]);
@@ -1088,6 +1161,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                 c->res_val.begin() + c->res_ptr[i]);
     }
     *nnz_out = c->res_ptr[n];
+    pt.mark("assemble");
   });
 }
 
