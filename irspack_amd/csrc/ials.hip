@@ -2,6 +2,7 @@
 // Mirrors irspack::ials::IALSTrainer (/root/reference/cpp_source/als/
 // IALSTrainer.hpp:709-984) behind include/irspack_amd.h.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -10,6 +11,7 @@
 #include <numeric>
 #include <random>
 #include <sstream>
+#include <thread>
 
 #include "common.hpp"
 #include "ials_kernels.hpp"
@@ -358,16 +360,19 @@ void download_factor(irs_ials_trainer *t, const float *dev, int64_t n, float *ho
 
 // Solver::initialize, hpp:64-76: libstdc++ mt19937 + normal_distribution<float>
 // on the host, so a libstdc++ build of the reference draws the same stream.
-void init_factor(irs_ials_trainer *t, int which) {
-  const int64_t n = t->rows_of(which);
-  std::vector<float> h(static_cast<size_t>(n) * t->K, 0.0f);
-  if (t->cfg.init_stdev > 0) {
-    std::mt19937 gen(t->cfg.random_seed);
-    std::normal_distribution<float> dist(
-        0.0, t->cfg.init_stdev / std::sqrt(static_cast<float>(t->K)));
-    for (int64_t i = 0; i < n; i++)
-      for (int64_t k = 0; k < t->K; k++) h[i * t->K + k] = dist(gen);
+// Both matrices are drawn from generators with the SAME seed (hpp:718-719), so the shorter one
+// is a prefix of the longer one's stream: `n` rows are drawn once.
+std::vector<float> draw_factor(const irs_ials_model_config &cfg, int64_t K, int64_t n) {
+  std::vector<float> h(static_cast<size_t>(n) * K, 0.0f);
+  if (cfg.init_stdev > 0) {
+    std::mt19937 gen(cfg.random_seed);
+    std::normal_distribution<float> dist(0.0, cfg.init_stdev / std::sqrt(static_cast<float>(K)));
+    for (size_t i = 0; i < h.size(); i++) h[i] = dist(gen);
   }  // init_stdev <= 0: the reference leaves the matrix uninitialised; we zero it
+  return h;
+}
+void init_factor(irs_ials_trainer *t, int which) {
+  const std::vector<float> h = draw_factor(t->cfg, t->K, t->rows_of(which));
   upload_factor(t, which, h.data());
 }
 
@@ -729,7 +734,30 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
   return guard([&] {
     check_arg(config && out, "null argument.");
     validate_config(*config);
+    const bool timing = std::getenv("IRSPACK_AMD_IALS_TIMING") != nullptr;
+    auto tm0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+      if (!timing) return;
+      const auto t1 = std::chrono::steady_clock::now();
+      fprintf(stderr, "ials create phase %-16s %8.2f ms\n", what,
+              std::chrono::duration<double, std::milli>(t1 - tm0).count());
+      tm0 = t1;
+    };
+    // the initial factors (a sequential libstdc++ random stream, ~0.4 s for 10 M values) and the
+    // transposed matrix are prepared on two host threads while this one sets the device up
+    std::vector<float> init_draw;
+    std::thread draw_thread([&] {
+      init_draw = draw_factor(*config, static_cast<int64_t>(config->K), std::max(n_users, n_items));
+    });
+    struct Joiner {
+      std::thread &t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } draw_join{draw_thread};
     HostCsr X = host_csr(n_users, n_items, indptr, indices, data);
+    mark("copy + validate");
+    HostCsr Xt;
+    std::thread transpose_thread([&] { Xt = transpose(X); });
+    Joiner transpose_join{transpose_thread};
     require_device(device);
     auto t = std::make_unique<irs_ials_trainer>();
     t->cfg = *config;
@@ -743,14 +771,19 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
                   t->shard.item_begin <= t->shard.item_end && t->shard.item_end <= n_items,
               "shard out of range.");
     alloc_common(t.get());
+    mark("device alloc");
     t->side[0].build(X, t->shard.user_begin, t->shard.user_end, t->cfg, t->stream);
-    {
-      HostCsr Xt = transpose(X);
-      t->side[1].build(Xt, t->shard.item_begin, t->shard.item_end, t->cfg, t->stream);
-    }
+    mark("user side");
+    transpose_thread.join();
+    mark("transpose (rest)");
+    t->side[1].build(Xt, t->shard.item_begin, t->shard.item_end, t->cfg, t->stream);
+    mark("item side");
     t->has_X = true;
-    init_factor(t.get(), 0);  // hpp:718-719: both sides from the same seed
-    init_factor(t.get(), 1);
+    draw_thread.join();
+    mark("draw (rest)");
+    upload_factor(t.get(), 0, init_draw.data());  // hpp:718-719: both sides from the same seed
+    upload_factor(t.get(), 1, init_draw.data());
+    mark("upload factors");
     *out = t.release();
   });
 }
