@@ -863,16 +863,21 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       std::vector<uint32_t> idx_p(padded / 2, 0u);
       for (size_t e = 0; e < nnz; e++)
         idx_p[e >> 1] |= static_cast<uint32_t>((Xt.indices[e] % TILE) * 4) << (16 * (e & 1));
-      std::vector<double> val_p(Xt.data);
-      val_p.resize(padded, 0.0);
       c->xt_idx16.upload(idx_p, s);
-      c->xt_val.upload(val_p, s);
+      c->xt_all_ones = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) { return v == 1.0; });
+      c->xt_nonzero = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) {
+        const double a = std::fabs(v);
+        return a > 1e-150 && a < 1e150;
+      });
+      if (c->xt_all_ones) {  // the ONES kernels never read the value stream
+        c->xt_val.alloc(2);
+      } else {
+        std::vector<double> val_p(Xt.data);
+        val_p.resize(padded, 0.0);
+        c->xt_val.upload(val_p, s);
+      }
+      IRS_HIP(hipStreamSynchronize(s));  // the host vectors go out of scope
     }
-    c->xt_all_ones = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) { return v == 1.0; });
-    c->xt_nonzero = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) {
-      const double a = std::fabs(v);
-      return a > 1e-150 && a < 1e150;
-    });
     c->norms.upload(norms, s);
     IRS_HIP(hipStreamSynchronize(s));
     *out = c.release();
