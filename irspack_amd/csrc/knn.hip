@@ -472,6 +472,7 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
       prefix = k_and;  // all stored keys are equal: everything ties
     } else {
       int shift = ((63 - __clzll(static_cast<long long>(diff))) >> 3) << 3;
+      const int low_shift = ((__ffsll(static_cast<long long>(k_or)) - 1) >> 3) << 3;
       prefix = shift + 8 >= 64 ? 0ull : k_and & (~0ull << (shift + 8));
       for (; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
@@ -527,7 +528,8 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
         need = sh_need;
         const int in_bin = sh_total;
         __syncthreads();
-        if (need < 0 || shift == 0) break;
+        // below the lowest set bit of any key every digit is zero: the prefix is the key
+        if (need < 0 || shift == 0 || shift <= low_shift) break;
         if (in_bin <= 64) {
           // few candidates left: one wave ranks them instead of more digit passes
           const uint64_t lo_mask = ~0ull << shift;
