@@ -84,6 +84,32 @@ def main():
                 d["lds_inst_busy_frac"] = d.get("SQ_ACTIVE_INST_LDS", 0.0) / (32 * d["GRBM_GUI_ACTIVE"])
             sq[name] = d
         json.dump(sq, open(os.path.join(DST, f"{TAG}_knn_eval_pmc_sq.json"), "w"), indent=1)
+    # SQ counters of the bench kernels (scripts/prof_pmc_sq.sh: two passes per solver)
+    sq_all = {}
+    for solver in ("CHOLESKY", "CG"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        launches = collections.defaultdict(set)
+        for d in (f"sq_{solver}", f"sq2_{solver}"):
+            for f in newest(os.path.join(SRC, d, "*", "*_counter_collection.csv")):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    if "irs::ials::ials_" not in name:
+                        continue
+                    short = name.split("irs::ials::")[1].split("(")[0]
+                    key = f"{solver}:{short}:grid{r['Grid_Size']}"
+                    agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
+                    launches[(key, d)].add(r["Dispatch_Id"])
+        for key, c in agg.items():
+            n = max(max(len(v) for (k, _), v in launches.items() if k == key), 1)
+            d = {k: v / n for k, v in sorted(c.items())}
+            if d.get("GRBM_GUI_ACTIVE"):
+                # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs; SQ_ACTIVE_INST_* count quad-cycles
+                simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 1024
+                d["mfma_busy_frac"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles
+                d["valu_active_frac"] = 4 * d.get("SQ_ACTIVE_INST_VALU", 0.0) / simd_cycles
+            sq_all[key] = d
+    if sq_all:
+        json.dump(sq_all, open(os.path.join(DST, f"{TAG}_bench_pmc_sq.json"), "w"), indent=1)
     out = {"units": "bytes per launch", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2",
            "write_correction": "WRITE_SIZE KiB x 1024", "kernels": {}}
     fetch = newest(os.path.join(SRC, "fetch", "*", "*_counter_collection.csv"))
