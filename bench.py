@@ -170,11 +170,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (one-GPU boxes): IRSPACK_AMD_BENCH_BACKEND=gloo and
+    # IRSPACK_AMD_BENCH_ONE_DEVICE=1 run the N > 1 control flow with every rank on cuda:0
+    backend = os.environ.get("IRSPACK_AMD_BENCH_BACKEND", "nccl")
+    if os.environ.get("IRSPACK_AMD_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback).")
     torch.cuda.set_device(local_rank)

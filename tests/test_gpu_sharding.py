@@ -79,3 +79,26 @@ def test_two_ranks_match_single_gpu(tmp_path, kind, equal):
     # epochs (truncated CG amplifies the last-bit differences) stay within 3e-4
     assert np.abs(r0["user"] - ref.user).max() / np.abs(ref.user).max() < 3e-4
     assert np.abs(r0["item"] - ref.item).max() / np.abs(ref.item).max() < 3e-4
+
+
+def test_bench_two_ranks_control_flow():
+    """bench.py's N > 1 path (process group, equal shards, barrier + max-over-ranks timing,
+    one JSON line from rank 0) with two ranks on one device over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IRSPACK_AMD_BENCH_BACKEND="gloo", IRSPACK_AMD_BENCH_ONE_DEVICE="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+         "--gpus", "2", "--steps", "2", "--warmup", "1", "--shape", "small"],
+        env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "roofline" in d and d["roofline"]["frac"] > 0
