@@ -965,22 +965,45 @@ __global__ __launch_bounds__(256) void user_scores_kernel(const float *__restric
   for (int p = 0; p < 4; p++)
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < KP; k += 16) {
-    f32x4 a[4], b[4];
+  // the operands of step k + 1 are requested before the 64 MFMAs of step k are issued (left to
+  // itself hipcc loads each operand right in front of its first use: 16 exposed L2 latencies
+  // per tile)
+  f32x4 a[2][4], b[2][4];
+  auto load_step = [&](int k, f32x4 (&aa)[4], f32x4 (&bb)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      a[q] = *reinterpret_cast<const f32x4 *>(up[q] + k);
-      b[q] = *reinterpret_cast<const f32x4 *>(ip[q] + k);
+      aa[q] = *reinterpret_cast<const f32x4 *>(up[q] + k);
+      bb[q] = *reinterpret_cast<const f32x4 *>(ip[q] + k);
     }
+  };
+  auto mfma_step = [&](const f32x4 (&aa)[4], const f32x4 (&bb)[4]) {
 #pragma unroll
     for (int p = 0; p < 4; p++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].x, b[q].x, acc[p][q], 0, 0, 0);
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].y, b[q].y, acc[p][q], 0, 0, 0);
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].z, b[q].z, acc[p][q], 0, 0, 0);
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p].w, b[q].w, acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].x, bb[q].x, acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].y, bb[q].y, acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].z, bb[q].z, acc[p][q], 0, 0, 0);
+        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].w, bb[q].w, acc[p][q], 0, 0, 0);
       }
+  };
+  static_assert(KP % 32 == 0 || KP == 16, "two steps per round");
+  load_step(0, a[0], b[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (KP == 16) {
+    mfma_step(a[0], b[0]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < KP; k += 32) {
+      load_step(k + 16, a[1], b[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a[0], b[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 32 < KP) load_step(k + 32, a[0], b[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(a[1], b[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   const int64_t col = it * 64 + 4 * m;
   const bool vec = (n_items & 3) == 0 && col + 3 < n_items &&
