@@ -548,7 +548,6 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
 // 8 waves per SIMD are resident, so the loads of some rows overlap the drawing of others.
 template <class T, int M>
 __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
-  using KT = typename KeyStore<T>::type;  // keys + 1 (0 = empty slot); no key reaches the type's maximum
   constexpr int U = 16;
   const int ln = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -572,43 +571,66 @@ __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
     if (ln < p.cutoff) disc_pref = p.disc[ln];
     idcg_pref = p.idcg_prefix[min(n_gt, p.cutoff)];
   }
-  KT bk[M];
+  // The lists hold the raw scores: float comparison is the reference's order (-0.0 == +0.0
+  // ties; equal scores keep index order because insertion is strict), -inf marks an empty
+  // slot and is never inserted - exactly the scores that are not rankable.  A NaN (ranks last
+  // among the rankable, evaluator.hip header) would never be inserted either, so a row that
+  // contains one goes to the general kernel.
+  const T NEG_INF = -std::numeric_limits<T>::infinity();
+  T bs[M];
   int32_t bi[M];
 #pragma unroll
   for (int t = 0; t < M; t++) {
-    bk[t] = 0;
+    bs[t] = NEG_INF;
     bi[t] = 0x7fffffff;
   }
-  int seen = 0;
+  int n_rankable = 0;             // wave-uniform
+  unsigned long long nan_any = 0;  // lanes that met a NaN
   const int32_t n = static_cast<int32_t>(p.n_items);
-  for (int32_t base = 0; base < n; base += 64 * U) {
+  auto insert = [&](T cs, int32_t ci) {
+    if (__any(cs > bs[M - 1])) {
+#pragma unroll
+      for (int t = 0; t < M; t++) {
+        const bool gt = cs > bs[t];
+        const T ts = bs[t];
+        const int32_t ti = bi[t];
+        bs[t] = gt ? cs : ts;
+        bi[t] = gt ? ci : ti;
+        cs = gt ? ts : cs;
+        ci = gt ? ti : ci;
+      }
+    }
+  };
+  int32_t base = 0;
+  for (; base + 64 * U <= n; base += 64 * U) {  // full groups: no bounds to check
+    const T *sp = srow + base + ln;
+    T sv[U];
+#pragma unroll
+    for (int q = 0; q < U; q++) sv[q] = sp[64 * q];
+#pragma unroll
+    for (int q = 0; q < U; q++) {
+      nan_any |= __ballot(sv[q] != sv[q]);
+      n_rankable += __popcll(__ballot(sv[q] != NEG_INF));
+      insert(sv[q], base + 64 * q + ln);
+    }
+  }
+  if (base < n) {  // the last, partial group
     T sv[U];
 #pragma unroll
     for (int q = 0; q < U; q++) sv[q] = srow[min(base + 64 * q + ln, n - 1)];
 #pragma unroll
     for (int q = 0; q < U; q++) {
       const int32_t j = base + 64 * q + ln;
-      const bool ok = j < n && !is_neg_inf(sv[q]);
-      KT ck = ok ? static_cast<KT>(order_key(sv[q])) + 1 : 0;
-      int32_t ci = j;
-      seen += ok;
-      if (__any(ck > bk[M - 1])) {  // insertion keeps equal keys in index order (strict >)
-#pragma unroll
-        for (int t = 0; t < M; t++) {
-          const bool gt = ck > bk[t];
-          const KT tk = bk[t];
-          const int32_t ti = bi[t];
-          bk[t] = gt ? ck : tk;
-          bi[t] = gt ? ci : ti;
-          ck = gt ? tk : ck;
-          ci = gt ? ti : ci;
-        }
-      }
+      const T s1 = j < n ? sv[q] : NEG_INF;
+      nan_any |= __ballot(s1 != s1);
+      n_rankable += __popcll(__ballot(s1 != NEG_INF));
+      insert(s1, j);
     }
   }
-  int n_rankable = seen;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) n_rankable += __shfl_xor(n_rankable, o, 64);
+  if (nan_any) {
+    if (ln == 0) p.todo[row] = 1;
+    return;
+  }
   const int n_rec = min(p.cutoff, n_rankable);
   res.valid = 1;
   res.n_rec = n_rec;
@@ -620,32 +642,30 @@ __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
   int32_t mi = 0x7fffffff;
   int popped = 0;
   for (int it = 0; it < n_rec; it++) {
-    KT wk = bk[0];
+    T ws = bs[0];
     int32_t wi = bi[0];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
-      KT ok_;
-      if constexpr (sizeof(KT) == 8) ok_ = __shfl_xor(static_cast<unsigned long long>(wk), o, 64);
-      else ok_ = __shfl_xor(wk, o, 64);
+      const T os = __shfl_xor(ws, o, 64);
       const int32_t oi = __shfl_xor(wi, o, 64);
-      const bool better = ok_ > wk || (ok_ == wk && oi < wi);
-      wk = better ? ok_ : wk;
+      const bool better = os > ws || (os == ws && oi < wi);
+      ws = better ? os : ws;
       wi = better ? oi : wi;
     }
     if (ln == it) mi = wi;
-    const bool mine = bk[0] == wk && bi[0] == wi;  // indices are unique: one lane
+    const bool mine = bi[0] == wi && bs[0] == ws;  // indices are unique: one lane
     if (mine) {
 #pragma unroll
       for (int t = 0; t + 1 < M; t++) {
-        bk[t] = bk[t + 1];
+        bs[t] = bs[t + 1];
         bi[t] = bi[t + 1];
       }
-      bk[M - 1] = 0;
+      bs[M - 1] = NEG_INF;
       bi[M - 1] = 0x7fffffff;
       popped++;
     }
-    // a lane that ran dry but saw more than it kept may hide the next best candidate
-    if (it + 1 < n_rec && __any(popped == M && seen > M)) {
+    // a lane that ran dry may hide the next best candidate (it kept only its M best)
+    if (it + 1 < n_rec && __any(popped == M)) {
       if (ln == 0) p.todo[row] = 1;
       return;
     }
