@@ -228,3 +228,25 @@ def test_many_ties_short_list_and_general_selection(dtype, levels, cutoff):
     core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
     f = "get_metrics_f64" if dtype == "float64" else "get_metrics_f32"
     compare(getattr(core, f)(scores, cutoff, 0, 4, False), getattr(ocore, f)(scores, cutoff, 0, 4, False))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_nan_scores_rank_last_and_signed_zeros_tie(dtype):
+    """The reference leaves NaN ordering undefined; this build ranks NaN after every other
+    rankable score (ties by index), so replacing NaN by a value below all others must not
+    change anything.  -0.0 and +0.0 tie (the reference compares floats)."""
+    rns = np.random.RandomState(11)
+    U, I = 40, 900
+    scores = rns.randn(U, I).astype(dtype)
+    scores[rns.rand(U, I) < 0.02] = np.nan
+    scores[3, :] = np.nan
+    scores[4, 10:] = -np.inf
+    scores[4, :10] = np.nan
+    scores[5, :] = 0.0
+    scores[5, ::2] = -0.0
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.9).astype(np.float64))
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    f = "get_metrics_f64" if dtype == "float64" else "get_metrics_f32"
+    replaced = np.where(np.isnan(scores), np.asarray(-1e30, dtype=dtype), scores)
+    for cutoff in (5, 20, 300):
+        compare(getattr(core, f)(scores, cutoff, 0, 2), getattr(ocore, f)(replaced, cutoff, 0, 2))
