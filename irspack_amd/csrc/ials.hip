@@ -772,12 +772,23 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
               "shard out of range.");
     alloc_common(t.get());
     mark("device alloc");
+    // the two orientations are prepared and uploaded side by side (host preparation of one
+    // overlaps the copies of the other)
+    std::exception_ptr item_error;
+    std::thread item_thread([&] {
+      try {
+        transpose_thread.join();
+        IRS_HIP(hipSetDevice(device));
+        t->side[1].build(Xt, t->shard.item_begin, t->shard.item_end, t->cfg, t->stream);
+      } catch (...) {
+        item_error = std::current_exception();
+      }
+    });
+    Joiner item_join{item_thread};
     t->side[0].build(X, t->shard.user_begin, t->shard.user_end, t->cfg, t->stream);
-    mark("user side");
-    transpose_thread.join();
-    mark("transpose (rest)");
-    t->side[1].build(Xt, t->shard.item_begin, t->shard.item_end, t->cfg, t->stream);
-    mark("item side");
+    item_thread.join();
+    if (item_error) std::rethrow_exception(item_error);
+    mark("both sides");
     t->has_X = true;
     draw_thread.join();
     mark("draw (rest)");
