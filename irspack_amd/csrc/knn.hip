@@ -716,6 +716,9 @@ static HostCsrD host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
   return m;
 }
 
+// Transpose on several host threads: every thread owns a contiguous block of rows (about equal
+// entry counts), counts its entries per column, and after a prefix over (column, thread) writes
+// them to its own slots - the entries of a column stay in row order whatever the thread count.
 static HostCsrD transpose(const HostCsrD &x) {
   HostCsrD t;
   t.rows = x.cols;
@@ -724,15 +727,45 @@ static HostCsrD transpose(const HostCsrD &x) {
   const int64_t nnz = x.indptr[x.rows];
   t.indices.resize(nnz);
   t.data.resize(nnz);
-  for (int64_t q = 0; q < nnz; q++) t.indptr[x.indices[q] + 1]++;
-  for (int64_t c = 0; c < t.rows; c++) t.indptr[c + 1] += t.indptr[c];
-  std::vector<int64_t> cur(t.indptr.begin(), t.indptr.end() - 1);
-  for (int64_t r = 0; r < x.rows; r++)
-    for (int64_t q = x.indptr[r]; q < x.indptr[r + 1]; q++) {
-      const int64_t d = cur[x.indices[q]]++;
-      t.indices[d] = static_cast<int32_t>(r);
-      t.data[d] = x.data[q];
+  const int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({8, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                            nnz / 1000000 + 1})));
+  std::vector<int64_t> row_lo(n_thr + 1, x.rows);
+  row_lo[0] = 0;
+  for (int k = 1; k < n_thr; k++)
+    row_lo[k] = std::lower_bound(x.indptr.begin(), x.indptr.end() - 1, nnz * k / n_thr) -
+                x.indptr.begin();
+  // cnt[k][c]: entries of column c in the rows of thread k; turned into write positions below
+  std::vector<std::vector<int64_t>> cnt(n_thr, std::vector<int64_t>(t.rows, 0));
+  auto run = [&](auto &&body) {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &w : th) w.join();
+  };
+  run([&](int k) {
+    auto &c = cnt[k];
+    for (int64_t q = x.indptr[row_lo[k]]; q < x.indptr[row_lo[k + 1]]; q++) c[x.indices[q]]++;
+  });
+  int64_t pos = 0;
+  for (int64_t c = 0; c < t.rows; c++) {
+    t.indptr[c] = pos;
+    for (int k = 0; k < n_thr; k++) {
+      const int64_t here = cnt[k][c];
+      cnt[k][c] = pos;
+      pos += here;
     }
+  }
+  t.indptr[t.rows] = pos;
+  run([&](int k) {
+    auto &cur = cnt[k];
+    for (int64_t r = row_lo[k]; r < row_lo[k + 1]; r++)
+      for (int64_t q = x.indptr[r]; q < x.indptr[r + 1]; q++) {
+        const int64_t d = cur[x.indices[q]]++;
+        t.indices[d] = static_cast<int32_t>(r);
+        t.data[d] = x.data[q];
+      }
+  });
   return t;
 }
 
@@ -771,6 +804,19 @@ struct irs_knn_computer {
 
 extern "C" {
 
+// IRSPACK_AMD_KNN_TIMING=1 prints the host phases of a compute call to stderr
+struct PhaseTimer {
+  bool on = std::getenv("IRSPACK_AMD_KNN_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char *what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "knn host phase %-18s %8.2f ms\n", what,
+            std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const int64_t *indptr,
                           const int32_t *indices, const double *data, double shrinkage,
                           double alpha, double beta, int32_t normalize, int64_t n_threads,
@@ -781,7 +827,9 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     check_lower(shrinkage, 0, "shrinkage");
     check_arg(n_threads >= 1, "n_threads must be greater than or equal to  1");
     check_arg(max_chunk_size >= 1, "max_chunk_size must be greater than or equal to  1");
+    PhaseTimer pt;
     HostCsrD X = host_csr(rows, cols, indptr, indices, data);
+    pt.mark("create: copy");
     check_arg(rows < (int64_t(1) << 31), "too many rows.");
     std::vector<double> norms(rows, 0.0);
     switch (sim_type) {
@@ -829,7 +877,9 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       default:
         throw std::invalid_argument("unknown similarity type.");
     }
+    pt.mark("create: norms");
     require_device(device);
+    pt.mark("create: device");
     auto c = std::make_unique<irs_knn_computer>();
     c->device = device;
     c->sim_type = sim_type;
@@ -840,6 +890,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     c->beta = beta;
     c->normalize = normalize != 0;
     HostCsrD Xt = transpose(X);
+    pt.mark("create: transpose");
     c->xt_row_len.resize(Xt.rows);
     for (int64_t u = 0; u < Xt.rows; u++) c->xt_row_len[u] = Xt.indptr[u + 1] - Xt.indptr[u];
     hipStream_t s = nullptr;
@@ -857,6 +908,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       }
       c->xt_tptr.upload(tptr, s);
     }
+    pt.mark("create: slices");
     {  // columns relative to their tile as 16-bit LDS byte offsets (column * 4), two per
        // dword; 256 padding entries: the accumulate loop reads whole 128-entry strips from
        // the (even) start of a slice
@@ -882,6 +934,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     }
     c->norms.upload(norms, s);
     IRS_HIP(hipStreamSynchronize(s));
+    pt.mark("create: pack+upload");
     *out = c.release();
   });
 }
@@ -894,19 +947,6 @@ irs_status irs_knn_destroy(irs_knn_computer *c) {
     }
   });
 }
-
-// IRSPACK_AMD_KNN_TIMING=1 prints the host phases of a compute call to stderr
-struct PhaseTimer {
-  bool on = std::getenv("IRSPACK_AMD_KNN_TIMING") != nullptr;
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  void mark(const char *what) {
-    if (!on) return;
-    const auto t1 = std::chrono::steady_clock::now();
-    fprintf(stderr, "knn host phase %-18s %8.2f ms\n", what,
-            std::chrono::duration<double, std::milli>(t1 - t0).count());
-    t0 = t1;
-  }
-};
 
 irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            const int64_t *indptr, const int32_t *indices, const double *data,
