@@ -116,6 +116,7 @@ struct Side {
   int32_t n_tasks = 0, n_split = 0, n_slots = 0, n_long = 0;
   // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
   int32_t n_short = 0, n_short16 = 0;
+  bool unit = false;  // every stored confidence is exactly 1 (UNIT kernels)
 
   void build(const HostCsr &m, int64_t rb, int64_t re, const irs_ials_model_config &cfg,
              hipStream_t s) {
@@ -124,6 +125,7 @@ struct Side {
     row_begin = rb;
     row_end = re;
     nnz = m.indptr[m.rows];
+    unit = std::all_of(m.data.begin(), m.data.end(), [](float v) { return v == 1.0f; });
     std::vector<int32_t> ip32(m.rows + 1);
     for (int64_t r = 0; r <= m.rows; r++) ip32[r] = static_cast<int32_t>(m.indptr[r]);
     std::vector<float> regs(m.rows);
@@ -327,7 +329,9 @@ void alloc_common(irs_ials_trainer *t) {
   for (int w = 0; w < 2; w++) {
     // rows padded to a multiple of 8 (zero, never solved, never gathered) so that 1 / 2 / 4 / 8
     // equal row shards tile the buffer exactly and one in-place all-gather can move them
-    t->factor[w].alloc(static_cast<size_t>(ceil_div(t->rows_of(w), 8) * 8) * t->KP);
+    // rows padded to a multiple of 8, plus 8 rows that stay zero (UNIT kernels gather row
+    // `padded rows` for the entries past a row's end)
+    t->factor[w].alloc(static_cast<size_t>(ceil_div(t->rows_of(w), 8) * 8 + 8) * t->KP);
     t->factor[w].zero(t->stream);
     t->P_raw[w].alloc(t->KP * t->KP);
     t->P[w].alloc(t->KP * t->KP);
@@ -534,6 +538,15 @@ static bool wave_path_at_128() {
   return v;
 }
 
+// IRSPACK_AMD_IALS_UNIT=0 keeps binary interactions on the general rank-update code.
+static bool unit_path_enabled() {
+  static bool v = [] {
+    const char *e = std::getenv("IRSPACK_AMD_IALS_UNIT");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  return v;
+}
+
 // IRSPACK_AMD_IALS_SHORT=0 sends the short rows of a CG step through the general kernels too.
 static bool short_rows_enabled() {
   static bool v = [] {
@@ -576,6 +589,8 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                                          : static_cast<int32_t>(std::min<uint64_t>(
                                                sc->max_cg_steps, 1u << 20));
   p.warm_start = 1;
+  p.zero_row = static_cast<int32_t>(ceil_div(sd.n_other, 8) * 8);
+  const bool unit = sd.unit && unit_path_enabled() && other == t->factor[1 - pidx].ptr;
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
   // CG, short rows: the matrix-free kernel takes the tail of the longest-first task list
   int n_regular = sd.n_tasks;
@@ -613,8 +628,12 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     p.partials = t->split_partial.ptr;
     if (n_regular > 0) {
       t->prof.begin(kNames[cg][0][pidx], t->stream);
-      if (cg)
+      if (cg && unit)
+        hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0, true>), dim3(n_regular), dim3(64), 0, t->stream, p);
+      else if (cg)
         hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0>), dim3(n_regular), dim3(64), 0, t->stream, p);
+      else if (unit)
+        hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0, true>), dim3(n_regular), dim3(64), 0, t->stream, p);
       else
         hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0>), dim3(n_regular), dim3(64), 0, t->stream, p);
       t->prof.end(t->stream);
@@ -634,8 +653,14 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       p.partials = t->split_partial.ptr;
       if (n_regular > 0) {
         t->prof.begin(kNames[cg][0][pidx], t->stream);
-        if (cg)
+        if (cg && unit)
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0, true>), dim3(ceil_div(n_regular, SOLVE_WAVES)),
+                             dim3(64 * SOLVE_WAVES), 0, t->stream, p);
+        else if (cg)
           hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(n_regular, SOLVE_WAVES)),
+                             dim3(64 * SOLVE_WAVES), 0, t->stream, p);
+        else if (unit)
+          hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0, true>), dim3(ceil_div(n_regular, SOLVE_WAVES)),
                              dim3(64 * SOLVE_WAVES), 0, t->stream, p);
         else
           hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0>), dim3(ceil_div(n_regular, SOLVE_WAVES)),

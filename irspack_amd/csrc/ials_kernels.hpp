@@ -69,6 +69,7 @@ struct SolveParams {
   int32_t K;            // unpadded latent dimension
   int32_t max_cg_steps; // already resolved (0 -> K), hpp:232-234
   int32_t warm_start;   // CG: start from the current row (hpp:199) or from 0 (hpp:132)
+  int32_t zero_row;     // an all-zero row of `other` (UNIT kernels: entries past a row's end)
   const float *prior;   // feature prior [n_rows, KP] or null: rhs += reg_r * prior_r
                         // (step_cholesky_with_prior hpp:363, step_cg hpp:212-215)
 };
@@ -163,13 +164,18 @@ __device__ __forceinline__ void mfma_tiles(const float (&cv)[T], const float (&v
 // NW > 1: the tiles are dealt round-robin to NW waves of a workgroup that all walk
 // the same row (tile t belongs to wave t % NW, local slot t / NW); D = gathered
 // sub-steps kept in flight (a sub-step = 4 stored entries).
-template <int T, int NW = 1, int W = 0, int D = 8>
+// UNIT: every stored confidence is exactly 1 (binary interactions).  Then c v = v feeds the
+// MFMAs directly, b = (bias + 1) sum v, the value stream is never read, and an entry past
+// the row's end is neutralised by gathering the all-zero row `zero_row` - 7 of the 26 vector
+// instructions of a sub-step disappear (they cost the same issue cycles as the MFMAs' own,
+// see DESIGN 3.1).
+template <int T, int NW = 1, int W = 0, int D = 8, bool UNIT = false>
 __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
                                             const int32_t *__restrict__ indices,
                                             const float *__restrict__ data, int begin,
                                             int end, float bias,
                                             f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW],
-                                            float (&bsum)[T]) {
+                                            float (&bsum)[T], unsigned zero_row = 0) {
   constexpr int KP = Geo<T>::KP;
   constexpr int NT = Geo<T>::NT;
   constexpr int TPW = (NT + NW - 1) / NW;
@@ -194,19 +200,28 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   auto fetch = [&](int k, int blk_idx, float blk_c, int j, int entry0) {
     // entry0 = index (within the row) of the block's first entry
     const int src = perm_base + 16 * j;
-    const unsigned idx = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, blk_idx));
-    const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, blk_c)));
+    unsigned idx = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, blk_idx));
     const bool valid = entry0 + 4 * j + g < n;
-    vc[k] = valid ? c : 0.f;
-    vw[k] = valid ? bias + c : 0.f;
+    if constexpr (UNIT) {
+      idx = valid ? idx : zero_row;
+    } else {
+      const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, blk_c)));
+      vc[k] = valid ? c : 0.f;
+      vw[k] = valid ? bias + c : 0.f;
+    }
     load_dims<T>(col_base + static_cast<size_t>(idx) * KP, v[k]);
   };
   auto consume = [&](int k) {
     float cv[T];
 #pragma unroll
     for (int i = 0; i < T; i++) {
-      cv[i] = vc[k] * v[k][i];
-      bsum[i] = fmaf(vw[k], v[k][i], bsum[i]);
+      if constexpr (UNIT) {
+        cv[i] = v[k][i];
+        bsum[i] += v[k][i];
+      } else {
+        cv[i] = vc[k] * v[k][i];
+        bsum[i] = fmaf(vw[k], v[k][i], bsum[i]);
+      }
     }
     if constexpr (NW == 1) {
       int t = 0;
@@ -229,7 +244,11 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   // While a block is consumed from one set, the other already holds the next
   // block; the set that was just exhausted is reloaded with the block after.
   int a_i = ip[0], b_i = ip[64];
-  float a_c = dp[0], b_c = dp[64];
+  float a_c = 0.f, b_c = 0.f;
+  if constexpr (!UNIT) {
+    a_c = dp[0];
+    b_c = dp[64];
+  }
 #pragma unroll
   for (int k = 0; k < D; k++) fetch(k, a_i, a_c, k, 0);
   __builtin_amdgcn_sched_barrier(0);
@@ -245,7 +264,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
         fetch(j % D, nxt_i, nxt_c, j + D - 16, 4 * s0 + 64);
       if (j == 15 - D) {  // last use of this set: reload it with block + 2
         cur_i = ip[4 * s0 + 128];
-        cur_c = dp[4 * s0 + 128];
+        if constexpr (!UNIT) cur_c = dp[4 * s0 + 128];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -282,6 +301,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   for (int i = 0; i < T; i++) {
     bsum[i] += __shfl_xor(bsum[i], 16, 64);
     bsum[i] += __shfl_xor(bsum[i], 32, 64);
+    if constexpr (UNIT) bsum[i] *= bias + 1.0f;
   }
 }
 
@@ -727,7 +747,7 @@ __device__ unsigned long long ials_phase_clk[2 * 4096];  // development: device-
 #define IPHASE(i)
 #endif
 
-template <int T, int SOLVER, int MODE>
+template <int T, int SOLVER, int MODE, bool UNIT = false>
 __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
   using G = Geo<T>;
   constexpr int LDS_PER_WAVE = (SOLVER == 0 || T == 8) ? CholGeo<T>::LDS_FLOATS : G::LDS_FLOATS;
@@ -756,7 +776,8 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
 #pragma unroll
       for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    syrk_gather<T>(p.other, p.indices, p.data, task.begin, task.end, p.bias, acc, bsum);
+    syrk_gather<T, 1, 0, 8, UNIT>(p.other, p.indices, p.data, task.begin, task.end, p.bias, acc,
+                                  bsum, static_cast<unsigned>(p.zero_row));
     IPHASE(0);
     if (task.slot >= 0) {
       float *dst = p.partials + static_cast<size_t>(task.slot) * G::PARTIAL_FLOATS;
