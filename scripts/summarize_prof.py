@@ -136,8 +136,9 @@ def main():
     for name, rows in out["kernels"].items():
         if "ials_solve_kernel" not in name:
             continue
-        solver = "cg" if ", 1, " in name else "cholesky"
-        kind = "split" if name.split(",")[2].strip().startswith("1") else "solve"
+        targs = [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")]
+        solver = "cg" if targs[1] == "1" else "cholesky"   # <T, SOLVER, MODE, UNIT>
+        kind = "split" if targs[2] == "1" else "solve"
         rows = sorted(rows, key=lambda r: r["grid_size"])
         if len(rows) >= 2:
             # users have more rows than items => larger grid for `solve`; for `split` the item side
