@@ -468,24 +468,26 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
   for (int q = 0; q < 4 * T; q++) {
     const int I = q / 4, gq = q % 4;
     const bool mine = g == gq;
-    // ---- panel: rows 4q .. 4q+3 (lanes of group gq, registers 0..3)
+    // ---- panel: rows 4q .. 4q+3 (lanes of group gq, registers 0..3).  Only the owning group
+    //      executes the row operations (EXEC mask instead of a select per operation: vector
+    //      instructions share the issue budget of the MFMAs); v_readlane ignores EXEC.
+    if (mine) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float piv = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r);
-      bad |= !(piv > 0.f);
-      const float rinv = __builtin_amdgcn_rsqf(piv);
-      const float mult = mine ? rinv : 1.0f;
+      for (int r = 0; r < 4; r++) {
+        const float piv = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r);
+        bad |= !(piv > 0.f);
+        const float rinv = __builtin_amdgcn_rsqf(piv);
 #pragma unroll
-      for (int j = I; j < T; j++) acc[C::tix(I, j)][r] *= mult;
-      bacc[I][r] *= mult;
+        for (int j = I; j < T; j++) acc[C::tix(I, j)][r] *= rinv;
+        bacc[I][r] *= rinv;
 #pragma unroll
-      for (int r2 = r + 1; r2 < 4; r2++) {
-        const float s = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r2);  // R[k][k2]
-        const float sm_ = mine ? s : 0.f;
+        for (int r2 = r + 1; r2 < 4; r2++) {
+          const float s = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r2);  // R[k][k2]
 #pragma unroll
-        for (int j = I; j < T; j++)
-          acc[C::tix(I, j)][r2] = fmaf(-sm_, acc[C::tix(I, j)][r], acc[C::tix(I, j)][r2]);
-        bacc[I][r2] = fmaf(-sm_, bacc[I][r], bacc[I][r2]);
+          for (int j = I; j < T; j++)
+            acc[C::tix(I, j)][r2] = fmaf(-s, acc[C::tix(I, j)][r], acc[C::tix(I, j)][r2]);
+          bacc[I][r2] = fmaf(-s, bacc[I][r], bacc[I][r2]);
+        }
       }
     }
     if (q == 4 * T - 1) break;
@@ -516,7 +518,7 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
       bacc[i2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, opb, bacc[i2], 0, 0, 0);
     }
   }
-  if (bad) {
+  if (__any(bad)) {  // (each group saw the pivots of its own panels)
     if (lane == 0) atomicOr(err_flag, 1);
   }
   // ---- spill R (upper tiles) and y, then lane k back-substitutes row k of R x = y
