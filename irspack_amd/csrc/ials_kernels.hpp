@@ -604,11 +604,11 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
     }
   }
   const float rinv_k = 1.0f / sm[(Ik * T - Ik * (Ik - 1) / 2) * C::TS + rk * C::RS + rk];
-  const float yk = ybuf[k];
+  const float ys = ybuf[k] * rinv_k;
   float partial = 0.f, xv = 0.f;
 #pragma unroll
   for (int j = KP - 1; j >= 0; j--) {
-    const float t = (yk - partial) * rinv_k;
+    const float t = fmaf(-partial, rinv_k, ys);  // (y_k - partial) / R_kk in one instruction
     const float xj = readlane_f(t, j);
     if (lane == j) xv = xj;
     partial = fmaf(rowk[j], xj, partial);
