@@ -590,7 +590,9 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                                                sc->max_cg_steps, 1u << 20));
   p.warm_start = 1;
   p.zero_row = static_cast<int32_t>(ceil_div(sd.n_other, 8) * 8);
-  const bool unit = sd.unit && unit_path_enabled() && other == t->factor[1 - pidx].ptr;
+  // (the UNIT kernels address the gathered table with 32-bit byte offsets)
+  const bool unit = sd.unit && unit_path_enabled() && other == t->factor[1 - pidx].ptr &&
+                    static_cast<uint64_t>(p.zero_row + 8) * t->KP * sizeof(float) < (uint64_t(1) << 32);
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
   // CG, short rows: the matrix-free kernel takes the tail of the longest-first task list
   int n_regular = sd.n_tasks;

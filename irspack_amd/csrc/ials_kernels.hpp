@@ -196,6 +196,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   const int32_t *ip = indices + begin + lane;
   const float *dp = data + begin + lane;
   const int perm_base = 4 * g;  // ds_bpermute byte address of lane (4j + g) is 16 j + 4 g
+  const uint32_t lane_off = static_cast<uint32_t>(T * m * sizeof(float));
   float v[D][T], vc[D], vw[D];
   auto fetch = [&](int k, int blk_idx, float blk_c, int j, int entry0) {
     // entry0 = index (within the row) of the block's first entry
@@ -204,6 +205,11 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
     const bool valid = entry0 + 4 * j + g < n;
     if constexpr (UNIT) {
       idx = valid ? idx : zero_row;
+      // 32-bit byte offset from the (wave-uniform) table base: one v_lshl_add instead of
+      // two 64-bit address operations; the host takes this path only for tables < 4 GB
+      const uint32_t off = idx * static_cast<uint32_t>(KP * sizeof(float)) + lane_off;
+      load_dims<T>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(other) + off), v[k]);
+      return;
     } else {
       const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, blk_c)));
       vc[k] = valid ? c : 0.f;
