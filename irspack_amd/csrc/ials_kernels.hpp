@@ -20,6 +20,7 @@
 // element (T*(4g+r) + I, T*m + J).  The permutation is undone when the matrix
 // is spilled to LDS for the solve.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -198,11 +199,13 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   const int perm_base = 4 * g;  // ds_bpermute byte address of lane (4j + g) is 16 j + 4 g
   const uint32_t lane_off = static_cast<uint32_t>(T * m * sizeof(float));
   float v[D][T], vc[D], vw[D];
-  auto fetch = [&](int k, int blk_idx, float blk_c, int j, int entry0) {
+  // `all_valid` (a compile-time tag): the caller guarantees that the sub-step lies before the
+  // row's last one, so no entry has to be neutralised (3 vector instructions less)
+  auto fetch = [&](int k, int blk_idx, float blk_c, int j, int entry0, auto all_valid) {
     // entry0 = index (within the row) of the block's first entry
     const int src = perm_base + 16 * j;
     unsigned idx = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, blk_idx));
-    const bool valid = entry0 + 4 * j + g < n;
+    const bool valid = decltype(all_valid)::value || entry0 + 4 * j + g < n;
     if constexpr (UNIT) {
       idx = valid ? idx : zero_row;
       // 32-bit byte offset from the (wave-uniform) table base: one v_lshl_add instead of
@@ -256,18 +259,18 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
     b_c = dp[64];
   }
 #pragma unroll
-  for (int k = 0; k < D; k++) fetch(k, a_i, a_c, k, 0);
+  for (int k = 0; k < D; k++) fetch(k, a_i, a_c, k, 0, std::false_type{});
   __builtin_amdgcn_sched_barrier(0);
   int s0 = 0;  // first sub-step of the current block
   static_assert(16 % D == 0 && D < 16, "the gather ring must divide the 16 sub-steps of a block");
-  auto block = [&](int &cur_i, float &cur_c, const int nxt_i, const float nxt_c) {
+  auto block = [&](int &cur_i, float &cur_c, const int nxt_i, const float nxt_c, auto all_valid) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {  // sub-step j of this block; its gather was issued D earlier
       consume(j % D);
       if (j + D < 16)
-        fetch(j % D, cur_i, cur_c, j + D, 4 * s0);
+        fetch(j % D, cur_i, cur_c, j + D, 4 * s0, all_valid);
       else
-        fetch(j % D, nxt_i, nxt_c, j + D - 16, 4 * s0 + 64);
+        fetch(j % D, nxt_i, nxt_c, j + D - 16, 4 * s0 + 64, all_valid);
       if (j == 15 - D) {  // last use of this set: reload it with block + 2
         cur_i = ip[4 * s0 + 128];
         if constexpr (!UNIT) cur_c = dp[4 * s0 + 128];
@@ -276,12 +279,20 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
     }
     s0 += 16;
   };
-  while (s0 + 32 <= nsub) {  // `block` advances s0
-    block(a_i, a_c, b_i, b_c);
-    block(b_i, b_c, a_i, a_c);
+  constexpr std::true_type all_valid_tag{};
+  constexpr std::false_type masked_tag{};
+  // a block fetches the sub-steps up to s0 + 15 + D; while even the second block of a round
+  // stays before the row's last sub-step nothing has to be masked (long rows: most blocks)
+  while (s0 + 32 + D + 1 <= nsub) {  // `block` advances s0
+    block(a_i, a_c, b_i, b_c, all_valid_tag);
+    block(b_i, b_c, a_i, a_c, all_valid_tag);
+  }
+  while (s0 + 32 <= nsub) {
+    block(a_i, a_c, b_i, b_c, masked_tag);
+    block(b_i, b_c, a_i, a_c, masked_tag);
   }
   if (s0 + 16 <= nsub) {
-    block(a_i, a_c, b_i, b_c);
+    block(a_i, a_c, b_i, b_c, masked_tag);
     a_i = b_i;  // the tail reads the current block from set A
     a_c = b_c;
   }
@@ -299,7 +310,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
     if (base + D < 15 && rest > base + D) {
 #pragma unroll
       for (int k = 0; k < D; k++)
-        if (base + D + k < rest) fetch(k, cur_i, cur_c, base + D + k, 4 * s0);
+        if (base + D + k < rest) fetch(k, cur_i, cur_c, base + D + k, 4 * s0, std::false_type{});
     }
   }
   // fold the four gathered-row groups: every lane ends with b[T*m + i]
