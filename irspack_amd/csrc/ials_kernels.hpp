@@ -456,21 +456,6 @@ template <int T> struct CholGeo {
   static constexpr int tix(int i, int j) { return i * T - i * (i - 1) / 2 + (j - i); }
 };
 
-// Steps J, J - 1, .. 0 of the back substitution: x_J = (y_J - partial_J) / R_JJ is computed by
-// every lane for its own row, lane J's value is the solution component; it is broadcast
-// (v_readlane) for the other rows' partial sums and dropped into lane J of `xv` with a
-// v_writelane, whose lane operand must be an immediate - hence the compile-time recursion
-// (a compare + select per step otherwise).
-template <int J, int KP>
-__device__ __forceinline__ void back_substitute(const float (&rowk)[KP], float rinv_k, float ys,
-                                                float &partial, float &xv) {
-  const float t = fmaf(-partial, rinv_k, ys);  // (y_k - partial) / R_kk in one instruction
-  const float xj = readlane_f(t, J);
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(xv) : "s"(xj), "n"(J));
-  partial = fmaf(rowk[J], xj, partial);
-  if constexpr (J > 0) back_substitute<J - 1, KP>(rowk, rinv_k, ys, partial, xv);
-}
-
 template <int T>
 __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
                                                    float reg, float *sm, float *xrow, int K,
@@ -500,28 +485,24 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
   for (int q = 0; q < 4 * T; q++) {
     const int I = q / 4, gq = q % 4;
     const bool mine = g == gq;
-    // ---- panel: rows 4q .. 4q+3 (lanes of group gq, registers 0..3).  Only the owning group
-    //      executes the row operations (EXEC mask instead of a select per operation: vector
-    //      instructions share the issue budget of the MFMAs); v_readlane ignores EXEC.
-    if (mine) {
+    // ---- panel: rows 4q .. 4q+3 (lanes of group gq, registers 0..3)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float piv = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r);
-        // piv > 0 as an integer test of the (wave-uniform) bits: scalar unit, not a vector
-        // compare (a NaN pivot passes here and is caught by the finiteness test of the solution)
-        bad |= __builtin_bit_cast(int, piv) <= 0;
-        const float rinv = __builtin_amdgcn_rsqf(piv);
+    for (int r = 0; r < 4; r++) {
+      const float piv = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r);
+      bad |= !(piv > 0.f);
+      const float rinv = __builtin_amdgcn_rsqf(piv);
+      const float mult = mine ? rinv : 1.0f;
 #pragma unroll
-        for (int j = I; j < T; j++) acc[C::tix(I, j)][r] *= rinv;
-        bacc[I][r] *= rinv;
+      for (int j = I; j < T; j++) acc[C::tix(I, j)][r] *= mult;
+      bacc[I][r] *= mult;
 #pragma unroll
-        for (int r2 = r + 1; r2 < 4; r2++) {
-          const float s = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r2);  // R[k][k2]
+      for (int r2 = r + 1; r2 < 4; r2++) {
+        const float s = readlane_f(acc[C::tix(I, I)][r], 20 * gq + r2);  // R[k][k2]
+        const float sm_ = mine ? s : 0.f;
 #pragma unroll
-          for (int j = I; j < T; j++)
-            acc[C::tix(I, j)][r2] = fmaf(-s, acc[C::tix(I, j)][r], acc[C::tix(I, j)][r2]);
-          bacc[I][r2] = fmaf(-s, bacc[I][r], bacc[I][r2]);
-        }
+        for (int j = I; j < T; j++)
+          acc[C::tix(I, j)][r2] = fmaf(-sm_, acc[C::tix(I, j)][r], acc[C::tix(I, j)][r2]);
+        bacc[I][r2] = fmaf(-sm_, bacc[I][r], bacc[I][r2]);
       }
     }
     if (q == 4 * T - 1) break;
@@ -640,7 +621,13 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
   const float rinv_k = 1.0f / sm[(Ik * T - Ik * (Ik - 1) / 2) * C::TS + rk * C::RS + rk];
   const float ys = ybuf[k] * rinv_k;
   float partial = 0.f, xv = 0.f;
-  back_substitute<KP - 1>(rowk, rinv_k, ys, partial, xv);
+#pragma unroll
+  for (int j = KP - 1; j >= 0; j--) {
+    const float t = fmaf(-partial, rinv_k, ys);  // (y_k - partial) / R_kk in one instruction
+    const float xj = readlane_f(t, j);
+    if (lane == j) xv = xj;
+    partial = fmaf(rowk[j], xj, partial);
+  }
   // virtual index k = 16 I + m'  <->  latent dim T m' + I
   const int dim = T * rk + Ik;
   const bool fin = __builtin_isfinite(xv) || lane >= KP || dim >= K;
