@@ -391,10 +391,20 @@ __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float 
     // conjugate gradient, hpp:199-264
     const bool act = lane < K;
     float x = (warm_start && act) ? xrow[li] : 0.f;
+    // the vector is parked in LDS (the spilled matrix is in registers by now) and read back
+    // four components per broadcast read: LDS instructions do not compete with the vector /
+    // matrix issue budget, KP v_readlane would
     auto matvec = [&](float vec) {
+      sm[lane] = vec;
       float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < KP; k++) s = fmaf(a[k], readlane_f(vec, k), s);
+      for (int q = 0; q < KP / 4; q++) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(sm + 4 * q);
+        s = fmaf(a[4 * q], v4.x, s);
+        s = fmaf(a[4 * q + 1], v4.y, s);
+        s = fmaf(a[4 * q + 2], v4.z, s);
+        s = fmaf(a[4 * q + 3], v4.w, s);
+      }
       return s;
     };
     float r = act ? bv - matvec(x) : 0.f;
