@@ -9,10 +9,19 @@ same matrix is solved by all ranks together (strong scaling), with an RCCL
 all-reduce of the K x K Gramian and an in-place all-gather of the solved factor
 shards every half-epoch.
 
-Extra objects on the line: ``roofline`` for the dominant kernel (HIP-event timed
-inside the library on the launch stream) and ``cpu_baseline`` (the CPU oracle —
-a restatement of the reference's Eigen path, which cannot be built offline —
-timed on this box's host cores on a bounded row sample, N = 1 only).
+Objects on the line:
+  roofline      dominant kernel of the headline (Cholesky) run, HIP-event timed inside the
+                library on the launch stream; both the flop side and the HBM side
+  ceilings      copy / triad GB/s, pure fp32-MFMA TF and LDS-atomic rate MEASURED in this run,
+                next to the spec peaks (frac_of_spec / frac_of_measured in every roofline)
+  cpu_baseline  the CPU oracle (a restatement of the reference's Eigen path, which cannot be
+                built offline) on this box's host cores, bounded row sample, N = 1 only
+  secondary     N = 1 only, each leg time-boxed and independent:
+    ials_cg       the reference's DEFAULT solver (CG, 3 steps) on the same matrix
+    knn           cosine / jaccard item-kNN top-100 (configs[2]); headline = wall-inclusive call
+    evaluator     fused score + nDCG@20 over all users (K = 64)
+    k256          configs[4] on one GPU: K = 256 Cholesky + CG epochs and the fused nDCG@20
+    c4            configs[3] shape (10 M x 1 M; 1/5 scale unless --extra) K = 128, CG + Cholesky
 """
 
 import argparse
@@ -41,7 +50,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the kNN / evaluator figures reported next to the headline metric")
+                    help="skip every leg reported next to the headline metric")
+    ap.add_argument("--legs", default="ials_cg,knn,evaluator,k256,c4",
+                    help="comma-separated secondary legs to run (N = 1)")
+    ap.add_argument("--extra", action="store_true",
+                    help="run the c4 leg at the full 10 M x 1 M size (about 3 minutes of host "
+                         "generation + trainer construction)")
     return ap.parse_args()
 
 
@@ -56,6 +70,35 @@ def algorithmic_half(nnz, rows, n_other, K, solver, cg_steps=3):
     if solver == "CG":
         byts += rows * 4 * K
     return float(flops), float(byts)
+
+
+def algorithmic_epoch(X, K, solver):
+    U, I = X.shape
+    fu, bu = algorithmic_half(X.nnz, U, I, K, solver)
+    fi, bi = algorithmic_half(X.nnz, I, U, K, solver)
+    return fu + fi, bu + bi
+
+
+def roof(bound, achieved, ceilings, **more):
+    """roofline object with the spec peak and the ceiling measured in this run"""
+    if bound == "mfma":
+        peak, unit, measured = PEAK_F32_TFLOPS, "TFLOP/s", (ceilings or {}).get("mfma_f32_tflops")
+    else:
+        peak, unit, measured = PEAK_HBM_GBS, "GB/s", (ceilings or {}).get("copy_gbs")
+    r = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+         "frac_of_spec": achieved / peak,
+         "frac_of_measured": (achieved / measured) if measured else None, "traffic": None}
+    r.update(more)
+    return r
+
+
+def both_terms(flops, byts, seconds, ceilings, **more):
+    """report max(B/t / BW_peak, F/t / FLOP_peak) with BOTH terms shown."""
+    tf, gbs = flops / seconds / 1e12, byts / seconds / 1e9
+    bound = "mfma" if tf / PEAK_F32_TFLOPS >= gbs / PEAK_HBM_GBS else "hbm"
+    return roof(bound, tf if bound == "mfma" else gbs, ceilings, f32_tflops=tf,
+                frac_f32=tf / PEAK_F32_TFLOPS, hbm_side_gbs=gbs, frac_hbm=gbs / PEAK_HBM_GBS,
+                **more)
 
 
 def cpu_baseline(X, K, solver, budget_s):
@@ -96,69 +139,197 @@ def cpu_baseline(X, K, solver, budget_s):
     }
 
 
-def secondary_metrics(X, trainer, K):
-    """The other two pieces of the hot path at the same ML-20M shape (reported, not the
-    headline): item-kNN (cosine, top_k = 100, BASELINE.json configs[2]) and the fused
-    score + nDCG@20 evaluator.  Kernel times are HIP-event timed inside the library."""
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
+    written by scripts/summarize_prof.py with the guide's gfx950 corrections)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return {}
+
+
+def time_epochs(trainer, sc, steps, warmup):
+    """(seconds per epoch, per-kernel profile) of `steps` epochs of an unsharded IALSTrainer"""
+    for _ in range(warmup):
+        trainer.step(sc)
+    trainer.synchronize()
+    trainer.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(sc)
+    trainer.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = trainer.profile_read()
+    trainer.profile(False)
+    return dt, {k: round(v["ms"] / v["launches"], 4) for k, v in prof.items()}
+
+
+def solver_config(kind):
+    from irspack_amd.recommenders._ials_core import IALSSolverConfigBuilder, SolverType
+
+    return (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType[kind])
+            .set_max_cg_steps(3).build())
+
+
+def model_config(K):
+    from irspack_amd.recommenders._ials_core import IALSModelConfigBuilder
+
+    return (IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(1e-3).set_nu(1.0)
+            .set_init_stdev(0.1).set_random_seed(42).build())
+
+
+def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
+    """One solver on one matrix: updates/s + roofline with both terms."""
+    dt, kernels = time_epochs(trainer, solver_config(kind), steps, warmup)
+    flops, byts = algorithmic_epoch(X, K, kind)
+    U, I = X.shape
+    return {
+        "solver": kind + (" max_cg_steps=3" if kind == "CG" else ""),
+        "ms_per_epoch": dt * 1e3, "updates_per_s": (U + I) / dt, "steps": steps, "warmup": warmup,
+        "kernels_ms_per_launch": kernels,
+        "roofline": both_terms(flops, byts, dt, ceilings, scope="whole epoch (all kernels)",
+                               algorithmic_gflop_per_epoch=flops / 1e9,
+                               algorithmic_gbyte_per_epoch=byts / 1e9),
+    }
+
+
+def holdout(X, seed=5):
+    """evaluator inputs: one held-out interaction per user = ground truth, the rest = mask"""
     import scipy.sparse as sps
 
-    from irspack_amd.evaluation._core_evaluator import EvaluatorCore
-    from irspack_amd.recommenders._knn import CosineSimilarityComputer, JaccardSimilarityComputer
-
-    U, I = X.shape
-    out = {}
-    Xt = sps.csr_matrix(X.T, dtype=np.float64)
-    Xt.data[:] = 1.0
-    comp = CosineSimilarityComputer(Xt, 0.0, True)
-    comp.compute_similarity(Xt, 100, rows=(0, 64))  # warm-up
-    t0 = time.perf_counter()
-    S = comp.compute_similarity(Xt, 100)
-    wall = time.perf_counter() - t0
-    ms = comp.last_kernel_ms
-    bytes_per_mac = 4.0  # int32 column id; the all-ones value stream is not read
-    out["knn"] = {
-        "workload": f"cosine item-kNN top_k=100, {I} items x {U} users, binary interactions, fp64",
-        "kernel_ms": ms, "wall_s_incl_pcie": wall, "macs": comp.last_macs,
-        "item_pairs_per_s": I * float(I) / (ms * 1e-3),
-        "gmacs_per_s": comp.last_macs / ms / 1e6,
-        "roofline": {"bound": "hbm", "achieved": comp.last_macs * bytes_per_mac / (ms * 1e-3) / 1e9,
-                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": comp.last_macs * bytes_per_mac / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                     "traffic": None},
-        "out_nnz": int(S.nnz),
-    }
-    # the other two SURVEY 8(d) variants, kernel time only
-    variants = {}
-    for name, other in (("cosine_normalize_false", CosineSimilarityComputer(Xt, 0.0, False)),
-                        ("jaccard", JaccardSimilarityComputer(Xt, 0.0))):
-        other.compute_similarity(Xt, 100)
-        variants[name] = {"kernel_ms": other.last_kernel_ms,
-                          "item_pairs_per_s": I * float(I) / (other.last_kernel_ms * 1e-3)}
-        del other
-    out["knn"]["variants"] = variants
-    # evaluator: hold out one interaction per user as ground truth, mask the rest
-    rng = np.random.default_rng(5)
+    U = X.shape[0]
+    rng = np.random.default_rng(seed)
     pick = X.indptr[:-1] + (rng.random(U) * np.diff(X.indptr)).astype(np.int64)
     gt = sps.csr_matrix((np.ones(U), (np.arange(U), X.indices[pick])), shape=X.shape)
-    ev = EvaluatorCore(gt, [])
     keep = np.ones(X.nnz, dtype=bool)
     keep[pick] = False
     rows = np.repeat(np.arange(U), np.diff(X.indptr))
     mask = sps.csr_matrix((np.ones(int(keep.sum()), dtype=np.float32),
                            (rows[keep], X.indices[keep])), shape=X.shape)
+    return gt, mask
+
+
+def evaluator_leg(X, trainer, K, ceilings):
+    from irspack_amd.evaluation._core_evaluator import EvaluatorCore
+
+    U, I = X.shape
+    gt, mask = holdout(X)
+    ev = EvaluatorCore(gt, [])
     ev.get_metrics_ials(trainer, 0, 2048, mask[:2048], 20, 0, False)  # warm-up
     t0 = time.perf_counter()
     m = ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
     wall_first = time.perf_counter() - t0  # converts and uploads the mask (80 MB)
-    t0 = time.perf_counter()
-    m = ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
-    wall = time.perf_counter() - t0        # the mask is resident, as in a tuning loop
-    out["evaluator"] = {
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        m = ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
+        walls.append(time.perf_counter() - t0)  # the mask is resident, as in a tuning loop
+    wall = min(walls)
+    # algorithmic work: the dense contraction (MFMA side) and, for an UNFUSED evaluator, the
+    # score block written once and read once (HBM side); both shown
+    flops, byts = 2.0 * U * I * K, 2.0 * U * I * 4
+    return {
         "workload": f"fused iALS k={K} scoring + nDCG@20 over {U} users x {I} items, fp32 scores",
         "wall_s_first_call_incl_mask_upload": wall_first,
         "wall_s_incl_pcie": wall, "users_per_s": U / wall,
         "scores_per_s": U * float(I) / wall, "ndcg@20": m.as_dict()["ndcg"],
+        "roofline": both_terms(flops, byts, wall, ceilings, scope="whole call (host wall clock)",
+                               algorithmic_gflop=flops / 1e9,
+                               score_block_gbyte_write_plus_read=byts / 1e9),
     }
+
+
+def knn_leg(X, ceilings):
+    """configs[2].  Headline = item pairs / s of the whole compute_similarity call (host CSR
+    in, top-k, host CSR out: SURVEY 8(d)); the kernel-only figure beside it.  Roofline: the
+    accumulation is one LDS atomic per multiply-add, so the ceiling is the LDS atomic rate
+    measured in this run (irs_measure_ceilings), not HBM."""
+    import scipy.sparse as sps
+
+    from irspack_amd.recommenders._knn import CosineSimilarityComputer, JaccardSimilarityComputer
+
+    U, I = X.shape
+    Xt = sps.csr_matrix(X.T, dtype=np.float64)
+    Xt.data[:] = 1.0
+    t0 = time.perf_counter()
+    comp = CosineSimilarityComputer(Xt, 0.0, True)
+    create_s = time.perf_counter() - t0
+    comp.compute_similarity(Xt, 100, rows=(0, 64))  # warm-up
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        S = comp.compute_similarity(Xt, 100)
+        walls.append(time.perf_counter() - t0)
+    wall, ms, macs = min(walls), comp.last_kernel_ms, comp.last_macs
+    atomic_peak = (ceilings or {}).get("lds_atomic_u32_gops")
+    gmacs = macs / ms / 1e6
+    traffic = pmc_traffic().get("knn_tile_kernel")
+    out = {
+        "workload": f"cosine item-kNN top_k=100, {I} items x {U} users, binary interactions, fp64",
+        "item_pairs_per_s": I * float(I) / wall,
+        "wall_s_incl_pcie": wall, "kernel_ms": ms,
+        "item_pairs_per_s_kernel_only": I * float(I) / (ms * 1e-3),
+        "create_s": create_s, "macs": macs, "gmacs_per_s_kernel": gmacs,
+        "roofline": {"bound": "lds_atomic", "achieved": gmacs, "peak": atomic_peak,
+                     "unit": "G lane-atomics/s (measured ds_add_u32, random banks)",
+                     "frac": (gmacs / atomic_peak) if atomic_peak else None,
+                     "frac_of_measured": (gmacs / atomic_peak) if atomic_peak else None,
+                     "frac_of_spec": None, "traffic": traffic,
+                     "hbm_side_gbs": macs * 4.0 / (ms * 1e-3) / 1e9,
+                     "frac_hbm": macs * 4.0 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     "note": "kernel time covers accumulate + epilogue + select + merge; "
+                             "HBM side prices the reference's 4 B column id per multiply-add"},
+        "out_nnz": int(S.nnz),
+    }
+    variants = {}
+    for name, other in (("cosine_normalize_false", CosineSimilarityComputer(Xt, 0.0, False)),
+                        ("jaccard", JaccardSimilarityComputer(Xt, 0.0))):
+        other.compute_similarity(Xt, 100, rows=(0, 64))
+        t0 = time.perf_counter()
+        other.compute_similarity(Xt, 100)
+        w = time.perf_counter() - t0
+        variants[name] = {"item_pairs_per_s": I * float(I) / w, "wall_s_incl_pcie": w,
+                          "kernel_ms": other.last_kernel_ms,
+                          "item_pairs_per_s_kernel_only": I * float(I) / (other.last_kernel_ms * 1e-3)}
+        del other
+    out["variants"] = variants
+    return out
+
+
+def k256_leg(X, ceilings):
+    """BASELINE configs[4] on one GPU: iALS K = 256 (Cholesky and CG) + fused nDCG@20."""
+    from irspack_amd.recommenders._ials_core import IALSTrainer
+
+    K = 256
+    t0 = time.perf_counter()
+    tr = IALSTrainer(model_config(K), X)
+    out = {"workload": f"ml20m-shape {X.shape[0]}x{X.shape[1]} nnz={X.nnz}, iALS k={K} fp32",
+           "create_s": time.perf_counter() - t0}
+    out["cholesky"] = ials_leg(tr, X, K, "CHOLESKY", 3, 1, ceilings)
+    out["cg"] = ials_leg(tr, X, K, "CG", 5, 1, ceilings)
+    out["evaluator"] = evaluator_leg(X, tr, K, ceilings)
+    return out
+
+
+def c4_leg(full, ceilings):
+    """BASELINE configs[3] shape on one GPU (K = 128): short rows, CG (reference default) and
+    Cholesky.  Default = the 1/5-scale matrix of the same generator; --extra = 10 M x 1 M."""
+    from irspack_amd.recommenders._ials_core import IALSTrainer
+    from irspack_amd.synthetic import describe, make_interactions
+
+    name, K = ("c4" if full else "c4_fifth"), 128
+    t0 = time.perf_counter()
+    X = make_interactions(name)
+    gen_s = time.perf_counter() - t0
+    info = describe(X)
+    t0 = time.perf_counter()
+    tr = IALSTrainer(model_config(K), X)
+    out = {"workload": (f"{name} synthetic CSR {X.shape[0]}x{X.shape[1]} nnz={X.nnz} "
+                        f"(geometric degrees, mean {info['mean_user_degree']:.1f}; Zipf items, "
+                        f"max item degree {info['max_item_degree']}), iALS k={K} fp32"),
+           "generate_s": gen_s, "create_s": time.perf_counter() - t0}
+    out["cg"] = ials_leg(tr, X, K, "CG", 5, 1, ceilings)
+    out["cholesky"] = ials_leg(tr, X, K, "CHOLESKY", 3, 1, ceilings)
     return out
 
 
@@ -187,8 +358,7 @@ def main():
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback).")
     torch.cuda.set_device(local_rank)
 
-    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
-                                                      IALSSolverConfigBuilder, SolverType)
+    from irspack_amd import _lib
     from irspack_amd.sharding import HipLocalSolver, ShardedIALSTrainer, equal_shard_bounds
     from irspack_amd.synthetic import describe, make_interactions
 
@@ -196,10 +366,8 @@ def main():
     info = describe(X)
     U, I = X.shape
     K = args.K
-    mc = (IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(1e-3).set_nu(1.0)
-          .set_init_stdev(0.1).set_random_seed(42).build())
-    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType[args.solver])
-          .set_max_cg_steps(3).build())
+    mc = model_config(K)
+    sc = solver_config(args.solver)
     # equal row blocks (random row order: cost-balanced to a few per cent) so that the solved
     # rows travel in ONE in-place all-gather per half-epoch
     ub, ib = equal_shard_bounds(X, world)
@@ -232,6 +400,17 @@ def main():
 
     result = None
     if rank == 0:
+        ceilings = None
+        try:
+            ceilings = _lib.measure_ceilings(local_rank)
+            ceilings.update({
+                "spec_hbm_gbs": PEAK_HBM_GBS, "spec_f32_tflops": PEAK_F32_TFLOPS,
+                "copy_frac_of_spec": ceilings["copy_gbs"] / PEAK_HBM_GBS,
+                "mfma_f32_frac_of_spec": ceilings["mfma_f32_tflops"] / PEAK_F32_TFLOPS,
+                "how": "irs_measure_ceilings: 1 GiB copy / triad, v_mfma_f32_16x16x4_f32 loop on "
+                       "every SIMD, random-bank ds_add_u32 loop on every CU; best of 5, HIP events"})
+        except Exception as exc:  # the headline line must still be printed
+            ceilings = {"error": repr(exc)}
         value = (U + I) * args.steps / elapsed
         # dominant kernel of this rank and its roofline
         dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
@@ -246,27 +425,11 @@ def main():
             n_other = I if side == 0 else U
             flops, byts = algorithmic_half(nnz_side, rows, n_other, K, args.solver)
             t_launch = st["ms"] / st["launches"] * 1e-3
-            if args.solver == "CHOLESKY":
-                ach = flops / t_launch / 1e12
-                roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS,
-                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_TFLOPS, "traffic": None}
-            else:
-                ach = byts / t_launch / 1e9
-                roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
-                            "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
-            roofline.update({
-                "kernel": name, "avg_launch_ms": st["ms"] / st["launches"],
-                "launches": st["launches"], "algorithmic_gflop_per_launch": flops / 1e9,
-                "algorithmic_gbyte_per_launch": byts / 1e9,
-                "hbm_side_gbs": byts / t_launch / 1e9,
-                "f32_tflops": flops / t_launch / 1e12,
-            })
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    roofline["traffic"] = json.load(open(pmc)).get(name)
-                except Exception:
-                    pass
+            roofline = both_terms(flops, byts, t_launch, ceilings, kernel=name,
+                                  avg_launch_ms=st["ms"] / st["launches"], launches=st["launches"],
+                                  algorithmic_gflop_per_launch=flops / 1e9,
+                                  algorithmic_gbyte_per_launch=byts / 1e9)
+            roofline["traffic"] = pmc_traffic().get(name)
         result = {
             "metric": "iALS user+item updates/sec at k=64, ML-20M-shape CSR",
             "value": value,
@@ -289,11 +452,38 @@ def main():
             },
             "kernels_ms_per_launch": {k: round(v["ms"] / v["launches"], 4) for k, v in prof.items()},
             "roofline": roofline,
+            "ceilings": ceilings,
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(X, K, args.solver, args.cpu_seconds)
-        if world == 1 and not args.no_secondary and K <= 64:
-            result["secondary"] = secondary_metrics(X, local.trainer, K)
+        if world == 1 and not args.no_secondary:
+            legs = [s for s in args.legs.split(",") if s]
+            sec = {}
+
+            def run(name, fn):
+                if name not in legs:
+                    return
+                t0 = time.perf_counter()
+                try:
+                    sec[name] = fn()
+                except Exception as exc:  # a failing leg must not lose the headline line
+                    sec[name] = {"error": repr(exc)}
+                sec[name]["leg_wall_s"] = time.perf_counter() - t0
+
+            # the solver the headline did not run (the reference's default is CG, 3 steps)
+            other = "CG" if args.solver == "CHOLESKY" else "CHOLESKY"
+            other_leg = "ials_" + other.lower()
+            if "ials_cg" in legs and other_leg not in legs:
+                legs.append(other_leg)
+            run(other_leg, lambda: ials_leg(local.trainer, X, K, other, args.steps, 2, ceilings))
+            if K <= 64:
+                run("knn", lambda: knn_leg(X, ceilings))
+                run("evaluator", lambda: evaluator_leg(X, local.trainer, K, ceilings))
+            trainer = local = None  # free the K = 64 trainer before the larger legs
+            if args.shape == "ml20m":
+                run("k256", lambda: k256_leg(X, ceilings))
+                run("c4", lambda: c4_leg(args.extra, ceilings))
+            result["secondary"] = sec
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -285,6 +285,21 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t,
 irs_status irs_eval_cache_mask(irs_evaluator *e, int64_t rows, const int64_t *mask_indptr,
                                const int32_t *mask_indices);
 
+/* ------------------------------------------------------------ measurement
+ * No reference counterpart: SURVEY.md 8(d) asks for ceilings MEASURED on the box next to the
+ * spec peaks.  Runs a 1 GiB device copy and STREAM triad (HBM bytes moved / time), a loop of
+ * nothing but v_mfma_f32_16x16x4_f32 on every SIMD, and a loop of random-bank ds_add_u32 on
+ * every CU (the kNN count accumulation's instruction); all HIP-event timed, best of 5. */
+typedef struct irs_ceilings {
+  double copy_gbs;            /* read + write bytes per second of dst = src, GB/s */
+  double triad_gbs;           /* a = b + s c: 3 x bytes, GB/s */
+  double mfma_f32_tflops;     /* dense fp32 MFMA rate, TFLOP/s */
+  double lds_atomic_u32_gops; /* lane-level LDS atomic adds per second (whole device), G/s */
+  double clock_mhz;           /* hipDeviceAttributeClockRate */
+  int32_t n_cu;
+} irs_ceilings;
+irs_status irs_measure_ceilings(int32_t device, irs_ceilings *out);
+
 #ifdef __cplusplus
 }
 #endif

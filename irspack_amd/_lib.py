@@ -62,6 +62,17 @@ class MetricsStruct(C.Structure):
     ]
 
 
+class CeilingsStruct(C.Structure):  # irs_ceilings
+    _fields_ = [
+        ("copy_gbs", C.c_double),
+        ("triad_gbs", C.c_double),
+        ("mfma_f32_tflops", C.c_double),
+        ("lds_atomic_u32_gops", C.c_double),
+        ("clock_mhz", C.c_double),
+        ("n_cu", C.c_int32),
+    ]
+
+
 # every symbol include/irspack_amd.h declares
 EXPORTED_SYMBOLS = [
     "irs_last_error",
@@ -102,6 +113,7 @@ EXPORTED_SYMBOLS = [
     "irs_eval_get_metrics",
     "irs_eval_get_metrics_ials",
     "irs_eval_cache_mask",
+    "irs_measure_ceilings",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -139,6 +151,14 @@ def ptr(a: np.ndarray, ctype):
 
 def device_count() -> int:
     return int(lib().irs_device_count())
+
+
+def measure_ceilings(device: Optional[int] = None) -> dict:
+    """Measured device ceilings (irs_measure_ceilings) as a dict."""
+    st = CeilingsStruct()
+    check(lib().irs_measure_ceilings(C.c_int32(default_device() if device is None else device),
+                                     C.byref(st)))
+    return {name: getattr(st, name) for name, _ in CeilingsStruct._fields_}
 
 
 def default_device() -> int:

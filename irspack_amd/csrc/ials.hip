@@ -271,6 +271,7 @@ struct irs_ials_trainer {
   DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   Profiler prof;
+  bool opt_wave128 = true, opt_unit = true, opt_short = true;  // read_switches()
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
 };
@@ -323,7 +324,10 @@ void validate_config(const irs_ials_model_config &c) {
             "unknown loss_type.");
 }
 
+void read_switches(irs_ials_trainer *t);
+
 void alloc_common(irs_ials_trainer *t) {
+  read_switches(t);
   t->KP = padded_k(t->K);
   t->T = t->KP / 16;
   for (int w = 0; w < 2; w++) {
@@ -370,7 +374,10 @@ std::vector<float> draw_factor(const irs_ials_model_config &cfg, int64_t K, int6
   std::vector<float> h(static_cast<size_t>(n) * K, 0.0f);
   if (cfg.init_stdev > 0) {
     std::mt19937 gen(cfg.random_seed);
-    std::normal_distribution<float> dist(0.0, cfg.init_stdev / std::sqrt(static_cast<float>(K)));
+    // std::sqrt(factor.cols()) takes the integral overload (hpp:68-69): the quotient is formed
+    // in double and rounded to float once
+    std::normal_distribution<float> dist(
+        0.0, static_cast<float>(static_cast<double>(cfg.init_stdev) / std::sqrt(static_cast<double>(K))));
     for (size_t i = 0; i < h.size(); i++) h[i] = dist(gen);
   }  // init_stdev <= 0: the reference leaves the matrix uninitialised; we zero it
   return h;
@@ -529,31 +536,18 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
   IRS_HIP(hipGetLastError());
 }
 
-// IRSPACK_AMD_IALS_WAVE128=0 sends K in (64, 128] to the workgroup-per-row kernels.
-static bool wave_path_at_128() {
-  static bool v = [] {
-    const char *e = std::getenv("IRSPACK_AMD_IALS_WAVE128");
-    return e ? std::atoi(e) != 0 : true;
-  }();
-  return v;
+// Development switches, read when a trainer is created (so one process can A/B two trainers):
+//   IRSPACK_AMD_IALS_WAVE128=0  sends K in (64, 128] to the workgroup-per-row kernels
+//   IRSPACK_AMD_IALS_UNIT=0     keeps binary interactions on the general rank-update code
+//   IRSPACK_AMD_IALS_SHORT=0    sends the short rows of a CG step through the general kernels
+static bool env_flag(const char *name, bool dflt) {
+  const char *e = std::getenv(name);
+  return e ? std::atoi(e) != 0 : dflt;
 }
-
-// IRSPACK_AMD_IALS_UNIT=0 keeps binary interactions on the general rank-update code.
-static bool unit_path_enabled() {
-  static bool v = [] {
-    const char *e = std::getenv("IRSPACK_AMD_IALS_UNIT");
-    return e ? std::atoi(e) != 0 : true;
-  }();
-  return v;
-}
-
-// IRSPACK_AMD_IALS_SHORT=0 sends the short rows of a CG step through the general kernels too.
-static bool short_rows_enabled() {
-  static bool v = [] {
-    const char *e = std::getenv("IRSPACK_AMD_IALS_SHORT");
-    return e ? std::atoi(e) != 0 : true;
-  }();
-  return v;
+void read_switches(irs_ials_trainer *t) {
+  t->opt_wave128 = env_flag("IRSPACK_AMD_IALS_WAVE128", true);
+  t->opt_unit = env_flag("IRSPACK_AMD_IALS_UNIT", true);
+  t->opt_short = env_flag("IRSPACK_AMD_IALS_SHORT", true);
 }
 
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
@@ -591,12 +585,12 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   p.warm_start = 1;
   p.zero_row = static_cast<int32_t>(ceil_div(sd.n_other, 8) * 8);
   // (the UNIT kernels address the gathered table with 32-bit byte offsets)
-  const bool unit = sd.unit && unit_path_enabled() && other == t->factor[1 - pidx].ptr &&
+  const bool unit = sd.unit && t->opt_unit && other == t->factor[1 - pidx].ptr &&
                     static_cast<uint64_t>(p.zero_row + 8) * t->KP * sizeof(float) < (uint64_t(1) << 32);
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
   // CG, short rows: the matrix-free kernel takes the tail of the longest-first task list
   int n_regular = sd.n_tasks;
-  if (cg && prior == nullptr && sd.n_short > 0 && (t->T <= 4 || t->T == 8) && short_rows_enabled()) {
+  if (cg && prior == nullptr && sd.n_short > 0 && (t->T <= 4 || t->T == 8) && t->opt_short) {
     n_regular = sd.n_tasks - sd.n_short;
     int n_cu = 0;
     IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device));
@@ -621,7 +615,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     t->prof.end(t->stream);
     p.n_tasks = n_regular;
   }
-  if (t->T == 8 && wave_path_at_128()) {
+  if (t->T == 8 && t->opt_wave128) {
     // 64 < K <= 128: the 36 tiles still fit one wave's 512 registers (144 of them
     // accumulators), so the one-wave-per-task kernel is reused with the MFMA panel Cholesky /
     // a two-rows-per-lane CG (46 KB LDS per wave for the spilled tiles: three waves per CU)

@@ -22,6 +22,16 @@ SHAPES: Dict[str, Dict] = {
                  dmax=150, pop_exp=0.8),
     "small": dict(n_users=4_000, n_items=1_500, nnz=200_000, seed=11, mu=3.6, sigma=1.0,
                   dmin=2, dmax=1_200, pop_exp=1.0),
+    # C4  BASELINE configs[3]: 10 M users x 1 M items, ~1e8 stored entries, short rows
+    # (degree = 1 + geometric(p = 1/9) clipped at 2,000; Zipf(1.0) items); SURVEY.md 8(d)
+    "c4": dict(kind="geometric", n_users=10_000_000, n_items=1_000_000, p=1.0 / 9, dmax=2_000,
+               seed=4000, pop_exp=1.0),
+    # the same generator at 1/50 of the size (parity tests) and at 1/5 (a bench leg that fits
+    # any host)
+    "c4_small": dict(kind="geometric", n_users=200_000, n_items=20_000, p=1.0 / 9, dmax=2_000,
+                     seed=4001, pop_exp=1.0),
+    "c4_fifth": dict(kind="geometric", n_users=2_000_000, n_items=200_000, p=1.0 / 9, dmax=2_000,
+                     seed=4002, pop_exp=1.0),
 }
 
 
@@ -41,6 +51,8 @@ def _degrees(rng: np.random.Generator, n: int, target_nnz: int, mu: float, sigma
 def make_interactions(name: str = "ml20m", dtype=np.float32) -> sps.csr_matrix:
     """CSR [n_users, n_items] for one of SHAPES (realised nnz is close to the target)."""
     cfg = SHAPES[name]
+    if cfg.get("kind") == "geometric":
+        return _make_geometric(cfg, dtype)
     rng = np.random.default_rng(cfg["seed"])
     U, I = cfg["n_users"], cfg["n_items"]
     deg = _degrees(rng, U, cfg["nnz"], cfg["mu"], cfg["sigma"], cfg["dmin"], min(cfg["dmax"], I))
@@ -73,6 +85,30 @@ def make_interactions(name: str = "ml20m", dtype=np.float32) -> sps.csr_matrix:
     indices = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int32)
     data = np.ones(indices.size, dtype=dtype)
     X = sps.csr_matrix((data, indices, indptr), shape=(U, I))
+    X.has_sorted_indices = True
+    return X
+
+
+def _make_geometric(cfg: Dict, dtype) -> sps.csr_matrix:
+    """Vectorised generator of the short-row shapes: draws with replacement by popularity,
+    duplicates inside a row removed (the realised nnz is a little below the draw count)."""
+    rng = np.random.default_rng(cfg["seed"])
+    U, I = cfg["n_users"], cfg["n_items"]
+    deg = np.minimum(1 + rng.geometric(cfg["p"], size=U), min(cfg["dmax"], I)).astype(np.int64)
+    rows = np.repeat(np.arange(U, dtype=np.int64), deg)
+    w = (np.arange(I, dtype=np.float64) + 1.0) ** (-cfg["pop_exp"])
+    cdf = np.cumsum(w / w.sum())
+    cols = np.minimum(np.searchsorted(cdf, rng.random(rows.shape[0]), side="right"), I - 1)
+    cols = rng.permutation(I)[cols]  # popularity rank -> item id
+    key = np.unique(rows * I + cols)  # sorted by (row, column)
+    del rows, cols
+    r = key // I
+    indices = (key - r * I).astype(np.int32)
+    del key
+    indptr = np.zeros(U + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=U), out=indptr[1:])
+    del r
+    X = sps.csr_matrix((np.ones(indices.shape[0], dtype=dtype), indices, indptr), shape=(U, I))
     X.has_sorted_indices = True
     return X
 

@@ -94,7 +94,8 @@ void initialize(float *factor, int64_t rows, int64_t K, const ModelConfig &c) {
   if (c.init_stdev > 0) {
     std::mt19937 gen(c.random_seed);
     std::normal_distribution<float> dist(
-        0.0, c.init_stdev / std::sqrt(static_cast<float>(K)));
+        // hpp:68-69: std::sqrt(factor.cols()) is the integral overload -> double quotient
+        0.0, static_cast<float>(static_cast<double>(c.init_stdev) / std::sqrt(static_cast<double>(K))));
     for (int64_t i = 0; i < rows; i++)
       for (int64_t k = 0; k < K; k++) factor[i * K + k] = dist(gen);
   } else {

@@ -82,3 +82,19 @@ def random_csr(n_rows, n_cols, density, seed, dtype=np.float32, binary=False, em
     M = M.tocsr().astype(dtype)
     M.sort_indices()
     return M
+
+
+def row_rel_err(a, b) -> float:
+    """Worst row of ``||a_r - b_r||_2 / ||b_r||_2`` — the reading of north_star's "1e-4 relative
+    on factor matrices / scores" that a small row cannot hide behind a large one.  A row that is
+    exactly zero in ``b`` must be exactly zero in ``a`` (else inf)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    num = np.linalg.norm(a2 - b2, axis=1)
+    den = np.linalg.norm(b2, axis=1)
+    err = np.where(den > 0, num / np.where(den > 0, den, 1.0), np.where(num > 0, np.inf, 0.0))
+    return float(err.max())

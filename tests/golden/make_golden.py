@@ -5,8 +5,9 @@ values are produced the way the reference's OWN tests produce theirs: float64
 closed forms in numpy / sklearn on the inputs those tests use
 (/root/reference/tests/recommenders/test_ials.py, test_knn.py,
 tests/evaluation/test_evaluator.py).  The one exception is the factor-init
-stream, which comes from libstdc++'s mt19937 + normal_distribution<float>
-(the classes IALSTrainer.hpp:64-76 calls) via the oracle.
+stream, which is restated here in Python from libstdc++'s mt19937 +
+normal_distribution<float> (the classes IALSTrainer.hpp:64-76 calls), independently of the
+oracle.
 
     python tests/golden/make_golden.py
 """
@@ -22,11 +23,62 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 X_SMALL = np.asarray([[1, 1, 2, 3, 4], [0, 1, 0, 1, 0], [0, 0, 1, 0, 0], [0, 0, 0, 0, 0]], dtype=float)
 
 
-def golden_init():
-    import oracle as O
+def libstdcxx_normal_stream(seed, n, stddev_f32):
+    """Independent restatement of libstdc++'s ``std::mt19937(seed)`` +
+    ``std::normal_distribution<float>(0, stddev)`` (bits/random.tcc: Marsaglia polar method on
+    ``generate_canonical<float, 24>``, the second variate saved), the classes
+    IALSTrainer.hpp:64-76 calls.  Raw 32-bit words come from numpy's legacy MT19937
+    (``RandomState(seed)`` seeds with init_genrand like std::mt19937); the float arithmetic is
+    done step by step in float32 with libm's logf / sqrtf (what libstdc++ calls)."""
+    import ctypes
 
-    np.savez(os.path.join(HERE, "ials_init_seed42.npz"),
-             K16=O.ials_init(8, 16, 0.1, 42), K64=O.ials_init(8, 64, 0.1, 42))
+    libm = ctypes.CDLL("libm.so.6")
+    libm.logf.restype = libm.sqrtf.restype = ctypes.c_float
+    libm.logf.argtypes = libm.sqrtf.argtypes = [ctypes.c_float]
+    f = np.float32
+    rs = np.random.RandomState(seed)
+    words = iter(())
+
+    def canonical():
+        nonlocal words
+        try:
+            w = next(words)
+        except StopIteration:
+            words = iter(np.frombuffer(rs.bytes(4 * 4096), dtype="<u4").tolist())
+            w = next(words)
+        r = f(w) / f(4294967296.0)  # (urng() - min) / 2^32 in float
+        return np.nextafter(f(1), f(0)) if r >= f(1) else r
+
+    out = np.empty(n, dtype=np.float32)
+    saved = None
+    for i in range(n):
+        if saved is not None:
+            ret, saved = saved, None
+        else:
+            while True:
+                x = f(f(2) * canonical() - f(1))
+                y = f(f(2) * canonical() - f(1))
+                r2 = f(f(x * x) + f(y * y))
+                if not (r2 > f(1) or r2 == f(0)):
+                    break
+            mult = f(libm.sqrtf(f(f(f(-2) * f(libm.logf(r2))) / r2)))
+            saved = f(x * mult)
+            ret = f(y * mult)
+        out[i] = f(f(ret * stddev_f32) + f(0))
+    return out
+
+
+def golden_init():
+    """Initial factors, hpp:64-76.  The stddev is init_stdev / std::sqrt(factor.cols()) with the
+    INTEGRAL sqrt overload, i.e. a double quotient rounded to float once; K = 10 / 40 are
+    dimensions where a float quotient would differ by one ulp."""
+    out = {}
+    for K in (10, 16, 40, 64):
+        sd = np.float32(np.float64(np.float32(0.1)) / np.sqrt(np.float64(K)))
+        out[f"K{K}"] = libstdcxx_normal_stream(42, 8 * K, sd).reshape(8, K)
+    assert np.float32(np.float32(0.1) / np.sqrt(np.float32(40))) != np.float32(
+        np.float64(np.float32(0.1)) / np.sqrt(40.0))
+    np.savez(os.path.join(HERE, "ials_init_seed42.npz"), **out)
 
 
 def golden_ials_halfstep():

@@ -1,0 +1,237 @@
+"""Parity AT BENCHMARK SIZE for the code paths bench.py times (BASELINE.json configs[1..4]).
+
+Everything here runs the product on the full ML-20M-shaped matrix (138,493 x 26,744,
+20.0 M stored entries) - the unit-confidence rank update with split rows, the two kNN column
+tiles, the 16,384-user evaluator blocks, the fused evaluator at K = 256 - and compares a ROW
+SAMPLE of the result with the CPU oracle, which would need minutes for the whole matrix.
+The sample always contains every row the kernels treat specially (all split rows, the longest
+unsplit rows, the heaviest kNN rows).
+
+Bars: factors per row ``||gpu_r - oracle_r|| / ||oracle_r|| < 1e-4`` (north_star); kNN indices
+bit-exact, values 1e-12; evaluator counters and histogram bit-exact, fp64 sums 1e-12.
+Reference semantics: IALSTrainer.hpp:273-331 (Cholesky), :170-271 (CG), knn.hpp:111-136,
+evaluator.cpp:292-367.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import oracle as O
+from conftest import row_rel_err
+from irspack_amd.evaluation._core_evaluator import EvaluatorCore
+from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder, IALSSolverConfigBuilder,
+                                                  IALSTrainer, SolverType)
+from irspack_amd.synthetic import make_interactions
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+CORES = os.cpu_count() or 1
+ALPHA0, REG = 0.1, 1e-3  # bench.py's hyper-parameters
+
+
+@pytest.fixture(scope="module")
+def X20():
+    X = make_interactions("ml20m")
+    assert X.shape == (138_493, 26_744) and np.all(X.data == 1.0)
+    return X
+
+
+@pytest.fixture(scope="module")
+def X20t(X20):
+    Xt = X20.T.tocsr()
+    Xt.sort_indices()
+    return Xt
+
+
+def configs(K, kind, alpha0=ALPHA0, reg=REG):
+    mc = (IALSModelConfigBuilder().set_K(K).set_alpha0(alpha0).set_reg(reg).set_nu(1.0)
+          .set_init_stdev(0.1).set_random_seed(42).build())
+    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType[kind])
+          .set_max_cg_steps(3).build())
+    omc = O.model_config(K, alpha0=alpha0, reg=reg, nu=1.0, init_stdev=0.1, random_seed=42)
+    osc = O.solver_config(CORES, kind, 3)
+    return mc, sc, omc, osc
+
+
+def half_step(t, side, sc):
+    t.partial_gramian_async(side)
+    t.finish_gramian_async(side)
+    t.half_step_async(side, sc)
+    t.synchronize()
+
+
+def row_sample(Xs, n_random, seed, chunk=1024, n_longest_unsplit=64):
+    """every split row (> chunk stored entries), the longest unsplit rows, random rows"""
+    nnz = np.diff(Xs.indptr)
+    split = np.flatnonzero(nnz > chunk)
+    unsplit = np.flatnonzero(nnz <= chunk)
+    longest = unsplit[np.argsort(-nnz[unsplit], kind="stable")[:n_longest_unsplit]]
+    rnd = np.random.default_rng(seed).choice(Xs.shape[0], size=min(n_random, Xs.shape[0]), replace=False)
+    return np.unique(np.concatenate([split, longest, rnd])), split
+
+
+def oracle_rows(target0, Xs, rows, other0, omc, osc):
+    """Solver::step of the oracle over `rows` only (sub-CSR with the same columns, so the
+    per-row regulariser reg * (alpha0 * n_other + nnz_r)^nu is unchanged)."""
+    P = O.ials_gramian(other0, omc.alpha0, CORES)
+    return O.ials_solver_step(target0[rows], Xs[rows], other0, P, omc, osc)
+
+
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_ials_k64_ml20m_benchmarked_kernels_vs_oracle(X20, X20t, kind):
+    """configs[1]: K = 64, binary data -> ials_solve_kernel<4, *, 0, UNIT> with split rows
+    (the 116 k-entry item row runs as 32 chunks) + the MODE 1 reduction.  One half-step per
+    side from identical factors; sample = all split rows + 64 longest unsplit + 2,000 random."""
+    K = 64
+    mc, sc, omc, osc = configs(K, kind)
+    t = IALSTrainer(mc, X20)
+    t.step(sc)  # factors with structure (a trained epoch), then frozen as the common input
+    user0, item0 = t.user, t.item
+    worst = {}
+    for side, (Xs, tgt0, oth0) in enumerate(((X20, user0, item0), (X20t, item0, user0))):
+        t.user, t.item = user0, item0
+        half_step(t, side, sc)
+        got = t.user if side == 0 else t.item
+        rows, split = row_sample(Xs, 2000, seed=side)
+        assert split.size > 1000  # the split path is really exercised
+        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+        worst[side] = row_rel_err(got[rows], want)
+        assert worst[side] < RTOL, (kind, side, worst)
+        assert np.isfinite(got).all()
+    # the general (non-unit) rank update on the same inputs: with loss = IALSPP (bias 0) the
+    # two code paths perform the same float operations
+    os.environ["IRSPACK_AMD_IALS_UNIT"] = "0"
+    try:
+        g = IALSTrainer(mc, X20)
+    finally:
+        del os.environ["IRSPACK_AMD_IALS_UNIT"]
+    for side in (0, 1):
+        t.user, t.item = user0, item0
+        g.user, g.item = user0, item0
+        half_step(t, side, sc)
+        half_step(g, side, sc)
+        a, b = (t.user, g.user) if side == 0 else (t.item, g.item)
+        assert row_rel_err(a, b) < 1e-6, (kind, side)
+
+
+@pytest.mark.parametrize("name,normalize", [("cosine", True), ("cosine", False), ("jaccard", False)])
+def test_knn_top100_ml20m_rows_vs_oracle(X20t, name, normalize):
+    """configs[2]: the whole 26,744 x 26,744 top-100 call bench.py times (two column tiles,
+    16-bit tile-relative offsets, persistent workgroups), checked on the 100 heaviest target
+    rows + 400 random ones.  `normalize=False` is the reference's default: raw co-occurrence
+    counts, where the (value desc, column asc) rule decides most rows (knn.hpp:119-125)."""
+    from irspack_amd.recommenders._knn import CosineSimilarityComputer, JaccardSimilarityComputer
+
+    Xt = sps.csr_matrix(X20t, dtype=np.float64)
+    if name == "cosine":
+        comp = CosineSimilarityComputer(Xt, 0.0, normalize)
+        ocomp = O.KNNComputer("cosine", Xt, 0.0, normalize=normalize, n_threads=CORES, max_chunk_size=4)
+    else:
+        comp = JaccardSimilarityComputer(Xt, 0.0)
+        ocomp = O.KNNComputer("jaccard", Xt, 0.0, n_threads=CORES, max_chunk_size=4)
+    got = comp.compute_similarity(Xt, 100)
+    got.sort_indices()
+    nnz = np.diff(Xt.indptr)
+    heavy = np.argsort(-nnz, kind="stable")[:100]
+    rnd = np.random.default_rng(9).choice(Xt.shape[0], size=400, replace=False)
+    rows = np.unique(np.concatenate([heavy, rnd]))
+    want = ocomp.compute_similarity(Xt[rows], 100)
+    want.sort_indices()
+    sub = got[rows]
+    sub.sort_indices()
+    assert np.array_equal(sub.indptr, want.indptr)
+    assert np.array_equal(sub.indices, want.indices)  # bit-exact top-k sets
+    np.testing.assert_allclose(sub.data, want.data, rtol=1e-12, atol=0)
+    assert np.diff(got.indptr).max() <= 100
+
+
+def holdout(X, seed=5):
+    """one held-out interaction per user as ground truth, the rest as the mask (bench.py)"""
+    U = X.shape[0]
+    rng = np.random.default_rng(seed)
+    pick = X.indptr[:-1] + (rng.random(U) * np.diff(X.indptr)).astype(np.int64)
+    gt = sps.csr_matrix((np.ones(U), (np.arange(U), X.indices[pick])), shape=X.shape)
+    keep = np.ones(X.nnz, dtype=bool)
+    keep[pick] = False
+    rows = np.repeat(np.arange(U), np.diff(X.indptr))
+    mask = sps.csr_matrix((np.ones(int(keep.sum()), dtype=np.float32), (rows[keep], X.indices[keep])),
+                          shape=X.shape)
+    return gt, mask
+
+
+def compare_metrics(m, om):
+    np.testing.assert_array_equal(m.item_cnt, om.item_cnt())  # bit-exact histogram
+    raw = om.raw()
+    assert m.valid_user == int(raw[0]) and m.total_user == int(raw[1])  # bit-exact counters
+    np.testing.assert_allclose([m.hit, m.recall, m.ndcg, m.precision, m.map], raw[2:], rtol=1e-12)
+    d, od = m.as_dict(), om.as_dict()
+    for k in O.METRIC_KEYS:
+        assert d[k] == pytest.approx(od[k], rel=1e-12, abs=1e-15), k
+
+
+def masked_scores(t, b, e, mask, sc):
+    scores = t.user_scores(b, e, sc)
+    m = mask[b:e].tocoo()
+    scores[m.row, m.col] = -np.inf  # base.py:308-337
+    return scores
+
+
+def test_evaluator_ndcg20_block_at_ml20m_width(X20):
+    """A 4,096 x 26,744 float32 score block with masked (-inf) training entries through
+    get_metrics_f32 (rank_wave_kernel and its hand-off to the general kernel at I = 26,744)."""
+    mc, sc, _, _ = configs(64, "CG")
+    t = IALSTrainer(mc, X20)
+    t.step(sc)
+    gt, mask = holdout(X20)
+    b, e = 50_000, 54_096
+    scores = masked_scores(t, b, e, mask, sc)
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    for cutoff in (20, 100):
+        compare_metrics(core.get_metrics_f32(scores, cutoff, b, 1),
+                        ocore.get_metrics_f32(scores, cutoff, b, CORES))
+
+
+@pytest.mark.parametrize("K", [64, 256])
+def test_fused_evaluator_ml20m_vs_oracle(X20, K):
+    """configs[4] (K = 256) and the bench's secondary leg (K = 64): the fused device path
+    (score + mask + rank without the block leaving HBM) over 20,000 users = two 16,384-user
+    device blocks, against the oracle fed the same scores (user_scores) masked on the host."""
+    mc, sc, _, _ = configs(K, "CG")
+    t = IALSTrainer(mc, X20)
+    t.step(sc)
+    gt, mask = holdout(X20)
+    b, e = 1_000, 21_000
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    sub = sps.csr_matrix(mask[b:e])
+    got = core.get_metrics_ials(t, b, e, sub, 20, b, False)
+    scores = masked_scores(t, b, e, mask, sc)
+    compare_metrics(got, ocore.get_metrics_f32(scores, 20, b, CORES))
+    # and the whole user range runs (the bench call); totals must cover every user
+    full = core.get_metrics_ials(t, 0, X20.shape[0], mask, 20, 0, False)
+    assert full.total_user == X20.shape[0] and full.valid_user == X20.shape[0]
+
+
+@pytest.mark.parametrize("kind", ["CG", "CHOLESKY"])
+def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
+    """configs[3] shape at 1/50 scale: 200 k x 20 k, geometric degrees (mean 9), Zipf items whose
+    head rows are split (107 k entries); K = 128.  CG takes the matrix-free short-row kernels
+    for <= 32 entries, the wave kernel above; every row is compared."""
+    X = make_interactions("c4_small")
+    Xt = X.T.tocsr()
+    Xt.sort_indices()
+    K = 128
+    mc, sc, omc, osc = configs(K, kind)
+    t = IALSTrainer(mc, X)
+    t.step(sc)
+    user0, item0 = t.user, t.item
+    for side, (Xs, tgt0, oth0) in enumerate(((X, user0, item0), (Xt, item0, user0))):
+        t.user, t.item = user0, item0
+        half_step(t, side, sc)
+        got = t.user if side == 0 else t.item
+        rows, _ = row_sample(Xs, 20_000, seed=10 + side)
+        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+        assert row_rel_err(got[rows], want) < RTOL, (kind, side)
+        assert np.isfinite(got).all()

@@ -9,7 +9,7 @@ import pytest
 import scipy.sparse as sps
 
 import oracle as O
-from conftest import random_csr
+from conftest import random_csr, row_rel_err
 from irspack_amd.recommenders._ials_core import (
     IALSModelConfigBuilder,
     IALSSolverConfigBuilder,
@@ -23,8 +23,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # relative, on factor matrices and scores
 
 
-def rel_err(a, b):
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+rel_err = row_rel_err  # per row: ||a_r - b_r|| / ||b_r||, worst row
 
 
 def build(K, alpha0=0.1, reg=1e-3, nu=1.0, loss="IALSPP", init=0.1, seed=42):
