@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "ials_kernels.hpp"
 #include "ials_wg_kernels.hpp"
+#include "ials_wg16_kernels.hpp"
 #include "ials_pp_kernels.hpp"
 #include "ials_feature_kernels.hpp"
 #include "ials_short_kernels.hpp"
@@ -271,7 +272,7 @@ struct irs_ials_trainer {
   DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   Profiler prof;
-  bool opt_wave128 = true, opt_unit = true, opt_short = true;  // read_switches()
+  bool opt_wave128 = true, opt_unit = true, opt_short = true, opt_wg16 = true;  // read_switches()
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
 };
@@ -540,6 +541,7 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
 //   IRSPACK_AMD_IALS_WAVE128=0  sends K in (64, 128] to the workgroup-per-row kernels
 //   IRSPACK_AMD_IALS_UNIT=0     keeps binary interactions on the general rank-update code
 //   IRSPACK_AMD_IALS_SHORT=0    sends the short rows of a CG step through the general kernels
+//   IRSPACK_AMD_IALS_WG16=0     Cholesky at K > 64 on the first-generation kernels (4-row panels)
 static bool env_flag(const char *name, bool dflt) {
   const char *e = std::getenv(name);
   return e ? std::atoi(e) != 0 : dflt;
@@ -548,6 +550,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_wave128 = env_flag("IRSPACK_AMD_IALS_WAVE128", true);
   t->opt_unit = env_flag("IRSPACK_AMD_IALS_UNIT", true);
   t->opt_short = env_flag("IRSPACK_AMD_IALS_SHORT", true);
+  t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
 }
 
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
@@ -615,7 +618,26 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     t->prof.end(t->stream);
     p.n_tasks = n_regular;
   }
-  if (t->T == 8 && t->opt_wave128) {
+  if (!cg && t->T >= 8 && t->opt_wg16) {
+    // 64 < K <= 256, Cholesky: 16-row block steps on the matrix cores (ials_wg16_kernels.hpp)
+    IRS_DISPATCH_TW(t->T, {
+      using G = Geo<TT>;
+      constexpr size_t lds = WgChol<TT>::LDS_FLOATS * sizeof(float);
+      t->split_partial.alloc(static_cast<size_t>(std::max(sd.n_slots, 1)) * G::PARTIAL_FLOATS);
+      p.partials = t->split_partial.ptr;
+      auto launch = [&](auto kernel, int n_items, const char *name) {
+        if (n_items <= 0) return;
+        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        t->prof.begin(name, t->stream);
+        hipLaunchKernelGGL(kernel, dim3(n_items), dim3(256), lds, t->stream, p);
+        t->prof.end(t->stream);
+      };
+      launch(ials_wg16_cholesky_kernel<TT, 0>, n_regular, kNames[0][0][pidx]);
+      launch(ials_wg16_cholesky_kernel<TT, 1>, sd.n_split, kNames[0][1][pidx]);
+    });
+  } else if (t->T == 8 && t->opt_wave128) {
     // 64 < K <= 128: the 36 tiles still fit one wave's 512 registers (144 of them
     // accumulators), so the one-wave-per-task kernel is reused with the MFMA panel Cholesky /
     // a two-rows-per-lane CG (46 KB LDS per wave for the spilled tiles: three waves per CU)
