@@ -15,6 +15,7 @@
 
 #include "common.hpp"
 #include "ials_kernels.hpp"
+#include "ials_chol16.hpp"
 #include "ials_wg_kernels.hpp"
 #include "ials_wg16_kernels.hpp"
 #include "ials_pp_kernels.hpp"
@@ -258,7 +259,7 @@ struct irs_ials_trainer {
   irs_ials_shard shard{0, 0, 0, 0};
   DeviceBuffer<float> factor[2];                  // 0 user, 1 item
   Side side[2];                                   // 0: X (solve users), 1: X^T (solve items)
-  DeviceBuffer<float> P_raw[2], P[2], P_acc[2];   // [s]: Gramian used by the solve of side s
+  DeviceBuffer<float> P_raw[2], P[2], P_acc[2], P_accL[2];   // [s]: Gramian used by the solve of side s
   DeviceBuffer<float> gram_partial, split_partial, row_loss;
   DeviceBuffer<double> loss_sum;
   DeviceBuffer<int32_t> err_flag;
@@ -341,6 +342,8 @@ void alloc_common(irs_ials_trainer *t) {
     t->P_raw[w].alloc(t->KP * t->KP);
     t->P[w].alloc(t->KP * t->KP);
     t->P_acc[w].alloc(t->KP * t->KP);
+    t->P_accL[w].alloc(t->KP * t->KP);
+    t->P_accL[w].zero(t->stream);
     t->P_raw[w].zero(t->stream);
     t->P[w].zero(t->stream);
     t->P_acc[w].zero(t->stream);
@@ -435,7 +438,7 @@ void launch_finish_gramian(irs_ials_trainer *t, int dst) {
     t->prof.begin("gramian_finish", t->stream);
     hipLaunchKernelGGL((gramian_finish_kernel<TT>), dim3(ceil_div(G::KP * G::KP, 256)),
                        dim3(256), 0, t->stream, t->P_raw[dst].ptr, t->cfg.alpha0,
-                       t->P[dst].ptr, t->P_acc[dst].ptr);
+                       t->P[dst].ptr, t->P_acc[dst].ptr, t->P_accL[dst].ptr);
     t->prof.end(t->stream);
   });
   IRS_HIP(hipGetLastError());
@@ -579,6 +582,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   p.target = target;
   p.reg = sd.reg.ptr;
   p.P_acc = t->P_acc[pidx].ptr;
+  p.P_accL = t->P_accL[pidx].ptr;
   p.err_flag = t->err_flag.ptr;
   p.bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;  // hpp:190-191
   p.K = static_cast<int32_t>(t->K);
@@ -618,8 +622,11 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     t->prof.end(t->stream);
     p.n_tasks = n_regular;
   }
-  if (!cg && t->T >= 8 && t->opt_wg16) {
-    // 64 < K <= 256, Cholesky: 16-row block steps on the matrix cores (ials_wg16_kernels.hpp)
+  if (!cg && (t->T >= 12 || (t->T == 8 && !t->opt_wave128)) && t->opt_wg16) {
+    // 128 < K <= 256, Cholesky: one workgroup per row, 16-row block steps on the matrix cores
+    // (ials_wg16_kernels.hpp).  K <= 128 stays on the one-wave-per-row kernel, whose solve is the
+    // same block algorithm in one wave (ials_chol16.hpp): ML-20M shape, K = 128: 8.7 ms against
+    // 12.5 ms per epoch, because four waves per row repeat the gather's vector work four times.
     IRS_DISPATCH_TW(t->T, {
       using G = Geo<TT>;
       constexpr size_t lds = WgChol<TT>::LDS_FLOATS * sizeof(float);

@@ -63,7 +63,8 @@ struct SolveParams {
   const float *other;   // gathered factors [n_other, KP]
   float *target;        // solved factors   [n_rows, KP]
   const float *reg;     // per-row regulariser, hpp:117-120 (host powf)
-  const float *P_acc;   // alpha0 * F^T F in accumulator layout
+  const float *P_acc;   // alpha0 * F^T F in accumulator layout (upper tiles)
+  const float *P_accL;  // the same in LOWER form: slot (a, b) = tile (row block b, column block a)
   float *partials;      // split-row scratch
   int32_t *err_flag;    // bit 0: pivot <= 0, bit 1: non-finite solution, bit 2: CG singular
   float bias;           // observation_bias, hpp:289-290
@@ -170,7 +171,9 @@ __device__ __forceinline__ void mfma_tiles(const float (&cv)[T], const float (&v
 // the row's end is neutralised by gathering the all-zero row `zero_row` - 7 of the 26 vector
 // instructions of a sub-step disappear (they cost the same issue cycles as the MFMAs' own,
 // see DESIGN 3.1).
-template <int T, int NW = 1, int W = 0, int D = 8, bool UNIT = false>
+// LOWER: slot tix(i, j), i <= j, accumulates the tile (row block j, column block i) instead of
+// its transpose (the single-wave block Cholesky of ials_chol16.hpp works on lower tiles).
+template <int T, int NW = 1, int W = 0, int D = 8, bool UNIT = false, bool LOWER = false>
 __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
                                             const int32_t *__restrict__ indices,
                                             const float *__restrict__ data, int begin,
@@ -238,7 +241,10 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
       for (int i = 0; i < T; i++)
 #pragma unroll
         for (int j = i; j < T; j++) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], v[k][j], acc[t], 0, 0, 0);
+          if constexpr (LOWER)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[j], v[k][i], acc[t], 0, 0, 0);
+          else
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], v[k][j], acc[t], 0, 0, 0);
           t++;
         }
     } else {
@@ -263,6 +269,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   __builtin_amdgcn_sched_barrier(0);
   int s0 = 0;  // first sub-step of the current block
   static_assert(16 % D == 0 && D < 16, "the gather ring must divide the 16 sub-steps of a block");
+  static_assert(!LOWER || NW == 1, "lower-form tiles: single-wave kernels only");
   auto block = [&](int &cur_i, float &cur_c, const int nxt_i, const float nxt_c, auto all_valid) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {  // sub-step j of this block; its gather was issued D earlier
@@ -764,6 +771,13 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
   for (int q = 0; q < 2; q++) xrow[dim[q]] = act[q] ? x[q] : 0.f;
 }
 
+// The Cholesky solve of these kernels lives in ials_chol16.hpp (which includes this header).
+template <int T> struct Chol16Geo;
+template <int T>
+__device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
+                                                     float reg, float *sm, float *xrow, int K,
+                                                     int32_t *err_flag);
+
 // MODE 0: one wave per task.  Whole rows are solved inline; chunks of split
 //         rows store their partial Gramian / rhs.
 // MODE 1: one wave per split row: sum the partials in slot order and solve.
@@ -775,9 +789,13 @@ __device__ unsigned long long ials_phase_clk[2 * 4096];  // development: device-
 #endif
 
 template <int T, int SOLVER, int MODE, bool UNIT = false>
-__global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
+__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
   using G = Geo<T>;
-  constexpr int LDS_PER_WAVE = (SOLVER == 0 || T == 8) ? CholGeo<T>::LDS_FLOATS : G::LDS_FLOATS;
+  // Cholesky: lower-form tiles + the 16-row block solve of ials_chol16.hpp
+  constexpr bool LOWER = SOLVER == 0;
+  constexpr int RING = (T > 4 && SOLVER == 0) ? 4 : 8;  // gathered sub-steps in flight
+  constexpr int LDS_PER_WAVE = SOLVER == 0 ? Chol16Geo<T>::LDS_FLOATS
+                                           : (T == 8 ? CholGeo<T>::LDS_FLOATS : G::LDS_FLOATS);
   __shared__ __attribute__((aligned(16))) float lds[SOLVE_WAVES * LDS_PER_WAVE];
   const int wid = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
   float bsum[T];
 #pragma unroll
   for (int i = 0; i < T; i++) bsum[i] = 0.f;
-  const f32x4 *Pacc = reinterpret_cast<const f32x4 *>(p.P_acc);
+  const f32x4 *Pacc = reinterpret_cast<const f32x4 *>(LOWER ? p.P_accL : p.P_acc);
 
 #ifdef IRS_IALS_PHASES
   unsigned long long ph_t = wall_clock64();
@@ -803,8 +821,8 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
 #pragma unroll
       for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    syrk_gather<T, 1, 0, 8, UNIT>(p.other, p.indices, p.data, task.begin, task.end, p.bias, acc,
-                                  bsum, static_cast<unsigned>(p.zero_row));
+    syrk_gather<T, 1, 0, RING, UNIT, LOWER>(p.other, p.indices, p.data, task.begin, task.end, p.bias,
+                                            acc, bsum, static_cast<unsigned>(p.zero_row));
     IPHASE(0);
     if (task.slot >= 0) {
       float *dst = p.partials + static_cast<size_t>(task.slot) * G::PARTIAL_FLOATS;
@@ -821,8 +839,8 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
     // with a prior an empty row is solved like any other (hpp:207): hide nnz == 0 from CG
     const int nnz_cg = p.prior ? max(task.end - task.begin, 1) : task.end - task.begin;
     if constexpr (SOLVER == 0)
-      solve_row_cholesky<T>(acc, bsum, p.reg[task.row], sm,
-                            p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag);
+      solve_row_cholesky16<T>(acc, bsum, p.reg[task.row], sm,
+                              p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag);
     else if constexpr (T == 8)
       solve_row_cg128<T>(acc, bsum, p.reg[task.row], sm,
                          p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
@@ -865,8 +883,8 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, T > 4 ? 1 : SOLVE_MIN_WAVES_PER_S
     }
     add_prior<T>(p, sr.row, bsum);
     if constexpr (SOLVER == 0)
-      solve_row_cholesky<T>(acc, bsum, p.reg[sr.row], sm,
-                            p.target + static_cast<size_t>(sr.row) * G::KP, p.K, p.err_flag);
+      solve_row_cholesky16<T>(acc, bsum, p.reg[sr.row], sm,
+                              p.target + static_cast<size_t>(sr.row) * G::KP, p.K, p.err_flag);
     else if constexpr (T == 8)
       solve_row_cg128<T>(acc, bsum, p.reg[sr.row], sm,
                          p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
@@ -963,7 +981,8 @@ __global__ __launch_bounds__(256) void gramian_reduce_kernel(const float *__rest
 // P = alpha0 * P_raw (hpp:113) in both row-major and accumulator layout.
 template <int T>
 __global__ void gramian_finish_kernel(const float *__restrict__ P_raw, float alpha0,
-                                      float *__restrict__ P, float *__restrict__ P_acc) {
+                                      float *__restrict__ P, float *__restrict__ P_acc,
+                                      float *__restrict__ P_accL) {
   using G = Geo<T>;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < G::KP * G::KP) P[e] = alpha0 * P_raw[e];
@@ -977,6 +996,9 @@ __global__ void gramian_finish_kernel(const float *__restrict__ P_raw, float alp
     const int gg = lane >> 4, m = lane & 15;
     const int row = T * (4 * gg + r) + ti, col = T * m + tj;
     P_acc[e] = alpha0 * P_raw[row * G::KP + col];
+    // lower form: slot (ti, tj) holds the tile (row block tj, column block ti)
+    const int rowL = T * (4 * gg + r) + tj, colL = T * m + ti;
+    P_accL[e] = alpha0 * P_raw[rowL * G::KP + colL];
   }
 }
 

@@ -23,6 +23,7 @@
 // Everything works in the virtual basis k = 16 I + m' <-> latent dim T m' + I (the basis the
 // MFMA tiles are in), a symmetric permutation that changes neither the factorisation nor x.
 #pragma once
+#include "ials_chol16.hpp"
 #include "ials_wg_kernels.hpp"
 
 namespace irs {
@@ -177,53 +178,6 @@ __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 4, 64);
   v += __shfl_xor(v, 8, 64);
   return v;
-}
-
-// (1) S = R^T R of one 16 x 16 tile in accumulator layout, E = R^-T alongside.
-//     `Cd` is consumed; its strictly lower triangle only ever holds rounding noise and is
-//     never read as a result.  scrR / scrE: 4 x 17 floats each, private to the wave.
-__device__ __forceinline__ void diag_factor16(f32x4 &Cd, f32x4 &E, float *scrR, float *scrE,
-                                              bool &bad) {
-  const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, m = lane & 15;
-#pragma unroll
-  for (int r = 0; r < 4; r++) E[r] = (4 * g + r == m) ? 1.0f : 0.0f;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const bool mine = g == q;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float piv = readlane_f(Cd[r], 20 * q + r);
-      bad |= !(piv > 0.f);
-      const float rinv = __builtin_amdgcn_rsqf(piv);
-      const float mult = mine ? rinv : 1.0f;
-      Cd[r] *= mult;
-      E[r] *= mult;
-#pragma unroll
-      for (int r2 = r + 1; r2 < 4; r2++) {
-        const float sv = readlane_f(Cd[r], 20 * q + r2);  // R[k][k2]
-        const float sm_ = mine ? sv : 0.f;
-        Cd[r2] = fmaf(-sm_, Cd[r], Cd[r2]);
-        E[r2] = fmaf(-sm_, E[r], E[r2]);
-      }
-    }
-    if (q == 3) break;
-    // rows 4q .. 4q+3 are final: rank-4 update of the rows below them (and of E)
-    if (mine) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        scrR[r * 17 + m] = Cd[r];
-        scrE[r * 17 + m] = E[r];
-      }
-    }
-    __threadfence_block();
-    const float a = scrR[g * 17 + m];
-    const float e = scrE[g * 17 + m];
-    __threadfence_block();
-    const float na = (m > 4 * q + 3) ? -a : 0.f;  // rows up to the sub-panel are final
-    Cd = __builtin_amdgcn_mfma_f32_16x16x4f32(na, a, Cd, 0, 0, 0);
-    E = __builtin_amdgcn_mfma_f32_16x16x4f32(na, e, E, 0, 0, 0);
-  }
 }
 
 // (2) one tile of block row I: S -> R = E S, returned in accumulator layout.
