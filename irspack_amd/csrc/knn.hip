@@ -33,7 +33,8 @@ namespace irs {
 namespace knn {
 
 constexpr int TILE = 16384;     // columns per workgroup (128 KB of fp64 accumulators)
-constexpr int TOPK_CAP = 2048;  // largest top_k: two candidate sets must fit one merge round
+constexpr int TOPK_CAP = 2048;  // largest top_k of the LDS row merge (two candidate sets must fit one
+                                // round); above it the rows are merged by knn_merge_big_kernel
 constexpr int MERGE_CAP = 4096; // candidates a row merge can hold
 constexpr int THREADS = 1024;
 
@@ -58,8 +59,9 @@ struct Params {
   int32_t normalize;
   double shrinkage, alpha, beta;
   int32_t top_k;
-  // per (row slot, tile) winners
-  int32_t *cand_idx;   // [n_rows * n_tiles * top_k]
+  int32_t tile_k;      // winners one (row, tile) pair can hold: min(top_k, TILE)
+  // per (row slot, tile) winners, in ascending column order
+  int32_t *cand_idx;   // [n_rows * n_tiles * tile_k]
   double *cand_val;
   int32_t *cand_cnt;   // [n_rows * n_tiles]
   // final rows
@@ -455,8 +457,8 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   }
   __syncthreads();  // red / wave_cnt are reused below
   const int n_sel = min(p.top_k, n_stored);
-  int32_t *cidx = p.cand_idx + static_cast<size_t>(bid) * p.top_k;
-  double *cval = p.cand_val + static_cast<size_t>(bid) * p.top_k;
+  int32_t *cidx = p.cand_idx + static_cast<size_t>(bid) * p.tile_k;
+  double *cval = p.cand_val + static_cast<size_t>(bid) * p.tile_k;
   if (tid == 0) p.cand_cnt[bid] = n_sel;
   if (n_sel == 0) continue;
   PHASE_MARK(3);
@@ -572,40 +574,52 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   } else {
     need = 0;  // everything is taken
   }
-  if (tid == 0) sh_count = 0;
-  __syncthreads();
   PHASE_MARK(4);
-  // Sweep 1 appends every key above the threshold (any order; the merge sorts) and counts
-  // this wave's ties; sweep 2 hands the `need` lowest-column ties their slots (knn.hpp:119-136:
-  // index-ordered on equal values).
+  // Ordered compaction: (wave, slot k, lane) order is column order, so the winners are
+  // written in ascending column order without atomics and the tile's list is column-sorted
+  // (the row merge for top_k > TOPK_CAP relies on it).  Pass A counts this wave's ties with
+  // the threshold key; pass B ranks the ties in column order (the `need` lowest columns win,
+  // knn.hpp:119-136) and counts this wave's winners; pass C writes them.
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int my_ties = 0;
+  if (!take_all && need > 0) {
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+      my_ties += __popcll(__ballot(((have >> k) & 1u) && key[k] == prefix));
+  }
+  __syncthreads();  // wave_cnt (stored entries per wave) has been read by everyone
+  if (lane == 0) wave_cnt[wv] = my_ties;
+  __syncthreads();
+  int ties_before = 0;
+  for (int w = 0; w < wv; w++) ties_before += wave_cnt[w];
+  uint32_t winmask = 0;
+  int my_wins = 0;
 #pragma unroll
   for (int k = 0; k < PER; k++) {
     const bool st = (have >> k) & 1u;
-    const bool win = st && (take_all || key[k] > prefix);
-    if (win) {
-      const int pos = atomicAdd(&sh_count, 1);
-      cidx[pos] = c0 + cbase + 64 * k;
-      cval[pos] = acc[cbase + 64 * k];
-    }
-    my_ties += __popcll(__ballot(st && !take_all && key[k] == prefix));
+    const bool tie = st && !take_all && key[k] == prefix;
+    const unsigned long long bal = __ballot(tie);
+    const int rank = ties_before + __popcll(bal & lt_mask);
+    const bool win = st && (take_all || key[k] > prefix || (tie && rank < need));
+    ties_before += __popcll(bal);
+    if (win) winmask |= 1u << k;
+    my_wins += __popcll(__ballot(win));
   }
-  if (take_all || need == 0) continue;
-  if (lane == 0) wave_cnt[wv] = my_ties;
+  __syncthreads();  // the tie counts have been read
+  if (lane == 0) wave_cnt[wv] = my_wins;
   __syncthreads();
-  int before = 0;
-  for (int w = 0; w < wv; w++) before += wave_cnt[w];
+  int pos0 = 0;
+  for (int w = 0; w < wv; w++) pos0 += wave_cnt[w];
 #pragma unroll
   for (int k = 0; k < PER; k++) {
-    const bool tie = ((have >> k) & 1u) && key[k] == prefix;
-    const unsigned long long bal = __ballot(tie);
-    const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (tie && rank < need) {
-      const int pos = atomicAdd(&sh_count, 1);
+    const bool win = (winmask >> k) & 1u;
+    const unsigned long long bal = __ballot(win);
+    if (win) {
+      const int pos = pos0 + __popcll(bal & lt_mask);
       cidx[pos] = c0 + cbase + 64 * k;
       cval[pos] = acc[cbase + 64 * k];
     }
-    before += __popcll(bal);
+    pos0 += __popcll(bal);
   }
   PHASE_MARK(5);
   }  // persistent loop
@@ -637,10 +651,10 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(Params p) {
       const int c = p.cand_cnt[b];
       if (n + c > p.merge_cap) break;
       for (int i = tid; i < c; i += 256) {
-        const double v = p.cand_val[static_cast<size_t>(b) * p.top_k + i];
+        const double v = p.cand_val[static_cast<size_t>(b) * p.tile_k + i];
         val[n + i] = v;
         key[n + i] = order_key(v);
-        idx[n + i] = p.cand_idx[static_cast<size_t>(b) * p.top_k + i];
+        idx[n + i] = p.cand_idx[static_cast<size_t>(b) * p.tile_k + i];
       }
       n += c;
       t++;
@@ -691,6 +705,98 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(Params p) {
     p.out_val[static_cast<size_t>(slot) * p.top_k + i] = val[i];
   }
   if (tid == 0) p.out_cnt[slot] = keep;
+}
+
+// Row merge for top_k > TOPK_CAP (e.g. P3alpha / RP3beta with their default top_k = None, or a
+// user-kNN over every user): the tiles' winner lists are column-sorted and the tiles are in
+// column order, so the row only needs the top_k-th best key as a threshold - an MSB-first
+// 8-bit radix select over the keys in global memory - and one ordered compaction: everything
+// above the threshold plus the `need` lowest-column ties (knn.hpp:119-136).  The output comes
+// out sorted by column.  One 256-thread workgroup per target row.
+__global__ __launch_bounds__(256) void knn_merge_big_kernel(Params p) {
+  __shared__ int32_t hist[256];
+  __shared__ int32_t wsum[4];
+  __shared__ uint64_t sh_prefix;
+  __shared__ int32_t sh_need;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int slot = blockIdx.x;
+  const int32_t *cnt = p.cand_cnt + static_cast<size_t>(slot) * p.n_tiles;
+  int n_total = 0;
+  for (int t = 0; t < p.n_tiles; t++) n_total += cnt[t];
+  int32_t *oidx = p.out_idx + static_cast<size_t>(slot) * p.top_k;
+  double *oval = p.out_val + static_cast<size_t>(slot) * p.top_k;
+  const size_t cbase = static_cast<size_t>(slot) * p.n_tiles * p.tile_k;
+  uint64_t thr = 0;
+  int need = 0;
+  const bool all = n_total <= p.top_k;
+  if (!all) {
+    uint64_t prefix = 0;
+    int remaining = p.top_k;  // rank of the wanted key among those matching the prefix so far
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      hist[tid] = 0;
+      __syncthreads();
+      const uint64_t hi_mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+      for (int t = 0; t < p.n_tiles; t++) {
+        const double *v = p.cand_val + cbase + static_cast<size_t>(t) * p.tile_k;
+        for (int i = tid; i < cnt[t]; i += 256) {
+          const uint64_t k = order_key(v[i]);
+          if ((k & hi_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int d = 255, above = 0;
+        while (above + hist[d] < remaining) { above += hist[d]; d--; }
+        sh_prefix = prefix | (static_cast<uint64_t>(d) << shift);
+        sh_need = remaining - above;
+      }
+      __syncthreads();
+      prefix = sh_prefix;
+      remaining = sh_need;
+      __syncthreads();
+    }
+    thr = prefix;
+    need = remaining;  // ties with the threshold key that are taken (lowest columns)
+  }
+  // ordered compaction, 256 entries per round in list order
+  int out_n = 0, ties_seen = 0;
+  for (int t = 0; t < p.n_tiles; t++) {
+    const double *v = p.cand_val + cbase + static_cast<size_t>(t) * p.tile_k;
+    const int32_t *ix = p.cand_idx + cbase + static_cast<size_t>(t) * p.tile_k;
+    for (int i0 = 0; i0 < cnt[t]; i0 += 256) {
+      const int i = i0 + tid;
+      const bool in = i < cnt[t];
+      const double val = in ? v[i] : 0.0;
+      const int32_t col = in ? ix[i] : 0;
+      const uint64_t k = order_key(val);
+      const bool tie = in && !all && k == thr;
+      // rank of this tie among the row's ties, in column order
+      const unsigned long long tb = __ballot(tie);
+      if (lane == 0) wsum[wv] = __popcll(tb);
+      __syncthreads();
+      int tbefore = ties_seen;
+      for (int w = 0; w < wv; w++) tbefore += wsum[w];
+      const int tie_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      __syncthreads();
+      const int trank = tbefore + __popcll(tb & ((1ull << lane) - 1ull));
+      const bool win = in && (all || k > thr || (tie && trank < need));
+      const unsigned long long wb = __ballot(win);
+      if (lane == 0) wsum[wv] = __popcll(wb);
+      __syncthreads();
+      int wbefore = out_n;
+      for (int w = 0; w < wv; w++) wbefore += wsum[w];
+      const int win_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      __syncthreads();
+      if (win) {
+        const int pos = wbefore + __popcll(wb & ((1ull << lane) - 1ull));
+        oidx[pos] = col;
+        oval[pos] = val;
+      }
+      out_n += win_total;
+      ties_seen += tie_total;
+    }
+  }
+  if (tid == 0) p.out_cnt[slot] = out_n;
 }
 
 struct HostCsrD {
@@ -1060,9 +1166,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     *nnz_out = 0;
     if (n == 0 || out_k == 0 || c->N == 0) return;
     const int n_tiles = static_cast<int>(ceil_div(c->N, TILE));
-    if (out_k > TOPK_CAP)
-      throw std::invalid_argument("irspack_amd: top_k above " + std::to_string(TOPK_CAP) +
-                                  " is not supported by the device kNN kernel.");
+    const bool big = out_k > TOPK_CAP;  // row merge by threshold select (knn_merge_big_kernel)
+    const int64_t tile_k = std::min<int64_t>(out_k, TILE);
     IRS_HIP(hipSetDevice(c->device));
     hipStream_t s = nullptr;
     // rows of the call, heaviest product row first (ids relative to row_begin)
@@ -1099,8 +1204,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     }
     d_order.upload(order, s);
     const size_t slots = static_cast<size_t>(n) * n_tiles;
-    cand_idx.alloc(slots * out_k);
-    cand_val.alloc(slots * out_k);
+    cand_idx.alloc(slots * tile_k);
+    cand_val.alloc(slots * tile_k);
     cand_cnt.alloc(slots);
     out_idx.alloc(static_cast<size_t>(n) * out_k);
     out_val.alloc(static_cast<size_t>(n) * out_k);
@@ -1124,6 +1229,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     p.alpha = c->alpha;
     p.beta = c->beta;
     p.top_k = static_cast<int32_t>(out_k);
+    p.tile_k = static_cast<int32_t>(tile_k);
     p.cand_idx = cand_idx.ptr;
     p.cand_val = cand_val.ptr;
     p.cand_cnt = cand_cnt.ptr;
@@ -1165,10 +1271,14 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     } else {
       if (sentinel) launch(knn_tile_kernel<false, true>); else launch(knn_tile_kernel<false, false>);
     }
-    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_CAP * 20));
-    hipLaunchKernelGGL(knn_merge_kernel, dim3(static_cast<unsigned>(n)), dim3(256),
-                       static_cast<size_t>(p.merge_cap) * 20, s, p);
+    if (big) {
+      hipLaunchKernelGGL(knn_merge_big_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, s, p);
+    } else {
+      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_CAP * 20));
+      hipLaunchKernelGGL(knn_merge_kernel, dim3(static_cast<unsigned>(n)), dim3(256),
+                         static_cast<size_t>(p.merge_cap) * 20, s, p);
+    }
     IRS_HIP(hipEventRecord(ev1, s));
     IRS_HIP(hipGetLastError());
     std::vector<int32_t> h_cnt(n), h_idx(static_cast<size_t>(n) * out_k);

@@ -201,12 +201,21 @@ class EvaluatorCore:
         # on the device while calls keep passing the same matrix object over the same users
         # (a tuning loop evaluates hundreds of times against one mask).  The object is held
         # here so that its identity stays valid; a mask edited in place needs a new object.
-        key = None if mask is None else (id(mask), mask.shape, mask.nnz, begin, end)
+        key = None if mask is None else (id(mask), mask.shape, mask.nnz, begin, end,
+                                         self._mask_fingerprint(mask))
         if key != getattr(self, "_mask_key", None):
             if mask is not None:
-                M, mp, mi, _ = _lib.csr_arrays(mask, np.float32)
+                M, mp, mi, md = _lib.csr_arrays(mask, np.float32)
                 if M.shape != (end - begin, self.n_items):
                     raise ValueError("mask must have shape (end - begin, n_items).")
+                if md.size and not md.all():
+                    # the reference masks ``mask.nonzero()`` (evaluator.py:426-432): stored
+                    # zeros are not masked
+                    keep = md != 0
+                    rows = np.repeat(np.arange(M.shape[0]), np.diff(mp))[keep]
+                    mi = np.ascontiguousarray(mi[keep])
+                    mp = np.zeros(M.shape[0] + 1, dtype=np.int64)
+                    np.cumsum(np.bincount(rows, minlength=M.shape[0]), out=mp[1:])
                 if mi.size == 0:
                     mi = np.zeros(1, dtype=np.int32)
                 check(lib().irs_eval_cache_mask(self._h, C.c_int64(end - begin),
@@ -223,6 +232,19 @@ class EvaluatorCore:
             )
         )
         return Metrics._from_struct(self.n_items, st, cnt)
+
+    @staticmethod
+    def _mask_fingerprint(mask: sps.spmatrix) -> int:
+        """Cheap content check for the device-resident mask: CRC of the row pointers and of a
+        strided sample of the column indices and values (an in-place edit that keeps nnz and
+        every sampled entry would still go unnoticed: pass a new object for that)."""
+        import zlib
+
+        m = mask if sps.isspmatrix_csr(mask) else sps.csr_matrix(mask)
+        step = max(1, m.indices.size // 65536)
+        h = zlib.crc32(np.ascontiguousarray(m.indptr).tobytes())
+        h = zlib.crc32(np.ascontiguousarray(m.indices[::step]).tobytes(), h)
+        return zlib.crc32(np.ascontiguousarray(m.data[::step]).tobytes(), h)
 
     def get_ground_truth(self) -> sps.csr_matrix:
         return self._X.copy()

@@ -81,3 +81,24 @@ class BaseSimilarityRecommender(BaseRecommender):
 
     def get_score_block(self, begin: int, end: int) -> np.ndarray:
         return _sparse_to_array(self.X_train_all[begin:end].dot(self.W))
+
+
+class BaseUserSimilarityRecommender(BaseRecommender):
+    """base.py:432-453: score = U[u] @ X with the learnt user-user weights."""
+
+    def __init__(self, *args: Any, **kwargs: Any) -> None:
+        super().__init__(*args, **kwargs)
+        self._X_csc: sps.csc_matrix = self.X_train_all.tocsc()
+        self.U_: Optional[Union[sps.csr_matrix, sps.csc_matrix, np.ndarray]] = None
+
+    @property
+    def U(self):
+        if self.U_ is None:
+            raise RuntimeError("W fetched before fit.")  # (the reference's wording, base.py:446)
+        return self.U_
+
+    def get_score(self, user_indices: np.ndarray) -> np.ndarray:
+        return _sparse_to_array(self.U[user_indices].dot(self._X_csc).toarray())
+
+    def get_score_block(self, begin: int, end: int) -> np.ndarray:
+        return _sparse_to_array(self.U[begin:end].dot(self._X_csc))

@@ -23,16 +23,21 @@ from ._ials_core import LossType, SolverType
 from .base import BaseRecommender
 
 
+def _enum_by_name(enum_cls: Any, name: str) -> Any:
+    """Case-insensitive lookup of an enum member; unknown names raise like the reference's
+    ``getattr`` does (ials.py:46-55)."""
+    try:
+        return enum_cls[name.upper()]
+    except KeyError:
+        raise AttributeError(f"{enum_cls.__name__} has no member {name!r}.") from None
+
+
 def str_to_solver_type(t: str) -> SolverType:
-    result: SolverType = getattr(SolverType, t.upper())
-    assert result in {SolverType.CG, SolverType.CHOLESKY, SolverType.IALSPP}
-    return result
+    return _enum_by_name(SolverType, t)
 
 
 def str_to_loss_type(t: str) -> LossType:
-    result: LossType = getattr(LossType, t.upper())
-    assert result in {LossType.ORIGINAL, LossType.IALSPP}
-    return result
+    return _enum_by_name(LossType, t)
 
 
 class IALSTrainer:
@@ -72,19 +77,19 @@ class IALSTrainer:
             .set_ialspp_iteration(prediction_time_ialspp_iteration).build()
         )
 
+    _STATE_FIELDS = ("user", "item", "user_feature_weight", "item_feature_weight")
+
     def load_state(self, ifs: IO) -> None:
-        params = pickle.load(ifs)
-        self.core_trainer.user = params["user"]
-        self.core_trainer.item = params["item"]
-        if "user_feature_weight" in params:
-            self.core_trainer.user_feature_weight = params["user_feature_weight"]
-            self.core_trainer.item_feature_weight = params["item_feature_weight"]
+        """Restores what ``save_state`` wrote (ials.py:140-147); states written before the
+        feature-aware model hold the two factor matrices only."""
+        state = pickle.load(ifs)
+        for field in self._STATE_FIELDS:
+            if field in state:
+                setattr(self.core_trainer, field, state[field])
 
     def save_state(self, ofs: IO) -> None:
-        pickle.dump(dict(user=self.core_trainer.user, item=self.core_trainer.item,
-                         user_feature_weight=self.core_trainer.user_feature_weight,
-                         item_feature_weight=self.core_trainer.item_feature_weight), ofs,
-                    protocol=pickle.HIGHEST_PROTOCOL)
+        pickle.dump({field: getattr(self.core_trainer, field) for field in self._STATE_FIELDS},
+                    ofs, protocol=pickle.HIGHEST_PROTOCOL)
 
     def compute_loss(self) -> float:
         return self.core_trainer.compute_loss(self.solver_config)
@@ -110,9 +115,8 @@ class IALSTrainer:
                                                              self.prediction_time_solver_config)
 
 
-class IALSConfigScaling(enum.Enum):
-    none = enum.auto()
-    log = enum.auto()
+# confidence scaling modes accepted by IALSRecommender (ials.py:113-115): "none" | "log"
+IALSConfigScaling = enum.Enum("IALSConfigScaling", ["none", "log"])
 
 
 def compute_reg_scale(X: sps.csr_matrix, alpha0: float, nu: float) -> float:
@@ -240,9 +244,10 @@ class IALSRecommender(BaseRecommender):
 
     @property
     def trainer_as_ials(self) -> IALSTrainer:
-        if self.trainer is None:
+        trainer = getattr(self, "trainer", None)
+        if trainer is None:  # ials.py:472-476
             raise RuntimeError("tried to fetch trainer before the training.")
-        return self.trainer
+        return trainer
 
     # -- scoring (ials.py:476-562) ---------------------------------------------
     def get_score(self, user_indices: np.ndarray) -> np.ndarray:

@@ -78,7 +78,12 @@ def _retrieve(score: np.ndarray, allowed_item_indices: Sequence[Sequence[int]], 
     litems = np.zeros(max(int(lptr[-1]), 1), dtype=np.int64)
     for i, l in enumerate(allowed_item_indices):
         litems[lptr[i]:lptr[i + 1]] = np.asarray(l, dtype=np.int64)
-    width = max(min(int(cutoff), 2 ** 31 - 1), 0)
+    # the reference clamps the list length to the candidate count (util.hpp:476-481): a cutoff
+    # of n_items ("rank everything") needs n_items slots at most.  The device ranking kernel
+    # holds at most 2048 slots per row: refuse a longer request BEFORE allocating rows x cutoff
+    width = max(min(int(cutoff), int(n_items)), 0)
+    if width > 2048:
+        raise ValueError("irspack_amd: cutoff above 2048 is not supported by the device ranking kernel.")
     out = np.full((rows, max(width, 1)), -1, dtype=np.int32)
     check(lib().irs_retrieve_recommend(
         C.c_int32(1 if score.dtype == np.float64 else 0), score.ctypes.data_as(C.c_void_p),

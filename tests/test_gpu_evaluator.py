@@ -199,6 +199,22 @@ def test_fused_ials_path_matches_block_path():
     assert unmasked.ndcg == nomask.ndcg and (nomask.item_cnt != fused.item_cnt).any()
     back = core.get_metrics_ials(t, 0, U, tr, 20, 0, False)
     np.testing.assert_array_equal(back.item_cnt, fused.item_cnt)
+    # stored zeros of the mask are not masked (the reference uses mask.nonzero(),
+    # evaluator.py:426-432), and an in-place edit of the resident mask is noticed
+    holes = tr.copy().astype(np.float32)
+    holes.data[::3] = 0.0
+    pruned = holes.copy()
+    pruned.eliminate_zeros()
+    with_holes = core.get_metrics_ials(t, 0, U, holes, 20, 0, False)
+    expect = core.get_metrics_ials(t, 0, U, pruned, 20, 0, False)
+    np.testing.assert_array_equal(with_holes.item_cnt, expect.item_cnt)
+    assert with_holes.ndcg == expect.ndcg and (expect.item_cnt != fused.item_cnt).any()
+    edited = tr.copy().astype(np.float32)
+    first = core.get_metrics_ials(t, 0, U, edited, 20, 0, False)
+    edited.data[:] = 0.0  # same object, same nnz: now nothing is masked
+    second = core.get_metrics_ials(t, 0, U, edited, 20, 0, False)
+    np.testing.assert_array_equal(first.item_cnt, fused.item_cnt)
+    np.testing.assert_array_equal(second.item_cnt, nomask.item_cnt)
     # cutoffs on the wave-per-row kernel with 8 entries per lane, and on the general kernel
     for cutoff in (50, 64, 100):
         f2 = core.get_metrics_ials(t, 0, U, tr, cutoff, 0, True)

@@ -254,3 +254,41 @@ def test_long_slices_many_strips_per_block(values):
     got = comp.compute_similarity(tgt, 40)
     want = ref.compute_similarity(tgt, 40)
     assert_same_csr(got, want, rtol=0)
+
+
+@pytest.mark.parametrize("n_items,top_k", [(3000, 2500), (17000, 3000), (17000, 17000)])
+def test_top_k_above_the_lds_merge_cap(n_items, top_k):
+    """top_k > 2048 (one and two column tiles; top_k = N keeps every stored product): the row
+    merge selects a threshold key over the column-sorted tile lists instead of sorting in LDS.
+    Binary data: massive ties at the cut, decided by column order (knn.hpp:119-136)."""
+    from conftest import random_csr
+
+    X = random_csr(n_items, 60, 0.25, 31, dtype=np.float64, binary=True)  # [items, users]
+    comp = K.CosineSimilarityComputer(X, 0.0, False)  # raw co-occurrence counts
+    ref = O.KNNComputer("cosine", X, 0.0, normalize=False, n_threads=8, max_chunk_size=8)
+    rows = (40, 72)
+    got = comp.compute_similarity(X, top_k, rows=rows)
+    want = ref.compute_similarity(X[rows[0]:rows[1]], top_k)
+    assert np.diff(want.indptr).max() > 2048
+    if top_k < n_items:
+        assert np.diff(want.indptr).max() == top_k  # the cut is exercised
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    np.testing.assert_array_equal(got.data, want.data)  # integer counts: exact
+
+
+def test_p3alpha_default_top_k_none_on_a_catalogue_above_2048_items():
+    """P3alphaRecommender / RP3betaRecommender keep the reference's default
+    top_k = None (-> n_items, p3.py:62-66); with more than 2048 items that used to raise."""
+    from conftest import random_csr
+    from irspack_amd.recommenders import P3alphaRecommender, RP3betaRecommender
+
+    X = random_csr(150, 2600, 0.02, 5, dtype=np.float64, binary=True)  # users x items
+    rec = P3alphaRecommender(X, alpha=1.0).learn()
+    want = O.KNNComputer("p3alpha", sps.csr_matrix(X.T), alpha=1.0).compute_W(sps.csr_matrix(X.T), 2600)
+    got = sps.csc_matrix(rec.W)
+    got.sort_indices()
+    want.sort_indices()
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    np.testing.assert_allclose(got.data, want.data, rtol=1e-12, atol=0)
+    rec2 = RP3betaRecommender(X, alpha=1.0, beta=0.6).learn()
+    assert rec2.W.shape == (2600, 2600) and rec2.W.nnz > 0

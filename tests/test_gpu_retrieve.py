@@ -93,3 +93,15 @@ def test_ml100k_width_rows_with_list_longer_than_items():
     score = rng.standard_normal((3, 40)).astype(np.float32)
     lst = [list(rng.integers(0, 40, size=500))]
     assert_same(retrieve_recommend_from_score(score, lst, 20, 1), restated(score, lst, 20))
+
+
+def test_cutoff_is_clamped_to_the_candidate_count_before_allocating():
+    """cutoff = n_items ("rank everything") is clamped like util.hpp:476-481; a request the
+    device kernel cannot hold is refused up front instead of after a rows x cutoff allocation."""
+    rng = np.random.default_rng(1)
+    score = rng.standard_normal((6, 40)).astype(np.float32)
+    got = retrieve_recommend_from_score(score, [], 10 ** 9, 1)
+    assert_same(got, restated(score, [], 40))
+    big = np.zeros((2, 3000), dtype=np.float32)
+    with pytest.raises(ValueError, match="2048"):
+        retrieve_recommend_from_score(big, [], 3000, 1)
