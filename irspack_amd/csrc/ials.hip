@@ -76,6 +76,58 @@ static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
   return m;
 }
 
+// Rows [rb, re) of a CSR as a matrix of the same shape whose other rows are empty: what a
+// rank of a sharded run needs of X (its user rows).  Only the slice is copied and validated.
+static HostCsr host_csr_rows(int64_t rows, int64_t cols, const int64_t *indptr,
+                             const int32_t *indices, const float *data, int64_t rb, int64_t re) {
+  check_arg(rows >= 0 && cols >= 0, "negative matrix shape.");
+  check_arg(indptr != nullptr, "indptr is null.");
+  const int64_t nnz = indptr[rows];
+  check_arg(indptr[0] == 0 && nnz >= 0, "malformed indptr.");
+  check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31 (32-bit CSR like Eigen's).");
+  for (int64_t r = 0; r < rows; r++) check_arg(indptr[r + 1] >= indptr[r], "malformed indptr.");
+  HostCsr m;
+  m.rows = rows;
+  m.cols = cols;
+  m.indptr.assign(rows + 1, 0);
+  const int64_t b = indptr[rb], e = indptr[re];
+  for (int64_t r = rb; r <= rows; r++) m.indptr[r] = std::min(indptr[r], e) - b;
+  m.indices.assign(indices + b, indices + e);
+  m.data.assign(data + b, data + e);
+  for (int64_t p = 0; p < e - b; p++)
+    check_arg(m.indices[p] >= 0 && m.indices[p] < cols, "column index out of range.");
+  return m;
+}
+
+// Rows [cb, ce) of X^T (the columns [cb, ce) of X), other rows empty: a rank's item rows.
+// One scan of X; every column index is validated on the way.
+static HostCsr transpose_cols(int64_t rows, int64_t cols, const int64_t *indptr,
+                              const int32_t *indices, const float *data, int64_t cb, int64_t ce) {
+  HostCsr t;
+  t.rows = cols;
+  t.cols = rows;
+  t.indptr.assign(cols + 1, 0);
+  const int64_t nnz = indptr[rows];
+  for (int64_t p = 0; p < nnz; p++) {
+    const int32_t c = indices[p];
+    check_arg(c >= 0 && c < cols, "column index out of range.");
+    if (c >= cb && c < ce) t.indptr[c + 1]++;
+  }
+  for (int64_t c = 0; c < cols; c++) t.indptr[c + 1] += t.indptr[c];
+  t.indices.resize(t.indptr[cols]);
+  t.data.resize(t.indptr[cols]);
+  std::vector<int64_t> cur(t.indptr.begin() + cb, t.indptr.begin() + ce);
+  for (int64_t r = 0; r < rows; r++)
+    for (int64_t p = indptr[r]; p < indptr[r + 1]; p++) {
+      const int32_t c = indices[p];
+      if (c < cb || c >= ce) continue;
+      const int64_t d = cur[c - cb]++;
+      t.indices[d] = static_cast<int32_t>(r);
+      t.data[d] = data[p];
+    }
+  return t;
+}
+
 // X.transpose() as compressed row-major (hpp:713)
 static HostCsr transpose(const HostCsr &x) {
   HostCsr t;
@@ -256,6 +308,7 @@ struct irs_ials_trainer {
   int device = 0;
   hipStream_t stream = nullptr;
   bool has_X = false;
+  bool whole = true;  // unsharded: both CSR orientations are complete on this device
   irs_ials_shard shard{0, 0, 0, 0};
   DeviceBuffer<float> factor[2];                  // 0 user, 1 item
   Side side[2];                                   // 0: X (solve users), 1: X^T (solve items)
@@ -803,10 +856,29 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
       std::thread &t;
       ~Joiner() { if (t.joinable()) t.join(); }
     } draw_join{draw_thread};
-    HostCsr X = host_csr(n_users, n_items, indptr, indices, data);
+    // A rank of a sharded run prepares only its own user rows of X and item rows of X^T (the
+    // ranks together do the work once, not once each); the unsharded trainer keeps everything.
+    const irs_ials_shard sh = shard ? *shard : irs_ials_shard{0, n_users, 0, n_items};
+    check_arg(0 <= sh.user_begin && sh.user_begin <= sh.user_end && sh.user_end <= n_users &&
+                  0 <= sh.item_begin && sh.item_begin <= sh.item_end && sh.item_end <= n_items,
+              "shard out of range.");
+    const bool whole = sh.user_begin == 0 && sh.user_end == n_users && sh.item_begin == 0 &&
+                       sh.item_end == n_items;
+    HostCsr X = whole ? host_csr(n_users, n_items, indptr, indices, data)
+                      : host_csr_rows(n_users, n_items, indptr, indices, data, sh.user_begin,
+                                      sh.user_end);
     mark("copy + validate");
     HostCsr Xt;
-    std::thread transpose_thread([&] { Xt = transpose(X); });
+    std::exception_ptr transpose_error;
+    std::thread transpose_thread([&] {
+      try {
+        Xt = whole ? transpose(X)
+                   : transpose_cols(n_users, n_items, indptr, indices, data, sh.item_begin,
+                                    sh.item_end);
+      } catch (...) {
+        transpose_error = std::current_exception();
+      }
+    });
     Joiner transpose_join{transpose_thread};
     require_device(device);
     auto t = std::make_unique<irs_ials_trainer>();
@@ -815,11 +887,8 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     t->n_users = n_users;
     t->n_items = n_items;
     t->device = device;
-    t->shard = shard ? *shard : irs_ials_shard{0, n_users, 0, n_items};
-    check_arg(0 <= t->shard.user_begin && t->shard.user_begin <= t->shard.user_end &&
-                  t->shard.user_end <= n_users && 0 <= t->shard.item_begin &&
-                  t->shard.item_begin <= t->shard.item_end && t->shard.item_end <= n_items,
-              "shard out of range.");
+    t->shard = sh;
+    t->whole = whole;
     alloc_common(t.get());
     mark("device alloc");
     // the two orientations are prepared and uploaded side by side (host preparation of one
@@ -828,6 +897,7 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     std::thread item_thread([&] {
       try {
         transpose_thread.join();
+        if (transpose_error) std::rethrow_exception(transpose_error);
         IRS_HIP(hipSetDevice(device));
         t->side[1].build(Xt, t->shard.item_begin, t->shard.item_end, t->cfg, t->stream);
       } catch (...) {
@@ -1138,6 +1208,7 @@ irs_status irs_ials_set_features(irs_ials_trainer *t, int32_t which, int64_t row
     check_arg(t && (which == 0 || which == 1), "bad argument.");
     if (rows != t->rows_of(which))  // initialize_feature_aware, hpp:1005-1007
       throw std::invalid_argument("Feature matrix row count mismatch.");
+    check_arg(t->whole, "feature-aware iALS needs an unsharded trainer.");
     HostCsr F = host_csr(rows, n_feat, indptr, indices, data);
     HostCsr Ft = transpose(F);
     IRS_HIP(hipSetDevice(t->device));
@@ -1218,6 +1289,7 @@ irs_status irs_ials_compute_loss(irs_ials_trainer *t, const irs_ials_solver_conf
     check_arg(t && out, "null argument.");
     check_solver(sc);
     require_X(t);
+    check_arg(t->whole, "compute_loss needs an unsharded trainer (a shard holds only its rows).");
     IRS_HIP(hipSetDevice(t->device));
     full_gramian(t, 0);  // hpp:837-838
     full_gramian(t, 1);

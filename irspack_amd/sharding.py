@@ -8,11 +8,28 @@ factor matrices and, per half-epoch, takes part in
 
   1. an all-reduce of the K x K partial Gramian of its own rows
      (``Solver::prepare_p``, hpp:78-115, summed over ranks), and
-  2. an all-gather of the freshly solved factor rows: ONE in-place
-     ``all_gather_into_tensor`` when the shards are equal row blocks of the (row padded)
-     factor buffer (``equal_bounds``; what ``bench.py`` uses - with RCCL over xGMI every
-     shard leaves on its own links), else one broadcast per rank (cost-balanced uneven
-     shards, ``shard_bounds``).
+  2. an all-gather of the freshly solved factor rows, always ONE collective:
+     in place when the shards are equal row blocks of the (row padded) factor buffer
+     (``equal_bounds``; what ``bench.py`` uses - with RCCL over xGMI every shard leaves on
+     its own links), through a staging buffer of ``world x max-shard`` rows when they are
+     cost-balanced and uneven (``shard_bounds``).
+
+Overlap: the Gramian of the NEXT half-epoch only needs the rows this rank has just solved,
+so its partial sum and its K x K all-reduce (on a second process group = a second RCCL
+communicator and stream) are issued while the all-gather is still in flight.
+
+Which exchange the backend supports is probed ONCE at construction with a collective every
+rank takes part in (``gloo`` cannot gather device tensors in one call and uses per-rank
+broadcasts); nothing on the hot path catches exceptions.
+
+Host side of a sharded run: every rank prepares only its own rows of X and X^T
+(``irs_ials_create`` with a shard), and the initial factors - a sequential libstdc++ random
+stream, 56 s for the 10 M x 1 M shape - are drawn by rank 0 only and broadcast.
+
+kNN and the evaluator shard without a data-path collective: ``sharded_similarity`` (target
+rows) and ``sharded_metrics`` (users) give every rank a contiguous range and combine the
+results on the host (CSR blocks stacked in rank order; ``Metrics.merge``, a plain sum,
+evaluator.cpp:76-85).
 
 Collectives go through ``torch.distributed`` (backend "nccl" = RCCL on ROCm,
 "gloo" in the CPU tests) and run IN PLACE on torch views of the solver's own
@@ -63,6 +80,11 @@ def equal_bounds(n: int, parts: int, multiple: int = 8) -> List[int]:
     return [min(r * S, n) for r in range(parts)] + [n]
 
 
+def even_bounds(n: int, parts: int) -> List[int]:
+    """``parts`` contiguous ranges of ``n`` units whose sizes differ by at most one."""
+    return [n * r // parts for r in range(parts + 1)]
+
+
 def equal_shard_bounds(X: sps.csr_matrix, world: int) -> Tuple[List[int], List[int]]:
     return equal_bounds(X.shape[0], world), equal_bounds(X.shape[1], world)
 
@@ -111,18 +133,37 @@ class _DeviceArray:
         }
 
 
+def _group_info(group) -> Tuple[int, int]:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
 class HipLocalSolver(LocalSolver):
-    """Product implementation: the HIP trainer of this rank's GPU, on torch's current stream."""
+    """Product implementation: the HIP trainer of this rank's GPU, on torch's current stream.
 
-    def __init__(self, model_config, X, shard: Tuple[int, int, int, int], device: int):
+    With more than one rank only group rank 0 draws the initial factors (a sequential host
+    random stream); the others start from zeros and receive them by broadcast."""
+
+    def __init__(self, model_config, X, shard: Tuple[int, int, int, int], device: int, group=None):
         import torch
+        import torch.distributed as dist
 
-        from .recommenders._ials_core import IALSTrainer
+        from .recommenders._ials_core import IALSModelConfig, IALSTrainer
 
         self.torch = torch
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self.trainer = IALSTrainer(model_config, X, device=device, shard=shard)
+        rank, world = _group_info(group)
+        cfg = model_config
+        if world > 1 and rank != 0:
+            state = list(model_config.__getstate__())
+            state[4] = 0.0  # init_stdev <= 0: no draw, zero factors (filled by the broadcast)
+            cfg = IALSModelConfig(*state)
+        self.trainer = IALSTrainer(cfg, X, device=device, shard=shard)
+        self.trainer._config = model_config
         self.trainer.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         self._views = {}
         for which in range(4):
@@ -131,6 +172,10 @@ class HipLocalSolver(LocalSolver):
                 self._views[which] = torch.empty((rows, ld), dtype=torch.float32, device=self.device)
             else:
                 self._views[which] = torch.as_tensor(_DeviceArray(ptr, rows, ld), device=self.device)
+        if world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            for which in (0, 1):
+                dist.broadcast(self._views[which], src=src, group=group)
 
     def factor_view(self, which: int):
         return self._views[which]
@@ -155,53 +200,128 @@ class ShardedIALSTrainer:
     """``IALSTrainer.step`` over ``world_size`` ranks (see the module docstring)."""
 
     def __init__(self, local: LocalSolver, user_bounds: Sequence[int], item_bounds: Sequence[int],
-                 group=None):
+                 group=None, overlap: bool = True):
+        import torch
         import torch.distributed as dist
 
-        self.dist = dist
+        self.torch, self.dist = torch, dist
         self.group = group
         self.local = local
-        if dist.is_available() and dist.is_initialized():
-            self.rank = dist.get_rank(group)
-            self.world = dist.get_world_size(group)
-        else:  # single process: no collectives are issued
-            self.rank, self.world = 0, 1
+        self.rank, self.world = _group_info(group)
         assert len(user_bounds) == self.world + 1 and len(item_bounds) == self.world + 1
         self.bounds = (list(user_bounds), list(item_bounds))
-        self._gather_ok = True
+        self.overlap = bool(overlap) and self.world > 1
+        self._gram_ready = [False, False]  # Gramian of side s already reduced (prefetched)
+        self.exchange = ["none", "none"]
+        self._stage = [None, None]
+        self.gram_group = group
+        if self.world > 1:
+            # a second communicator: the K x K all-reduce of the next half-epoch's Gramian must
+            # not queue behind the all-gather of the solved rows
+            if self.overlap:
+                ranks = (list(range(self.world)) if group is None
+                         else [dist.get_global_rank(group, r) for r in range(self.world)])
+                self.gram_group = dist.new_group(ranks=ranks)
+            gather_ok = self._probe_gather(local.factor_view(0))
+            for side in (0, 1):
+                view, b = local.factor_view(side), self.bounds[side]
+                if not gather_ok:
+                    self.exchange[side] = "broadcast"
+                    continue
+                S = view.shape[0] // self.world
+                equal = (view.shape[0] % self.world == 0 and
+                         all(b[r] == min(r * S, b[-1]) for r in range(self.world)))
+                if equal:
+                    self.exchange[side] = "inplace"
+                else:
+                    self.exchange[side] = "padded"
+                    smax = max(b[r + 1] - b[r] for r in range(self.world))
+                    self._stage[side] = torch.zeros((self.world * max(smax, 1), view.shape[1]),
+                                                    dtype=view.dtype, device=view.device)
+
+    def _probe_gather(self, like) -> bool:
+        """Can this backend all-gather tensors on the factors' device in ONE call?  Decided
+        once, by a collective every rank executes (so the ranks cannot disagree), not by
+        catching errors on the hot path.  RCCL / NCCL and gloo-on-CPU can; gloo cannot for
+        device tensors."""
+        torch, dist = self.torch, self.dist
+        backend = str(dist.get_backend(self.group)).lower()
+        if "nccl" in backend:
+            return True
+        if like.device.type == "cpu":
+            out = torch.zeros(self.world, dtype=torch.float32)
+            dist.all_gather_into_tensor(out, out[self.rank:self.rank + 1].clone(), group=self.group)
+            return True
+        return False
+
+    def _exchange_rows(self, side: int):
+        """Start moving the rows this rank has just solved into every replica; returns the
+        pending work items (waited for by the caller)."""
+        dist, local = self.dist, self.local
+        b, view = self.bounds[side], local.factor_view(side)
+        how = self.exchange[side]
+        if how == "inplace":  # equal blocks of the padded buffer: input = own block of output
+            S = view.shape[0] // self.world
+            return [dist.all_gather_into_tensor(view, view[self.rank * S:(self.rank + 1) * S],
+                                                group=self.group, async_op=True)]
+        if how == "padded":  # uneven, cost-balanced shards: one collective through staging rows
+            stage = self._stage[side]
+            S = stage.shape[0] // self.world
+            mine = stage[self.rank * S:(self.rank + 1) * S]
+            n = b[self.rank + 1] - b[self.rank]
+            mine[:n].copy_(view[b[self.rank]:b[self.rank + 1]])
+            return [dist.all_gather_into_tensor(stage, mine, group=self.group, async_op=True)]
+        works = []  # "broadcast": one per rank (backends without a device all-gather)
+        for r in range(self.world):
+            if b[r + 1] > b[r]:
+                works.append(dist.broadcast(view[b[r]:b[r + 1]], src=self._global_rank(r),
+                                            group=self.group, async_op=True))
+        return works
+
+    def _finish_exchange(self, side: int, works) -> None:
+        for w in works:
+            w.wait()
+        if self.exchange[side] == "padded":
+            b, view, stage = self.bounds[side], self.local.factor_view(side), self._stage[side]
+            S = stage.shape[0] // self.world
+            for r in range(self.world):
+                if r != self.rank and b[r + 1] > b[r]:
+                    view[b[r]:b[r + 1]].copy_(stage[r * S:r * S + (b[r + 1] - b[r])])
+
+    def _reduce_gramian(self, side: int, async_op: bool):
+        self.local.partial_gramian(side)
+        if self.world > 1:
+            return self.dist.all_reduce(self.local.gramian_view(side), op=self.dist.ReduceOp.SUM,
+                                        group=self.gram_group, async_op=async_op)
+        return None
 
     def half_epoch(self, side: int, solver_config) -> None:
-        dist, local = self.dist, self.local
-        # (1) Gramian of the other side: own rows, then sum over ranks (K x K, latency bound)
-        local.partial_gramian(side)
-        if self.world > 1:
-            dist.all_reduce(local.gramian_view(side), op=dist.ReduceOp.SUM, group=self.group)
+        local = self.local
+        # (1) Gramian of the other side: own rows, summed over ranks (K x K, latency bound) -
+        #     unless the previous half-epoch already prefetched it
+        if not self._gram_ready[side]:
+            self._reduce_gramian(side, async_op=False)
+        self._gram_ready[side] = False
         local.finish_gramian(side)
         # (2) solve this rank's rows of `side`
         local.half_step(side, solver_config)
-        # (3) all-gather of the freshly solved rows, in place on the view of the factor matrix
-        if self.world > 1:
-            b = self.bounds[side]
-            view = local.factor_view(side)
-            S = view.shape[0] // self.world
-            equal = (view.shape[0] % self.world == 0 and
-                     all(b[r] == min(r * S, b[-1]) for r in range(self.world)))
-            if equal and self._gather_ok:
-                # equal blocks of the padded buffer: one collective, input = own block of output
-                try:
-                    dist.all_gather_into_tensor(view, view[self.rank * S:(self.rank + 1) * S],
-                                                group=self.group)
-                    return
-                except (RuntimeError, NotImplementedError):
-                    self._gather_ok = False  # backend without it (gloo on device tensors)
-            # uneven shards: every rank broadcasts its rows straight into the replicas
-            works = []
-            for r in range(self.world):
-                if b[r + 1] > b[r]:
-                    works.append(dist.broadcast(view[b[r]:b[r + 1]], src=self._global_rank(r),
-                                                group=self.group, async_op=True))
-            for w in works:
-                w.wait()
+        if self.world == 1:
+            return
+        # (3) all-gather of the freshly solved rows; meanwhile (4) the next half-epoch's
+        #     Gramian, which needs only those rows: partial sum + all-reduce on the second
+        #     communicator
+        works = self._exchange_rows(side)
+        if self.overlap:
+            red = self._reduce_gramian(1 - side, async_op=True)
+            self._finish_exchange(side, works)
+            red.wait()
+            self._gram_ready[1 - side] = True
+        else:
+            self._finish_exchange(side, works)
+
+    def invalidate(self) -> None:
+        """Call after changing the factors from outside (the prefetched Gramian is stale)."""
+        self._gram_ready = [False, False]
 
     def _global_rank(self, group_rank: int) -> int:
         if self.group is None:
@@ -215,3 +335,46 @@ class ShardedIALSTrainer:
 
     def synchronize(self) -> None:
         self.local.synchronize()
+
+
+# ---------------------------------------------------------------------------------------
+# kNN and evaluator: independent units, no data-path collective
+
+def sharded_similarity(compute_rows, n_rows: int, group=None) -> sps.csr_matrix:
+    """Item- / user-kNN over ``world`` ranks: rank r computes the target rows
+    ``even_bounds(n_rows, world)[r : r + 2]`` with ``compute_rows(begin, end)`` (a CSR
+    block, e.g. ``computer.compute_similarity(X, top_k, rows=(begin, end))``); the blocks are
+    exchanged as host objects and stacked in rank order on every rank."""
+    import torch.distributed as dist
+
+    rank, world = _group_info(group)
+    b = even_bounds(n_rows, world)
+    mine = sps.csr_matrix(compute_rows(b[rank], b[rank + 1]))
+    if world == 1:
+        return mine
+    parts = [None] * world
+    dist.all_gather_object(parts, (mine.data, mine.indices, mine.indptr, mine.shape), group=group)
+    blocks = [sps.csr_matrix((d, i, p), shape=sh) for d, i, p, sh in parts]
+    out = sps.vstack(blocks, format="csr")
+    out.has_sorted_indices = all(blk.has_sorted_indices for blk in blocks)
+    return out
+
+
+def sharded_metrics(evaluate_users, n_users: int, merged, group=None):
+    """Evaluator over ``world`` ranks: rank r evaluates the users
+    ``even_bounds(n_users, world)[r : r + 2]`` with ``evaluate_users(begin, end)`` (a
+    ``Metrics``); ``merged`` (an empty ``Metrics``) receives the sum of all ranks' results in
+    rank order (``Metrics::merge``, evaluator.cpp:76-85) on every rank."""
+    import torch.distributed as dist
+
+    rank, world = _group_info(group)
+    b = even_bounds(n_users, world)
+    mine = evaluate_users(b[rank], b[rank + 1])
+    if world == 1:
+        merged.merge(mine)
+        return merged
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    for part in parts:
+        merged.merge(part)
+    return merged

@@ -105,3 +105,62 @@ def test_bench_two_ranks_control_flow():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert "roofline" in d and d["roofline"]["frac"] > 0
+
+
+def _knn_eval_worker(rank, world, port, out_dir):
+    """Product kNN computer and evaluator sharded over two ranks on one device."""
+    import pickle
+
+    import scipy.sparse as sps
+    import torch.distributed as dist
+
+    from irspack_amd.evaluation._core_evaluator import EvaluatorCore, Metrics
+    from irspack_amd.recommenders._knn import CosineSimilarityComputer
+    from irspack_amd.sharding import sharded_metrics, sharded_similarity
+    from irspack_amd.synthetic import make_interactions
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X = make_interactions("small")
+    Xt = sps.csr_matrix(X.T, dtype=np.float64)
+    comp = CosineSimilarityComputer(Xt, 0.0, True)
+    S = sharded_similarity(lambda b, e: comp.compute_similarity(Xt, 20, rows=(b, e)), Xt.shape[0])
+    rng = np.random.default_rng(1)
+    scores = rng.standard_normal(X.shape).astype(np.float32)
+    gt = sps.csr_matrix((rng.random(X.shape) > 0.97).astype(np.float64))
+    core = EvaluatorCore(gt, [])
+    total = sharded_metrics(lambda b, e: core.get_metrics_f32(scores[b:e], 20, b, 1), X.shape[0],
+                            Metrics(X.shape[1]))
+    with open(os.path.join(out_dir, f"ke{rank}.pkl"), "wb") as fh:
+        pickle.dump((S, total), fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_knn_rows_and_evaluator_users_over_two_ranks(tmp_path):
+    import pickle
+
+    import scipy.sparse as sps
+    import torch.multiprocessing as mp
+
+    from irspack_amd.evaluation._core_evaluator import EvaluatorCore
+    from irspack_amd.recommenders._knn import CosineSimilarityComputer
+    from irspack_amd.synthetic import make_interactions
+
+    mp.spawn(_knn_eval_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = [pickle.load(open(tmp_path / f"ke{r}.pkl", "rb")) for r in range(2)]
+    X = make_interactions("small")
+    Xt = sps.csr_matrix(X.T, dtype=np.float64)
+    want = CosineSimilarityComputer(Xt, 0.0, True).compute_similarity(Xt, 20)
+    rng = np.random.default_rng(1)
+    scores = rng.standard_normal(X.shape).astype(np.float32)
+    gt = sps.csr_matrix((rng.random(X.shape) > 0.97).astype(np.float64))
+    whole = EvaluatorCore(gt, []).get_metrics_f32(scores, 20, 0, 1)
+    for S, m in res:
+        assert np.array_equal(S.indptr, want.indptr) and np.array_equal(S.indices, want.indices)
+        np.testing.assert_array_equal(S.data, want.data)
+        np.testing.assert_array_equal(m.item_cnt, whole.item_cnt)
+        assert m.valid_user == whole.valid_user and m.total_user == whole.total_user
+        for k in ("hit", "ndcg", "recall", "map", "precision"):
+            assert getattr(m, k) == pytest.approx(getattr(whole, k), rel=1e-12)

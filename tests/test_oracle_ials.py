@@ -178,3 +178,50 @@ def test_init_golden_stream():
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ials_init_seed42.npz"))
     for K in (10, 16, 40, 64):  # 10, 40: float vs double stddev quotient differ by an ulp
         np.testing.assert_array_equal(O.ials_init(8, K, 0.1, 42), g[f"K{K}"])
+
+
+def ialspp_half_step_float64(X, target, other, alpha0, reg, nu, bias, sub, iterations):
+    """float64 restatement of Solver::step_ialspp / _step_dimrange / _prediction
+    (hpp:387-535): block-coordinate Newton steps on the row objective, with the prediction
+    cache corrected after every block."""
+    X = sps.csr_matrix(X).astype(np.float64)
+    x_all = target.astype(np.float64).copy()
+    V = other.astype(np.float64)
+    K = V.shape[1]
+    P = alpha0 * V.T @ V
+    for _ in range(iterations):
+        for r in range(X.shape[0]):
+            sl = slice(X.indptr[r], X.indptr[r + 1])
+            Vr, c = V[X.indices[sl]], X.data[sl]
+            reg_r = float(np.float32(reg) * np.float32(np.float32(alpha0) * V.shape[0] + (sl.stop - sl.start)) ** np.float32(nu))
+            x = x_all[r]
+            pred = Vr @ x  # hpp:410-413
+            for ds in range(0, K, sub):
+                b = slice(ds, min(ds + sub, K))
+                grad = P[b] @ x + reg_r * x[b] + Vr[:, b].T @ (c * (pred - 1.0) - bias)  # hpp:468-482
+                A = P[b, b] + (Vr[:, b] * c[:, None]).T @ Vr[:, b] + reg_r * np.eye(b.stop - b.start)
+                delta = np.linalg.solve(A, grad)  # hpp:495-497
+                x[b] -= delta
+                pred -= Vr[:, b] @ delta  # hpp:500-506
+    return x_all
+
+
+@pytest.mark.parametrize("K,sub,loss", [(8, 3, "IALSPP"), (16, 16, "ORIGINAL"), (24, 8, "IALSPP"),
+                                        (20, 64, "ORIGINAL"), (12, 1, "IALSPP")])
+def test_ialspp_half_step_matches_float64_block_newton(K, sub, loss):
+    """Pins the iALS++ / iCD oracle to 2e-5 per row (the over-fit check above only sees 1e-2).
+    sub = 1 is the iCD branch (hpp:673-677, _step_icd :555-630: the same update per dimension)."""
+    rng = np.random.default_rng(3)
+    X = sps.random(60, 45, density=0.2, format="csr", random_state=5, dtype=np.float64)
+    X.data = rng.uniform(0.5, 3.0, X.nnz)
+    alpha0, reg, nu = 0.2, 0.05, 0.5
+    mc = O.model_config(K, alpha0=alpha0, reg=reg, nu=nu, loss_type=loss)
+    sc = O.solver_config(2, "IALSPP", 3, ialspp_subspace_dimension=sub, ialspp_iteration=2)
+    user0 = (rng.standard_normal((60, K)) * 0.3).astype(np.float32)
+    item0 = (rng.standard_normal((45, K)) * 0.3).astype(np.float32)
+    P = O.ials_gramian(item0, alpha0, 1)
+    got = O.ials_solver_step(user0, X, item0, P, mc, sc)
+    bias = 0.0 if loss == "IALSPP" else alpha0
+    want = ialspp_half_step_float64(X.astype(np.float32), user0, item0, alpha0, reg, nu, bias, sub, 2)
+    err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    assert err.max() < 2e-5, err.max()

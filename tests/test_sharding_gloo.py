@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from irspack_amd.sharding import (LocalSolver, ShardedIALSTrainer, balanced_bounds,  # noqa: E402
-                                  equal_bounds, equal_shard_bounds, row_cost, shard_bounds)
+                                  equal_bounds, equal_shard_bounds, even_bounds, row_cost,
+                                  shard_bounds, sharded_metrics, sharded_similarity)
 
 
 class OracleLocalSolver(LocalSolver):
@@ -93,8 +94,10 @@ def _worker(rank, world, port, kind, out_dir, equal=False):
     tr = ShardedIALSTrainer(local, ub, ib)
     for _ in range(2):
         tr.step(sc)
-    if equal:  # the equal-block path must have used the single in-place all-gather
-        assert tr._gather_ok
+    # one collective per half-epoch either way: in place for equal blocks, through the
+    # padded staging rows for the cost-balanced uneven shards
+    assert tr.exchange == (["inplace", "inplace"] if equal else ["padded", "padded"])
+    assert tr.gram_group is not None and tr.overlap
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), user=local.factor[0], item=local.factor[1])
     dist.barrier()
     dist.destroy_process_group()
@@ -167,3 +170,81 @@ def test_single_process_needs_no_group():
     ref = O.IALSTrainer(omc, X)
     ref.step(sc)
     np.testing.assert_allclose(local.factor[0], ref.user, rtol=1e-5, atol=1e-7)
+
+
+def test_even_bounds():
+    assert even_bounds(10, 3) == [0, 3, 6, 10]
+    assert even_bounds(2, 4) == [0, 0, 1, 1, 2]
+    assert even_bounds(7, 1) == [0, 7]
+
+
+class _RawMetrics:
+    """picklable stand-in with Metrics' merge contract (a plain sum of the raw terms)"""
+
+    def __init__(self, n_items, raw=None, cnt=None):
+        self.raw = np.zeros(7) if raw is None else raw
+        self.cnt = np.zeros(n_items, np.int64) if cnt is None else cnt
+
+    def merge(self, other):
+        self.raw = self.raw + other.raw
+        self.cnt = self.cnt + other.cnt
+
+
+def _knn_eval_worker(rank, world, port, out_dir):
+    """kNN target rows and evaluator users sharded over two ranks, the oracle standing in for
+    the device computers (sharding.sharded_similarity / sharded_metrics are host logic)."""
+    import pickle
+
+    import torch.distributed as dist
+
+    import oracle as O
+    from conftest import random_csr
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X = random_csr(83, 57, 0.2, 5, dtype=np.float64)
+    Xt = sps.csr_matrix(X.T)
+    comp = O.KNNComputer("cosine", Xt, 0.5, normalize=True)
+    S = sharded_similarity(lambda b, e: comp.compute_similarity(Xt[b:e], 7), Xt.shape[0])
+    rng = np.random.default_rng(3)
+    scores = rng.standard_normal(X.shape)
+    gt = sps.csr_matrix((rng.random(X.shape) > 0.8).astype(np.float64))
+    core = O.EvaluatorCore(gt, [])
+
+    def evaluate(b, e):
+        if e == b:
+            return _RawMetrics(X.shape[1])
+        m = core.get_metrics_f64(scores[b:e], 5, b, 1)
+        return _RawMetrics(X.shape[1], m.raw(), m.item_cnt())
+
+    total = sharded_metrics(evaluate, X.shape[0], _RawMetrics(X.shape[1]))
+    with open(os.path.join(out_dir, f"knn_eval{rank}.pkl"), "wb") as fh:
+        pickle.dump((S, total.raw, total.cnt), fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_knn_rows_and_evaluator_users(tmp_path):
+    import pickle
+
+    import torch.multiprocessing as mp
+
+    import oracle as O
+    from conftest import random_csr
+
+    mp.spawn(_knn_eval_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    res = [pickle.load(open(tmp_path / f"knn_eval{r}.pkl", "rb")) for r in range(2)]
+    X = random_csr(83, 57, 0.2, 5, dtype=np.float64)
+    Xt = sps.csr_matrix(X.T)
+    want = O.KNNComputer("cosine", Xt, 0.5, normalize=True).compute_similarity(Xt, 7)
+    rng = np.random.default_rng(3)
+    scores = rng.standard_normal(X.shape)
+    gt = sps.csr_matrix((rng.random(X.shape) > 0.8).astype(np.float64))
+    whole = O.EvaluatorCore(gt, []).get_metrics_f64(scores, 5, 0, 1)
+    for S, raw, cnt in res:  # every rank ends with the complete result
+        assert np.array_equal(S.indptr, want.indptr) and np.array_equal(S.indices, want.indices)
+        np.testing.assert_array_equal(S.data, want.data)
+        np.testing.assert_array_equal(cnt, whole.item_cnt())
+        assert raw[0] == whole.raw()[0] and raw[1] == whole.raw()[1]  # valid / total users
+        np.testing.assert_allclose(raw[2:], whole.raw()[2:], rtol=1e-12)
