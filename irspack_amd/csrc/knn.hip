@@ -51,6 +51,8 @@ struct Params {
   const int32_t *t_idx;
   const double *t_val;
   const double *t_stat;       // per target row (norm / pow / count), see epilogue
+  const double *t_scale;      // per target row: power of two that maps its products to the
+                              // 64-bit fixed-point accumulators (weighted paths)
   const int32_t *row_order;   // work-sorted list of target rows of this call
   int32_t n_rows;             // rows in this call
   int32_t n_tiles;
@@ -190,13 +192,22 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   //      spends ~16 instructions: positions are 32-bit (nnz < 2^31), bounds travel by
   //      v_readlane, the column fields are stored as LDS byte offsets (column * 4) and the
   //      atomic is issued by every lane (lanes outside the slice add to their sink).
+  const double fx_scale = ACC32 ? 1.0 : p.t_scale[r];
   auto add = [&](uint32_t off4, bool ok, double v) {
     if (ACC32) {
       const uint32_t a = ok ? off4 : TILE * 4 + 4 * lane;
       atomicAdd(reinterpret_cast<uint32_t *>(smem + a), 1u);
     } else {
+      // Weighted products are summed in 64-bit FIXED POINT (v * 2^s rounded to an integer, s
+      // per target row such that the row's largest possible sum stays below 2^61): integer
+      // adds commute, so the sums - and with them the top-k - do not depend on the order in
+      // which the LDS atomics land, run to run.  |error| of a column <= (its product count)
+      // * 2^-(s+1).  With the sentinel (positive data) a product never rounds to 0: the
+      // column must leave the "untouched" pattern.
       const uint32_t a = ok ? 2 * off4 : SINK_BYTES + 8 * lane;
-      atomicAdd(reinterpret_cast<double *>(smem + a), v);
+      long long q = __double2ll_rn(v * fx_scale);
+      if (SENTINEL) q = q == 0 ? 1 : q;
+      atomicAdd(reinterpret_cast<unsigned long long *>(smem + a), static_cast<unsigned long long>(q));
       if (!SENTINEL && ok) {
         const uint32_t j = off4 >> 2, bit = 1u << (j & 31);
         if (!(bits[j >> 5] & bit)) atomicOr(&bits[j >> 5], bit);
@@ -384,6 +395,7 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   //      order-preserving key stays in registers: the selection below never reads LDS keys.
   static_assert(PER == 16 && THREADS / 64 * PER * 64 == TILE, "column ownership");
   const double tstat = p.t_stat[r];
+  const double fx_inv = 1.0 / fx_scale;  // a power of two: exact
   uint64_t key[PER];
   uint32_t have = 0;  // bit k: column k of this thread is a stored entry of the product row
   uint32_t cv[ACC32 ? PER : 1];
@@ -409,8 +421,12 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
       if (ACC32) {
         raw[k] = static_cast<double>(cv[ACC32 ? h + k : 0]);
       } else {
-        raw[k] = acc[min(i, TILE - 1)];
-        const bool st = SENTINEL ? static_cast<uint64_t>(__double_as_longlong(raw[k])) != NEG_ZERO_BITS
+        // fixed-point sum -> double (one rounding).  Sentinel: the accumulator started at the
+        // bit pattern of -0.0 = INT64_MIN, the sum is the difference.
+        const uint64_t fx = static_cast<uint64_t>(__double_as_longlong(acc[min(i, TILE - 1)]));
+        raw[k] = static_cast<double>(static_cast<long long>(fx ^ (SENTINEL ? NEG_ZERO_BITS : 0ull))) *
+                 fx_inv;
+        const bool st = SENTINEL ? fx != NEG_ZERO_BITS
                                  : ((bits[min(i, TILE - 1) >> 5] >> (i & 31)) & 1u) != 0u;
         if (i < width && st) have |= 1u << (h + k);
       }
@@ -799,6 +815,26 @@ __global__ __launch_bounds__(256) void knn_merge_big_kernel(Params p) {
   if (tid == 0) p.out_cnt[slot] = out_n;
 }
 
+// The merged rows (work-ordered slots, top_k entries apart) -> one contiguous CSR in target-row
+// order on the device, so that the result crosses PCIe once, straight into the caller's arrays.
+__global__ __launch_bounds__(256) void knn_compact_kernel(const int32_t *__restrict__ out_idx,
+                                                          const double *__restrict__ out_val,
+                                                          const int32_t *__restrict__ slot_of,
+                                                          const int64_t *__restrict__ res_ptr,
+                                                          int64_t n_rows, int32_t top_k,
+                                                          int32_t *__restrict__ dst_idx,
+                                                          double *__restrict__ dst_val) {
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t b = res_ptr[row], e = res_ptr[row + 1];
+  const size_t src = static_cast<size_t>(slot_of[row]) * top_k;
+  for (int64_t i = lane; i < e - b; i += 64) {
+    dst_idx[b + i] = out_idx[src + i];
+    dst_val[b + i] = out_val[src + i];
+  }
+}
+
 struct HostCsrD {
   int64_t rows = 0, cols = 0;
   std::vector<int64_t> indptr;
@@ -900,10 +936,13 @@ struct irs_knn_computer {
   DeviceBuffer<double> xt_val, norms;
   bool xt_all_ones = false;
   bool xt_nonzero = false;  // |x| in (1e-150, 1e150) for every stored x
+  bool xt_positive = false; // every stored x > 0
+  std::vector<double> xt_rowmax;  // host: max |x| per feature row (bound of a target row's sums)
   // last result (host)
   std::vector<int64_t> res_ptr;
-  std::vector<int32_t> res_idx;
-  std::vector<double> res_val;
+  DeviceBuffer<int32_t> res_idx;  // the last result stays on the device until irs_knn_fetch
+  DeviceBuffer<double> res_val;
+  int64_t res_nnz = 0;
   double last_ms = 0;
   int64_t last_macs = 0;
 };
@@ -998,7 +1037,13 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     HostCsrD Xt = transpose(X);
     pt.mark("create: transpose");
     c->xt_row_len.resize(Xt.rows);
-    for (int64_t u = 0; u < Xt.rows; u++) c->xt_row_len[u] = Xt.indptr[u + 1] - Xt.indptr[u];
+    c->xt_rowmax.assign(Xt.rows, 0.0);
+    for (int64_t u = 0; u < Xt.rows; u++) {
+      c->xt_row_len[u] = Xt.indptr[u + 1] - Xt.indptr[u];
+      double mx = 0.0;
+      for (int64_t q = Xt.indptr[u]; q < Xt.indptr[u + 1]; q++) mx = std::max(mx, std::fabs(Xt.data[q]));
+      c->xt_rowmax[u] = mx;
+    }
     hipStream_t s = nullptr;
     {
       const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
@@ -1029,6 +1074,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         const double a = std::fabs(v);
         return a > 1e-150 && a < 1e150;
       });
+      c->xt_positive = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) { return v > 0.0; });
       if (c->xt_all_ones) {  // the ONES kernels never read the value stream
         c->xt_val.alloc(2);
       } else {
@@ -1102,14 +1148,15 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     // statistic of the epilogue, the multiply-add count that orders the launch, and whether the
     // values are all ones / free of zeros (which accumulator the kernel may use).
     std::vector<double> tstat(std::max<int64_t>(n, 1), 0.0);
+    std::vector<double> tscale(std::max<int64_t>(n, 1), 1.0);
     std::vector<int64_t> work(std::max<int64_t>(n, 1), 0);
     const int64_t e_begin = ip[row_begin], e_end = ip[row_end];
     check_arg(e_begin >= 0 && e_end >= e_begin, "malformed indptr.");
     check_arg(e_end < (int64_t(1) << 31), "nnz must be below 2^31.");
-    std::atomic<int> bad_index(0), not_ones(0), unsafe(0);
+    std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0);
     {
       const int n_thr = static_cast<int>(std::max<int64_t>(
-          1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+          1, std::min<int64_t>({32, static_cast<int64_t>(std::thread::hardware_concurrency()),
                                 (e_end - e_begin) / 200000 + 1})));
       auto body = [&](int th) {
         // contiguous row chunks of about equal entry counts
@@ -1118,10 +1165,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         int64_t r0 = std::lower_bound(ip + row_begin, ip + row_end, lo_e) - ip;
         int64_t r1 = th + 1 == n_thr ? row_end : std::lower_bound(ip + row_begin, ip + row_end, hi_e) - ip;
         if (th == 0) r0 = row_begin;
-        bool bad = false, ones = true, safe = true;
+        bool bad = false, ones = true, safe = true, positive = true;
         for (int64_t i = r0; i < r1; i++) {
           if (ip[i + 1] < ip[i]) { bad = true; break; }
-          double ss = 0;
+          double ss = 0, bound = 0;
           int64_t w = 0;
           for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
             const int32_t j = ix[q];
@@ -1130,8 +1177,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
             ss += x * x;
             w += c->xt_row_len[j];
             ones &= x == 1.0;
+            positive &= x > 0.0;
             const double ax = std::fabs(x);
             safe &= ax > 1e-150 && ax < 1e150;  // no stored zero, no underflow of x * y
+            bound += ax * c->xt_rowmax[j];      // >= |any sum of this product row|
           }
           if (bad) break;
           switch (c->sim_type) {
@@ -1144,7 +1193,14 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
             default: break;
           }
           work[i - row_begin] = w;
+          // fixed-point scale of the row: 2^s with bound * 2^s < 2^61
+          if (bound > 0 && std::isfinite(bound)) {
+            int ex = 0;
+            (void)std::frexp(bound, &ex);  // bound < 2^ex
+            tscale[i - row_begin] = std::ldexp(1.0, 61 - ex);
+          }
         }
+        if (!positive) not_positive.store(1);
         if (bad) bad_index.store(1);
         if (!ones) not_ones.store(1);
         if (!safe) unsafe.store(1);
@@ -1159,8 +1215,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     pt.mark("target pass");
     const int64_t out_k = std::min<int64_t>(top_k, c->N);
     c->res_ptr.assign(n + 1, 0);
-    c->res_idx.clear();
-    c->res_val.clear();
+    c->res_nnz = 0;
     c->last_ms = 0;
     c->last_macs = 0;
     *nnz_out = 0;
@@ -1179,10 +1234,12 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     pt.mark("work + order");
     DeviceBuffer<int64_t> t_ptr;
     DeviceBuffer<int32_t> t_idx, d_order, cand_idx, cand_cnt, out_idx, out_cnt;
-    DeviceBuffer<double> t_val, t_stat, cand_val, out_val;
+    DeviceBuffer<double> t_val, t_stat, t_scale, cand_val, out_val;
     // which accumulator: 32-bit counts when every product is 1, else fp64 sums with the -0.0
     // sentinel unless some product could be a zero
-    const bool sentinel = c->xt_nonzero && t_safe;
+    // (the sentinel of the fixed-point sums needs positive data: a sum must not return to the
+    // "untouched" pattern by cancellation)
+    const bool sentinel = c->xt_nonzero && t_safe && c->xt_positive && not_positive.load() == 0;
     const bool acc32 = c->xt_all_ones && sentinel && t_all_ones;
     {  // only the rows of the call travel; the values only if the kernel reads them
       std::vector<int64_t> rel(n + 1);
@@ -1200,6 +1257,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         t_val.upload(dv + e_begin, std::max<size_t>(ne, 1), s);
       }
       t_stat.upload(tstat, s);
+      t_scale.upload(tscale, s);
       IRS_HIP(hipStreamSynchronize(s));  // `rel` goes out of scope
     }
     d_order.upload(order, s);
@@ -1219,6 +1277,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     p.t_idx = t_idx.ptr;
     p.t_val = t_val.ptr;
     p.t_stat = t_stat.ptr;
+    p.t_scale = t_scale.ptr;
     p.row_order = d_order.ptr;
     p.n_rows = static_cast<int32_t>(n);
     p.n_tiles = n_tiles;
@@ -1281,13 +1340,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     }
     IRS_HIP(hipEventRecord(ev1, s));
     IRS_HIP(hipGetLastError());
-    std::vector<int32_t> h_cnt(n), h_idx(static_cast<size_t>(n) * out_k);
-    std::vector<double> h_val(static_cast<size_t>(n) * out_k);
+    std::vector<int32_t> h_cnt(n);
     IRS_HIP(hipMemcpyAsync(h_cnt.data(), out_cnt.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    IRS_HIP(hipMemcpyAsync(h_idx.data(), out_idx.ptr, h_idx.size() * sizeof(int32_t),
-                           hipMemcpyDeviceToHost, s));
-    IRS_HIP(hipMemcpyAsync(h_val.data(), out_val.ptr, h_val.size() * sizeof(double),
-                           hipMemcpyDeviceToHost, s));
     IRS_HIP(hipStreamSynchronize(s));
     float ms = 0;
     IRS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
@@ -1304,18 +1358,23 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
               static_cast<long long>(slots), h[0], h[1], h[2], h[3], h[4], h[5]);
     }
 #endif
-    // assemble the CSR in target-row order (slots are work-ordered)
+    // the CSR in target-row order (slots are work-ordered), compacted on the device
     std::vector<int32_t> slot_of(n);
     for (int64_t sl = 0; sl < n; sl++) slot_of[order[sl]] = static_cast<int32_t>(sl);
     for (int64_t i = 0; i < n; i++) c->res_ptr[i + 1] = c->res_ptr[i] + h_cnt[slot_of[i]];
-    c->res_idx.resize(c->res_ptr[n]);
-    c->res_val.resize(c->res_ptr[n]);
-    for (int64_t i = 0; i < n; i++) {
-      const size_t src = static_cast<size_t>(slot_of[i]) * out_k;
-      std::copy(h_idx.begin() + src, h_idx.begin() + src + h_cnt[slot_of[i]],
-                c->res_idx.begin() + c->res_ptr[i]);
-      std::copy(h_val.begin() + src, h_val.begin() + src + h_cnt[slot_of[i]],
-                c->res_val.begin() + c->res_ptr[i]);
+    c->res_nnz = c->res_ptr[n];
+    if (c->res_nnz > 0) {
+      DeviceBuffer<int32_t> d_slot_of;
+      DeviceBuffer<int64_t> d_res_ptr;
+      d_slot_of.upload(slot_of, s);
+      d_res_ptr.upload(c->res_ptr, s);
+      c->res_idx.alloc(static_cast<size_t>(c->res_nnz));
+      c->res_val.alloc(static_cast<size_t>(c->res_nnz));
+      hipLaunchKernelGGL(knn_compact_kernel, dim3(static_cast<unsigned>(ceil_div(n, 4))), dim3(256), 0, s,
+                         out_idx.ptr, out_val.ptr, d_slot_of.ptr, d_res_ptr.ptr, n,
+                         static_cast<int32_t>(out_k), c->res_idx.ptr, c->res_val.ptr);
+      IRS_HIP(hipGetLastError());
+      IRS_HIP(hipStreamSynchronize(s));  // the scratch buffers of this call go out of scope
     }
     *nnz_out = c->res_ptr[n];
     pt.mark("assemble");
@@ -1326,10 +1385,13 @@ irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
   return guard([&] {
     check_arg(c && indptr, "null argument.");
     std::copy(c->res_ptr.begin(), c->res_ptr.end(), indptr);
-    if (!c->res_idx.empty()) {
+    if (c->res_nnz > 0) {  // device -> the caller's arrays, one copy each
       check_arg(indices && data, "null argument.");
-      std::copy(c->res_idx.begin(), c->res_idx.end(), indices);
-      std::copy(c->res_val.begin(), c->res_val.end(), data);
+      IRS_HIP(hipSetDevice(c->device));
+      IRS_HIP(hipMemcpy(indices, c->res_idx.ptr, static_cast<size_t>(c->res_nnz) * sizeof(int32_t),
+                        hipMemcpyDeviceToHost));
+      IRS_HIP(hipMemcpy(data, c->res_val.ptr, static_cast<size_t>(c->res_nnz) * sizeof(double),
+                        hipMemcpyDeviceToHost));
     }
   });
 }

@@ -292,3 +292,59 @@ def test_p3alpha_default_top_k_none_on_a_catalogue_above_2048_items():
     np.testing.assert_allclose(got.data, want.data, rtol=1e-12, atol=0)
     rec2 = RP3betaRecommender(X, alpha=1.0, beta=0.6).learn()
     assert rec2.W.shape == (2600, 2600) and rec2.W.nnz > 0
+
+
+def test_weighted_sums_do_not_depend_on_arrival_order():
+    """tf-idf weighted item-kNN (knn.py:67-80: computer on the weighted matrix, query with the
+    unweighted one), 2,000 users x 5,000 items: the weighted products are summed in 64-bit
+    fixed point, so two runs are bit-identical (the LDS atomics land in a different order
+    every run) and the top-k sets equal the oracle's."""
+    from conftest import random_csr
+
+    X = random_csr(2000, 5000, 0.02, 77, dtype=np.float64, binary=True)
+    Xw = O.tf_idf_weight(X)
+    arg, tgt = sps.csr_matrix(Xw.T), sps.csr_matrix(X.T)
+    comp = K.CosineSimilarityComputer(arg, 0.0, True)
+    a = comp.compute_similarity(tgt, 50)
+    b = comp.compute_similarity(tgt, 50)
+    assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+    assert np.array_equal(a.data.view(np.uint64), b.data.view(np.uint64))  # bit for bit
+    want = O.KNNComputer("cosine", arg, 0.0, normalize=True, n_threads=8).compute_similarity(tgt, 50)
+    a.sort_indices()
+    want.sort_indices()
+    assert np.array_equal(a.indptr, want.indptr) and np.array_equal(a.indices, want.indices)
+    np.testing.assert_allclose(a.data, want.data, rtol=1e-12, atol=0)
+    # both operands weighted (user-kNN with BM25, user_knn.py:62-76), both signs of rounding
+    Xb = O.okapi_BM_25_weight(X[:600])
+    cw = K.CosineSimilarityComputer(Xb, 0.5, True)
+    c1, c2 = cw.compute_similarity(Xb, 30), cw.compute_similarity(Xb, 30)
+    assert np.array_equal(c1.indices, c2.indices)
+    assert np.array_equal(c1.data.view(np.uint64), c2.data.view(np.uint64))
+    w2 = O.KNNComputer("cosine", Xb, 0.5, normalize=True, n_threads=8).compute_similarity(Xb, 30)
+    c1.sort_indices()
+    w2.sort_indices()
+    assert np.array_equal(c1.indices, w2.indices)
+    np.testing.assert_allclose(c1.data, w2.data, rtol=1e-12, atol=0)
+
+
+def test_adversarial_exact_ties_with_weights():
+    """Dyadic weights (every sum exact in fp64 and in fixed point) and duplicated columns:
+    many exactly tied similarities at the cut, decided by column order like knn.hpp:119-125;
+    values must be EQUAL to the oracle's, not just close."""
+    rng2 = np.random.default_rng(5)
+    U, I = 300, 400
+    dense = (rng2.random((U, I)) < 0.1) * (rng2.integers(1, 257, size=(U, I)) / 64.0)
+    dense[:, 200:260] = dense[:, 100:160]  # 60 duplicated items: exact ties everywhere
+    X = sps.csr_matrix(dense)
+    arg = sps.csr_matrix(X.T)
+    for normalize in (False, True):
+        comp = K.CosineSimilarityComputer(arg, 0.0, normalize)
+        got = comp.compute_similarity(arg, 7)
+        want = O.KNNComputer("cosine", arg, 0.0, normalize=normalize).compute_similarity(arg, 7)
+        got.sort_indices()
+        want.sort_indices()
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        if not normalize:
+            np.testing.assert_array_equal(got.data, want.data)
+        else:
+            np.testing.assert_allclose(got.data, want.data, rtol=1e-14, atol=0)
