@@ -821,6 +821,9 @@ extern "C" {
 
 irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
                                    float *device_out, void **stream_out, int32_t *device_index);
+irs_status irs_ials_factors_device_(irs_ials_trainer *t, const float **user, const float **item,
+                                    int32_t *KP, int64_t *n_users, int64_t *n_items,
+                                    void **stream_out, int32_t *device_index);
 
 const char *irs_last_error(void) { return irs::last_error().c_str(); }
 int32_t irs_abi_version(void) { return 1; }
@@ -1116,6 +1119,23 @@ irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t e
     });
     t->prof.end(t->stream);
     IRS_HIP(hipGetLastError());
+  });
+}
+
+// Internal hook for evaluator.hip's fused scoring + ranking kernel: the factor buffers where
+// they live ([rows, KP] row-major, padded columns zero).  Not part of the public ABI.
+irs_status irs_ials_factors_device_(irs_ials_trainer *t, const float **user, const float **item,
+                                    int32_t *KP, int64_t *n_users, int64_t *n_items,
+                                    void **stream_out, int32_t *device_index) {
+  return guard([&] {
+    check_arg(t && user && item && KP && n_users && n_items, "null argument.");
+    *user = t->factor[0].ptr;
+    *item = t->factor[1].ptr;
+    *KP = t->KP;
+    *n_users = t->n_users;
+    *n_items = t->n_items;
+    if (stream_out) *stream_out = t->stream;
+    if (device_index) *device_index = t->device;
   });
 }
 

@@ -1046,16 +1046,17 @@ __global__ __launch_bounds__(256) void user_scores_kernel(const float *__restric
       bb[q] = *reinterpret_cast<const f32x4 *>(ip[q] + k);
     }
   };
+  // (per accumulator the products are added in ascending k; the four dependent MFMAs of one
+  // accumulator are issued 16 instructions apart - back to back each waits 40 cycles for its
+  // predecessor instead of 32)
   auto mfma_step = [&](const f32x4 (&aa)[4], const f32x4 (&bb)[4]) {
 #pragma unroll
-    for (int p = 0; p < 4; p++)
+    for (int c = 0; c < 4; c++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].x, bb[q].x, acc[p][q], 0, 0, 0);
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].y, bb[q].y, acc[p][q], 0, 0, 0);
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].z, bb[q].z, acc[p][q], 0, 0, 0);
-        acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p].w, bb[q].w, acc[p][q], 0, 0, 0);
-      }
+      for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[p][c], bb[q][c], acc[p][q], 0, 0, 0);
   };
   static_assert(KP % 32 == 0 || KP == 16, "two steps per round");
   load_step(0, a[0], b[0]);

@@ -252,11 +252,15 @@ def test_evaluator_ndcg20_block_at_ml20m_width(X20):
                         ocore.get_metrics_f32(scores, cutoff, b, CORES))
 
 
+@pytest.mark.parametrize("single_pass", [False, True])
 @pytest.mark.parametrize("K", [64, 256])
-def test_fused_evaluator_ml20m_vs_oracle(X20, K):
+def test_fused_evaluator_ml20m_vs_oracle(X20, K, single_pass, monkeypatch):
     """configs[4] (K = 256) and the bench's secondary leg (K = 64): the fused device path
-    (score + mask + rank without the block leaving HBM) over 20,000 users = two 16,384-user
-    device blocks, against the oracle fed the same scores (user_scores) masked on the host."""
+    (score + mask + rank without the block leaving the device) over 20,000 users, against the
+    oracle fed the same scores (user_scores) masked on the host.  Both implementations: the
+    default two-pass one (16,384-user score blocks in HBM) and the single-pass kernels of
+    eval_fused_kernels.hpp (IRSPACK_AMD_EVAL_FUSED=1: the block never reaches HBM)."""
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_FUSED", "1" if single_pass else "0")
     mc, sc, _, _ = configs(K, "CG")
     t = IALSTrainer(mc, X20)
     t.step(sc)
