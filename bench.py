@@ -283,8 +283,12 @@ def knn_leg(X, ceilings):
                      "frac_of_spec": None, "traffic": traffic,
                      "hbm_side_gbs": macs * 4.0 / (ms * 1e-3) / 1e9,
                      "frac_hbm": macs * 4.0 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     "traffic_gbs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
                      "note": "kernel time covers accumulate + epilogue + select + merge; "
-                             "HBM side prices the reference's 4 B column id per multiply-add"},
+                             "HBM side prices the reference's 4 B column id per multiply-add; "
+                             "traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE of the tile kernel "
+                             "(profiles/r02_knn_pmc_hbm.json): the 2-byte column stream is "
+                             "re-read per target row from Infinity Cache / HBM"},
         "out_nnz": int(S.nnz),
     }
     variants = {}

@@ -1252,7 +1252,9 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
     // users scored and ranked per pass: enough rows to fill the device with one wave per row
     // (32 waves x 256 CUs), within a 2 GiB score block
     const int64_t fit = (int64_t(1) << 31) / (std::max<int64_t>(e->n_items, 1) * 4);
-    const int64_t BLOCK = std::min<int64_t>(16384, std::max<int64_t>(1024, fit / 1024 * 1024));
+    int64_t block_cap = 16384;
+    if (const char *eb = std::getenv("IRSPACK_AMD_EVAL_BLOCK")) block_cap = std::max<int64_t>(256, std::atoll(eb));
+    const int64_t BLOCK = std::min<int64_t>(block_cap, std::max<int64_t>(1024, fit / 1024 * 1024));
     DeviceBuffer<int64_t> mptr;
     DeviceBuffer<int32_t> midx;
     void *sv = nullptr;

@@ -2,9 +2,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/prof/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/prof/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/prof/write.log 2>&1
 rocprofv3 -L > gpurun_out/prof/counters.txt 2>&1
 find gpurun_out/prof -name "*.csv" | head -30
 du -sh gpurun_out/prof
