@@ -18,6 +18,8 @@ Objects on the line:
                 built offline) on this box's host cores, bounded row sample, N = 1 only
   secondary     N = 1 only, each leg time-boxed and independent:
     ials_cg       the reference's DEFAULT solver (CG, 3 steps) on the same matrix
+    ials_bf16x3   the Cholesky epoch again with the OPT-IN bf16x3 rank update (fp32-equivalent
+                  accuracy from exact three-way bf16 splits; not the headline path)
     knn           cosine / jaccard item-kNN top-100 (configs[2]); headline = wall-inclusive call
     evaluator     fused score + nDCG@20 over all users (K = 64)
     k256          configs[4] on one GPU: K = 256 Cholesky + CG epochs and the fused nDCG@20
@@ -51,7 +53,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip every leg reported next to the headline metric")
-    ap.add_argument("--legs", default="ials_cg,knn,evaluator,k256,c4",
+    ap.add_argument("--legs", default="ials_cg,ials_bf16x3,knn,evaluator,k256,c4",
                     help="comma-separated secondary legs to run (N = 1)")
     ap.add_argument("--extra", action="store_true",
                     help="run the c4 leg at the full 10 M x 1 M size (about 3 minutes of host "
@@ -197,6 +199,25 @@ def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
                                algorithmic_gflop_per_epoch=flops / 1e9,
                                algorithmic_gbyte_per_epoch=byts / 1e9),
     }
+
+
+def bf16x3_leg(X, K, steps, ceilings):
+    """NOT the headline path: the same Cholesky epoch with the opt-in rank update on the bf16
+    matrix cores (IRSPACK_AMD_IALS_BF16X3=1: every fp32 factor value split exactly into three
+    bf16 terms, six partial products accumulated in fp32 - fp32-equivalent accuracy, checked
+    by tests/test_gpu_fullsize.py).  Reported so that the two rank updates can be compared on
+    the driver's own box; its roofline is still priced against the fp32 peak."""
+    from irspack_amd.recommenders._ials_core import IALSTrainer
+
+    os.environ["IRSPACK_AMD_IALS_BF16X3"] = "1"
+    try:
+        tr = IALSTrainer(model_config(K), X)  # the switch is read when a trainer is created
+    finally:
+        del os.environ["IRSPACK_AMD_IALS_BF16X3"]
+    out = ials_leg(tr, X, K, "CHOLESKY", steps, 2, ceilings)
+    out["rank_update"] = ("bf16x3: v_mfma_f32_16x16x32_bf16 on exact 3-way splits of the fp32 values, "
+                          "fp32 accumulate (opt-in, unit confidences, K <= 64)")
+    return out
 
 
 def holdout(X, seed=5):
@@ -487,6 +508,8 @@ def main():
             if "ials_cg" in legs and other_leg not in legs:
                 legs.append(other_leg)
             run(other_leg, lambda: ials_leg(local.trainer, X, K, other, args.steps, 2, ceilings))
+            if K <= 64 and args.solver == "CHOLESKY":
+                run("ials_bf16x3", lambda: bf16x3_leg(X, K, args.steps, ceilings))
             if K <= 64:
                 run("knn", lambda: knn_leg(X, ceilings))
                 run("evaluator", lambda: evaluator_leg(X, local.trainer, K, ceilings))

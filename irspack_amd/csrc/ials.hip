@@ -327,6 +327,7 @@ struct irs_ials_trainer {
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   Profiler prof;
   bool opt_wave128 = true, opt_unit = true, opt_short = true, opt_wg16 = true;  // read_switches()
+  bool opt_bf16x3 = false;
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
 };
@@ -598,6 +599,9 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
 //   IRSPACK_AMD_IALS_UNIT=0     keeps binary interactions on the general rank-update code
 //   IRSPACK_AMD_IALS_SHORT=0    sends the short rows of a CG step through the general kernels
 //   IRSPACK_AMD_IALS_WG16=0     Cholesky at K > 64 on the first-generation kernels (4-row panels)
+//   IRSPACK_AMD_IALS_BF16X3=1   binary interactions, Cholesky, K <= 64 padded to 64: the rank update
+//                               on the bf16 matrix cores from exact three-way splits of the fp32
+//                               values (syrk_gather_bf16x3, ials_kernels.hpp); off by default
 static bool env_flag(const char *name, bool dflt) {
   const char *e = std::getenv(name);
   return e ? std::atoi(e) != 0 : dflt;
@@ -607,6 +611,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_unit = env_flag("IRSPACK_AMD_IALS_UNIT", true);
   t->opt_short = env_flag("IRSPACK_AMD_IALS_SHORT", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
+  t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
 }
 
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
@@ -736,6 +741,9 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                              dim3(64 * SOLVE_WAVES), 0, t->stream, p);
         else if (cg)
           hipLaunchKernelGGL((ials_solve_kernel<TT, 1, 0>), dim3(ceil_div(n_regular, SOLVE_WAVES)),
+                             dim3(64 * SOLVE_WAVES), 0, t->stream, p);
+        else if (unit && t->opt_bf16x3 && TT == 4)
+          hipLaunchKernelGGL((ials_solve_kernel<4, 0, 0, true, true>), dim3(ceil_div(n_regular, SOLVE_WAVES)),
                              dim3(64 * SOLVE_WAVES), 0, t->stream, p);
         else if (unit)
           hipLaunchKernelGGL((ials_solve_kernel<TT, 0, 0, true>), dim3(ceil_div(n_regular, SOLVE_WAVES)),

@@ -330,6 +330,121 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
 }
 
 // ---------------------------------------------------------------------------
+// The same rank update on the bf16 matrix cores with fp32-equivalent accuracy ("bf16x3"):
+// unit confidences only (binary interactions), lower-form tiles.  Opt-in
+// (IRSPACK_AMD_IALS_BF16X3=1), not the default and not the benchmark's headline path.
+//
+// v_mfma_f32_16x16x32_bf16 contracts 32 stored entries in 16 cycles where
+// v_mfma_f32_16x16x4_f32 contracts 4 in 32 (MI355X_MICROARCH.md: the fp32-input MFMA runs at
+// the vector rate, 1/16 of bf16) - and, unlike the fp32 one, leaves half of its cycles to the
+// vector ALU.  Every gathered fp32 value is split EXACTLY into three bf16 terms
+// x = hi + mid + lo (8 + 8 + 8 mantissa bits; each residual is exactly representable), and a
+// product x y is accumulated in fp32 from the six partial products
+// hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; each is exact in fp32, the three dropped ones
+// are below 2^-24 |x y|.  60 MFMAs (960 cycles) + ~180 conversion instructions per 32 entries
+// against 80 MFMAs (2,560 cycles) + ~150 instructions for the fp32 path.
+//
+// Layout: a group = 32 entries; lane (g, m) gathers the entries 8 g .. 8 g + 7 of the group,
+// dims T m .. T m + 3 of each (one 16 B load per entry, as in syrk_gather).  The operand of
+// dims {T m + I} is then the lane's 8 values of dim I, packed two per register - the same
+// registers serve as A (row block) and B (column block), so the instruction's own k-to-lane
+// map does not matter.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
+}
+
+template <int T>
+__device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ other,
+                                                   const int32_t *__restrict__ indices, int begin,
+                                                   int end, float bias, f32x4 (&acc)[Geo<T>::NT],
+                                                   float (&bsum)[T], unsigned zero_row) {
+  static_assert(T == 4, "dims per lane = one 16 B load");
+  constexpr int KP = Geo<T>::KP;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int n = end - begin;
+  const int ngroups = (n + 31) >> 5;
+  const uint32_t lane_off = static_cast<uint32_t>(T * m * sizeof(float));
+  const int32_t *ip = indices + begin + lane;
+  f32x4 raw[2][8];  // two groups in flight
+  // entries 32 gi + 8 g + kk of the 64-entry index block held one per lane in blk_idx
+  auto issue = [&](int slot, int blk_idx, int gi, int entry0) {
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const int src = 4 * (32 * gi + 8 * g + kk);
+      unsigned idx = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, blk_idx));
+      idx = entry0 + 32 * gi + 8 * g + kk < n ? idx : zero_row;
+      const uint32_t off = idx * static_cast<uint32_t>(KP * sizeof(float)) + lane_off;
+      raw[slot][kk] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(other) + off);
+    }
+  };
+  auto consume = [&](int slot) {
+    u32x4_t hi[T], mid[T], lo[T];
+#pragma unroll
+    for (int d = 0; d < T; d++) {
+#pragma unroll
+      for (int pp = 0; pp < 4; pp++) {
+        const float x0 = raw[slot][2 * pp][d], x1 = raw[slot][2 * pp + 1][d];
+        bsum[d] += x0 + x1;
+        const unsigned h = pack_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        const unsigned mi = pack_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(mi << 16), s1 = r1 - __uint_as_float(mi & 0xffff0000u);
+        hi[d][pp] = h;
+        mid[d][pp] = mi;
+        lo[d][pp] = pack_bf16(s0, s1);
+      }
+    }
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < T; i++)
+#pragma unroll
+      for (int j = i; j < T; j++) {  // tile (row block j, column block i)
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, hi[j]), am = __builtin_bit_cast(bf16x8_t, mid[j]),
+                       al = __builtin_bit_cast(bf16x8_t, lo[j]);
+        const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, hi[i]), bm = __builtin_bit_cast(bf16x8_t, mid[i]),
+                       bl = __builtin_bit_cast(bf16x8_t, lo[i]);
+        // smallest terms first
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[t], 0, 0, 0);
+        t++;
+      }
+  };
+  // index blocks of 64 entries, one per lane, two blocks ahead (padded arrays: every load is
+  // unconditional, the loop is one basic block)
+  int cur = ip[0], nxt = ip[64];
+  issue(0, cur, 0, 0);
+  issue(1, cur, 1, 0);
+  for (int g0 = 0; g0 < ngroups; g0 += 2) {
+    const int e_next = 32 * (g0 + 2);       // first entry of the next block
+    const int nn = ip[e_next + 64];         // the block after it
+    consume(0);
+    issue(0, nxt, 0, e_next);
+    // (an early exit here for odd group counts measured slower: user half 1.19 -> 1.32 ms; the
+    // idle half-pair only gathers the all-zero row)
+    consume(1);
+    issue(1, nxt, 1, e_next);
+    cur = nxt;
+    nxt = nn;
+  }
+  (void)cur;
+#pragma unroll
+  for (int i = 0; i < T; i++) {
+    bsum[i] += __shfl_xor(bsum[i], 16, 64);
+    bsum[i] += __shfl_xor(bsum[i], 32, 64);
+    bsum[i] *= bias + 1.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Per-row solve by one wave.  The KP x KP system is spilled to this wave's LDS
 // slab in natural coordinates, then lane i owns row i in registers.
 //   SOLVER 0: Cholesky A = L L^T with forward / backward substitution
@@ -788,8 +903,10 @@ __device__ unsigned long long ials_phase_clk[2 * 4096];  // development: device-
 #define IPHASE(i)
 #endif
 
-template <int T, int SOLVER, int MODE, bool UNIT = false>
+// BF16X3: the rank update of syrk_gather_bf16x3 (opt-in; UNIT, Cholesky, T == 4 only).
+template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false>
 __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
+  static_assert(!BF16X3 || (UNIT && SOLVER == 0 && T == 4 && MODE == 0), "bf16x3: unit-confidence Cholesky at K <= 64");
   using G = Geo<T>;
   // Cholesky: lower-form tiles + the 16-row block solve of ials_chol16.hpp
   constexpr bool LOWER = SOLVER == 0;
@@ -821,8 +938,12 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : SOLV
 #pragma unroll
       for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    syrk_gather<T, 1, 0, RING, UNIT, LOWER>(p.other, p.indices, p.data, task.begin, task.end, p.bias,
-                                            acc, bsum, static_cast<unsigned>(p.zero_row));
+    if constexpr (BF16X3)
+      syrk_gather_bf16x3<T>(p.other, p.indices, task.begin, task.end, p.bias, acc, bsum,
+                            static_cast<unsigned>(p.zero_row));
+    else
+      syrk_gather<T, 1, 0, RING, UNIT, LOWER>(p.other, p.indices, p.data, task.begin, task.end, p.bias,
+                                              acc, bsum, static_cast<unsigned>(p.zero_row));
     IPHASE(0);
     if (task.slot >= 0) {
       float *dst = p.partials + static_cast<size_t>(task.slot) * G::PARTIAL_FLOATS;

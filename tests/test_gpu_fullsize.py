@@ -297,3 +297,34 @@ def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
         assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0, (kind, side))
         assert np.isfinite(got).all()
+
+
+def test_ials_k64_bf16x3_rank_update_is_fp32_accurate(X20, X20t, monkeypatch):
+    """Opt-in IRSPACK_AMD_IALS_BF16X3=1: the rank update on the bf16 matrix cores from exact
+    three-way splits of the fp32 factors (syrk_gather_bf16x3).  Same bar as the fp32 path
+    (per row 1e-4 against the oracle on all split rows + the longest + 2,000 random ones), and
+    against the float64 normal equations its error must stay within 2x the fp32 path's."""
+    K, kind = 64, "CHOLESKY"
+    mc, sc, omc, osc = configs(K, kind)
+    t = IALSTrainer(mc, X20)
+    monkeypatch.setenv("IRSPACK_AMD_IALS_BF16X3", "1")
+    b = IALSTrainer(mc, X20)
+    monkeypatch.delenv("IRSPACK_AMD_IALS_BF16X3")
+    t.step(sc)
+    user0, item0 = t.user, t.item
+    for side, (Xs, tgt0, oth0) in enumerate(((X20, user0, item0), (X20t, item0, user0))):
+        for tr in (t, b):
+            tr.user, tr.item = user0, item0
+            half_step(tr, side, sc)
+        got32 = t.user if side == 0 else t.item
+        got16 = b.user if side == 0 else b.item
+        rows, split = row_sample(Xs, 2000, seed=20 + side)
+        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+        assert_rows_match(kind, got16[rows], want, Xs, rows, tgt0, oth0, ("bf16x3", side))
+        sub = rows[:: max(1, len(rows) // 300)]  # ~300 rows against float64
+        ref = rows_float64(kind, Xs, sub, tgt0, oth0)
+        nref = np.linalg.norm(ref, axis=1)
+        e32 = np.linalg.norm(got32[sub] - ref, axis=1) / nref
+        e16 = np.linalg.norm(got16[sub] - ref, axis=1) / nref
+        assert e16.max() < 2 * e32.max() + 1e-6, (side, float(e16.max()), float(e32.max()))
+        assert np.median(e16) < 2 * np.median(e32) + 1e-7, (side, float(np.median(e16)), float(np.median(e32)))
