@@ -23,7 +23,7 @@ Objects on the line:
     knn           cosine / jaccard item-kNN top-100 (configs[2]); headline = wall-inclusive call
     evaluator     fused score + nDCG@20 over all users (K = 64)
     k256          configs[4] on one GPU: K = 256 Cholesky + CG epochs and the fused nDCG@20
-    c4            configs[3] shape (10 M x 1 M; 1/5 scale unless --extra) K = 128, CG + Cholesky
+    c4            configs[3] shape on one GPU (10 M x 1 M, 95 M stored entries), K = 128, CG + Cholesky
 """
 
 import argparse
@@ -55,9 +55,9 @@ def parse_args():
                     help="skip every leg reported next to the headline metric")
     ap.add_argument("--legs", default="ials_cg,ials_bf16x3,knn,evaluator,k256,c4",
                     help="comma-separated secondary legs to run (N = 1)")
-    ap.add_argument("--extra", action="store_true",
-                    help="run the c4 leg at the full 10 M x 1 M size (about 3 minutes of host "
-                         "generation + trainer construction)")
+    ap.add_argument("--c4-small", action="store_true",
+                    help="run the c4 leg on the 1/5-scale matrix of the same generator instead of "
+                         "the full 10 M x 1 M one (~20 s of host generation + construction)")
     return ap.parse_args()
 
 
@@ -344,7 +344,7 @@ def k256_leg(X, ceilings):
 
 def c4_leg(full, ceilings):
     """BASELINE configs[3] shape on one GPU (K = 128): short rows, CG (reference default) and
-    Cholesky.  Default = the 1/5-scale matrix of the same generator; --extra = 10 M x 1 M."""
+    Cholesky.  Default = the full 10 M x 1 M matrix; --c4-small = the 1/5-scale one."""
     from irspack_amd.recommenders._ials_core import IALSTrainer
     from irspack_amd.synthetic import describe, make_interactions
 
@@ -516,7 +516,7 @@ def main():
             trainer = local = None  # free the K = 64 trainer before the larger legs
             if args.shape == "ml20m":
                 run("k256", lambda: k256_leg(X, ceilings))
-                run("c4", lambda: c4_leg(args.extra, ceilings))
+                run("c4", lambda: c4_leg(not args.c4_small, ceilings))
             result["secondary"] = sec
     if world > 1:
         dist.barrier()

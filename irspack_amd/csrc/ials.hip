@@ -430,14 +430,87 @@ void download_factor(irs_ials_trainer *t, const float *dev, int64_t n, float *ho
 // is a prefix of the longer one's stream: `n` rows are drawn once.
 std::vector<float> draw_factor(const irs_ials_model_config &cfg, int64_t K, int64_t n) {
   std::vector<float> h(static_cast<size_t>(n) * K, 0.0f);
-  if (cfg.init_stdev > 0) {
-    std::mt19937 gen(cfg.random_seed);
-    // std::sqrt(factor.cols()) takes the integral overload (hpp:68-69): the quotient is formed
-    // in double and rounded to float once
-    std::normal_distribution<float> dist(
-        0.0, static_cast<float>(static_cast<double>(cfg.init_stdev) / std::sqrt(static_cast<double>(K))));
-    for (size_t i = 0; i < h.size(); i++) h[i] = dist(gen);
-  }  // init_stdev <= 0: the reference leaves the matrix uninitialised; we zero it
+  if (!(cfg.init_stdev > 0)) return h;  // the reference leaves the matrix uninitialised; we zero it
+  // std::sqrt(factor.cols()) takes the integral overload (hpp:68-69): the quotient is formed
+  // in double and rounded to float once
+  const float sd = static_cast<float>(static_cast<double>(cfg.init_stdev) / std::sqrt(static_cast<double>(K)));
+  std::mt19937 gen(cfg.random_seed);
+  const size_t total = h.size();
+  if (total < (size_t(1) << 18)) {
+    std::normal_distribution<float> dist(0.0, sd);
+    for (size_t i = 0; i < total; i++) h[i] = dist(gen);
+    return h;
+  }
+  // Large matrices (1.3 G values at the 10 M x 1 M shape: 56 s of sequential
+  // std::normal_distribution): the SAME stream, bit for bit, in parallel.  libstdc++'s
+  // normal_distribution<float> (bits/random.tcc) is Marsaglia's polar method on
+  // generate_canonical<float, 24>: every attempt consumes exactly two 32-bit words of the
+  // engine, accepted or not, and an accepted attempt yields two variates (y * m first, the
+  // saved x * m next).  So attempt j owns the words 2 j, 2 j + 1 whatever happened before it,
+  // and the output position of an accepted attempt is twice the number of accepted attempts
+  // before it: the engine's words are generated sequentially (the only serial part, ~2.5 ns a
+  // word) and the attempts are evaluated by all host threads with a prefix count.
+  auto canonical = [](uint32_t w) {
+    const float r = static_cast<float>(w) / 4294967296.0f;
+    return r >= 1.0f ? std::nextafter(1.0f, 0.0f) : r;
+  };
+  struct Attempt {
+    float x, y, r2;
+    bool ok;
+  };
+  auto attempt = [&](uint32_t w0, uint32_t w1) {
+    Attempt a;
+    a.x = static_cast<float>(2.0f * canonical(w0) - 1.0);
+    a.y = static_cast<float>(2.0f * canonical(w1) - 1.0);
+    a.r2 = a.x * a.x + a.y * a.y;
+    a.ok = !(a.r2 > 1.0f || a.r2 == 0.0f);
+    return a;
+  };
+  const size_t BLK = size_t(1) << 24;  // attempts per block (128 MB of words)
+  const int n_thr = static_cast<int>(std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
+  std::vector<uint32_t> words(2 * BLK);
+  std::vector<size_t> cnt(n_thr + 1);
+  size_t produced = 0;
+  while (produced < total) {
+    const size_t want_pairs = (total - produced + 1) / 2;
+    // ~78.5 % of the attempts are accepted; a short block at the end
+    const size_t na = std::min(BLK, static_cast<size_t>(want_pairs * 1.3) + 4096);
+    for (size_t i = 0; i < 2 * na; i++) words[i] = static_cast<uint32_t>(gen());
+    auto range = [&](int th, size_t &b, size_t &e) {
+      b = na * th / n_thr;
+      e = na * (th + 1) / n_thr;
+    };
+    auto count = [&](int th) {
+      size_t b, e, c = 0;
+      range(th, b, e);
+      for (size_t j = b; j < e; j++) c += attempt(words[2 * j], words[2 * j + 1]).ok ? 1 : 0;
+      cnt[th + 1] = c;
+    };
+    auto emit = [&](int th) {
+      size_t b, e;
+      range(th, b, e);
+      size_t pos = produced + 2 * cnt[th];
+      for (size_t j = b; j < e && pos < total; j++) {
+        const Attempt a = attempt(words[2 * j], words[2 * j + 1]);
+        if (!a.ok) continue;
+        const float mult = std::sqrt(-2 * std::log(a.r2) / a.r2);
+        h[pos] = a.y * mult * sd + 0.0f;
+        if (pos + 1 < total) h[pos + 1] = a.x * mult * sd + 0.0f;
+        pos += 2;
+      }
+    };
+    auto run = [&](auto fn) {
+      std::vector<std::thread> th;
+      for (int k = 1; k < n_thr; k++) th.emplace_back(fn, k);
+      fn(0);
+      for (auto &t : th) t.join();
+    };
+    cnt[0] = 0;
+    run(count);
+    for (int k = 0; k < n_thr; k++) cnt[k + 1] += cnt[k];
+    run(emit);
+    produced = std::min(total, produced + 2 * cnt[n_thr]);
+  }
   return h;
 }
 void init_factor(irs_ials_trainer *t, int which) {

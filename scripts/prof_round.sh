@@ -12,5 +12,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/sec_fetch -- p
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/sec_write -- python3 scripts/quick_knn_eval.py --skip-eval > gpurun_out/prof/sec_write.log 2>&1
 # short-row kernels (C4 shape at 1/5 scale, K = 128, CG and Cholesky)
 rm -rf gpurun_out/prof/c4_kt
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/c4_kt -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs c4 > gpurun_out/prof/c4_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/c4_kt -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs c4 --c4-small > gpurun_out/prof/c4_kt.log 2>&1
 ls gpurun_out/prof | head -40

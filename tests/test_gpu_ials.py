@@ -83,6 +83,19 @@ def test_init_matches_libstdcxx_stream(K):
     np.testing.assert_array_equal(t.user[:29], t.item)  # hpp:718-719 same seed for both
 
 
+@pytest.mark.parametrize("rows,K", [(5000, 64), (7001, 40), (300001, 3)])
+def test_parallel_init_stream_is_the_sequential_one(rows, K):
+    """Above 2^18 values the initial factors are drawn by all host threads (attempt j of the
+    polar method owns the engine words 2 j, 2 j + 1); the result must be libstdc++'s
+    sequential mt19937 + normal_distribution<float> stream bit for bit (hpp:64-76)."""
+    X = sps.csr_matrix((rows, 11), dtype=np.float32)
+    mc, _ = build(K, init=0.1, seed=7)
+    t = IALSTrainer(mc, X)
+    ref = O.ials_init(rows, K, 0.1, 7)
+    np.testing.assert_array_equal(t.user, ref)
+    np.testing.assert_array_equal(t.item, ref[:11])
+
+
 @pytest.mark.parametrize("K", [3, 16, 20, 31, 32, 48, 64])
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
 def test_one_epoch_matches_oracle(K, kind):
