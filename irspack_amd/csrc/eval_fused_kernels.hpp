@@ -355,3 +355,215 @@ __global__ __launch_bounds__(256) void mask_count_kernel(const uint64_t *__restr
 
 }  // namespace eval
 }  // namespace irs
+
+// ===========================================================================================
+// Threshold-filtered scoring ("emit" path, the default of irs_eval_get_metrics_ials when it
+// applies).  Three launches, none of which writes the [users, items] score block:
+//   1. sample pass (existing kernels): the scores of the first S items, masked, and per user
+//      the cutoff-th best of them = tau_u (sample_tau_kernel).  The user's final cutoff-th
+//      best score is >= tau_u, so every item of the final list has a score >= tau_u.
+//   2. score_emit_kernel: the whole score matrix, one wave per 64 x 64 tile exactly as
+//      user_scores_kernel computes it (bit-identical scores); the tile goes to the wave's LDS
+//      slab, lane l becomes user l, and the scores >= tau_l that are not masked are appended
+//      to the user's candidate list in global memory (one returning atomic per user and tile
+//      that has any; ~1 % of the scores pass, I / S x cutoff per user).
+//   3. rank_cand_kernel: one wave per user ranks the candidates by (score desc, index asc)
+//      like rank_wave_kernel ranks a score row, and finishes with the same metrics code.
+// A non-finite score, a user with fewer than `cutoff` rankable sample items, or an overflowing
+// candidate list abandon the path (flag) and the host runs the two-pass one.
+namespace irs {
+namespace eval {
+
+constexpr int EM_CAP = 1024;     // candidate slots per user
+constexpr int EM_SAMPLE = 2048;  // items of the sample pass
+
+struct EmitParams {
+  const float *user, *item;
+  int64_t begin, rows, n_items;
+  const uint64_t *mask_bits;  // [rows, words] or null
+  int64_t words;
+  const float *tau;           // [rows]
+  float *cand_score;          // [rows, EM_CAP]
+  int32_t *cand_item;
+  int32_t *cand_cnt;          // [rows]
+  int32_t *bad_flag;          // bit 0: non-finite score, bit 2: list overflow
+};
+
+// tau_u = the cutoff-th best score of the user's (masked) sample block, -inf when the block
+// holds fewer rankable scores (the caller then abandons the path).  One wave per user; lane l
+// keeps the M best of the scores l, l + 64, ...; the list is drawn from the 64 heads and a
+// lane that runs dry is simply exhausted: what it hides could only RAISE the true cutoff-th
+// best, so the value found is still a lower bound.
+template <int M>
+__global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict__ scores,
+                                                         int64_t rows, int64_t n_sample,
+                                                         int32_t cutoff, float *__restrict__ tau,
+                                                         int32_t *__restrict__ bad_flag) {
+  const int ln = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float NEG_INF = -std::numeric_limits<float>::infinity();
+  const float *srow = scores + row * n_sample;
+  float bs[M];
+#pragma unroll
+  for (int t = 0; t < M; t++) bs[t] = NEG_INF;
+  int n_rankable = 0;
+  bool bad = false;
+  for (int64_t base = 0; base < n_sample; base += 64 * 8) {
+    float sv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) sv[q] = srow[min<int64_t>(base + 64 * q + ln, n_sample - 1)];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      float cs = base + 64 * q + ln < n_sample ? sv[q] : NEG_INF;
+      bad |= cs != cs || cs == std::numeric_limits<float>::infinity();
+      n_rankable += __popcll(__ballot(cs != NEG_INF));
+      if (__any(cs > bs[M - 1])) {
+#pragma unroll
+        for (int t = 0; t < M; t++) {
+          const bool gt = cs > bs[t];
+          const float ts = bs[t];
+          bs[t] = gt ? cs : ts;
+          cs = gt ? ts : cs;
+        }
+      }
+    }
+  }
+  if (__any(bad)) {
+    if (ln == 0) atomicOr(bad_flag, 1);
+  }
+  float last = NEG_INF;
+  if (n_rankable >= cutoff) {
+    for (int it = 0; it < cutoff; it++) {
+      float ws = bs[0];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) ws = fmaxf(ws, __shfl_xor(ws, o, 64));
+      last = ws;
+      const unsigned long long who = __ballot(bs[0] == ws);
+      if (ln == __ffsll(static_cast<long long>(who)) - 1) {  // one lane pops its head
+#pragma unroll
+        for (int t = 0; t + 1 < M; t++) bs[t] = bs[t + 1];
+        bs[M - 1] = NEG_INF;
+      }
+    }
+  } else {
+    if (ln == 0) atomicOr(bad_flag, 8);  // too few rankable sample items for a threshold
+  }
+  if (ln == 0) tau[row] = last;
+}
+
+template <int KP>
+__global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
+  const int wid = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int g = ln >> 4, m = ln & 15;
+  float *S = reinterpret_cast<float *>(em_smem) + wid * (64 * FZ_SROW);
+  const int64_t item_tiles = (p.n_items + 63) / 64;
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wid;
+  const int64_t ut = w / item_tiles, it = w % item_tiles;
+  if (ut * 64 >= p.rows) return;
+  // lane l as user l: threshold and mask word of this tile (requested now, used after the MFMAs)
+  const int64_t my_row = ut * 64 + ln;
+  const bool my_valid = my_row < p.rows;
+  const float tau = my_valid ? p.tau[my_row] : std::numeric_limits<float>::infinity();
+  const uint64_t mword = (p.mask_bits && my_valid) ? p.mask_bits[my_row * p.words + it] : 0ull;
+  // ---- the 64 x 64 score tile, as user_scores_kernel
+  const float *up[4], *ip[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int64_t u = min(ut * 64 + q * 16 + m, p.rows - 1);
+    const int64_t i = min(it * 64 + 4 * m + q, p.n_items - 1);
+    up[q] = p.user + (p.begin + u) * KP + 4 * g;
+    ip[q] = p.item + i * KP + 4 * g;
+  }
+  fz_f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[a][b] = fz_f32x4{0.f, 0.f, 0.f, 0.f};
+  fz_f32x4 av[2][4], bv[2][4];
+  auto load_step = [&](int k, fz_f32x4 (&aa)[4], fz_f32x4 (&bb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      aa[q] = *reinterpret_cast<const fz_f32x4 *>(up[q] + k);
+      bb[q] = *reinterpret_cast<const fz_f32x4 *>(ip[q] + k);
+    }
+  };
+  auto mfma_step = [&](const fz_f32x4 (&aa)[4], const fz_f32x4 (&bb)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[a][c], bb[b][c], acc[a][b], 0, 0, 0);
+  };
+  load_step(0, av[0], bv[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (KP == 16) {
+    mfma_step(av[0], bv[0]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < KP; k += 32) {
+      load_step(k + 16, av[1], bv[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(av[0], bv[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 32 < KP) load_step(k + 32, av[0], bv[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(av[1], bv[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- tile -> LDS (row = user 16 a + 4 g + r, columns 4 m .. 4 m + 3 = items 4 m + q)
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      *reinterpret_cast<fz_f32x4 *>(S + (16 * a + 4 * g + r) * FZ_SROW + 4 * m) =
+          fz_f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+  FZ_LDS_FENCE();
+  // ---- lane l scans user l's 64 scores: which pass?
+  const int valid_items = static_cast<int>(min<int64_t>(64, p.n_items - it * 64));
+  uint32_t plo = 0, phi = 0;
+  float fsum = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 16; jj++) {
+    const fz_f32x4 v = *reinterpret_cast<const fz_f32x4 *>(S + ln * FZ_SROW + 4 * jj);
+    fsum += (v.x + v.y) + (v.z + v.w);  // NaN / infinity anywhere poisons the sum
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int j = 4 * jj + c;
+      const uint32_t bit = v[c] >= tau ? (1u << (j & 31)) : 0u;
+      if (j < 32) plo |= bit; else phi |= bit;
+    }
+  }
+  if (__any(my_valid && !(fabsf(fsum) < 3.0e38f))) {
+    if (ln == 0) atomicOr(p.bad_flag, 1);
+  }
+  uint64_t pm = (static_cast<uint64_t>(phi) << 32) | plo;
+  pm &= ~mword;
+  if (valid_items < 64) pm &= (1ull << valid_items) - 1ull;
+  if (!my_valid) pm = 0ull;
+  if (!__any(pm != 0ull)) return;
+  const int n_pass = __popcll(pm);
+  int base = 0;
+  if (n_pass > 0) base = atomicAdd(p.cand_cnt + my_row, n_pass);
+  if (n_pass > 0 && base + n_pass > EM_CAP) {
+    atomicOr(p.bad_flag, 4);
+    pm = 0ull;
+  }
+  while (__any(pm != 0ull)) {
+    if (pm != 0ull) {
+      const int j = __ffsll(static_cast<long long>(pm)) - 1;
+      pm &= pm - 1;
+      const size_t dst = static_cast<size_t>(my_row) * EM_CAP + base;
+      p.cand_score[dst] = S[ln * FZ_SROW + j];
+      p.cand_item[dst] = static_cast<int32_t>(it * 64 + j);
+      base++;
+    }
+  }
+}
+
+}  // namespace eval
+}  // namespace irs

@@ -601,6 +601,150 @@ __device__ __forceinline__ void wave_metrics_tail(const EvalParams &p, int64_t r
   if (ln == 0) p.out[row] = res;
 }
 
+// Emit path, last kernel: one wave per user ranks its candidate list (score_emit_kernel:
+// every unmasked item with score >= tau_u, in arbitrary order) by (score desc, index asc).
+// Lane l keeps the M best of the entries l, l + 64, ... sorted in registers, the list is drawn
+// from the 64 heads; a lane that runs dry with entries left over may hide a better one: the row
+// is then ranked by rank_cand_slow_kernel.
+template <int M>
+__global__ __launch_bounds__(256) void rank_cand_kernel(EvalParams p, EmitParams f,
+                                                        const int32_t *__restrict__ n_masked) {
+  const int ln = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= p.rows) return;
+  const int64_t u = row + p.offset;
+  RowOut res{0, 0, 0, 0, 0, 0, 0};
+  const int gb = p.gt_ptr[u], ge = p.gt_ptr[u + 1];
+  const int n_gt = ge - gb;
+  int32_t *rec_row = p.rec_out + row * p.cutoff;
+  if (ln < p.cutoff) rec_row[ln] = -1;  // cutoff <= 32
+  if (ln == 0) p.todo[row] = 0;
+  if (n_gt == 0) {  // counted in total_user only (:316-321)
+    if (ln == 0) p.out[row] = res;
+    return;
+  }
+  int32_t gt_pref = -1;
+  double disc_pref = 0.0;
+  if (n_gt <= 64 && ln < n_gt) gt_pref = p.gt_idx[gb + ln];
+  if (ln < p.cutoff) disc_pref = p.disc[ln];
+  const double idcg_pref = p.idcg_prefix[min(n_gt, p.cutoff)];
+  const int n = min(f.cand_cnt[row], EM_CAP);
+  const int64_t n_rankable = f.n_items - (n_masked ? n_masked[row] : 0);
+  const int n_rec = static_cast<int>(min<int64_t>(p.cutoff, n_rankable));
+  res.valid = 1;
+  res.n_rec = n_rec;
+  if (n_rec == 0) {  // :132-135
+    if (ln == 0) p.out[row] = res;
+    return;
+  }
+  if (n < n_rec) {  // cannot happen with a valid threshold: have the host repeat the call
+    if (ln == 0) atomicOr(f.bad_flag, 2);
+    if (ln == 0) p.out[row] = res;
+    return;
+  }
+  const float NEG_INF = -std::numeric_limits<float>::infinity();
+  const float *cs = f.cand_score + static_cast<size_t>(row) * EM_CAP;
+  const int32_t *ci = f.cand_item + static_cast<size_t>(row) * EM_CAP;
+  float bs[M];
+  int32_t bi[M];
+#pragma unroll
+  for (int t = 0; t < M; t++) {
+    bs[t] = NEG_INF;
+    bi[t] = 0x7fffffff;
+  }
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const int e = e0 + ln;
+    float s = e < n ? cs[e] : NEG_INF;
+    int32_t i = e < n ? ci[e] : 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < M; t++) {
+      const bool better = s > bs[t] || (s == bs[t] && i < bi[t]);
+      const float ts = bs[t];
+      const int32_t ti = bi[t];
+      bs[t] = better ? s : ts;
+      bi[t] = better ? i : ti;
+      s = better ? ts : s;
+      i = better ? ti : i;
+    }
+  }
+  const int mine_total = (n - ln + 63) / 64;  // entries this lane has seen
+  int32_t mi = 0x7fffffff;
+  int popped = 0;
+  for (int it = 0; it < n_rec; it++) {
+    float ws = bs[0];
+    int32_t wi = bi[0];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float os = __shfl_xor(ws, o, 64);
+      const int32_t oi = __shfl_xor(wi, o, 64);
+      const bool better = os > ws || (os == ws && oi < wi);
+      ws = better ? os : ws;
+      wi = better ? oi : wi;
+    }
+    if (ln == it) mi = wi;
+    if (bi[0] == wi && bs[0] == ws) {  // item ids are unique: one lane
+#pragma unroll
+      for (int t = 0; t + 1 < M; t++) {
+        bs[t] = bs[t + 1];
+        bi[t] = bi[t + 1];
+      }
+      bs[M - 1] = NEG_INF;
+      bi[M - 1] = 0x7fffffff;
+      popped++;
+    }
+    if (it + 1 < n_rec && __any(popped == M && mine_total > M)) {
+      if (ln == 0) p.todo[row] = 1;
+      return;
+    }
+  }
+  wave_metrics_tail(p, row, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
+}
+
+// The rows rank_cand_kernel flagged: exact rank of every candidate by counting (LDS copy).
+__global__ __launch_bounds__(256) void rank_cand_slow_kernel(EvalParams p, EmitParams f,
+                                                             const int32_t *__restrict__ n_masked) {
+  __shared__ float cs[4][EM_CAP];
+  __shared__ int32_t ci[4][EM_CAP];
+  __shared__ int32_t sel[4][64];
+  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wv;
+  if (row >= p.rows || p.todo[row] == 0) return;
+  const int64_t u = row + p.offset;
+  RowOut res{0, 0, 0, 0, 0, 0, 0};
+  const int gb = p.gt_ptr[u], ge = p.gt_ptr[u + 1];
+  const int n_gt = ge - gb;
+  int32_t *rec_row = p.rec_out + row * p.cutoff;
+  int32_t gt_pref = -1;
+  double disc_pref = 0.0;
+  if (n_gt <= 64 && ln < n_gt) gt_pref = p.gt_idx[gb + ln];
+  if (ln < p.cutoff) disc_pref = p.disc[ln];
+  const double idcg_pref = p.idcg_prefix[min(n_gt, p.cutoff)];
+  const int n = min(f.cand_cnt[row], EM_CAP);
+  const int64_t n_rankable = f.n_items - (n_masked ? n_masked[row] : 0);
+  const int n_rec = static_cast<int>(min<int64_t>(p.cutoff, n_rankable));
+  res.valid = 1;
+  res.n_rec = n_rec;
+  for (int e = ln; e < n; e += 64) {
+    cs[wv][e] = f.cand_score[static_cast<size_t>(row) * EM_CAP + e];
+    ci[wv][e] = f.cand_item[static_cast<size_t>(row) * EM_CAP + e];
+  }
+  __threadfence_block();
+  for (int e = ln; e < n; e += 64) {
+    const float s = cs[wv][e];
+    const int32_t i = ci[wv][e];
+    int rank = 0;
+    for (int k = 0; k < n; k++) {
+      const float sk = cs[wv][k];
+      const int32_t ik = ci[wv][k];
+      rank += (sk > s || (sk == s && ik < i)) ? 1 : 0;
+    }
+    if (rank < n_rec) sel[wv][rank] = i;
+  }
+  __threadfence_block();
+  const int32_t mi = ln < n_rec ? sel[wv][ln] : 0x7fffffff;
+  wave_metrics_tail(p, row, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
+}
+
 // Fused path, second kernel: one wave per user.  Merges the item chunks' lists (each the
 // chunk's top `cutoff`, so their union contains the user's), ranks the union by (score desc,
 // index asc) and finishes like rank_wave_kernel.  n_rec = min(cutoff, rankable items):
@@ -712,9 +856,13 @@ __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
   const int32_t n = static_cast<int32_t>(p.n_items);
   auto insert = [&](T cs, int32_t ci) {
     if (__any(cs > bs[M - 1])) {
+      // from the first entry the new score beats, the tail SHIFTS down one place (sticky
+      // `gt`): an entry pushed down by one place still goes before its equals, whose
+      // indices are higher
+      bool gt = false;
 #pragma unroll
       for (int t = 0; t < M; t++) {
-        const bool gt = cs > bs[t];
+        gt = gt || cs > bs[t];
         const T ts = bs[t];
         const int32_t ti = bi[t];
         bs[t] = gt ? cs : ts;
@@ -856,12 +1004,15 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const RowOut *rows, i
 }
 
 // scores[row, col] = -inf for the stored entries of the mask rows (evaluator.py:426-432)
+// (`n_items` = row stride = number of leading items the block holds: entries beyond are skipped)
 __global__ void mask_rows_kernel(float *scores, int64_t rows, int64_t n_items,
                                  const int64_t *mask_ptr, const int32_t *mask_idx) {
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
-  for (int64_t q = mask_ptr[row] + threadIdx.x; q < mask_ptr[row + 1]; q += blockDim.x)
-    scores[row * n_items + mask_idx[q]] = -std::numeric_limits<float>::infinity();
+  for (int64_t q = mask_ptr[row] + threadIdx.x; q < mask_ptr[row + 1]; q += blockDim.x) {
+    const int32_t j = mask_idx[q];
+    if (j < n_items) scores[row * n_items + j] = -std::numeric_limits<float>::infinity();
+  }
 }
 
 }  // namespace eval
@@ -874,6 +1025,8 @@ using namespace irs::eval;
 extern "C" irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
                                               float *device_out, void **stream_out,
                                               int32_t *device_index);
+extern "C" irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
+                                                     int64_t n_prefix, float *device_out);
 extern "C" irs_status irs_ials_factors_device_(irs_ials_trainer *t, const float **user,
                                                const float **item, int32_t *KP, int64_t *n_users,
                                                int64_t *n_items, void **stream_out,
@@ -900,7 +1053,7 @@ struct irs_evaluator {
   DeviceBuffer<uint64_t> mask_bits;
   DeviceBuffer<int32_t> mask_count;
   int64_t mask_bits_rows = -1;  // rows the bitmap was built for (-1: none)
-  DeviceBuffer<float> cand_score;
+  DeviceBuffer<float> cand_score, tau;
   DeviceBuffer<int32_t> cand_item, cand_cnt, tau_hint, bad_flag;
 };
 
@@ -923,7 +1076,11 @@ template <class T> void launch_rank(EvalParams p, int64_t max_cand, hipStream_t 
   // the usual case first (all items are candidates, cutoff <= 64): one wave per row; the
   // rows it flags (and every row otherwise) go through the general kernel
   p.todo = nullptr;
-  if (p.rec_mode == 0 && p.cutoff <= 64 && p.n_items < (int64_t(1) << 31) - 64 * 16 &&
+  static const bool wave_ok = [] {  // IRSPACK_AMD_EVAL_WAVE=0: general kernel only (debugging)
+    const char *e = std::getenv("IRSPACK_AMD_EVAL_WAVE");
+    return !(e && e[0] == '0');
+  }();
+  if (wave_ok && p.rec_mode == 0 && p.cutoff <= 64 && p.n_items < (int64_t(1) << 31) - 64 * 16 &&
       todo != nullptr) {
     p.todo = todo;
     const dim3 grid(static_cast<unsigned>((p.rows + 3) / 4));
@@ -1129,6 +1286,146 @@ bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int
   return true;
 }
 
+// IRSPACK_AMD_EVAL_EMIT=0 switches the threshold-filtered path off (A/B against the two-pass one).
+bool emit_enabled() {
+  const char *e = std::getenv("IRSPACK_AMD_EVAL_EMIT");
+  return e ? std::atoi(e) != 0 : true;
+}
+
+// Builds (or reuses) the bitmap + per-row count of the mask CSR; false when it would not fit.
+bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int64_t *d_mptr,
+                        const int32_t *d_midx, hipStream_t s) {
+  if (static_cast<double>(rows) * words * 8.0 > 2147483648.0) return false;
+  const bool cached = d_mptr == e->mask_ptr.ptr && e->mask_bits_rows == rows;
+  if (!cached) {
+    e->mask_bits.alloc(static_cast<size_t>(rows) * words);
+    e->mask_count.alloc(rows);
+    IRS_HIP(hipMemsetAsync(e->mask_bits.ptr, 0, static_cast<size_t>(rows) * words * 8, s));
+    hipLaunchKernelGGL(mask_bitmap_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, d_mptr, d_midx,
+                       rows, words, e->mask_bits.ptr);
+    hipLaunchKernelGGL(mask_count_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, e->mask_bits.ptr,
+                       rows, words, e->mask_count.ptr);
+    e->mask_bits_rows = d_mptr == e->mask_ptr.ptr ? rows : -1;  // only the resident mask is cached
+  }
+  return true;
+}
+
+// The threshold-filtered path of irs_eval_get_metrics_ials (eval_fused_kernels.hpp, second
+// half).  Returns false when the call is outside its domain or had to be abandoned; the caller
+// then runs the two-pass path.
+bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t rows,
+               const int64_t *d_mptr, const int32_t *d_midx, int64_t cutoff, int64_t offset,
+               bool rwc, hipStream_t s) {
+  if (!emit_enabled() || e->rec_mode != 0 || cutoff > FZ_MAX_CUTOFF || rows <= 0) return false;
+  const float *user = nullptr, *item = nullptr;
+  int32_t KP = 0, dev = 0;
+  int64_t nu = 0, ni = 0;
+  void *sv = nullptr;
+  if (irs_ials_factors_device_(t, &user, &item, &KP, &nu, &ni, &sv, &dev) != IRS_OK)
+    throw std::runtime_error(irs_last_error());
+  // worth it only when the sample is a small part of the catalogue
+  if (ni != e->n_items || ni < 4 * EM_SAMPLE || rows > (int64_t(1) << 31) / EM_CAP) return false;
+  const int64_t words = ceil_div(ni, 64);
+  const uint64_t *bits = nullptr;
+  const int32_t *n_masked = nullptr;
+  if (d_mptr) {
+    if (!ensure_mask_bitmap(e, rows, words, d_mptr, d_midx, s)) return false;
+    bits = e->mask_bits.ptr;
+    n_masked = e->mask_count.ptr;
+  }
+  e->bad_flag.alloc(1);
+  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, sizeof(int32_t), s));
+  // ---- 1. sample pass: thresholds from the first EM_SAMPLE items, in blocks of users
+  e->tau.alloc(rows);
+  {
+    const int64_t SB = 32768;  // users per sample block (256 MB of scores)
+    e->fused_scores.alloc(static_cast<size_t>(std::min(SB, rows)) * EM_SAMPLE);
+    for (int64_t b = 0; b < rows; b += SB) {
+      const int64_t m = std::min(SB, rows - b);
+      if (irs_ials_scores_prefix_device_(t, begin + b, begin + b + m, EM_SAMPLE,
+                                         e->fused_scores.ptr) != IRS_OK)
+        throw std::runtime_error(irs_last_error());
+      if (d_mptr)
+        hipLaunchKernelGGL(mask_rows_kernel, dim3(m), dim3(64), 0, s, e->fused_scores.ptr, m,
+                           static_cast<int64_t>(EM_SAMPLE), d_mptr + b, d_midx);
+      hipLaunchKernelGGL((sample_tau_kernel<8>), dim3(static_cast<unsigned>(ceil_div(m, 4))), dim3(256),
+                         0, s, e->fused_scores.ptr, m, static_cast<int64_t>(EM_SAMPLE),
+                         static_cast<int32_t>(cutoff), e->tau.ptr + b, e->bad_flag.ptr);
+    }
+  }
+  // ---- 2. the whole score matrix, candidates only
+  e->cand_score.alloc(static_cast<size_t>(rows) * EM_CAP);
+  e->cand_item.alloc(static_cast<size_t>(rows) * EM_CAP);
+  e->cand_cnt.alloc(rows);
+  IRS_HIP(hipMemsetAsync(e->cand_cnt.ptr, 0, rows * sizeof(int32_t), s));
+  EmitParams f;
+  f.user = user;
+  f.item = item;
+  f.begin = begin;
+  f.rows = rows;
+  f.n_items = ni;
+  f.mask_bits = bits;
+  f.words = words;
+  f.tau = e->tau.ptr;
+  f.cand_score = e->cand_score.ptr;
+  f.cand_item = e->cand_item.ptr;
+  f.cand_cnt = e->cand_cnt.ptr;
+  f.bad_flag = e->bad_flag.ptr;
+  {
+    const int64_t tiles = ceil_div(rows, 64) * ceil_div(ni, 64);
+    const size_t lds = 4 * 64 * FZ_SROW * sizeof(float);
+    auto launch = [&](auto kernel) {
+      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ceil_div(tiles, 4))), dim3(256), lds, s, f);
+    };
+    switch (KP) {
+      case 16: launch(score_emit_kernel<16>); break;
+      case 32: launch(score_emit_kernel<32>); break;
+      case 64: launch(score_emit_kernel<64>); break;
+      case 128: launch(score_emit_kernel<128>); break;
+      case 192: launch(score_emit_kernel<192>); break;
+      case 256: launch(score_emit_kernel<256>); break;
+      default: return false;
+    }
+  }
+  // ---- 3. rank the candidates, metrics
+  e->row_out.alloc(rows);
+  e->rec_out.alloc(rows * cutoff);
+  e->todo.alloc(rows);
+  EvalParams p;
+  p.scores = nullptr;
+  p.rows = rows;
+  p.n_items = e->n_items;
+  p.offset = offset;
+  p.gt_ptr = e->gt_ptr.ptr;
+  p.gt_idx = e->gt_idx.ptr;
+  p.rec_mode = 0;
+  p.rec_ptr = e->rec_ptr.ptr;
+  p.rec_items = e->rec_items.ptr;
+  p.cutoff = static_cast<int32_t>(cutoff);
+  p.retrieve = 0;
+  p.recall_with_cutoff = rwc ? 1 : 0;
+  p.disc = e->disc.ptr;
+  p.idcg_prefix = e->idcg_prefix.ptr;
+  p.out = e->row_out.ptr;
+  p.rec_out = e->rec_out.ptr;
+  p.item_cnt = e->item_cnt.ptr;
+  p.todo = e->todo.ptr;
+  const dim3 grid(static_cast<unsigned>(ceil_div(rows, 4)));
+  hipLaunchKernelGGL((rank_cand_kernel<8>), grid, dim3(256), 0, s, p, f, n_masked);
+  hipLaunchKernelGGL(rank_cand_slow_kernel, grid, dim3(256), 0, s, p, f, n_masked);
+  IRS_HIP(hipGetLastError());
+  int32_t bad = 0;
+  IRS_HIP(hipMemcpyAsync(&bad, e->bad_flag.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
+  IRS_HIP(hipStreamSynchronize(s));
+  if (bad) return false;  // the two-pass path handles it (and defines the order of NaN scores)
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
+                     e->metrics.ptr);
+  IRS_HIP(hipGetLastError());
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1278,6 +1575,11 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
       d_mptr = e->mask_ptr.ptr;
       d_midx = e->mask_idx.ptr;
     }
+    if (emit_path(e, t, begin, rows, d_mptr, d_midx, cutoff, offset, recall_with_cutoff != 0, s)) {
+      finish_accumulate(e, out, item_cnt, s);
+      return;
+    }
+    begin_accumulate(e, s);  // (an abandoned attempt may have touched the sums)
     if (fused_single_pass(e, t, begin, rows, d_mptr, d_midx, cutoff, offset,
                           recall_with_cutoff != 0, s)) {
       finish_accumulate(e, out, item_cnt, s);

@@ -905,6 +905,8 @@ irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t e
 irs_status irs_ials_factors_device_(irs_ials_trainer *t, const float **user, const float **item,
                                     int32_t *KP, int64_t *n_users, int64_t *n_items,
                                     void **stream_out, int32_t *device_index);
+irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
+                                          int64_t n_prefix, float *device_out);
 
 const char *irs_last_error(void) { return irs::last_error().c_str(); }
 int32_t irs_abi_version(void) { return 1; }
@@ -1196,6 +1198,29 @@ irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t e
     IRS_DISPATCH_ANY(t->T, {
       hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
                          t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m, t->n_items,
+                         device_out);
+    });
+    t->prof.end(t->stream);
+    IRS_HIP(hipGetLastError());
+  });
+}
+
+// Internal hook for evaluator.hip's sample pass: user[begin:end] @ item[:n_prefix]^T into a
+// device buffer [end - begin, n_prefix] on the trainer's stream.  Not part of the public ABI.
+irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
+                                          int64_t n_prefix, float *device_out) {
+  return guard([&] {
+    check_arg(t && device_out, "null argument.");
+    check_arg(0 <= begin && begin <= end && end <= t->n_users && 0 < n_prefix &&
+                  n_prefix <= t->n_items, "block out of range.");
+    IRS_HIP(hipSetDevice(t->device));
+    const int64_t m = end - begin;
+    if (m == 0) return;
+    const int64_t waves = ceil_div(m, 64) * ceil_div(n_prefix, 64);
+    t->prof.begin("user_scores", t->stream);
+    IRS_DISPATCH_ANY(t->T, {
+      hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
+                         t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m, n_prefix,
                          device_out);
     });
     t->prof.end(t->stream);

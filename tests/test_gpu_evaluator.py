@@ -250,6 +250,31 @@ def test_many_ties_short_list_and_general_selection(dtype, levels, cutoff):
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("cutoff", [10, 20, 24, 32, 64])
+def test_moderately_tied_rows_keep_index_order(dtype, cutoff):
+    """Integer-valued scores with a bell-shaped distribution: a handful of items tie at the
+    cutoff-th score, few enough that the one-wave kernel keeps the row.  An entry pushed down
+    its lane's list by a better late arrival has to stay ahead of the equal entries behind it
+    (lowest index first, evaluator.cpp:329, 353-355); round 1's lists dropped it instead."""
+    rns = np.random.default_rng(11)
+    U, I, K = 700, 9000, 24
+    user = rns.integers(-2, 3, size=(U, K)).astype(np.float64)
+    item = rns.integers(-2, 3, size=(I, K)).astype(np.float64)
+    scores = (user @ item.T).astype(dtype)
+    scores[rns.random((U, I)) < 0.05] = -np.inf
+    gt = sps.random(U, I, density=0.002, format="csr", random_state=rns, dtype=np.float64)
+    gt.data[:] = 1.0
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    f = "get_metrics_f64" if dtype == "float64" else "get_metrics_f32"
+    m = getattr(core, f)(scores, cutoff, 0, 4, False)
+    compare(m, getattr(ocore, f)(scores, cutoff, 0, 4, False))
+    want = np.zeros(I, dtype=np.int64)
+    for u in np.flatnonzero(np.diff(gt.indptr)):
+        np.add.at(want, np.lexsort((np.arange(I), -scores[u]))[:cutoff], 1)
+    np.testing.assert_array_equal(m.item_cnt, want)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_nan_scores_rank_last_and_signed_zeros_tie(dtype):
     """The reference leaves NaN ordering undefined; this build ranks NaN after every other
     rankable score (ties by index), so replacing NaN by a value below all others must not
@@ -269,3 +294,39 @@ def test_nan_scores_rank_last_and_signed_zeros_tie(dtype):
     replaced = np.where(np.isnan(scores), np.asarray(-1e30, dtype=dtype), scores)
     for cutoff in (5, 20, 300):
         compare(getattr(core, f)(scores, cutoff, 0, 2), getattr(ocore, f)(replaced, cutoff, 0, 2))
+
+
+@pytest.mark.parametrize("cutoff", [5, 20, 32])
+def test_emit_path_on_a_wide_catalogue(cutoff, monkeypatch):
+    """The threshold-filtered path (catalogues of >= 8,192 items, cutoff <= 32): sample
+    thresholds -> candidates -> exact ranking must give the two-pass path's metrics bit for
+    bit (counters, histogram) on a model with many exactly tied scores (integer factors), a
+    dense mask and users without ground truth; and both must equal the oracle."""
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, IALSTrainer)
+
+    rng2 = np.random.default_rng(11)
+    U, I, K = 700, 9000, 24
+    mc = IALSModelConfigBuilder().set_K(K).build()
+    sc = IALSSolverConfigBuilder().build()
+    t = IALSTrainer(mc, sps.csr_matrix((U, I), dtype=np.float32))
+    t.user = rng2.integers(-2, 3, size=(U, K)).astype(np.float32)  # small integers: many ties
+    t.item = rng2.integers(-2, 3, size=(I, K)).astype(np.float32)
+    mask = sps.random(U, I, density=0.05, format="csr", random_state=rng2, dtype=np.float32)
+    mask.data[:] = 1.0
+    gt = sps.random(U, I, density=0.002, format="csr", random_state=rng2, dtype=np.float64)
+    gt.data[:] = 1.0
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_EMIT", "1")
+    a = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, True)
+    part = core.get_metrics_ials(t, 100, 571, sps.csr_matrix(mask[100:571]), cutoff, 100, False)
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_EMIT", "0")
+    b = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, True)
+    np.testing.assert_array_equal(a.item_cnt, b.item_cnt)
+    assert (a.valid_user, a.total_user) == (b.valid_user, b.total_user)
+    for k in ("hit", "ndcg", "recall", "map", "precision"):
+        assert getattr(a, k) == pytest.approx(getattr(b, k), rel=1e-12)
+    scores = t.user_scores(0, U, sc)
+    scores[mask.nonzero()] = -np.inf
+    compare(a, ocore.get_metrics_f32(scores, cutoff, 0, 4, True))
+    compare(part, ocore.get_metrics_f32(scores[100:571], cutoff, 100, 4, False))

@@ -252,15 +252,17 @@ def test_evaluator_ndcg20_block_at_ml20m_width(X20):
                         ocore.get_metrics_f32(scores, cutoff, b, CORES))
 
 
-@pytest.mark.parametrize("single_pass", [False, True])
+@pytest.mark.parametrize("path", ["emit", "two_pass", "single_pass"])
 @pytest.mark.parametrize("K", [64, 256])
-def test_fused_evaluator_ml20m_vs_oracle(X20, K, single_pass, monkeypatch):
+def test_fused_evaluator_ml20m_vs_oracle(X20, K, path, monkeypatch):
     """configs[4] (K = 256) and the bench's secondary leg (K = 64): the fused device path
     (score + mask + rank without the block leaving the device) over 20,000 users, against the
-    oracle fed the same scores (user_scores) masked on the host.  Both implementations: the
-    default two-pass one (16,384-user score blocks in HBM) and the single-pass kernels of
-    eval_fused_kernels.hpp (IRSPACK_AMD_EVAL_FUSED=1: the block never reaches HBM)."""
-    monkeypatch.setenv("IRSPACK_AMD_EVAL_FUSED", "1" if single_pass else "0")
+    oracle fed the same scores (user_scores) masked on the host.  All three implementations:
+    "emit" (default: sample thresholds, then only the candidates above them leave the scoring
+    kernel), "two_pass" (16,384-user score blocks in HBM, IRSPACK_AMD_EVAL_EMIT=0) and
+    "single_pass" (streaming top-k inside the scoring kernel, IRSPACK_AMD_EVAL_FUSED=1)."""
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_EMIT", "1" if path == "emit" else "0")
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_FUSED", "1" if path == "single_pass" else "0")
     mc, sc, _, _ = configs(K, "CG")
     t = IALSTrainer(mc, X20)
     t.step(sc)
