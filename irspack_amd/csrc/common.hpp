@@ -80,6 +80,11 @@ template <class T> struct DeviceBuffer {
   }
 };
 
+// device_sort.hip: key-value sort of n float keys (ascending or descending, stable) on stream s;
+// `tmp` is scratch that grows as needed and may be kept between calls
+void sort_pairs_f32(bool descending, const float *keys_in, float *keys_out, const int32_t *vals_in,
+                    int32_t *vals_out, size_t n, DeviceBuffer<char> &tmp, hipStream_t s);
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace irs

@@ -387,6 +387,12 @@ struct EmitParams {
   int32_t *cand_item;
   int32_t *cand_cnt;          // [rows]
   int32_t *bad_flag;          // bit 0: non-finite score, bit 2: list overflow
+  // bounded variant (below): sorted position -> item id / row of the call, and per 64-user
+  // tile the number of leading item tiles that can still hold a candidate
+  const int32_t *iperm, *uperm, *limit_tiles;
+  // rows the path cannot finish (no threshold from the sample, candidate list overflow): set
+  // to 1 here, ranked one by one from their full score rows afterwards
+  int32_t *hard;
 };
 
 // tau_u = the cutoff-th best score of the user's (masked) sample block, -inf when the block
@@ -398,7 +404,8 @@ template <int M>
 __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict__ scores,
                                                          int64_t rows, int64_t n_sample,
                                                          int32_t cutoff, float *__restrict__ tau,
-                                                         int32_t *__restrict__ bad_flag) {
+                                                         int32_t *__restrict__ bad_flag,
+                                                         int32_t *__restrict__ hard) {
   const int ln = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -447,32 +454,51 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
       }
     }
   } else {
-    if (ln == 0) atomicOr(bad_flag, 8);  // too few rankable sample items for a threshold
+    // too few rankable sample items for a threshold (a user who has seen nearly all of them)
+    last = std::numeric_limits<float>::infinity();
+    if (ln == 0) hard[row] = 1;
   }
   if (ln == 0) tau[row] = last;
 }
 
-template <int KP>
+// BOUNDED: users and items are addressed through the two sort permutations (tile rows = 64
+// users of similar pruning radius, tile columns = 64 items of similar norm), tiles at or beyond
+// the user tile's limit leave at once, and the mask is probed per passing score (the bitmap is
+// indexed by item id, not by sorted position).
+template <int KP, bool BOUNDED>
 __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
   const int wid = threadIdx.x >> 6, ln = threadIdx.x & 63;
   const int g = ln >> 4, m = ln & 15;
   float *S = reinterpret_cast<float *>(em_smem) + wid * (64 * FZ_SROW);
+  int32_t *IDS = reinterpret_cast<int32_t *>(em_smem + 4 * 64 * FZ_SROW * sizeof(float)) + wid * 64;
   const int64_t item_tiles = (p.n_items + 63) / 64;
   const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wid;
   const int64_t ut = w / item_tiles, it = w % item_tiles;
   if (ut * 64 >= p.rows) return;
+  if constexpr (BOUNDED) {
+    if (it >= p.limit_tiles[ut]) return;
+  }
   // lane l as user l: threshold and mask word of this tile (requested now, used after the MFMAs)
-  const int64_t my_row = ut * 64 + ln;
-  const bool my_valid = my_row < p.rows;
+  const int64_t my_pos = ut * 64 + ln;
+  const bool my_valid = my_pos < p.rows;
+  int64_t my_row = my_pos;
+  if constexpr (BOUNDED) my_row = my_valid ? p.uperm[my_pos] : 0;
   const float tau = my_valid ? p.tau[my_row] : std::numeric_limits<float>::infinity();
-  const uint64_t mword = (p.mask_bits && my_valid) ? p.mask_bits[my_row * p.words + it] : 0ull;
+  uint64_t mword = 0ull;
+  if constexpr (!BOUNDED) mword = (p.mask_bits && my_valid) ? p.mask_bits[my_row * p.words + it] : 0ull;
+  int32_t my_item = 0;
+  if constexpr (BOUNDED) my_item = p.iperm[min(it * 64 + ln, p.n_items - 1)];
   // ---- the 64 x 64 score tile, as user_scores_kernel
   const float *up[4], *ip[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const int64_t u = min(ut * 64 + q * 16 + m, p.rows - 1);
-    const int64_t i = min(it * 64 + 4 * m + q, p.n_items - 1);
+    int64_t u = min(ut * 64 + q * 16 + m, p.rows - 1);
+    int64_t i = min(it * 64 + 4 * m + q, p.n_items - 1);
+    if constexpr (BOUNDED) {
+      u = p.uperm[u];
+      i = p.iperm[i];
+    }
     up[q] = p.user + (p.begin + u) * KP + 4 * g;
     ip[q] = p.item + i * KP + 4 * g;
   }
@@ -522,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
     for (int r = 0; r < 4; r++)
       *reinterpret_cast<fz_f32x4 *>(S + (16 * a + 4 * g + r) * FZ_SROW + 4 * m) =
           fz_f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+  if constexpr (BOUNDED) IDS[ln] = my_item;
   FZ_LDS_FENCE();
   // ---- lane l scans user l's 64 scores: which pass?
   const int valid_items = static_cast<int>(min<int64_t>(64, p.n_items - it * 64));
@@ -530,7 +557,8 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
 #pragma unroll
   for (int jj = 0; jj < 16; jj++) {
     const fz_f32x4 v = *reinterpret_cast<const fz_f32x4 *>(S + ln * FZ_SROW + 4 * jj);
-    fsum += (v.x + v.y) + (v.z + v.w);  // NaN / infinity anywhere poisons the sum
+    // NaN / infinity anywhere poisons the sum (the bounded variant has checked the norms)
+    if constexpr (!BOUNDED) fsum += (v.x + v.y) + (v.z + v.w);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const int j = 4 * jj + c;
@@ -538,19 +566,43 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
       if (j < 32) plo |= bit; else phi |= bit;
     }
   }
-  if (__any(my_valid && !(fabsf(fsum) < 3.0e38f))) {
-    if (ln == 0) atomicOr(p.bad_flag, 1);
+  if constexpr (!BOUNDED) {
+    if (__any(my_valid && !(fabsf(fsum) < 3.0e38f))) {
+      if (ln == 0) atomicOr(p.bad_flag, 1);
+    }
   }
   uint64_t pm = (static_cast<uint64_t>(phi) << 32) | plo;
   pm &= ~mword;
   if (valid_items < 64) pm &= (1ull << valid_items) - 1ull;
   if (!my_valid) pm = 0ull;
   if (!__any(pm != 0ull)) return;
+  if constexpr (BOUNDED) {
+    if (p.mask_bits) {  // two independent probes per trip: bit (item id) of the user's bitmap row
+      const uint64_t *mrow = p.mask_bits + my_row * p.words;
+      uint64_t left = pm;
+      while (__any(left != 0ull)) {
+        int j0 = -1, j1 = -1;
+        if (left != 0ull) {
+          j0 = __ffsll(static_cast<long long>(left)) - 1;
+          left &= left - 1;
+        }
+        if (left != 0ull) {
+          j1 = __ffsll(static_cast<long long>(left)) - 1;
+          left &= left - 1;
+        }
+        const int32_t id0 = j0 >= 0 ? IDS[j0] : 0, id1 = j1 >= 0 ? IDS[j1] : 0;
+        const uint64_t w0 = j0 >= 0 ? mrow[id0 >> 6] : 0ull, w1 = j1 >= 0 ? mrow[id1 >> 6] : 0ull;
+        if (j0 >= 0 && ((w0 >> (id0 & 63)) & 1ull)) pm &= ~(1ull << j0);
+        if (j1 >= 0 && ((w1 >> (id1 & 63)) & 1ull)) pm &= ~(1ull << j1);
+      }
+      if (!__any(pm != 0ull)) return;
+    }
+  }
   const int n_pass = __popcll(pm);
   int base = 0;
   if (n_pass > 0) base = atomicAdd(p.cand_cnt + my_row, n_pass);
   if (n_pass > 0 && base + n_pass > EM_CAP) {
-    atomicOr(p.bad_flag, 4);
+    p.hard[my_row] = 1;
     pm = 0ull;
   }
   while (__any(pm != 0ull)) {
@@ -559,10 +611,126 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
       pm &= pm - 1;
       const size_t dst = static_cast<size_t>(my_row) * EM_CAP + base;
       p.cand_score[dst] = S[ln * FZ_SROW + j];
-      p.cand_item[dst] = static_cast<int32_t>(it * 64 + j);
+      p.cand_item[dst] = BOUNDED ? IDS[j] : static_cast<int32_t>(it * 64 + j);
       base++;
     }
   }
+}
+
+
+// ---- bounded variant: set-up kernels -------------------------------------------------------
+// A score is bounded by the product of the two factor norms (Cauchy-Schwarz), so an item whose
+// norm is below r_u = tau_u / |user_u| cannot reach user u's threshold.  With the items sorted
+// by norm (descending) and the users by r_u (ascending), a 64-user tile only needs the leading
+// item tiles up to its smallest radius: on interaction data with a popularity skew that is a
+// few percent of the score matrix, and the result is the same list (the bound is rigorous:
+// norm_up >= |x| (1 + K eps-ish) covers the rounding of the fp32 dot product and of the norm).
+
+// out[r] = upper bound of |F[begin + r, :]|: sqrt(sum x^2) * c + 3e-18 (the constant covers
+// squares that underflow).  16 lanes per row.  Non-finite or > 1e18 -> bad_flag bit 0.
+__global__ __launch_bounds__(256) void row_norm_up_kernel(const float *__restrict__ F, int64_t begin,
+                                                          int64_t n, int32_t KP, float c,
+                                                          float *__restrict__ out,
+                                                          int32_t *__restrict__ bad_flag) {
+  const int sub = threadIdx.x & 15;
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 16 + (threadIdx.x >> 4);
+  float acc = 0.f;
+  if (r < n) {
+    const float *row = F + (begin + r) * KP;
+    for (int k = 4 * sub; k < KP; k += 64) {
+      const fz_f32x4 v = *reinterpret_cast<const fz_f32x4 *>(row + k);
+      acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (r < n && sub == 0) {
+    const float up = sqrtf(acc) * c + 3.0e-18f;
+    out[r] = up;
+    if (!(up < 1.0e18f)) atomicOr(bad_flag, 1);
+  }
+}
+
+__global__ void iota_kernel(int32_t *out, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = static_cast<int32_t>(i);
+}
+
+__global__ void inverse_perm_kernel(const int32_t *__restrict__ perm, int64_t n,
+                                    int32_t *__restrict__ inv) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) inv[perm[i]] = static_cast<int32_t>(i);
+}
+
+// out[j, :] = F[perm[j], :] for j < n (the sample items, contiguous for user_scores_kernel)
+__global__ void gather_rows_kernel(const float *__restrict__ F, const int32_t *__restrict__ perm,
+                                   int64_t n, int32_t KP, float *__restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int q = KP / 4;
+  if (i >= n * q) return;
+  const int64_t j = i / q;
+  const int k = static_cast<int>(i % q) * 4;
+  *reinterpret_cast<fz_f32x4 *>(out + j * KP + k) =
+      *reinterpret_cast<const fz_f32x4 *>(F + static_cast<int64_t>(perm[j]) * KP + k);
+}
+
+// sample block [rows, n_sample] over the first n_sample SORTED items: -inf at the stored mask
+// entries whose item sits in the sample (evaluator.py:426-432)
+__global__ void mask_rows_perm_kernel(float *scores, int64_t rows, int64_t n_sample,
+                                      const int64_t *mask_ptr, const int32_t *mask_idx,
+                                      const int32_t *__restrict__ inv) {
+  const int64_t row = blockIdx.x;
+  if (row >= rows) return;
+  for (int64_t q = mask_ptr[row] + threadIdx.x; q < mask_ptr[row + 1]; q += blockDim.x) {
+    const int32_t j = inv[mask_idx[q]];
+    if (j < n_sample) scores[row * n_sample + j] = -std::numeric_limits<float>::infinity();
+  }
+}
+
+// r_u = tau_u / norm_up(u), a hair low (the division's rounding); -inf (keep everything) for a
+// threshold that is not positive; +inf (nothing to do; tau likewise) for a user without ground
+// truth and for a hard row
+__global__ void prune_radius_kernel(float *__restrict__ tau, const float *__restrict__ unorm,
+                                    const int32_t *__restrict__ gt_ptr, int64_t offset, int64_t rows,
+                                    const int32_t *__restrict__ hard, float *__restrict__ radius) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float INF = std::numeric_limits<float>::infinity();
+  const float t = tau[r];
+  float rad;
+  if (gt_ptr[offset + r + 1] == gt_ptr[offset + r] || hard[r]) {
+    rad = INF;
+    tau[r] = INF;
+  } else if (t > 0.f) {
+    rad = (t / unorm[r]) * (1.0f - 4.0e-7f);
+  } else {
+    rad = -INF;
+  }
+  radius[r] = rad;
+}
+
+// list[0 .. *count) = the hard rows that have ground truth (any order)
+__global__ void collect_hard_kernel(const int32_t *__restrict__ hard, const int32_t *__restrict__ gt_ptr,
+                                    int64_t offset, int64_t rows, int32_t *__restrict__ list,
+                                    int32_t *__restrict__ count) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= rows || !hard[r] || gt_ptr[offset + r + 1] == gt_ptr[offset + r]) return;
+  list[atomicAdd(count, 1)] = static_cast<int32_t>(r);
+}
+
+// limit_tiles[ut] = item tiles holding the sorted items whose norm_up >= the tile's smallest radius
+__global__ void tile_limit_kernel(const float *__restrict__ radius_sorted, int64_t rows,
+                                  const float *__restrict__ inorm_sorted, int64_t n_items,
+                                  int32_t *__restrict__ limit_tiles) {
+  const int64_t ut = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (ut * 64 >= rows) return;
+  const float rmin = radius_sorted[ut * 64];  // ascending order: the first is the smallest
+  int64_t lo = 0, hi = n_items;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (inorm_sorted[mid] >= rmin) lo = mid + 1; else hi = mid;
+  }
+  limit_tiles[ut] = static_cast<int32_t>((lo + 63) / 64);
 }
 
 }  // namespace eval

@@ -426,10 +426,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
       return;
     }
     bool hit = false;
-    if (ln < n_rec) {
-      rec_row[ln] = mi;
-      atomicAdd(&p.item_cnt[mi], 1ull);  // :146
-    }
+    if (ln < n_rec) rec_row[ln] = mi;  // (counted by item_hist_kernel, :146)
     if (n_gt <= 64) {
       // short ground-truth row (prefetched at kernel start): compare against every entry
       // instead of a chain of dependent loads
@@ -505,8 +502,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
   // --- hits, histogram, output list
   for (int i = tid; i < n_rec; i += NT) {
     const int32_t it = sel_idx[i];
-    rec_row[i] = it;
-    atomicAdd(&p.item_cnt[it], 1ull);  // :146
+    rec_row[i] = it;  // (counted by item_hist_kernel, :146)
     int lo = gb, hi = ge;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
@@ -564,10 +560,7 @@ __device__ __forceinline__ void wave_metrics_tail(const EvalParams &p, int64_t r
     return;
   }
   bool hit = false;
-  if (ln < n_rec) {
-    rec_row[ln] = mi;
-    atomicAdd(&p.item_cnt[mi], 1ull);  // :146
-  }
+  if (ln < n_rec) rec_row[ln] = mi;  // (counted by item_hist_kernel, :146)
   if (n_gt <= 64) {
     for (int c = 0; c < n_gt; c++) hit |= __builtin_amdgcn_readlane(gt_pref, c) == mi;
     hit = hit && ln < n_rec;
@@ -628,6 +621,7 @@ __global__ __launch_bounds__(256) void rank_cand_kernel(EvalParams p, EmitParams
   if (n_gt <= 64 && ln < n_gt) gt_pref = p.gt_idx[gb + ln];
   if (ln < p.cutoff) disc_pref = p.disc[ln];
   const double idcg_pref = p.idcg_prefix[min(n_gt, p.cutoff)];
+  if (f.hard[row]) return;  // ranked from its full score row afterwards
   const int n = min(f.cand_cnt[row], EM_CAP);
   const int64_t n_rankable = f.n_items - (n_masked ? n_masked[row] : 0);
   const int n_rec = static_cast<int>(min<int64_t>(p.cutoff, n_rankable));
@@ -1003,6 +997,43 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const RowOut *rows, i
   }
 }
 
+// item_cnt[i] += how often item i stands in the recommended lists of a call (Metrics::update,
+// evaluator.cpp:146).  `rec` = the lists the ranking kernels wrote ([rows, cutoff], -1 where
+// there is no entry).  Everybody's list is full of the same popular items, so one global atomic
+// per entry queues up on a few addresses (1 ms for 2.7 M entries); each workgroup counts its
+// slice in an LDS table first (direct-mapped, a colliding item goes to memory at once) and adds
+// one total per item it met.
+constexpr int HIST_SLOTS = 8192;
+__global__ __launch_bounds__(1024) void item_hist_kernel(const int32_t *__restrict__ rec, int64_t n,
+                                                         unsigned long long *__restrict__ item_cnt) {
+  __shared__ int32_t ids[HIST_SLOTS];
+  __shared__ uint32_t cnt[HIST_SLOTS];
+  for (int i = threadIdx.x; i < HIST_SLOTS; i += 1024) {
+    ids[i] = -1;
+    cnt[i] = 0;
+  }
+  __syncthreads();
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b = per * blockIdx.x, e = min(b + per, n);
+  for (int64_t i = b + threadIdx.x; i < e; i += 1024) {
+    const int32_t it = rec[i];
+    if (it < 0) continue;
+    const uint32_t slot = (static_cast<uint32_t>(it) * 2654435761u) >> 19;  // 13 bits
+    const int32_t prev = atomicCAS(&ids[slot], -1, it);
+    if (prev == -1 || prev == it) atomicAdd(&cnt[slot], 1u);
+    else atomicAdd(&item_cnt[it], 1ull);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HIST_SLOTS; i += 1024)
+    if (ids[i] >= 0 && cnt[i] > 0) atomicAdd(&item_cnt[ids[i]], static_cast<unsigned long long>(cnt[i]));
+}
+
+inline void launch_item_hist(const int32_t *rec, int64_t n, unsigned long long *item_cnt, hipStream_t s) {
+  if (n <= 0) return;
+  const int64_t grid = std::min<int64_t>(1024, (n + 16383) / 16384);
+  hipLaunchKernelGGL(item_hist_kernel, dim3(static_cast<unsigned>(grid)), dim3(1024), 0, s, rec, n, item_cnt);
+}
+
 // scores[row, col] = -inf for the stored entries of the mask rows (evaluator.py:426-432)
 // (`n_items` = row stride = number of leading items the block holds: entries beyond are skipped)
 __global__ void mask_rows_kernel(float *scores, int64_t rows, int64_t n_items,
@@ -1026,7 +1057,8 @@ extern "C" irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin
                                               float *device_out, void **stream_out,
                                               int32_t *device_index);
 extern "C" irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
-                                                     int64_t n_prefix, float *device_out);
+                                                     int64_t n_prefix, const float *item_rows,
+                                                     float *device_out);
 extern "C" irs_status irs_ials_factors_device_(irs_ials_trainer *t, const float **user,
                                                const float **item, int32_t *KP, int64_t *n_users,
                                                int64_t *n_items, void **stream_out,
@@ -1055,6 +1087,10 @@ struct irs_evaluator {
   int64_t mask_bits_rows = -1;  // rows the bitmap was built for (-1: none)
   DeviceBuffer<float> cand_score, tau;
   DeviceBuffer<int32_t> cand_item, cand_cnt, tau_hint, bad_flag;
+  // bounded variant of the emit path: norms, the two sort permutations, per-tile limits
+  DeviceBuffer<float> inorm, inorm_sorted, unorm, radius, radius_sorted, sample_item;
+  DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list;
+  DeviceBuffer<char> sort_tmp;
 };
 
 namespace {
@@ -1130,6 +1166,7 @@ void rank_block(irs_evaluator *e, const void *d_scores, int64_t rows, int64_t cu
   p.rec_out = e->rec_out.ptr;
   p.item_cnt = e->item_cnt.ptr;
   launch_rank<T>(p, e->n_items, s, e->todo.ptr);
+  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
                      e->metrics.ptr);
   IRS_HIP(hipGetLastError());
@@ -1280,6 +1317,7 @@ bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int
   }
 #endif
   if (bad) return false;  // non-finite scores: the two-pass path defines their order
+  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
                      e->metrics.ptr);
   IRS_HIP(hipGetLastError());
@@ -1289,6 +1327,12 @@ bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int
 // IRSPACK_AMD_EVAL_EMIT=0 switches the threshold-filtered path off (A/B against the two-pass one).
 bool emit_enabled() {
   const char *e = std::getenv("IRSPACK_AMD_EVAL_EMIT");
+  return e ? std::atoi(e) != 0 : true;
+}
+
+// IRSPACK_AMD_EVAL_BOUND=0: the emit path scores every tile (no norm-bound pruning).
+bool bound_enabled() {
+  const char *e = std::getenv("IRSPACK_AMD_EVAL_BOUND");
   return e ? std::atoi(e) != 0 : true;
 }
 
@@ -1333,8 +1377,34 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     bits = e->mask_bits.ptr;
     n_masked = e->mask_count.ptr;
   }
-  e->bad_flag.alloc(1);
-  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, sizeof(int32_t), s));
+  e->bad_flag.alloc(2);  // [0] flags, [1] number of hard rows
+  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, 2 * sizeof(int32_t), s));
+  e->hard.alloc(rows);
+  e->hard_list.alloc(rows);
+  IRS_HIP(hipMemsetAsync(e->hard.ptr, 0, rows * sizeof(int32_t), s));
+  // ---- 0. bounded variant: items in order of decreasing norm (the sample is then the
+  //         EM_SAMPLE items of largest norm, which hold most of every user's final list)
+  const bool bounded = bound_enabled() && ni < (int64_t(1) << 31) && rows < (int64_t(1) << 31);
+  const float norm_c = 1.0f + (KP + 16) * 2.5e-7f;
+  if (bounded) {
+    e->iota.alloc(std::max(ni, rows));
+    hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(std::max(ni, rows), 256)), dim3(256), 0, s,
+                       e->iota.ptr, std::max(ni, rows));
+    e->inorm.alloc(ni);
+    e->inorm_sorted.alloc(ni);
+    e->iperm.alloc(ni);
+    e->iinv.alloc(ni);
+    hipLaunchKernelGGL(row_norm_up_kernel, dim3(ceil_div(ni, 16)), dim3(256), 0, s, item, int64_t(0),
+                       ni, KP, norm_c, e->inorm.ptr, e->bad_flag.ptr);
+    sort_pairs_f32(true, e->inorm.ptr, e->inorm_sorted.ptr, e->iota.ptr, e->iperm.ptr, ni,
+                   e->sort_tmp, s);
+    hipLaunchKernelGGL(inverse_perm_kernel, dim3(ceil_div(ni, 256)), dim3(256), 0, s, e->iperm.ptr, ni,
+                       e->iinv.ptr);
+    e->sample_item.alloc(static_cast<size_t>(EM_SAMPLE) * KP);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(int64_t(EM_SAMPLE) * (KP / 4), 256)), dim3(256),
+                       0, s, item, e->iperm.ptr, static_cast<int64_t>(EM_SAMPLE), KP,
+                       e->sample_item.ptr);
+  }
   // ---- 1. sample pass: thresholds from the first EM_SAMPLE items, in blocks of users
   e->tau.alloc(rows);
   {
@@ -1343,14 +1413,19 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     for (int64_t b = 0; b < rows; b += SB) {
       const int64_t m = std::min(SB, rows - b);
       if (irs_ials_scores_prefix_device_(t, begin + b, begin + b + m, EM_SAMPLE,
+                                         bounded ? e->sample_item.ptr : nullptr,
                                          e->fused_scores.ptr) != IRS_OK)
         throw std::runtime_error(irs_last_error());
-      if (d_mptr)
+      if (d_mptr && bounded)
+        hipLaunchKernelGGL(mask_rows_perm_kernel, dim3(m), dim3(64), 0, s, e->fused_scores.ptr, m,
+                           static_cast<int64_t>(EM_SAMPLE), d_mptr + b, d_midx, e->iinv.ptr);
+      else if (d_mptr)
         hipLaunchKernelGGL(mask_rows_kernel, dim3(m), dim3(64), 0, s, e->fused_scores.ptr, m,
                            static_cast<int64_t>(EM_SAMPLE), d_mptr + b, d_midx);
       hipLaunchKernelGGL((sample_tau_kernel<8>), dim3(static_cast<unsigned>(ceil_div(m, 4))), dim3(256),
                          0, s, e->fused_scores.ptr, m, static_cast<int64_t>(EM_SAMPLE),
-                         static_cast<int32_t>(cutoff), e->tau.ptr + b, e->bad_flag.ptr);
+                         static_cast<int32_t>(cutoff), e->tau.ptr + b, e->bad_flag.ptr,
+                         e->hard.ptr + b);
     }
   }
   // ---- 2. the whole score matrix, candidates only
@@ -1371,23 +1446,50 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
   f.cand_item = e->cand_item.ptr;
   f.cand_cnt = e->cand_cnt.ptr;
   f.bad_flag = e->bad_flag.ptr;
+  f.iperm = f.uperm = f.limit_tiles = nullptr;
+  f.hard = e->hard.ptr;
+  if (bounded) {
+    // users in order of increasing pruning radius, and what each 64-user tile still needs
+    e->unorm.alloc(rows);
+    e->radius.alloc(rows);
+    e->radius_sorted.alloc(rows);
+    e->uperm.alloc(rows);
+    e->limit_tiles.alloc(ceil_div(rows, 64));
+    hipLaunchKernelGGL(row_norm_up_kernel, dim3(ceil_div(rows, 16)), dim3(256), 0, s, user, begin, rows,
+                       KP, norm_c, e->unorm.ptr, e->bad_flag.ptr);
+    hipLaunchKernelGGL(prune_radius_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, e->tau.ptr,
+                       e->unorm.ptr, e->gt_ptr.ptr, offset, rows, e->hard.ptr, e->radius.ptr);
+    sort_pairs_f32(false, e->radius.ptr, e->radius_sorted.ptr, e->iota.ptr, e->uperm.ptr, rows,
+                   e->sort_tmp, s);
+    hipLaunchKernelGGL(tile_limit_kernel, dim3(ceil_div(ceil_div(rows, 64), 256)), dim3(256), 0, s,
+                       e->radius_sorted.ptr, rows, e->inorm_sorted.ptr, ni, e->limit_tiles.ptr);
+    f.iperm = e->iperm.ptr;
+    f.uperm = e->uperm.ptr;
+    f.limit_tiles = e->limit_tiles.ptr;
+  }
   {
     const int64_t tiles = ceil_div(rows, 64) * ceil_div(ni, 64);
-    const size_t lds = 4 * 64 * FZ_SROW * sizeof(float);
+    const size_t lds = 4 * 64 * FZ_SROW * sizeof(float) + 4 * 64 * sizeof(int32_t);
     auto launch = [&](auto kernel) {
       IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
       hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ceil_div(tiles, 4))), dim3(256), lds, s, f);
     };
+#define IRS_EMIT_CASE(KK)                                        \
+  case KK:                                                       \
+    if (bounded) launch(score_emit_kernel<KK, true>);            \
+    else launch(score_emit_kernel<KK, false>);                   \
+    break;
     switch (KP) {
-      case 16: launch(score_emit_kernel<16>); break;
-      case 32: launch(score_emit_kernel<32>); break;
-      case 64: launch(score_emit_kernel<64>); break;
-      case 128: launch(score_emit_kernel<128>); break;
-      case 192: launch(score_emit_kernel<192>); break;
-      case 256: launch(score_emit_kernel<256>); break;
+      IRS_EMIT_CASE(16)
+      IRS_EMIT_CASE(32)
+      IRS_EMIT_CASE(64)
+      IRS_EMIT_CASE(128)
+      IRS_EMIT_CASE(192)
+      IRS_EMIT_CASE(256)
       default: return false;
     }
+#undef IRS_EMIT_CASE
   }
   // ---- 3. rank the candidates, metrics
   e->row_out.alloc(rows);
@@ -1415,11 +1517,50 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
   const dim3 grid(static_cast<unsigned>(ceil_div(rows, 4)));
   hipLaunchKernelGGL((rank_cand_kernel<8>), grid, dim3(256), 0, s, p, f, n_masked);
   hipLaunchKernelGGL(rank_cand_slow_kernel, grid, dim3(256), 0, s, p, f, n_masked);
+  hipLaunchKernelGGL(collect_hard_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, e->hard.ptr,
+                     e->gt_ptr.ptr, offset, rows, e->hard_list.ptr, e->bad_flag.ptr + 1);
   IRS_HIP(hipGetLastError());
-  int32_t bad = 0;
-  IRS_HIP(hipMemcpyAsync(&bad, e->bad_flag.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
+  int32_t bad[2] = {0, 0};
+  IRS_HIP(hipMemcpyAsync(bad, e->bad_flag.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
   IRS_HIP(hipStreamSynchronize(s));
-  if (bad) return false;  // the two-pass path handles it (and defines the order of NaN scores)
+  static const bool debug = std::getenv("IRSPACK_AMD_EVAL_DEBUG") != nullptr;
+  if (debug) {
+    double kept = -1.0;
+    if (bounded) {
+      std::vector<int32_t> lim(ceil_div(rows, 64));
+      IRS_HIP(hipMemcpy(lim.data(), e->limit_tiles.ptr, lim.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      double sum = 0;
+      for (auto v : lim) sum += v;
+      kept = sum / (static_cast<double>(lim.size()) * ceil_div(ni, 64));
+    }
+    fprintf(stderr, "eval emit: flags %d, hard rows %d of %lld, tiles kept %.4f\n", bad[0], bad[1],
+            static_cast<long long>(rows), kept);
+  }
+  // non-finite scores (the two-pass path defines the order of NaN), or so many hard rows that
+  // one by one is the slower way: the caller runs the two-pass path
+  if (bad[0] || bad[1] > 1024) return false;
+  if (bad[1] > 0) {
+    // the hard rows, each from its full score row: scores -> mask -> the general ranking
+    std::vector<int32_t> list(bad[1]);
+    IRS_HIP(hipMemcpy(list.data(), e->hard_list.ptr, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    e->fused_scores.alloc(static_cast<size_t>(ni));
+    for (const int32_t r : list) {
+      if (irs_ials_scores_device_(t, begin + r, begin + r + 1, e->fused_scores.ptr, nullptr, nullptr) != IRS_OK)
+        throw std::runtime_error(irs_last_error());
+      if (d_mptr)
+        hipLaunchKernelGGL(mask_rows_kernel, dim3(1), dim3(256), 0, s, e->fused_scores.ptr, int64_t(1), ni,
+                           d_mptr + r, d_midx);
+      EvalParams q = p;
+      q.scores = e->fused_scores.ptr;
+      q.rows = 1;
+      q.offset = offset + r;
+      q.out = e->row_out.ptr + r;
+      q.rec_out = e->rec_out.ptr + static_cast<int64_t>(r) * cutoff;
+      launch_rank<float>(q, ni, s, e->todo.ptr + r);
+    }
+    IRS_HIP(hipGetLastError());
+  }
+  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
                      e->metrics.ptr);
   IRS_HIP(hipGetLastError());
