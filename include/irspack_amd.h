@@ -285,6 +285,18 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t,
 irs_status irs_eval_cache_mask(irs_evaluator *e, int64_t rows, const int64_t *mask_indptr,
                                const int32_t *mask_indices);
 
+/* What the last irs_eval_get_metrics_ials call did (measurement only, no reference
+ * counterpart).  path: 0 = score block + ranking (two passes), 1 = threshold-filtered
+ * candidates, 2 = threshold-filtered with norm-bound pruning, 3 = single-pass streaming top-k. */
+typedef struct irs_eval_stats {
+  int32_t path;
+  int32_t hard_rows;    /* rows ranked from their full score row after the filtered pass */
+  int64_t tiles_total;  /* 64 x 64 score tiles of the user block */
+  int64_t tiles_scored; /* tiles the scoring kernel computed (= tiles_total unless pruned) */
+  int64_t sample_items; /* items of the threshold sample pass (0: none) */
+} irs_eval_stats;
+irs_status irs_eval_last_stats(irs_evaluator *e, irs_eval_stats *out);
+
 /* ------------------------------------------------------------ measurement
  * No reference counterpart: SURVEY.md 8(d) asks for ceilings MEASURED on the box next to the
  * spec peaks.  Runs a 1 GiB device copy and STREAM triad (HBM bytes moved / time), a loop of

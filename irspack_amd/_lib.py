@@ -62,6 +62,16 @@ class MetricsStruct(C.Structure):
     ]
 
 
+class EvalStatsStruct(C.Structure):  # irs_eval_stats
+    _fields_ = [
+        ("path", C.c_int32),
+        ("hard_rows", C.c_int32),
+        ("tiles_total", C.c_int64),
+        ("tiles_scored", C.c_int64),
+        ("sample_items", C.c_int64),
+    ]
+
+
 class CeilingsStruct(C.Structure):  # irs_ceilings
     _fields_ = [
         ("copy_gbs", C.c_double),
@@ -113,6 +123,7 @@ EXPORTED_SYMBOLS = [
     "irs_eval_get_metrics",
     "irs_eval_get_metrics_ials",
     "irs_eval_cache_mask",
+    "irs_eval_last_stats",
     "irs_measure_ceilings",
 ]
 

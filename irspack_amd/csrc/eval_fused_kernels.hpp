@@ -375,7 +375,10 @@ namespace irs {
 namespace eval {
 
 constexpr int EM_CAP = 1024;     // candidate slots per user
-constexpr int EM_SAMPLE = 2048;  // items of the sample pass
+constexpr int EM_SAMPLE = 2048;  // items of the sample pass (items in catalogue order)
+constexpr int EM_SAMPLE_SORTED = 512;  // ... when the items are sorted by norm (bounded variant)
+constexpr int EM_SAMPLE2 = 4096;       // second-chance sample of the rows the first left hard
+constexpr int EM_HARD_CAP = 2048;      // rows the second chance handles
 
 struct EmitParams {
   const float *user, *item;
@@ -405,10 +408,15 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
                                                          int64_t rows, int64_t n_sample,
                                                          int32_t cutoff, float *__restrict__ tau,
                                                          int32_t *__restrict__ bad_flag,
-                                                         int32_t *__restrict__ hard) {
+                                                         int32_t *__restrict__ hard,
+                                                         const int32_t *__restrict__ row_list,
+                                                         const int32_t *__restrict__ n_list) {
   const int ln = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  // second chance of the hard rows: score row j belongs to row row_list[j] of the call
+  if (row_list && row >= *n_list) return;
+  const int64_t out_row = row_list ? row_list[row] : row;
   const float NEG_INF = -std::numeric_limits<float>::infinity();
   const float *srow = scores + row * n_sample;
   float bs[M];
@@ -456,9 +464,11 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
   } else {
     // too few rankable sample items for a threshold (a user who has seen nearly all of them)
     last = std::numeric_limits<float>::infinity();
-    if (ln == 0) hard[row] = 1;
   }
-  if (ln == 0) tau[row] = last;
+  if (ln == 0) {
+    hard[out_row] = n_rankable >= cutoff ? 0 : 1;
+    tau[out_row] = last;
+  }
 }
 
 // BOUNDED: users and items are addressed through the two sort permutations (tile rows = 64
@@ -663,25 +673,33 @@ __global__ void inverse_perm_kernel(const int32_t *__restrict__ perm, int64_t n,
 }
 
 // out[j, :] = F[perm[j], :] for j < n (the sample items, contiguous for user_scores_kernel)
+// (rows at or beyond *n_valid, when given, are zero: perm holds nothing for them)
 __global__ void gather_rows_kernel(const float *__restrict__ F, const int32_t *__restrict__ perm,
-                                   int64_t n, int32_t KP, float *__restrict__ out) {
+                                   int64_t n, int32_t KP, float *__restrict__ out,
+                                   const int32_t *__restrict__ n_valid) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const int q = KP / 4;
   if (i >= n * q) return;
   const int64_t j = i / q;
   const int k = static_cast<int>(i % q) * 4;
-  *reinterpret_cast<fz_f32x4 *>(out + j * KP + k) =
-      *reinterpret_cast<const fz_f32x4 *>(F + static_cast<int64_t>(perm[j]) * KP + k);
+  fz_f32x4 v{0.f, 0.f, 0.f, 0.f};
+  if (!n_valid || j < *n_valid)
+    v = *reinterpret_cast<const fz_f32x4 *>(F + static_cast<int64_t>(perm[j]) * KP + k);
+  *reinterpret_cast<fz_f32x4 *>(out + j * KP + k) = v;
 }
 
 // sample block [rows, n_sample] over the first n_sample SORTED items: -inf at the stored mask
 // entries whose item sits in the sample (evaluator.py:426-432)
+// (with a row list, score row j belongs to mask row row_list[j], j < *n_list)
 __global__ void mask_rows_perm_kernel(float *scores, int64_t rows, int64_t n_sample,
                                       const int64_t *mask_ptr, const int32_t *mask_idx,
-                                      const int32_t *__restrict__ inv) {
+                                      const int32_t *__restrict__ inv,
+                                      const int32_t *__restrict__ row_list,
+                                      const int32_t *__restrict__ n_list) {
   const int64_t row = blockIdx.x;
-  if (row >= rows) return;
-  for (int64_t q = mask_ptr[row] + threadIdx.x; q < mask_ptr[row + 1]; q += blockDim.x) {
+  if (row >= rows || (row_list && row >= *n_list)) return;
+  const int64_t mrow = row_list ? row_list[row] : row;
+  for (int64_t q = mask_ptr[mrow] + threadIdx.x; q < mask_ptr[mrow + 1]; q += blockDim.x) {
     const int32_t j = inv[mask_idx[q]];
     if (j < n_sample) scores[row * n_sample + j] = -std::numeric_limits<float>::infinity();
   }
@@ -709,19 +727,21 @@ __global__ void prune_radius_kernel(float *__restrict__ tau, const float *__rest
   radius[r] = rad;
 }
 
-// list[0 .. *count) = the hard rows that have ground truth (any order)
+// list[0 .. min(*count, cap)) = hard rows that have ground truth (any order); *count = all of them
 __global__ void collect_hard_kernel(const int32_t *__restrict__ hard, const int32_t *__restrict__ gt_ptr,
                                     int64_t offset, int64_t rows, int32_t *__restrict__ list,
-                                    int32_t *__restrict__ count) {
+                                    int32_t *__restrict__ count, int32_t cap) {
   const int64_t r = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= rows || !hard[r] || gt_ptr[offset + r + 1] == gt_ptr[offset + r]) return;
-  list[atomicAdd(count, 1)] = static_cast<int32_t>(r);
+  const int pos = atomicAdd(count, 1);
+  if (pos < cap) list[pos] = static_cast<int32_t>(r);
 }
 
 // limit_tiles[ut] = item tiles holding the sorted items whose norm_up >= the tile's smallest radius
 __global__ void tile_limit_kernel(const float *__restrict__ radius_sorted, int64_t rows,
                                   const float *__restrict__ inorm_sorted, int64_t n_items,
-                                  int32_t *__restrict__ limit_tiles) {
+                                  int32_t *__restrict__ limit_tiles,
+                                  unsigned long long *__restrict__ tiles_scored) {
   const int64_t ut = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (ut * 64 >= rows) return;
   const float rmin = radius_sorted[ut * 64];  // ascending order: the first is the smallest
@@ -731,6 +751,7 @@ __global__ void tile_limit_kernel(const float *__restrict__ radius_sorted, int64
     if (inorm_sorted[mid] >= rmin) lo = mid + 1; else hi = mid;
   }
   limit_tiles[ut] = static_cast<int32_t>((lo + 63) / 64);
+  if (lo > 0) atomicAdd(tiles_scored, static_cast<unsigned long long>((lo + 63) / 64));
 }
 
 }  // namespace eval

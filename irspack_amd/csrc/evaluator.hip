@@ -72,6 +72,8 @@ struct EvalParams {
   int32_t *rec_out;          // [rows, cutoff] recommended items (-1 padded)
   unsigned long long *item_cnt;
   int32_t *todo;             // per row: 1 = left to rank_rows_kernel by rank_wave_kernel (or null)
+  // score row r stands for row row_map[r] of the call (ground truth, outputs); null: r itself
+  const int32_t *row_map = nullptr;
 };
 
 // key value no score maps to (it is the image of a negative NaN pattern, and NaNs are
@@ -111,15 +113,16 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
   const int wv = tid >> 6, ln = tid & 63;
   const int64_t row = blockIdx.x;
   if (p.todo != nullptr && p.todo[row] == 0) return;  // ranked by rank_wave_kernel
-  const int64_t u = row + p.offset;
+  const int64_t orow = p.row_map ? p.row_map[row] : row;
+  const int64_t u = orow + p.offset;
   const T *srow = static_cast<const T *>(p.scores) + row * p.n_items;
   RowOut res{0, 0, 0, 0, 0, 0, 0};
   const int gb = p.retrieve ? 0 : p.gt_ptr[u], ge = p.retrieve ? 0 : p.gt_ptr[u + 1];
   const int n_gt = ge - gb;
-  int32_t *rec_row = p.rec_out + row * p.cutoff;
+  int32_t *rec_row = p.rec_out + orow * p.cutoff;
   for (int i = tid; i < p.cutoff; i += NT) rec_row[i] = -1;
   if (n_gt == 0 && !p.retrieve) {  // counted in total_user only (:316-321)
-    if (tid == 0) p.out[row] = res;
+    if (tid == 0) p.out[orow] = res;
     return;
   }
   // what the last phase needs from HBM is requested now, so that its latency hides behind
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
   res.valid = 1;
   res.n_rec = n_rec;
   if (n_rec == 0) {  // :132-135
-    if (tid == 0) p.out[row] = res;
+    if (tid == 0) p.out[orow] = res;
     return;
   }
 
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
                                p.recall_with_cutoff ? (n_gt > n_rec ? n_rec : n_gt) : n_gt);
     res.ndcg = dcg / idcg;
     res.map = ap / n_gt;
-    if (ln == 0) p.out[row] = res;
+    if (ln == 0) p.out[orow] = res;
     return;
   }
   // --- bitonic sort of the n_sel gathered candidates: key desc, index asc
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
                                p.recall_with_cutoff ? (n_gt > n_rec ? n_rec : n_gt) : n_gt);
     res.ndcg = dcg / idcg;
     res.map = ap / n_gt;
-    p.out[row] = res;
+    p.out[orow] = res;
   }
 }
 
@@ -813,16 +816,17 @@ __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
   const int ln = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= p.rows) return;
-  const int64_t u = row + p.offset;
+  const int64_t orow = p.row_map ? p.row_map[row] : row;
+  const int64_t u = orow + p.offset;
   const T *srow = static_cast<const T *>(p.scores) + row * p.n_items;
   RowOut res{0, 0, 0, 0, 0, 0, 0};
   const int gb = p.retrieve ? 0 : p.gt_ptr[u], ge = p.retrieve ? 0 : p.gt_ptr[u + 1];
   const int n_gt = ge - gb;
-  int32_t *rec_row = p.rec_out + row * p.cutoff;
+  int32_t *rec_row = p.rec_out + orow * p.cutoff;
   if (ln < p.cutoff) rec_row[ln] = -1;  // cutoff <= 64
   if (ln == 0) p.todo[row] = 0;
   if (n_gt == 0 && !p.retrieve) {  // counted in total_user only (:316-321)
-    if (ln == 0) p.out[row] = res;
+    if (ln == 0) p.out[orow] = res;
     return;
   }
   int32_t gt_pref = -1;
@@ -900,7 +904,7 @@ __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
   res.valid = 1;
   res.n_rec = n_rec;
   if (n_rec == 0) {  // :132-135
-    if (ln == 0) p.out[row] = res;
+    if (ln == 0) p.out[orow] = res;
     return;
   }
   // --- draw the list: rank `it` is the best head
@@ -935,7 +939,7 @@ __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
       return;
     }
   }
-  wave_metrics_tail(p, row, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
+  wave_metrics_tail(p, orow, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
 }
 
 // Sum of the per-user terms of one call (one 1024-thread workgroup) in a fixed order, so the
@@ -1036,11 +1040,14 @@ inline void launch_item_hist(const int32_t *rec, int64_t n, unsigned long long *
 
 // scores[row, col] = -inf for the stored entries of the mask rows (evaluator.py:426-432)
 // (`n_items` = row stride = number of leading items the block holds: entries beyond are skipped)
+// (`row_list`, when given: score row r is masked with the mask row row_list[r])
 __global__ void mask_rows_kernel(float *scores, int64_t rows, int64_t n_items,
-                                 const int64_t *mask_ptr, const int32_t *mask_idx) {
+                                 const int64_t *mask_ptr, const int32_t *mask_idx,
+                                 const int32_t *row_list = nullptr) {
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
-  for (int64_t q = mask_ptr[row] + threadIdx.x; q < mask_ptr[row + 1]; q += blockDim.x) {
+  const int64_t mrow = row_list ? row_list[row] : row;
+  for (int64_t q = mask_ptr[mrow] + threadIdx.x; q < mask_ptr[mrow + 1]; q += blockDim.x) {
     const int32_t j = mask_idx[q];
     if (j < n_items) scores[row * n_items + j] = -std::numeric_limits<float>::infinity();
   }
@@ -1058,7 +1065,7 @@ extern "C" irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin
                                               int32_t *device_index);
 extern "C" irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
                                                      int64_t n_prefix, const float *item_rows,
-                                                     float *device_out);
+                                                     const float *user_rows, float *device_out);
 extern "C" irs_status irs_ials_factors_device_(irs_ials_trainer *t, const float **user,
                                                const float **item, int32_t *KP, int64_t *n_users,
                                                int64_t *n_items, void **stream_out,
@@ -1088,9 +1095,11 @@ struct irs_evaluator {
   DeviceBuffer<float> cand_score, tau;
   DeviceBuffer<int32_t> cand_item, cand_cnt, tau_hint, bad_flag;
   // bounded variant of the emit path: norms, the two sort permutations, per-tile limits
-  DeviceBuffer<float> inorm, inorm_sorted, unorm, radius, radius_sorted, sample_item;
+  DeviceBuffer<float> inorm, inorm_sorted, unorm, radius, radius_sorted, sample_item, hard_user;
   DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list;
   DeviceBuffer<char> sort_tmp;
+  DeviceBuffer<unsigned long long> tiles_scored;
+  irs_eval_stats stats{};  // of the last irs_eval_get_metrics_ials call
 };
 
 namespace {
@@ -1369,6 +1378,17 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     throw std::runtime_error(irs_last_error());
   // worth it only when the sample is a small part of the catalogue
   if (ni != e->n_items || ni < 4 * EM_SAMPLE || rows > (int64_t(1) << 31) / EM_CAP) return false;
+  const bool bounded = bound_enabled() && ni < (int64_t(1) << 31) && rows < (int64_t(1) << 31);
+  // items of the sample pass.  Sorted by norm (bounded variant) a few hundred items already
+  // hold nearly every user's threshold; IRSPACK_AMD_EVAL_SAMPLE overrides (multiples of 64).
+  // The users it leaves without one (they have seen almost all of the sample) get a second
+  // chance on EM_SAMPLE2 items.
+  static const int64_t env_sample = [] {
+    const char *v = std::getenv("IRSPACK_AMD_EVAL_SAMPLE");
+    return v ? std::max<int64_t>(64, std::atoll(v) / 64 * 64) : int64_t(0);
+  }();
+  const int64_t n_sample = std::min<int64_t>(env_sample ? env_sample : (bounded ? EM_SAMPLE_SORTED : EM_SAMPLE),
+                                             EM_SAMPLE2);
   const int64_t words = ceil_div(ni, 64);
   const uint64_t *bits = nullptr;
   const int32_t *n_masked = nullptr;
@@ -1377,14 +1397,15 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     bits = e->mask_bits.ptr;
     n_masked = e->mask_count.ptr;
   }
-  e->bad_flag.alloc(2);  // [0] flags, [1] number of hard rows
-  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, 2 * sizeof(int32_t), s));
+  e->bad_flag.alloc(3);  // [0] flags, [1] hard rows at the end, [2] hard rows after the sample pass
+  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, 3 * sizeof(int32_t), s));
   e->hard.alloc(rows);
   e->hard_list.alloc(rows);
   IRS_HIP(hipMemsetAsync(e->hard.ptr, 0, rows * sizeof(int32_t), s));
-  // ---- 0. bounded variant: items in order of decreasing norm (the sample is then the
-  //         EM_SAMPLE items of largest norm, which hold most of every user's final list)
-  const bool bounded = bound_enabled() && ni < (int64_t(1) << 31) && rows < (int64_t(1) << 31);
+  e->tiles_scored.alloc(1);
+  IRS_HIP(hipMemsetAsync(e->tiles_scored.ptr, 0, sizeof(unsigned long long), s));
+  // ---- 0. bounded variant: items in order of decreasing norm (the sample is then the items
+  //         of largest norm, which hold most of every user's final list)
   const float norm_c = 1.0f + (KP + 16) * 2.5e-7f;
   if (bounded) {
     e->iota.alloc(std::max(ni, rows));
@@ -1400,32 +1421,58 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
                    e->sort_tmp, s);
     hipLaunchKernelGGL(inverse_perm_kernel, dim3(ceil_div(ni, 256)), dim3(256), 0, s, e->iperm.ptr, ni,
                        e->iinv.ptr);
-    e->sample_item.alloc(static_cast<size_t>(EM_SAMPLE) * KP);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(int64_t(EM_SAMPLE) * (KP / 4), 256)), dim3(256),
-                       0, s, item, e->iperm.ptr, static_cast<int64_t>(EM_SAMPLE), KP,
-                       e->sample_item.ptr);
+    e->sample_item.alloc(static_cast<size_t>(EM_SAMPLE2) * KP);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(int64_t(EM_SAMPLE2) * (KP / 4), 256)), dim3(256),
+                       0, s, item, e->iperm.ptr, static_cast<int64_t>(EM_SAMPLE2), KP,
+                       e->sample_item.ptr, static_cast<const int32_t *>(nullptr));
   }
-  // ---- 1. sample pass: thresholds from the first EM_SAMPLE items, in blocks of users
+  // ---- 1. sample pass: thresholds from the first n_sample items, in blocks of users
   e->tau.alloc(rows);
   {
-    const int64_t SB = 32768;  // users per sample block (256 MB of scores)
-    e->fused_scores.alloc(static_cast<size_t>(std::min(SB, rows)) * EM_SAMPLE);
+    const int64_t SB = 32768;  // users per sample block (<= 256 MB of scores)
+    const int64_t HCAP = std::min<int64_t>(EM_HARD_CAP, rows);
+    e->fused_scores.alloc(std::max(static_cast<size_t>(std::min(SB, rows)) * n_sample,
+                                   static_cast<size_t>(HCAP) * EM_SAMPLE2));
+    const int32_t *no_list = nullptr;
     for (int64_t b = 0; b < rows; b += SB) {
       const int64_t m = std::min(SB, rows - b);
-      if (irs_ials_scores_prefix_device_(t, begin + b, begin + b + m, EM_SAMPLE,
-                                         bounded ? e->sample_item.ptr : nullptr,
+      if (irs_ials_scores_prefix_device_(t, begin + b, begin + b + m, n_sample,
+                                         bounded ? e->sample_item.ptr : nullptr, nullptr,
                                          e->fused_scores.ptr) != IRS_OK)
         throw std::runtime_error(irs_last_error());
       if (d_mptr && bounded)
         hipLaunchKernelGGL(mask_rows_perm_kernel, dim3(m), dim3(64), 0, s, e->fused_scores.ptr, m,
-                           static_cast<int64_t>(EM_SAMPLE), d_mptr + b, d_midx, e->iinv.ptr);
+                           n_sample, d_mptr + b, d_midx, e->iinv.ptr, no_list, no_list);
       else if (d_mptr)
         hipLaunchKernelGGL(mask_rows_kernel, dim3(m), dim3(64), 0, s, e->fused_scores.ptr, m,
-                           static_cast<int64_t>(EM_SAMPLE), d_mptr + b, d_midx);
+                           n_sample, d_mptr + b, d_midx);
       hipLaunchKernelGGL((sample_tau_kernel<8>), dim3(static_cast<unsigned>(ceil_div(m, 4))), dim3(256),
-                         0, s, e->fused_scores.ptr, m, static_cast<int64_t>(EM_SAMPLE),
+                         0, s, e->fused_scores.ptr, m, n_sample,
                          static_cast<int32_t>(cutoff), e->tau.ptr + b, e->bad_flag.ptr,
-                         e->hard.ptr + b);
+                         e->hard.ptr + b, no_list, no_list);
+    }
+    if (bounded && n_sample < EM_SAMPLE2) {
+      // second chance: up to HCAP hard rows against the EM_SAMPLE2 items of largest norm (no
+      // host round trip: the kernels run on HCAP rows and stop at the device-side count)
+      int32_t *n_hard1 = e->bad_flag.ptr + 2;
+      hipLaunchKernelGGL(collect_hard_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, e->hard.ptr,
+                         e->gt_ptr.ptr, offset, rows, e->hard_list.ptr, n_hard1,
+                         static_cast<int32_t>(HCAP));
+      e->hard_user.alloc(static_cast<size_t>(HCAP) * KP);
+      hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(HCAP * (KP / 4), 256)), dim3(256), 0, s,
+                         user + begin * KP, e->hard_list.ptr, HCAP, KP, e->hard_user.ptr,
+                         static_cast<const int32_t *>(n_hard1));
+      if (irs_ials_scores_prefix_device_(t, 0, HCAP, EM_SAMPLE2, e->sample_item.ptr, e->hard_user.ptr,
+                                         e->fused_scores.ptr) != IRS_OK)
+        throw std::runtime_error(irs_last_error());
+      if (d_mptr)
+        hipLaunchKernelGGL(mask_rows_perm_kernel, dim3(HCAP), dim3(64), 0, s, e->fused_scores.ptr, HCAP,
+                           static_cast<int64_t>(EM_SAMPLE2), d_mptr, d_midx, e->iinv.ptr,
+                           static_cast<const int32_t *>(e->hard_list.ptr), static_cast<const int32_t *>(n_hard1));
+      hipLaunchKernelGGL((sample_tau_kernel<8>), dim3(static_cast<unsigned>(ceil_div(HCAP, 4))), dim3(256),
+                         0, s, e->fused_scores.ptr, HCAP, static_cast<int64_t>(EM_SAMPLE2),
+                         static_cast<int32_t>(cutoff), e->tau.ptr, e->bad_flag.ptr, e->hard.ptr,
+                         static_cast<const int32_t *>(e->hard_list.ptr), static_cast<const int32_t *>(n_hard1));
     }
   }
   // ---- 2. the whole score matrix, candidates only
@@ -1462,7 +1509,8 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     sort_pairs_f32(false, e->radius.ptr, e->radius_sorted.ptr, e->iota.ptr, e->uperm.ptr, rows,
                    e->sort_tmp, s);
     hipLaunchKernelGGL(tile_limit_kernel, dim3(ceil_div(ceil_div(rows, 64), 256)), dim3(256), 0, s,
-                       e->radius_sorted.ptr, rows, e->inorm_sorted.ptr, ni, e->limit_tiles.ptr);
+                       e->radius_sorted.ptr, rows, e->inorm_sorted.ptr, ni, e->limit_tiles.ptr,
+                       e->tiles_scored.ptr);
     f.iperm = e->iperm.ptr;
     f.uperm = e->uperm.ptr;
     f.limit_tiles = e->limit_tiles.ptr;
@@ -1518,45 +1566,50 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
   hipLaunchKernelGGL((rank_cand_kernel<8>), grid, dim3(256), 0, s, p, f, n_masked);
   hipLaunchKernelGGL(rank_cand_slow_kernel, grid, dim3(256), 0, s, p, f, n_masked);
   hipLaunchKernelGGL(collect_hard_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, s, e->hard.ptr,
-                     e->gt_ptr.ptr, offset, rows, e->hard_list.ptr, e->bad_flag.ptr + 1);
+                     e->gt_ptr.ptr, offset, rows, e->hard_list.ptr, e->bad_flag.ptr + 1,
+                     static_cast<int32_t>(rows));
   IRS_HIP(hipGetLastError());
-  int32_t bad[2] = {0, 0};
+  int32_t bad[3] = {0, 0, 0};
+  unsigned long long tiles_scored = 0;
   IRS_HIP(hipMemcpyAsync(bad, e->bad_flag.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
+  IRS_HIP(hipMemcpyAsync(&tiles_scored, e->tiles_scored.ptr, sizeof(tiles_scored), hipMemcpyDeviceToHost, s));
   IRS_HIP(hipStreamSynchronize(s));
+  e->stats.path = bounded ? 2 : 1;
+  e->stats.hard_rows = bad[1];
+  e->stats.tiles_total = ceil_div(rows, 64) * ceil_div(ni, 64);
+  e->stats.tiles_scored = bounded ? static_cast<int64_t>(tiles_scored) : e->stats.tiles_total;
+  e->stats.sample_items = n_sample;
   static const bool debug = std::getenv("IRSPACK_AMD_EVAL_DEBUG") != nullptr;
-  if (debug) {
-    double kept = -1.0;
-    if (bounded) {
-      std::vector<int32_t> lim(ceil_div(rows, 64));
-      IRS_HIP(hipMemcpy(lim.data(), e->limit_tiles.ptr, lim.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-      double sum = 0;
-      for (auto v : lim) sum += v;
-      kept = sum / (static_cast<double>(lim.size()) * ceil_div(ni, 64));
-    }
-    fprintf(stderr, "eval emit: flags %d, hard rows %d of %lld, tiles kept %.4f\n", bad[0], bad[1],
-            static_cast<long long>(rows), kept);
-  }
+  if (debug)
+    fprintf(stderr, "eval emit: flags %d, hard rows %d (after the first sample %d) of %lld, tiles scored %.4f\n",
+            bad[0], bad[1], bad[2], static_cast<long long>(rows),
+            static_cast<double>(e->stats.tiles_scored) / static_cast<double>(e->stats.tiles_total));
   // non-finite scores (the two-pass path defines the order of NaN), or so many hard rows that
   // one by one is the slower way: the caller runs the two-pass path
   if (bad[0] || bad[1] > 1024) return false;
   if (bad[1] > 0) {
-    // the hard rows, each from its full score row: scores -> mask -> the general ranking
-    std::vector<int32_t> list(bad[1]);
-    IRS_HIP(hipMemcpy(list.data(), e->hard_list.ptr, list.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    e->fused_scores.alloc(static_cast<size_t>(ni));
-    for (const int32_t r : list) {
-      if (irs_ials_scores_device_(t, begin + r, begin + r + 1, e->fused_scores.ptr, nullptr, nullptr) != IRS_OK)
+    // the hard rows from their full score rows, in chunks of <= 1 GB of scores: gather the
+    // user factors -> scores -> mask -> the general ranking, all through the row list
+    const int64_t n_hard = bad[1];
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_hard, (int64_t(1) << 28) / ni));
+    e->hard_user.alloc(static_cast<size_t>(chunk) * KP);
+    e->fused_scores.alloc(static_cast<size_t>(chunk) * ni);
+    for (int64_t b = 0; b < n_hard; b += chunk) {
+      const int64_t m = std::min(chunk, n_hard - b);
+      const int32_t *list = e->hard_list.ptr + b;
+      hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div(m * (KP / 4), 256)), dim3(256), 0, s,
+                         user + begin * KP, list, m, KP, e->hard_user.ptr,
+                         static_cast<const int32_t *>(nullptr));
+      if (irs_ials_scores_prefix_device_(t, 0, m, ni, nullptr, e->hard_user.ptr, e->fused_scores.ptr) != IRS_OK)
         throw std::runtime_error(irs_last_error());
       if (d_mptr)
-        hipLaunchKernelGGL(mask_rows_kernel, dim3(1), dim3(256), 0, s, e->fused_scores.ptr, int64_t(1), ni,
-                           d_mptr + r, d_midx);
+        hipLaunchKernelGGL(mask_rows_kernel, dim3(m), dim3(256), 0, s, e->fused_scores.ptr, m, ni, d_mptr,
+                           d_midx, list);
       EvalParams q = p;
       q.scores = e->fused_scores.ptr;
-      q.rows = 1;
-      q.offset = offset + r;
-      q.out = e->row_out.ptr + r;
-      q.rec_out = e->rec_out.ptr + static_cast<int64_t>(r) * cutoff;
-      launch_rank<float>(q, ni, s, e->todo.ptr + r);
+      q.rows = m;
+      q.row_map = list;
+      launch_rank<float>(q, ni, s, e->todo.ptr);
     }
     IRS_HIP(hipGetLastError());
   }
@@ -1643,6 +1696,13 @@ irs_status irs_eval_create(int64_t n_users, int64_t n_items, const int64_t *indp
   });
 }
 
+irs_status irs_eval_last_stats(irs_evaluator *e, irs_eval_stats *out) {
+  return guard([&] {
+    check_arg(e && out, "null argument.");
+    *out = e->stats;
+  });
+}
+
 irs_status irs_eval_destroy(irs_evaluator *e) {
   return guard([&] {
     if (e) {
@@ -1721,8 +1781,11 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
       return;
     }
     begin_accumulate(e, s);  // (an abandoned attempt may have touched the sums)
+    e->stats = irs_eval_stats{0, 0, ceil_div(rows, 64) * ceil_div(e->n_items, 64),
+                              ceil_div(rows, 64) * ceil_div(e->n_items, 64), 0};
     if (fused_single_pass(e, t, begin, rows, d_mptr, d_midx, cutoff, offset,
                           recall_with_cutoff != 0, s)) {
+      e->stats.path = 3;
       finish_accumulate(e, out, item_cnt, s);
       return;
     }

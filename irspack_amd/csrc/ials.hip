@@ -907,7 +907,7 @@ irs_status irs_ials_factors_device_(irs_ials_trainer *t, const float **user, con
                                     void **stream_out, int32_t *device_index);
 irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
                                           int64_t n_prefix, const float *item_rows,
-                                          float *device_out);
+                                          const float *user_rows, float *device_out);
 
 const char *irs_last_error(void) { return irs::last_error().c_str(); }
 int32_t irs_abi_version(void) { return 1; }
@@ -1208,10 +1208,11 @@ irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t e
 
 // Internal hook for evaluator.hip's sample pass: user[begin:end] @ item[:n_prefix]^T into a
 // device buffer [end - begin, n_prefix] on the trainer's stream; `item_rows` (device, [n_prefix,
-// KP]) replaces the leading item rows when given.  Not part of the public ABI.
+// KP]) replaces the leading item rows when given, `user_rows` (device, [>= end, KP]) the user
+// factors.  Not part of the public ABI.
 irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, int64_t end,
                                           int64_t n_prefix, const float *item_rows,
-                                          float *device_out) {
+                                          const float *user_rows, float *device_out) {
   return guard([&] {
     check_arg(t && device_out, "null argument.");
     check_arg(0 <= begin && begin <= end && end <= t->n_users && 0 < n_prefix &&
@@ -1223,7 +1224,8 @@ irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, in
     t->prof.begin("user_scores", t->stream);
     IRS_DISPATCH_ANY(t->T, {
       hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
-                         t->stream, t->factor[0].ptr, item_rows ? item_rows : t->factor[1].ptr,
+                         t->stream, user_rows ? user_rows : t->factor[0].ptr,
+                         item_rows ? item_rows : t->factor[1].ptr,
                          begin, m, n_prefix, device_out);
     });
     t->prof.end(t->stream);

@@ -233,6 +233,19 @@ class EvaluatorCore:
         )
         return Metrics._from_struct(self.n_items, st, cnt)
 
+    def last_call_stats(self) -> dict:
+        """What the last ``get_metrics_ials`` call did on the device (measurement only):
+        which path ran, how many 64 x 64 score tiles it computed of how many, and the rows it
+        had to rank from their full score row."""
+        from .._lib import EvalStatsStruct
+
+        st = EvalStatsStruct()
+        check(lib().irs_eval_last_stats(self._h, C.byref(st)))
+        names = {0: "two_pass", 1: "emit", 2: "emit_bounded", 3: "single_pass"}
+        return {"path": names.get(st.path, str(st.path)), "hard_rows": int(st.hard_rows),
+                "tiles_total": int(st.tiles_total), "tiles_scored": int(st.tiles_scored),
+                "sample_items": int(st.sample_items)}
+
     @staticmethod
     def _mask_fingerprint(mask: sps.spmatrix) -> int:
         """Cheap content check for the device-resident mask: CRC of the row pointers and of a

@@ -330,3 +330,65 @@ def test_emit_path_on_a_wide_catalogue(cutoff, monkeypatch):
     scores[mask.nonzero()] = -np.inf
     compare(a, ocore.get_metrics_f32(scores, cutoff, 0, 4, True))
     compare(part, ocore.get_metrics_f32(scores[100:571], cutoff, 100, 4, False))
+
+
+@pytest.mark.parametrize("K", [16, 48])
+def test_norm_bound_pruning_keeps_the_lists(K, monkeypatch):
+    """Bounded emit path on a catalogue with a popularity skew: item norms fall off like a
+    power law, so most score tiles are pruned (Cauchy-Schwarz against the per-user threshold).
+    The metrics must be those of the oracle on the full masked score block, including for the
+    rows the filtered pass cannot finish: users who have seen every popular item (no threshold
+    in the sample), users with an all-zero factor (every score ties at 0: list overflow), and
+    users without ground truth (skipped)."""
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, IALSTrainer)
+
+    rng2 = np.random.default_rng(3)
+    U, I, cutoff = 1500, 9000, 20
+    mc = IALSModelConfigBuilder().set_K(K).build()
+    sc = IALSSolverConfigBuilder().build()
+    t = IALSTrainer(mc, sps.csr_matrix((U, I), dtype=np.float32))
+    pop = (1.0 + np.arange(I)) ** -0.7
+    rng2.shuffle(pop)
+    item = rng2.standard_normal((I, K)).astype(np.float32) * pop[:, None].astype(np.float32)
+    user = rng2.standard_normal((U, K)).astype(np.float32)
+    user[5] = 0.0  # all scores tie at 0
+    user[6] = 0.0
+    t.user, t.item = user, item
+    mask = sps.random(U, I, density=0.01, format="lil", random_state=rng2, dtype=np.float32)
+    top = np.argsort(-np.linalg.norm(item.astype(np.float64), axis=1))  # the path's item order
+    for u in (10, 11, 700):  # these users have seen the 5000 items of largest norm
+        mask[u, top[:5000]] = 1.0
+    mask[12, top[:600]] = 1.0  # and this one the first sample
+    mask = sps.csr_matrix(mask)
+    mask.data[:] = 1.0
+    gt = sps.random(U, I, density=0.003, format="lil", random_state=rng2, dtype=np.float64)
+    gt[5, 17] = 1.0
+    gt[6, 18] = 1.0
+    gt[10, top[6000]] = 1.0
+    gt[11, top[5500]] = 1.0
+    gt[700, 3] = 1.0
+    gt[12, top[700]] = 1.0
+    gt[20] = 0  # no ground truth
+    gt = sps.csr_matrix(gt)
+    gt.data[:] = 1.0
+    gt.eliminate_zeros()
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    scores = t.user_scores(0, U, sc)
+    scores[mask.nonzero()] = -np.inf
+    want = ocore.get_metrics_f32(scores, cutoff, 0, 4, False)
+    a = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)
+    st = core.last_call_stats()
+    assert st["path"] == "emit_bounded" and st["tiles_scored"] < 0.5 * st["tiles_total"], st
+    assert st["hard_rows"] >= 5, st  # 5, 6 (overflow), 10, 11, 700 (no threshold)
+    compare(a, want)
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_BOUND", "0")
+    b = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)
+    assert core.last_call_stats()["path"] == "emit"
+    compare(b, want)
+    np.testing.assert_array_equal(a.item_cnt, b.item_cnt)
+    # a sub-block with an offset, and the tiny first sample (more second chances)
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_BOUND", "1")
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_SAMPLE", "64")
+    part = core.get_metrics_ials(t, 3, 1203, sps.csr_matrix(mask[3:1203]), cutoff, 3, True)
+    compare(part, ocore.get_metrics_f32(scores[3:1203], cutoff, 3, 4, True))
