@@ -255,11 +255,12 @@ def evaluator_leg(X, trainer, K, ceilings):
     # The call no longer computes the dense contraction: the norm bound leaves a few percent of
     # the 64 x 64 score tiles (same lists, tests/test_gpu_fullsize.py).  `scores_per_s` stays
     # the dense-equivalent rate (what a caller gets); the roofline is priced on the flops the
-    # kernels EXECUTED (sample pass + scored tiles) and the bytes an unfused evaluator would move.
+    # kernels EXECUTED (sample pass + scored tiles).
     st = ev.last_call_stats()
     dense_flops = 2.0 * U * I * K
     flops = 2.0 * K * (64.0 * 64.0 * st["tiles_scored"] + float(U) * st["sample_items"])
-    byts = 2.0 * U * I * 4
+    # HBM side of what runs: the sample score block (written, masked, read) and the candidate lists
+    byts = 2.0 * U * st["sample_items"] * 4 + 2.0 * U * 20 * 8
     return {
         "workload": f"fused iALS k={K} scoring + nDCG@20 over {U} users x {I} items, fp32 scores",
         "wall_s_first_call_incl_mask_upload": wall_first,
@@ -267,9 +268,12 @@ def evaluator_leg(X, trainer, K, ceilings):
         "scores_per_s": U * float(I) / wall, "ndcg@20": m.as_dict()["ndcg"],
         "device_path": st,
         "tiles_scored_frac": st["tiles_scored"] / max(1, st["tiles_total"]),
-        "roofline": both_terms(flops, byts, wall, ceilings, scope="whole call (host wall clock)",
+        "roofline": both_terms(flops, byts, wall, ceilings, bound="mfma",
+                               scope="whole call (host wall clock); after pruning the call is "
+                                     "launch / latency bound, not MFMA bound",
                                executed_gflop=flops / 1e9, dense_gflop=dense_flops / 1e9,
-                               score_block_gbyte_write_plus_read=byts / 1e9),
+                               dense_equivalent_tflops=dense_flops / wall / 1e12,
+                               sample_block_gbyte_write_plus_read=byts / 1e9),
     }
 
 

@@ -393,6 +393,9 @@ struct EmitParams {
   // bounded variant (below): sorted position -> item id / row of the call, and per 64-user
   // tile the number of leading item tiles that can still hold a candidate
   const int32_t *iperm, *uperm, *limit_tiles;
+  // the work list of the bounded variant: workgroup b scores item tiles 4 (b - wg_prefix[ut])
+  // .. + 3 of user tile ut = wg_ut[b] (only workgroups with a live tile are launched)
+  const int32_t *wg_ut, *wg_prefix;
   // rows the path cannot finish (no threshold from the sample, candidate list overflow): set
   // to 1 here, ranked one by one from their full score rows afterwards
   int32_t *hard;
@@ -483,11 +486,16 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
   float *S = reinterpret_cast<float *>(em_smem) + wid * (64 * FZ_SROW);
   int32_t *IDS = reinterpret_cast<int32_t *>(em_smem + 4 * 64 * FZ_SROW * sizeof(float)) + wid * 64;
   const int64_t item_tiles = (p.n_items + 63) / 64;
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wid;
-  const int64_t ut = w / item_tiles, it = w % item_tiles;
-  if (ut * 64 >= p.rows) return;
+  int64_t ut, it;
   if constexpr (BOUNDED) {
+    ut = p.wg_ut[blockIdx.x];
+    it = static_cast<int64_t>(blockIdx.x - p.wg_prefix[ut]) * 4 + wid;
     if (it >= p.limit_tiles[ut]) return;
+  } else {
+    const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wid;
+    ut = w / item_tiles;
+    it = w % item_tiles;
+    if (ut * 64 >= p.rows) return;
   }
   // lane l as user l: threshold and mask word of this tile (requested now, used after the MFMAs)
   const int64_t my_pos = ut * 64 + ln;
@@ -725,6 +733,45 @@ __global__ void prune_radius_kernel(float *__restrict__ tau, const float *__rest
     rad = -INF;
   }
   radius[r] = rad;
+}
+
+// wg_prefix[ut] = exclusive prefix sum of ceil(limit_tiles[ut] / 4) (workgroups of four item
+// tiles), wg_prefix[n_ut] = their number, also written to *total.  One workgroup.
+__global__ __launch_bounds__(1024) void wg_scan_kernel(const int32_t *__restrict__ limit_tiles,
+                                                       int64_t n_ut, int32_t *__restrict__ wg_prefix,
+                                                       int32_t *__restrict__ total) {
+  __shared__ int32_t part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (n_ut + 1023) / 1024;
+  const int64_t b = per * tid, e = min(b + per, n_ut);
+  int32_t sum = 0;
+  for (int64_t i = b; i < e; i++) sum += (limit_tiles[i] + 3) / 4;
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int32_t v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int32_t run = part[tid] - sum;
+  for (int64_t i = b; i < e; i++) {
+    wg_prefix[i] = run;
+    run += (limit_tiles[i] + 3) / 4;
+  }
+  if (tid == 1023) {
+    wg_prefix[n_ut] = part[1023];
+    *total = part[1023];
+  }
+}
+
+// wg_ut[b] = ut for the workgroups b of user tile ut (one wave per user tile)
+__global__ __launch_bounds__(256) void wg_fill_kernel(const int32_t *__restrict__ wg_prefix, int64_t n_ut,
+                                                      int32_t *__restrict__ wg_ut) {
+  const int64_t ut = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (ut >= n_ut) return;
+  const int32_t b = wg_prefix[ut], e = wg_prefix[ut + 1];
+  for (int32_t i = b + (threadIdx.x & 63); i < e; i += 64) wg_ut[i] = static_cast<int32_t>(ut);
 }
 
 // list[0 .. min(*count, cap)) = hard rows that have ground truth (any order); *count = all of them

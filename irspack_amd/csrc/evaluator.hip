@@ -1096,7 +1096,7 @@ struct irs_evaluator {
   DeviceBuffer<int32_t> cand_item, cand_cnt, tau_hint, bad_flag;
   // bounded variant of the emit path: norms, the two sort permutations, per-tile limits
   DeviceBuffer<float> inorm, inorm_sorted, unorm, radius, radius_sorted, sample_item, hard_user;
-  DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list;
+  DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_ut, wg_prefix;
   DeviceBuffer<char> sort_tmp;
   DeviceBuffer<unsigned long long> tiles_scored;
   irs_eval_stats stats{};  // of the last irs_eval_get_metrics_ials call
@@ -1397,8 +1397,9 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     bits = e->mask_bits.ptr;
     n_masked = e->mask_count.ptr;
   }
-  e->bad_flag.alloc(3);  // [0] flags, [1] hard rows at the end, [2] hard rows after the sample pass
-  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, 3 * sizeof(int32_t), s));
+  // [0] flags, [1] hard rows at the end, [2] hard rows after the sample pass, [3] workgroups
+  e->bad_flag.alloc(4);
+  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, 4 * sizeof(int32_t), s));
   e->hard.alloc(rows);
   e->hard_list.alloc(rows);
   IRS_HIP(hipMemsetAsync(e->hard.ptr, 0, rows * sizeof(int32_t), s));
@@ -1493,8 +1494,9 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
   f.cand_item = e->cand_item.ptr;
   f.cand_cnt = e->cand_cnt.ptr;
   f.bad_flag = e->bad_flag.ptr;
-  f.iperm = f.uperm = f.limit_tiles = nullptr;
+  f.iperm = f.uperm = f.limit_tiles = f.wg_ut = f.wg_prefix = nullptr;
   f.hard = e->hard.ptr;
+  int32_t n_wg = 0;
   if (bounded) {
     // users in order of increasing pruning radius, and what each 64-user tile still needs
     e->unorm.alloc(rows);
@@ -1514,9 +1516,22 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     f.iperm = e->iperm.ptr;
     f.uperm = e->uperm.ptr;
     f.limit_tiles = e->limit_tiles.ptr;
+    // the work list: only workgroups with a live tile are launched (the others would still
+    // queue for a workgroup slot and its LDS just to leave); its length comes back to the host
+    const int64_t n_ut = ceil_div(rows, 64);
+    e->wg_prefix.alloc(n_ut + 1);
+    hipLaunchKernelGGL(wg_scan_kernel, dim3(1), dim3(1024), 0, s, e->limit_tiles.ptr, n_ut,
+                       e->wg_prefix.ptr, e->bad_flag.ptr + 3);
+    IRS_HIP(hipMemcpyAsync(&n_wg, e->bad_flag.ptr + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    IRS_HIP(hipStreamSynchronize(s));
+    e->wg_ut.alloc(std::max<int64_t>(n_wg, 1));
+    hipLaunchKernelGGL(wg_fill_kernel, dim3(ceil_div(n_ut, 4)), dim3(256), 0, s, e->wg_prefix.ptr, n_ut,
+                       e->wg_ut.ptr);
+    f.wg_ut = e->wg_ut.ptr;
+    f.wg_prefix = e->wg_prefix.ptr;
   }
-  {
-    const int64_t tiles = ceil_div(rows, 64) * ceil_div(ni, 64);
+  if (!bounded || n_wg > 0) {
+    const int64_t tiles = bounded ? int64_t(n_wg) * 4 : ceil_div(rows, 64) * ceil_div(ni, 64);
     const size_t lds = 4 * 64 * FZ_SROW * sizeof(float) + 4 * 64 * sizeof(int32_t);
     auto launch = [&](auto kernel) {
       IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
