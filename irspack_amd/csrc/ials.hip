@@ -327,6 +327,7 @@ struct irs_ials_trainer {
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   Profiler prof;
   bool opt_wave128 = true, opt_unit = true, opt_short = true, opt_wg16 = true;  // read_switches()
+  bool opt_short2 = true;  // two short rows per wave (IRSPACK_AMD_IALS_SHORT2)
   bool opt_bf16x3 = false;
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
@@ -683,6 +684,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_wave128 = env_flag("IRSPACK_AMD_IALS_WAVE128", true);
   t->opt_unit = env_flag("IRSPACK_AMD_IALS_UNIT", true);
   t->opt_short = env_flag("IRSPACK_AMD_IALS_SHORT", true);
+  t->opt_short2 = env_flag("IRSPACK_AMD_IALS_SHORT2", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
   t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
 }
@@ -736,19 +738,24 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     IRS_DISPATCH_T8(t->T, {
       constexpr int KPP = 16 * TT;
       const size_t lds = ShortGeo<KPP>::LDS_BYTES;
-      auto launch = [&](auto kernel, int first, int count) {
+      auto launch = [&](auto kernel, int first, int count, int nr) {
         if (count <= 0) return;
         IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     static_cast<int>(lds)));
         const int grid = static_cast<int>(
-            std::min<int64_t>(ceil_div(count, SHORT_WAVES), 2 * std::max(n_cu, 1)));
+            std::min<int64_t>(ceil_div(count, SHORT_WAVES * nr), 2 * std::max(n_cu, 1)));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * SHORT_WAVES), lds, t->stream, p,
                            t->P[pidx].ptr, first, count);
       };
       // the list is longest first: [general | 17..32 entries | <= 16 entries]
-      launch(ials_cg_short_kernel<KPP, 32>, n_regular, sd.n_short - sd.n_short16);
-      launch(ials_cg_short_kernel<KPP, 16>, sd.n_tasks - sd.n_short16, sd.n_short16);
+      if (t->opt_short2) {
+        launch(ials_cg_short_kernel<KPP, 32, 1>, n_regular, sd.n_short - sd.n_short16, 1);
+        launch(ials_cg_short_kernel<KPP, 16, 2>, sd.n_tasks - sd.n_short16, sd.n_short16, 2);
+      } else {
+        launch(ials_cg_short_kernel<KPP, 32, 1>, n_regular, sd.n_short - sd.n_short16, 1);
+        launch(ials_cg_short_kernel<KPP, 16, 1>, sd.n_tasks - sd.n_short16, sd.n_short16, 1);
+      }
     });
     t->prof.end(t->stream);
     p.n_tasks = n_regular;
