@@ -164,3 +164,50 @@ def test_knn_rows_and_evaluator_users_over_two_ranks(tmp_path):
         assert m.valid_user == whole.valid_user and m.total_user == whole.total_user
         for k in ("hit", "ndcg", "recall", "map", "precision"):
             assert getattr(m, k) == pytest.approx(getattr(whole, k), rel=1e-12)
+
+
+def _rccl_world1_worker(rank, port, out_dir):
+    """The RCCL calls of the sharded loop on the library's own device buffers, world size 1
+    (the only RCCL configuration a one-GPU box can run: RCCL refuses two ranks on a device)."""
+    import torch
+    import torch.distributed as dist
+
+    from irspack_amd.recommenders._ials_core import IALSModelConfigBuilder
+    from irspack_amd.sharding import HipLocalSolver, equal_shard_bounds
+    from irspack_amd.synthetic import make_interactions
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    X = make_interactions("small")
+    mc = IALSModelConfigBuilder().set_K(64).set_alpha0(0.1).set_reg(1e-2).build()
+    ub, ib = equal_shard_bounds(X, 1)
+    local = HipLocalSolver(mc, X, (ub[0], ub[1], ib[0], ib[1]), 0)
+    second = dist.new_group(ranks=[0])  # the Gramian's communicator
+    user = local.factor_view(0)
+    before = user.clone()
+    # in-place all-gather of the (whole) row block, as ShardedIALSTrainer._exchange_rows issues it
+    w = dist.all_gather_into_tensor(user, user[0:user.shape[0]], async_op=True)
+    local.partial_gramian(1)
+    red = dist.all_reduce(local.gramian_view(1), op=dist.ReduceOp.SUM, group=second, async_op=True)
+    w.wait()
+    red.wait()
+    local.finish_gramian(1)
+    dist.broadcast(local.factor_view(1), src=0)
+    local.synchronize()
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(user, before)) and bool(torch.isfinite(local.gramian_view(1)).all())
+    with open(os.path.join(out_dir, "rccl1.txt"), "w") as fh:
+        fh.write("ok" if ok else "mismatch")
+    dist.destroy_process_group()
+
+
+def test_rccl_calls_on_library_buffers_world_size_one(tmp_path):
+    """all_gather_into_tensor (in place), all_reduce on a second communicator and broadcast run
+    through RCCL on zero-copy views of the library's device buffers."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rccl_world1_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "rccl1.txt").read_text() == "ok"
