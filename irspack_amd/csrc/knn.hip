@@ -945,9 +945,25 @@ struct irs_knn_computer {
   int64_t res_nnz = 0;
   double last_ms = 0;
   int64_t last_macs = 0;
+  // scratch of a compute call, kept between calls (hipMalloc / hipFree of ~200 MB per call
+  // cost more than a millisecond, and hipFree synchronises the device)
+  struct Scratch {
+    DeviceBuffer<int64_t> t_ptr, res_ptr;
+    DeviceBuffer<int32_t> t_idx, order, cand_idx, cand_cnt, out_idx, out_cnt, cursor, slot_of;
+    DeviceBuffer<double> t_val, t_stat, t_scale, cand_val, out_val;
+  } scratch;
 };
 
 extern "C" {
+
+// host threads of the target pass (IRSPACK_AMD_KNN_THREADS overrides)
+static int64_t host_thread_cap() {
+  static const int64_t cap = [] {
+    const char *e = std::getenv("IRSPACK_AMD_KNN_THREADS");
+    return e ? std::max<int64_t>(1, std::atoll(e)) : int64_t(32);
+  }();
+  return cap;
+}
 
 // IRSPACK_AMD_KNN_TIMING=1 prints the host phases of a compute call to stderr
 struct PhaseTimer {
@@ -1154,9 +1170,34 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     check_arg(e_begin >= 0 && e_end >= e_begin, "malformed indptr.");
     check_arg(e_end < (int64_t(1) << 31), "nnz must be below 2^31.");
     std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0);
+    // The row pointers and column indices of the call's rows travel to the device on a second
+    // host thread while this one walks them (the values follow later, and only if the kernel
+    // reads them).  An index out of range is found by the walk below before any kernel runs.
+    irs_knn_computer::Scratch &sc = c->scratch;
+    std::string upload_error;
+    std::thread uploader;
+    const bool have_work = n > 0 && std::min<int64_t>(top_k, c->N) > 0 && c->N > 0;
+    if (have_work) {
+      uploader = std::thread([&] {
+        try {
+          IRS_HIP(hipSetDevice(c->device));
+          std::vector<int64_t> rel(n + 1);
+          for (int64_t i = 0; i <= n; i++) rel[i] = ip[row_begin + i] - e_begin;
+          sc.t_ptr.upload(rel, nullptr);
+          sc.t_idx.upload(ix + e_begin, std::max<size_t>(static_cast<size_t>(e_end - e_begin), 1), nullptr);
+          IRS_HIP(hipStreamSynchronize(nullptr));  // `rel` goes out of scope
+        } catch (const std::exception &e) {
+          upload_error = e.what();
+        }
+      });
+    }
+    struct Joiner {
+      std::thread &t;
+      ~Joiner() { if (t.joinable()) t.join(); }
+    } upload_join{uploader};
     {
       const int n_thr = static_cast<int>(std::max<int64_t>(
-          1, std::min<int64_t>({32, static_cast<int64_t>(std::thread::hardware_concurrency()),
+          1, std::min<int64_t>({host_thread_cap(), static_cast<int64_t>(std::thread::hardware_concurrency()),
                                 (e_end - e_begin) / 200000 + 1})));
       auto body = [&](int th) {
         // contiguous row chunks of about equal entry counts
@@ -1228,13 +1269,29 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     // rows of the call, heaviest product row first (ids relative to row_begin)
     for (int64_t i = 0; i < n; i++) c->last_macs += work[i];
     std::vector<int32_t> order(n);
-    for (int64_t i = 0; i < n; i++) order[i] = static_cast<int32_t>(i);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int32_t a, int32_t b) { return work[a] > work[b]; });
+    {  // Heaviest rows first, for the load balance of the persistent launch only (results do
+       // not depend on it): a counting sort by 1/64-octave of the work, rows of a bucket in
+       // row order - O(n) instead of a 1.2 ms comparison sort.
+      constexpr int NB = 64 * 64;
+      auto bucket = [&](int64_t w) {
+        const int b = static_cast<int>(std::log2(static_cast<double>(w) + 1.0) * 64.0);
+        return NB - 1 - std::min(std::max(b, 0), NB - 1);
+      };
+      std::vector<int32_t> start(NB + 1, 0);
+      std::vector<int32_t> bk(n);
+      for (int64_t i = 0; i < n; i++) {
+        bk[i] = bucket(work[i]);
+        start[bk[i] + 1]++;
+      }
+      for (int b = 0; b < NB; b++) start[b + 1] += start[b];
+      for (int64_t i = 0; i < n; i++) order[start[bk[i]]++] = static_cast<int32_t>(i);
+    }
     pt.mark("work + order");
-    DeviceBuffer<int64_t> t_ptr;
-    DeviceBuffer<int32_t> t_idx, d_order, cand_idx, cand_cnt, out_idx, out_cnt;
-    DeviceBuffer<double> t_val, t_stat, t_scale, cand_val, out_val;
+    DeviceBuffer<int64_t> &t_ptr = sc.t_ptr;
+    DeviceBuffer<int32_t> &t_idx = sc.t_idx, &d_order = sc.order, &cand_idx = sc.cand_idx,
+                          &cand_cnt = sc.cand_cnt, &out_idx = sc.out_idx, &out_cnt = sc.out_cnt;
+    DeviceBuffer<double> &t_val = sc.t_val, &t_stat = sc.t_stat, &t_scale = sc.t_scale,
+                         &cand_val = sc.cand_val, &out_val = sc.out_val;
     // which accumulator: 32-bit counts when every product is 1, else fp64 sums with the -0.0
     // sentinel unless some product could be a zero
     // (the sentinel of the fixed-point sums needs positive data: a sum must not return to the
@@ -1242,11 +1299,9 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     const bool sentinel = c->xt_nonzero && t_safe && c->xt_positive && not_positive.load() == 0;
     const bool acc32 = c->xt_all_ones && sentinel && t_all_ones;
     {  // only the rows of the call travel; the values only if the kernel reads them
-      std::vector<int64_t> rel(n + 1);
-      for (int64_t i = 0; i <= n; i++) rel[i] = ip[row_begin + i] - e_begin;
-      t_ptr.upload(rel, s);
+      uploader.join();  // row pointers + column indices (started before the target pass)
+      if (!upload_error.empty()) throw std::runtime_error(upload_error);
       const size_t ne = static_cast<size_t>(e_end - e_begin);
-      t_idx.upload(ix + e_begin, std::max<size_t>(ne, 1), s);
       if (acc32) {
         t_val.alloc(1);
       } else if (binarise) {
@@ -1258,7 +1313,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       }
       t_stat.upload(tstat, s);
       t_scale.upload(tscale, s);
-      IRS_HIP(hipStreamSynchronize(s));  // `rel` goes out of scope
     }
     d_order.upload(order, s);
     const size_t slots = static_cast<size_t>(n) * n_tiles;
@@ -1300,7 +1354,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     // persistent launch: one resident workgroup per CU (its LDS footprint allows no second)
     int n_cu = 0;
     IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-    DeviceBuffer<int32_t> cursor;
+    DeviceBuffer<int32_t> &cursor = sc.cursor;
     cursor.alloc(1);
     IRS_HIP(hipMemsetAsync(cursor.ptr, 0, sizeof(int32_t), s));
     p.cursor = cursor.ptr;
@@ -1364,8 +1418,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     for (int64_t i = 0; i < n; i++) c->res_ptr[i + 1] = c->res_ptr[i] + h_cnt[slot_of[i]];
     c->res_nnz = c->res_ptr[n];
     if (c->res_nnz > 0) {
-      DeviceBuffer<int32_t> d_slot_of;
-      DeviceBuffer<int64_t> d_res_ptr;
+      DeviceBuffer<int32_t> &d_slot_of = sc.slot_of;
+      DeviceBuffer<int64_t> &d_res_ptr = sc.res_ptr;
       d_slot_of.upload(slot_of, s);
       d_res_ptr.upload(c->res_ptr, s);
       c->res_idx.alloc(static_cast<size_t>(c->res_nnz));
