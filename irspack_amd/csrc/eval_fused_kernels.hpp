@@ -713,6 +713,30 @@ __global__ void mask_rows_perm_kernel(float *scores, int64_t rows, int64_t n_sam
   }
 }
 
+// mask_row[q] = row of mask entry q (one wave per row): lets the sample pass walk the mask by
+// ENTRY - a flat, coalesced stream - instead of one small workgroup per row
+__global__ __launch_bounds__(256) void mask_row_ids_kernel(const int64_t *__restrict__ mask_ptr,
+                                                           int64_t rows, int32_t *__restrict__ mask_row) {
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  for (int64_t q = mask_ptr[row] + (threadIdx.x & 63); q < mask_ptr[row + 1]; q += 64)
+    mask_row[q] = static_cast<int32_t>(row);
+}
+
+// the mask walk of the sample pass by entry: entries [q0, q1) belong to the rows [row0, ...) of
+// the score block [*, n_sample] over the first n_sample SORTED items
+__global__ __launch_bounds__(256) void mask_entries_perm_kernel(float *__restrict__ scores, int64_t n_sample,
+                                                                int64_t row0, int64_t q0, int64_t q1,
+                                                                const int32_t *__restrict__ mask_row,
+                                                                const int32_t *__restrict__ mask_idx,
+                                                                const int32_t *__restrict__ inv) {
+  const int64_t q = q0 + static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (q >= q1) return;
+  const int32_t j = inv[mask_idx[q]];
+  if (j < n_sample)
+    scores[(static_cast<int64_t>(mask_row[q]) - row0) * n_sample + j] = -std::numeric_limits<float>::infinity();
+}
+
 // r_u = tau_u / norm_up(u), a hair low (the division's rounding); -inf (keep everything) for a
 // threshold that is not positive; +inf (nothing to do; tau likewise) for a user without ground
 // truth and for a hard row

@@ -1099,6 +1099,8 @@ struct irs_evaluator {
   DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_ut, wg_prefix;
   DeviceBuffer<char> sort_tmp;
   DeviceBuffer<unsigned long long> tiles_scored;
+  DeviceBuffer<int32_t> mask_row;         // row of every mask entry (built with the bitmap)
+  std::vector<int64_t> mask_ptr_host;     // host copy of the mask's row pointers
   irs_eval_stats stats{};  // of the last irs_eval_get_metrics_ials call
 };
 
@@ -1211,6 +1213,9 @@ bool fused_enabled() {
 // The single-pass path of irs_eval_get_metrics_ials (eval_fused_kernels.hpp).  Returns false
 // when the call is outside its domain (candidate lists, cutoff > 32, a bitmap that would not
 // fit, a non-finite score met on the way): the caller then runs the two-pass path.
+bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int64_t *d_mptr,
+                        const int32_t *d_midx, hipStream_t s);
+
 bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t rows,
                        const int64_t *d_mptr, const int32_t *d_midx, int64_t cutoff,
                        int64_t offset, bool rwc, hipStream_t s) {
@@ -1233,18 +1238,7 @@ bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int
   const uint64_t *bits = nullptr;
   const int32_t *n_masked = nullptr;
   if (d_mptr) {
-    if (static_cast<double>(rows) * words * 8.0 > 2147483648.0) return false;
-    const bool cached = d_mptr == e->mask_ptr.ptr && e->mask_bits_rows == rows;
-    if (!cached) {
-      e->mask_bits.alloc(static_cast<size_t>(rows) * words);
-      e->mask_count.alloc(rows);
-      IRS_HIP(hipMemsetAsync(e->mask_bits.ptr, 0, static_cast<size_t>(rows) * words * 8, s));
-      hipLaunchKernelGGL(mask_bitmap_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, d_mptr, d_midx,
-                         rows, words, e->mask_bits.ptr);
-      hipLaunchKernelGGL(mask_count_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s,
-                         e->mask_bits.ptr, rows, words, e->mask_count.ptr);
-      e->mask_bits_rows = d_mptr == e->mask_ptr.ptr ? rows : -1;  // only the resident mask is cached
-    }
+    if (!ensure_mask_bitmap(e, rows, words, d_mptr, d_midx, s)) return false;
     bits = e->mask_bits.ptr;
     n_masked = e->mask_count.ptr;
   }
@@ -1358,6 +1352,14 @@ bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int
                        rows, words, e->mask_bits.ptr);
     hipLaunchKernelGGL(mask_count_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, e->mask_bits.ptr,
                        rows, words, e->mask_count.ptr);
+    // row ids per entry + the row pointers on the host (entry ranges of the sample blocks)
+    e->mask_ptr_host.resize(rows + 1);
+    IRS_HIP(hipMemcpyAsync(e->mask_ptr_host.data(), d_mptr, (rows + 1) * sizeof(int64_t),
+                           hipMemcpyDeviceToHost, s));
+    IRS_HIP(hipStreamSynchronize(s));
+    e->mask_row.alloc(static_cast<size_t>(std::max<int64_t>(e->mask_ptr_host[rows], 1)));
+    hipLaunchKernelGGL(mask_row_ids_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, d_mptr, rows,
+                       e->mask_row.ptr);
     e->mask_bits_rows = d_mptr == e->mask_ptr.ptr ? rows : -1;  // only the resident mask is cached
   }
   return true;
@@ -1441,10 +1443,13 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
                                          bounded ? e->sample_item.ptr : nullptr, nullptr,
                                          e->fused_scores.ptr) != IRS_OK)
         throw std::runtime_error(irs_last_error());
-      if (d_mptr && bounded)
-        hipLaunchKernelGGL(mask_rows_perm_kernel, dim3(m), dim3(64), 0, s, e->fused_scores.ptr, m,
-                           n_sample, d_mptr + b, d_midx, e->iinv.ptr, no_list, no_list);
-      else if (d_mptr)
+      if (d_mptr && bounded) {
+        const int64_t q0 = e->mask_ptr_host[b], q1 = e->mask_ptr_host[b + m];
+        if (q1 > q0)
+          hipLaunchKernelGGL(mask_entries_perm_kernel, dim3(ceil_div(q1 - q0, 256)), dim3(256), 0, s,
+                             e->fused_scores.ptr, n_sample, b, q0, q1, e->mask_row.ptr, d_midx,
+                             e->iinv.ptr);
+      } else if (d_mptr)
         hipLaunchKernelGGL(mask_rows_kernel, dim3(m), dim3(64), 0, s, e->fused_scores.ptr, m,
                            n_sample, d_mptr + b, d_midx);
       hipLaunchKernelGGL((sample_tau_kernel<8>), dim3(static_cast<unsigned>(ceil_div(m, 4))), dim3(256),

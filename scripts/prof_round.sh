@@ -14,3 +14,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/sec_write -- p
 rm -rf gpurun_out/prof/c4_kt
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/c4_kt -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --legs c4 --c4-small > gpurun_out/prof/c4_kt.log 2>&1
 ls gpurun_out/prof | head -40
+# fused iALS evaluator (quick_eval_fused.py: 4 calls over all users at K = 64 and K = 256)
+bash scripts/prof_eval_fused.sh > gpurun_out/prof/ef.log 2>&1
+ls gpurun_out/prof | head -40
