@@ -149,6 +149,24 @@ def main():
             traffic[f"ials_{kind}_{solver}_user"] = user["hbm_bytes"]
             traffic[f"ials_{kind}_{solver}_item"] = item["hbm_bytes"]
     json.dump(out, open(os.path.join(DST, f"{TAG}_bench_pmc_hbm.json"), "w"), indent=1)
+    # kNN tile kernel: FETCH_SIZE / WRITE_SIZE passes over scripts/quick_knn_eval.py --skip-eval
+    # (full-matrix calls only: the warm-up call of 64 rows has a smaller grid of slots)
+    kf = newest(os.path.join(SRC, "sec_fetch", "*", "*_counter_collection.csv"))
+    kw = newest(os.path.join(SRC, "sec_write", "*", "*_counter_collection.csv"))
+    if kf and kw:
+        def knn_sum(path, counter):
+            best = collections.defaultdict(list)
+            for r in csv.DictReader(open(path)):
+                if "knn_tile_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    best[r["Dispatch_Id"]].append(float(r["Counter_Value"]))
+            per = sorted(sum(v) for v in best.values())
+            return per[-1] if per else 0.0  # the heaviest launch = a full-matrix call
+        fb, wb = knn_sum(kf[0], "FETCH_SIZE") * 1024 * 2, knn_sum(kw[0], "WRITE_SIZE") * 1024
+        if fb > 0:
+            traffic["knn_tile_kernel"] = fb + wb
+            json.dump({"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
+                       "units": "FETCH_SIZE x 2 KiB (gfx950 correction), WRITE_SIZE x 1 KiB; heaviest launch"},
+                      open(os.path.join(DST, f"{TAG}_knn_pmc_hbm.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
