@@ -294,7 +294,9 @@ def knn_leg(X, ceilings):
     create_s = time.perf_counter() - t0
     comp.compute_similarity(Xt, 100, rows=(0, 64))  # warm-up
     walls = []
+    S = None
     for _ in range(3):
+        S = None  # the previous result (32 MB) is released outside the timed call
         t0 = time.perf_counter()
         S = comp.compute_similarity(Xt, 100)
         walls.append(time.perf_counter() - t0)

@@ -1207,21 +1207,48 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         int64_t r1 = th + 1 == n_thr ? row_end : std::lower_bound(ip + row_begin, ip + row_end, hi_e) - ip;
         if (th == 0) r0 = row_begin;
         bool bad = false, ones = true, safe = true, positive = true;
+        // The usual case - every stored value of the chunk is exactly 1 (binary interactions) -
+        // is recognised by one tight pass over the values (a branch-free AND the compiler
+        // vectorises); the row loop then only walks the indices.
+        bool chunk_ones = true;
+        if (!binarise && r1 > r0) {
+          uint64_t diff = 0;
+          const uint64_t one_bits = 0x3ff0000000000000ull;
+          const uint64_t *vb = reinterpret_cast<const uint64_t *>(dv);
+          for (int64_t q = ip[r0]; q < ip[r1]; q++) diff |= vb[q] ^ one_bits;
+          chunk_ones = diff == 0;
+        }
+        const bool unit = binarise || chunk_ones;
         for (int64_t i = r0; i < r1; i++) {
           if (ip[i + 1] < ip[i]) { bad = true; break; }
           double ss = 0, bound = 0;
           int64_t w = 0;
-          for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
-            const int32_t j = ix[q];
-            if (j < 0 || j >= cols) { bad = true; break; }
-            const double x = binarise ? 1.0 : dv[q];  // similarities.hpp:113-118, 165-170
-            ss += x * x;
-            w += c->xt_row_len[j];
-            ones &= x == 1.0;
-            positive &= x > 0.0;
-            const double ax = std::fabs(x);
-            safe &= ax > 1e-150 && ax < 1e150;  // no stored zero, no underflow of x * y
-            bound += ax * c->xt_rowmax[j];      // >= |any sum of this product row|
+          if (unit) {
+            if (cols <= 0 && ip[i + 1] > ip[i]) { bad = true; break; }
+            int32_t lo_j = 0, hi_j = 0;  // running min / max: one range test per row
+            for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
+              const int32_t j = ix[q];
+              lo_j = std::min(lo_j, j);
+              hi_j = std::max(hi_j, j);
+              const int32_t jc = std::min(std::max(j, 0), static_cast<int32_t>(cols - 1));
+              w += c->xt_row_len[jc];
+              bound += c->xt_rowmax[jc];
+            }
+            if (lo_j < 0 || hi_j >= cols) { bad = true; break; }
+            ss = static_cast<double>(ip[i + 1] - ip[i]);
+          } else {
+            for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
+              const int32_t j = ix[q];
+              if (j < 0 || j >= cols) { bad = true; break; }
+              const double x = dv[q];  // similarities.hpp:113-118, 165-170
+              ss += x * x;
+              w += c->xt_row_len[j];
+              ones &= x == 1.0;
+              positive &= x > 0.0;
+              const double ax = std::fabs(x);
+              safe &= ax > 1e-150 && ax < 1e150;  // no stored zero, no underflow of x * y
+              bound += ax * c->xt_rowmax[j];      // >= |any sum of this product row|
+            }
           }
           if (bad) break;
           switch (c->sim_type) {
