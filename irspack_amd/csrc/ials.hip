@@ -328,6 +328,7 @@ struct irs_ials_trainer {
   Profiler prof;
   bool opt_wave128 = true, opt_unit = true, opt_short = true, opt_wg16 = true;  // read_switches()
   bool opt_short2 = true;  // two short rows per wave (IRSPACK_AMD_IALS_SHORT2)
+  bool opt_pp_direct = true;  // iALS++ with one block = the direct solve (IRSPACK_AMD_IALSPP_DIRECT)
   bool opt_bf16x3 = false;
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
@@ -685,6 +686,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_unit = env_flag("IRSPACK_AMD_IALS_UNIT", true);
   t->opt_short = env_flag("IRSPACK_AMD_IALS_SHORT", true);
   t->opt_short2 = env_flag("IRSPACK_AMD_IALS_SHORT2", true);
+  t->opt_pp_direct = env_flag("IRSPACK_AMD_IALSPP_DIRECT", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
   t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
 }
@@ -697,11 +699,24 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
        {"ials_split_cholesky_user", "ials_split_cholesky_item"}},
       {{"ials_solve_cg_user", "ials_solve_cg_item"},
        {"ials_split_cg_user", "ials_split_cg_item"}}};
+  bool pp_direct = false;
   if (sc->solver_type == IRS_SOLVER_IALSPP) {
     if (prior)  // hpp:659-661
       throw std::invalid_argument("Feature-aware iALS does not support IALSPP.");
-    launch_ialspp(t, sd, other, target, pidx, sc);
-    return;
+    // One block that covers every dimension (subspace dimension >= K, the default at K <= 64):
+    // the block step of hpp:436-502 is a Newton step of a quadratic, x - A^-1 (A x - b) with the
+    // A and b of step_cholesky (hpp:289-324; the gradient P x + reg x + sum (c (x.v - 1) - bias) v
+    // is A x - b), i.e. the exact minimiser A^-1 b whatever x was, and further sweeps do not
+    // move it.  It is computed as that - the tuned rank-update + Cholesky kernel, no
+    // prediction pass - and agrees with the reference's two-step form to rounding.  Like the
+    // reference on this path (hpp:495-497) a failed factorisation is not reported.
+    pp_direct = t->opt_pp_direct && sc->ialspp_subspace_dimension > 1 &&
+                static_cast<uint64_t>(sc->ialspp_subspace_dimension) >= t->K &&
+                sc->ialspp_iteration >= 1;
+    if (!pp_direct) {
+      launch_ialspp(t, sd, other, target, pidx, sc);
+      return;
+    }
   }
   SolveParams p;
   p.prior = prior;
@@ -717,6 +732,13 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   p.P_acc = t->P_acc[pidx].ptr;
   p.P_accL = t->P_accL[pidx].ptr;
   p.err_flag = t->err_flag.ptr;
+  if (pp_direct) {
+    if (!t->pp_llt_sink.ptr) {
+      t->pp_llt_sink.alloc(1);
+      t->pp_llt_sink.zero(t->stream);
+    }
+    p.err_flag = t->pp_llt_sink.ptr;
+  }
   p.bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;  // hpp:190-191
   p.K = static_cast<int32_t>(t->K);
   p.max_cg_steps = sc->max_cg_steps == 0 ? static_cast<int32_t>(t->K)

@@ -39,9 +39,16 @@ def solvers(sub, iters):
                                    (64, 64), (64, 16), (64, 24), (64, 33), (40, 64), (128, 64),
                                    (130, 32)])
 @pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
-def test_epoch_matches_oracle(K, sub, loss):
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_epoch_matches_oracle(K, sub, loss, direct, monkeypatch):
     """Every epoch starts from the oracle's factors (teacher forcing), so the comparison is one
-    iALS++ epoch (user half then item half) for the same input."""
+    iALS++ epoch (user half then item half) for the same input.  ``direct``: when one block
+    covers every dimension (sub >= K) the library computes the block Newton step as the exact
+    solve it is (``IRSPACK_AMD_IALSPP_DIRECT``, default on); both forms must match the oracle's
+    two-step restatement of hpp:436-502."""
+    if direct == "0" and sub < K:
+        pytest.skip("the switch only matters when one block covers the row")
+    monkeypatch.setenv("IRSPACK_AMD_IALSPP_DIRECT", direct)
     X = random_csr(150, 110, 0.1, 3, empty_rows=(7, 40))
     mc, omc = build(K, loss=loss)
     sc, osc = solvers(sub, 2)
