@@ -325,10 +325,12 @@ struct irs_ials_trainer {
   int f_chunks[2] = {1, 1};  // feature_rhs_kernel: chunks of FEATURE_RHS_CHUNK stored rows per feature
   DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
+  DeviceBuffer<float> pp_pblk;         // iALS++ chain path: blocks of P in accumulator layout
   Profiler prof;
   bool opt_wave128 = true, opt_unit = true, opt_short = true, opt_wg16 = true;  // read_switches()
   bool opt_short2 = true;  // two short rows per wave (IRSPACK_AMD_IALS_SHORT2)
   bool opt_pp_direct = true;  // iALS++ with one block = the direct solve (IRSPACK_AMD_IALSPP_DIRECT)
+  bool opt_pp_chain = true;   // iALS++ prediction passes merged into the rank updates (IRSPACK_AMD_IALSPP_CHAIN)
   bool opt_bf16x3 = false;
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
@@ -613,6 +615,15 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
   // a subspace dimension of 0 or 1 is the iCD branch (hpp:673-677)
   p.sub = static_cast<int32_t>(std::max<uint64_t>(1, sc->ialspp_subspace_dimension));
   p.zero_start = 0;
+  p.chain = t->opt_pp_chain ? 1 : 0;
+  p.P_blk = nullptr;
+  if (p.chain && p.sub == 64 && p.K > 64) {  // the blocks of P in accumulator layout
+    const int nb = (p.K + 63) / 64;
+    t->pp_pblk.alloc(static_cast<size_t>(nb) * 10 * 256);
+    hipLaunchKernelGGL(pp_pack_p_kernel, dim3(nb), dim3(64), 0, t->stream, t->P[pidx].ptr, p.K, p.KP,
+                       t->pp_pblk.ptr);
+    p.P_blk = t->pp_pblk.ptr;
+  }
   const int D = std::min<int>(p.sub, p.K);
   const int TS = D <= 16 ? 1 : D <= 32 ? 2 : 4;
   const bool aligned = p.sub % TS == 0;
@@ -687,6 +698,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_short = env_flag("IRSPACK_AMD_IALS_SHORT", true);
   t->opt_short2 = env_flag("IRSPACK_AMD_IALS_SHORT2", true);
   t->opt_pp_direct = env_flag("IRSPACK_AMD_IALSPP_DIRECT", true);
+  t->opt_pp_chain = env_flag("IRSPACK_AMD_IALSPP_CHAIN", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
   t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
 }

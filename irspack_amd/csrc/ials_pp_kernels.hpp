@@ -9,12 +9,13 @@
 //     delta = A^-1 B (LLT),   x[blk] -= delta,   pred_q -= delta . v_q[blk]
 // Rows are independent, so one wave owns a row for a whole sweep: the prediction cache
 // lives in a global scratch array indexed like the CSR, the D x D system lives in the
-// MFMA accumulator registers (same tile layout and the same panel Cholesky as the full
-// solve in ials_kernels.hpp, with TS = ceil(D / 16) tiles per side), the row's factor
-// vector in LDS.  Subspace dimension 1 is the iCD branch (hpp:673-677), which is the
+// MFMA accumulator registers (same lower-form tile layout and the same 16-row block Cholesky,
+// ials_chol16.hpp, as the full solve, with TS = ceil(D / 16) tiles per side), the row's
+// factor vector in LDS.  Subspace dimension 1 is the iCD branch (hpp:673-677), which is the
 // D = 1 case of the same arithmetic.  The reference does not test the LLT status here
 // (hpp:495-497), so a failed factorisation propagates NaN instead of raising.
 #pragma once
+#include "ials_chol16.hpp"
 #include "ials_kernels.hpp"
 
 namespace irs {
@@ -36,14 +37,17 @@ struct PpParams {
   int32_t K, KP;
   int32_t sub;             // subspace dimension, >= 1
   int32_t zero_start;      // fold-in: the row starts from 0 (hpp:132)
+  int32_t chain;           // 64-dim blocks: prediction passes merged into the rank updates
+  const float *P_blk;      // chain: the blocks of P in accumulator layout (pp_pack_p_kernel)
 };
 
 template <int TS> struct PpGeo {
   static constexpr int DP = 16 * TS;
   static constexpr int NT = TS * (TS + 1) / 2;
   static constexpr int XS = 256;  // largest padded K
+  static constexpr int CHOL_FLOATS = Chol16Geo<TS>::LDS_FLOATS;  // scratch of solve_row_cholesky16
   // Cholesky scratch | x (whole row) | P-part of the rhs | delta
-  static constexpr int LDS_FLOATS = CholGeo<TS>::LDS_FLOATS + XS + 2 * DP;
+  static constexpr int LDS_FLOATS = CHOL_FLOATS + XS + 2 * DP;
 };
 
 // v[t] = factor[row, c0 + off[t]]; ALIGNED: c0 and off[0] are multiples of TS and the
@@ -137,8 +141,8 @@ __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int
 #pragma unroll
       for (int i = 0; i < TS; i++)
 #pragma unroll
-        for (int j = i; j < TS; j++) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[i], vk[j], acc[t], 0, 0, 0);
+        for (int j = i; j < TS; j++) {  // lower form: slot (i, j) = tile (row block j, column block i)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[j], vk[i], acc[t], 0, 0, 0);
           t++;
         }
     }
@@ -161,19 +165,195 @@ __device__ __forceinline__ void pp_rank_update(const PpParams &p, int begin, int
   }
 }
 
+// Multi-block sweep over 64-dim blocks (TS = 4) with the cache correction merged into the next
+// block's rank update.  The pass that builds block b > 0 reads two sub-rows of every gathered
+// row - this block's and the previous one's - and first brings the prediction up to date,
+// pred_q -= delta_prev . v_q[prev block] (hpp:500-506), in the coalesced 16-lanes-per-row layout.
+// Together with pp_predict16 this replaces the two lane-per-entry passes (pp_predict /
+// pp_pred_update: uncoalesced row walks, a device-scope fence each), which were 47 % of the
+// K = 128 user half-step.  The cache entry of an entry is written by lane m = 0 of its 16-lane
+// group and read back by the whole group in the next pass of the SAME wave (workgroup-scope
+// fence between the passes).  Sub-row s = 0 is the current block.
+__device__ __forceinline__ void pp_chain_pass(const PpParams &p, int begin, int end, int c0, int D,
+                                              const float *xs, const float *delta_prev,
+                                              bool store_pred, f32x4 (&acc)[10], float (&bsum)[4]) {
+  constexpr int TS = 4, NS = 2;
+  constexpr bool FIRST = false;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int n = end - begin;
+  const int nit = (n + 15) >> 4;
+  const int32_t *ip = p.indices + begin + g;
+  const float *dp = p.data + begin + g;
+  float *pp = p.pred + begin + g;
+  int cs[NS];
+  float wt[NS][TS];  // weights of the dot that updates the prediction
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    cs[j] = FIRST ? 64 * j : (j == 0 ? c0 : c0 - 64);
+#pragma unroll
+    for (int t = 0; t < TS; t++)
+      wt[j][t] = FIRST ? xs[cs[j] + TS * m + t] : (j == 0 ? 0.f : -delta_prev[TS * m + t]);
+  }
+  bool dim_ok[TS];
+#pragma unroll
+  for (int t = 0; t < TS; t++) dim_ok[t] = TS * m + t < D;
+  int ia[4], ib[4];
+  float ca[4], cb[4], pa[4], pb[4];
+  float va[4][NS][TS], vb[4][NS][TS];
+  auto load_idx = [&](int it, int (&ix)[4], float (&cx)[4], float (&px)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ix[u] = ip[16 * it + 4 * u];
+      cx[u] = dp[16 * it + 4 * u];
+      px[u] = FIRST ? 0.f : pp[16 * it + 4 * u];
+    }
+  };
+  auto gather = [&](const int (&ix)[4], float (&v)[4][NS][TS]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float *row = p.other + static_cast<size_t>(static_cast<unsigned>(ix[u])) * p.KP + TS * m;
+#pragma unroll
+      for (int j = 0; j < NS; j++) load_dims<TS>(row + cs[j], v[u][j]);
+    }
+  };
+  auto consume = [&](int it, const float (&v)[4][NS][TS], const float (&cx)[4], const float (&px)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool valid = 16 * it + 4 * u + g < n;
+      float dot = 0.f;
+#pragma unroll
+      for (int j = FIRST ? 0 : 1; j < NS; j++)
+#pragma unroll
+        for (int t = 0; t < TS; t++) dot = fmaf(wt[j][t], v[u][j][t], dot);
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);
+      dot += __shfl_xor(dot, 4, 64);
+      dot += __shfl_xor(dot, 8, 64);
+      const float pred = FIRST ? dot : px[u] + dot;
+      if (store_pred && valid && m == 0) pp[16 * it + 4 * u] = pred;
+      const float c = valid ? cx[u] : 0.f;
+      const float w = valid ? c * (pred - 1.0f) - p.bias : 0.f;  // hpp:485-486
+      float cv[TS], vk[TS];
+#pragma unroll
+      for (int i = 0; i < TS; i++) {
+        vk[i] = dim_ok[i] ? v[u][0][i] : 0.f;
+        cv[i] = c * vk[i];
+        bsum[i] = fmaf(w, vk[i], bsum[i]);
+      }
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < TS; i++)
+#pragma unroll
+        for (int j = i; j < TS; j++) {  // lower form: slot (i, j) = tile (row block j, column block i)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[j], vk[i], acc[t], 0, 0, 0);
+          t++;
+        }
+    }
+  };
+  // two-deep pipeline of 16-entry groups, unconditional loads (padded arrays)
+  load_idx(0, ia, ca, pa);
+  gather(ia, va);
+  load_idx(1, ib, cb, pb);
+  for (int it = 0; it < nit; it += 2) {
+    gather(ib, vb);
+    consume(it, va, ca, pa);
+    load_idx(it + 2, ia, ca, pa);
+    gather(ia, va);
+    consume(it + 1, vb, cb, pb);  // an all-masked group when nit is odd
+    load_idx(it + 3, ib, cb, pb);
+  }
+#pragma unroll
+  for (int i = 0; i < TS; i++) {
+    bsum[i] += __shfl_xor(bsum[i], 16, 64);
+    bsum[i] += __shfl_xor(bsum[i], 32, 64);
+  }
+}
+
+// pred_q = x . v_q over entries [b, e) in the same coalesced layout (16 lanes per gathered row,
+// lane m reads floats 64 j + 4 m .. + 3 of it), two 16-entry groups in flight (hpp:387-421)
+__device__ __forceinline__ void pp_predict16(const PpParams &p, const float *xs, int begin, int end) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const int n = end - begin;
+  const int nit = (n + 7) >> 3;  // groups of 8 entries: 2 per 16-lane group (register budget)
+  const int nj = p.KP >> 6;  // 64-float segments of a row (KP is a multiple of 64 when K > 64)
+  const int32_t *ip = p.indices + begin + g;
+  float *pp = p.pred + begin + g;
+  f32x4 xw[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    xw[j] = j < nj ? *reinterpret_cast<const f32x4 *>(xs + 64 * j + 4 * m) : f32x4{0.f, 0.f, 0.f, 0.f};
+  int ia[2], ib[2];
+  f32x4 va[2][4], vb[2][4];
+  auto load_idx = [&](int it, int (&ix)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) ix[u] = ip[8 * it + 4 * u];
+  };
+  auto gather = [&](const int (&ix)[2], f32x4 (&v)[2][4]) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const float *row = p.other + static_cast<size_t>(static_cast<unsigned>(ix[u])) * p.KP + 4 * m;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        v[u][j] = *reinterpret_cast<const f32x4 *>(row + 64 * min(j, nj - 1));
+    }
+  };
+  auto consume = [&](int it, const f32x4 (&v)[2][4]) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {  // (segments past the row carry zero weights)
+        dot = fmaf(xw[j].x, v[u][j].x, dot);
+        dot = fmaf(xw[j].y, v[u][j].y, dot);
+        dot = fmaf(xw[j].z, v[u][j].z, dot);
+        dot = fmaf(xw[j].w, v[u][j].w, dot);
+      }
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);
+      dot += __shfl_xor(dot, 4, 64);
+      dot += __shfl_xor(dot, 8, 64);
+      if (m == 0 && 8 * it + 4 * u + g < n) pp[8 * it + 4 * u] = dot;
+    }
+  };
+  load_idx(0, ia);
+  gather(ia, va);
+  load_idx(1, ib);
+  for (int it = 0; it < nit; it += 2) {
+    gather(ib, vb);
+    consume(it, va);
+    load_idx(it + 2, ia);
+    gather(ia, va);
+    consume(it + 1, vb);
+    load_idx(it + 3, ib);
+  }
+}
+
 // pred_q = x . v_q over entries [b, e): lane per stored entry, x broadcast from LDS (hpp:387-421)
 __device__ __forceinline__ void pp_predict(const PpParams &p, const float *xs, int b, int e) {
   const int lane = threadIdx.x & 63;
+  // (the row is read sixteen floats x 4 loads at a time, all issued before the first FMA: a
+  // load per trip of a K / 4-trip loop is a chain of K / 4 exposed memory latencies - 48 us per
+  // 64 entries at K = 128; KP is a multiple of 16.  Same FMA order as a plain loop.)
   for (int q = b + lane; q < e; q += 64) {
     const float *v = p.other + static_cast<size_t>(static_cast<unsigned>(p.indices[q])) * p.KP;
     float s = 0.f;
-    for (int k = 0; k < p.KP; k += 4) {
-      const f32x4 t = *reinterpret_cast<const f32x4 *>(v + k);
-      const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + k);
-      s = fmaf(t.x, x4.x, s);
-      s = fmaf(t.y, x4.y, s);
-      s = fmaf(t.z, x4.z, s);
-      s = fmaf(t.w, x4.w, s);
+    for (int k = 0; k < p.KP; k += 32) {
+      f32x4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        t[j] = *reinterpret_cast<const f32x4 *>(v + min(k + 4 * j, p.KP - 4));
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (k + 4 * j < p.KP) {
+          const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + k + 4 * j);
+          s = fmaf(t[j].x, x4.x, s);
+          s = fmaf(t[j].y, x4.y, s);
+          s = fmaf(t[j].z, x4.z, s);
+          s = fmaf(t[j].w, x4.w, s);
+        }
+      }
     }
     p.pred[q] = s;
   }
@@ -203,8 +383,9 @@ __device__ __forceinline__ void pp_pred_update(const PpParams &p, const float *d
   }
 }
 
-// A <- P[blk, blk] in accumulator layout: tile (I, J) register r of lane (g, m) is element
-// (TS (4g + r) + I, TS m + J) of the block
+// A <- P[blk, blk] in accumulator layout, LOWER form (ials_chol16.hpp): slot (I, J), I <= J, is the
+// tile (row block J, column block I): register r of lane (g, m) is element
+// (TS (4g + r) + J, TS m + I) of the block
 template <int TS>
 __device__ __forceinline__ void pp_block_of_p(const PpParams &p, int c0, int D,
                                               f32x4 (&acc)[PpGeo<TS>::NT]) {
@@ -217,7 +398,7 @@ __device__ __forceinline__ void pp_block_of_p(const PpParams &p, int c0, int D,
     for (int J = I; J < TS; J++) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int rr = TS * (4 * g + r) + I, cc = TS * m + J;
+        const int rr = TS * (4 * g + r) + J, cc = TS * m + I;
         acc[t][r] = (rr < D && cc < D) ? p.P[(c0 + rr) * p.KP + c0 + cc] : 0.f;
       }
       t++;
@@ -236,6 +417,13 @@ __device__ __forceinline__ void pp_rhs_of_p(const PpParams &p, const float *xs, 
       float s4[4] = {0.f, 0.f, 0.f, 0.f};
       const float *col = p.P + c0 + lane;
       int k = 0;
+      for (; k + 16 <= p.K; k += 16) {  // sixteen loads in flight, same four chains
+        float c[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) c[q] = col[(k + q) * p.KP];
+#pragma unroll
+        for (int q = 0; q < 16; q++) s4[q & 3] = fmaf(c[q], xs[k + q], s4[q & 3]);
+      }
       for (; k + 4 <= p.K; k += 4) {
 #pragma unroll
         for (int q = 0; q < 4; q++) s4[q] = fmaf(col[(k + q) * p.KP], xs[k + q], s4[q]);
@@ -248,18 +436,79 @@ __device__ __forceinline__ void pp_rhs_of_p(const PpParams &p, const float *xs, 
   }
 }
 
+// ---- 64-dim blocks (chain path): P prepared once per half-step ----------------------------
+// p.P_blk holds, per block b, the 10 lower-form tiles of P[blk, blk] exactly as the
+// accumulators want them (64 lanes x f32x4 per tile, dims past K zero): a row starts a block
+// with 10 coalesced 1 KB loads instead of 40 strided scalar loads per lane.
+__global__ __launch_bounds__(64) void pp_pack_p_kernel(const float *__restrict__ P, int K, int KP,
+                                                       float *__restrict__ P_blk) {
+  constexpr int TS = 4;
+  const int b = blockIdx.x, c0 = 64 * b, D = min(64, K - c0);
+  const int lane = threadIdx.x, g = lane >> 4, m = lane & 15;
+  f32x4 *dst = reinterpret_cast<f32x4 *>(P_blk) + static_cast<size_t>(b) * 10 * 64;
+  int t = 0;
+  for (int I = 0; I < TS; I++)
+    for (int J = I; J < TS; J++) {
+      f32x4 v;
+      for (int r = 0; r < 4; r++) {
+        const int rr = TS * (4 * g + r) + J, cc = TS * m + I;
+        v[r] = (rr < D && cc < D) ? P[(c0 + rr) * KP + c0 + cc] : 0.f;
+      }
+      dst[t * 64 + lane] = v;
+      t++;
+    }
+}
+
+__device__ __forceinline__ void pp_block_of_p_packed(const PpParams &p, int c0, f32x4 (&acc)[10]) {
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(p.P_blk) + static_cast<size_t>(c0 >> 6) * 10 * 64 +
+                     (threadIdx.x & 63);
+#pragma unroll
+  for (int t = 0; t < 10; t++) acc[t] = src[t * 64];
+}
+
+// b4[i] (dim 4 m + i of the block, the layout of bsum) <- P[blk, :] x + reg x[blk]  (hpp:473-477).
+// Lane (g, m) reads P[k, c0 + 4 m .. + 3] for k = g, g + 4, ...: one 1 KB wave load covers four
+// rows of P, eight of them in flight.  The sums are those of pp_rhs_of_p bit for bit: chain g
+// adds the terms k = g (mod 4) in increasing k, the chains are combined as (s0 + s1) + (s2 + s3).
+__device__ __forceinline__ void pp_rhs_of_p16(const PpParams &p, const float *xs, float reg, int c0,
+                                              float (&b4)[4]) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  const float *col = p.P + c0 + 4 * m;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < p.KP; k0 += 32) {  // KP is a multiple of 64 here
+    f32x4 pv[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      pv[j] = *reinterpret_cast<const f32x4 *>(col + static_cast<size_t>(k0 + 4 * j + g) * p.KP);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const float xk = xs[k0 + 4 * j + g];
+      s[0] = fmaf(pv[j].x, xk, s[0]);
+      s[1] = fmaf(pv[j].y, xk, s[1]);
+      s[2] = fmaf(pv[j].z, xk, s[2]);
+      s[3] = fmaf(pv[j].w, xk, s[3]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    s[i] += __shfl_xor(s[i], 16, 64);
+    s[i] += __shfl_xor(s[i], 32, 64);
+    b4[i] = fmaf(reg, xs[c0 + 4 * m + i], s[i]);
+  }
+}
+
 // One wave per row, four independent rows per workgroup.
 template <int TS, bool ALIGNED>
 __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
   using G = PpGeo<TS>;
-  using C = CholGeo<TS>;
   extern __shared__ __attribute__((aligned(16))) float pp_lds[];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 15;
   const int w = blockIdx.x * 4 + wid;
   if (w >= p.n_rows) return;  // the kernel uses no workgroup barrier
   float *sm = pp_lds + wid * G::LDS_FLOATS;
-  float *xs = sm + C::LDS_FLOATS;
+  float *xs = sm + G::CHOL_FLOATS;
   float *bnat = xs + G::XS;
   float *delta = bnat + G::DP;
 
@@ -274,29 +523,73 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
   }
   __threadfence_block();
   const bool single = p.sub >= p.K;  // one block = the whole row: no prediction cache needed
-  if (!single) {
+  // 64-dim blocks of a longer row: the prediction passes ride in the rank-update passes
+  const bool chain = TS == 4 && ALIGNED && p.chain && p.sub == 64 && p.K > 64;
+  if (!single && !chain) {
+#ifndef IRS_PP_SKIP_PRED
     pp_predict(p, xs, begin, end);
     __threadfence();  // the cache is re-read through other lanes' addresses below
+#endif
+  }
+  if (chain) {
+    pp_predict16(p, xs, begin, end);
+    __threadfence_block();
   }
 
   for (int c0 = 0; c0 < p.K; c0 += p.sub) {
     const int D = min(p.sub, p.K - c0);
     f32x4 acc[G::NT];
-    pp_block_of_p<TS>(p, c0, D, acc);
-    pp_rhs_of_p<TS>(p, xs, reg, c0, D, bnat);
+#ifndef IRS_PP_SKIP_P
+    float bp[TS];  // chain: the P part of the rhs, already in the layout of bsum
+    if constexpr (TS == 4 && ALIGNED) {
+      if (chain) {
+        pp_block_of_p_packed(p, c0, acc);
+        pp_rhs_of_p16(p, xs, reg, c0, bp);
+      }
+    }
+    if (!chain) {
+      pp_block_of_p<TS>(p, c0, D, acc);
+      pp_rhs_of_p<TS>(p, xs, reg, c0, D, bnat);
+    }
+#else
+#pragma unroll
+    for (int t = 0; t < G::NT; t++) acc[t] = f32x4{1.f, 0.f, 0.f, 0.f};
+    if (lane < G::DP) bnat[lane] = 0.f;
+#endif
     float bsum[TS];
 #pragma unroll
     for (int i = 0; i < TS; i++) bsum[i] = 0.f;
+#ifndef IRS_PP_SKIP_RANK
+    bool chained = false;
+    if constexpr (TS == 4 && ALIGNED) {
+      if (chain && c0 > 0) {
+        pp_chain_pass(p, begin, end, c0, D, xs, delta, c0 + 64 < p.K, acc, bsum);
+        chained = true;
+      }
+    }
     if (single)
       pp_rank_update<TS, ALIGNED, true>(p, begin, end, c0, D, acc, bsum, xs);
-    else
+    else if (!chained)
       pp_rank_update<TS, ALIGNED>(p, begin, end, c0, D, acc, bsum);
+#endif
     __threadfence_block();
     float b4[TS];
 #pragma unroll
     for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bnat[TS * m + i];
+#ifndef IRS_PP_SKIP_P
+    if constexpr (TS == 4 && ALIGNED) {
+      if (chain) {
+#pragma unroll
+        for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bp[i];
+      }
+    }
+#endif
     // ---- delta = (A + reg I)^-1 B   (hpp:490-497)
-    solve_row_cholesky<TS>(acc, b4, reg, sm, delta, D, p.ignored_flag);
+#ifndef IRS_PP_SKIP_SOLVE
+    solve_row_cholesky16<TS>(acc, b4, reg, sm, delta, D, p.ignored_flag);
+#else
+    if (lane < G::DP) delta[lane] = b4[0] + acc[0][0];
+#endif
     __threadfence_block();
     if (lane < D) {  // hpp:498
       const float nx = xs[c0 + lane] - delta[lane];
@@ -306,9 +599,11 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
     __threadfence_block();
     // the cache is rebuilt at the start of every sweep (hpp:521-523): the correction after
     // the last block would never be read
-    if (c0 + p.sub < p.K) {
+    if (c0 + p.sub < p.K && !chain) {
+#ifndef IRS_PP_SKIP_PRED
       pp_pred_update<ALIGNED>(p, delta, c0, D, begin, end);
       __threadfence();
+#endif
     }
   }
 }
@@ -328,13 +623,12 @@ template <int TS> struct PpLongGeo {
 template <int TS, bool ALIGNED>
 __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParams p) {
   using G = PpGeo<TS>;
-  using C = CholGeo<TS>;
   using L = PpLongGeo<TS>;
   extern __shared__ __attribute__((aligned(16))) float pp_lds[];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = lane & 15;
   float *sm = pp_lds;
-  float *xs = sm + C::LDS_FLOATS;
+  float *xs = sm + G::CHOL_FLOATS;
   float *bnat = xs + G::XS;
   float *delta = bnat + G::DP;
   float *parts = delta + G::DP;
@@ -353,17 +647,29 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
   }
   __syncthreads();
   const bool single = p.sub >= p.K;  // see ialspp_kernel
-  if (!single) {
+  const bool chain = TS == 4 && ALIGNED && p.chain && p.sub == 64 && p.K > 64;
+  if (!single && !chain) {
     pp_predict(p, xs, wb, we);
     __threadfence();
     __syncthreads();
+  }
+  if (chain) {
+    pp_predict16(p, xs, wb, we);
+    __threadfence_block();
   }
 
   for (int c0 = 0; c0 < p.K; c0 += p.sub) {
     const int D = min(p.sub, p.K - c0);
     f32x4 acc[G::NT];
     if (wid == 0) {
-      pp_block_of_p<TS>(p, c0, D, acc);
+      bool packed = false;
+      if constexpr (TS == 4 && ALIGNED) {
+        if (chain) {
+          pp_block_of_p_packed(p, c0, acc);
+          packed = true;
+        }
+      }
+      if (!packed) pp_block_of_p<TS>(p, c0, D, acc);
       pp_rhs_of_p<TS>(p, xs, reg, c0, D, bnat);
     } else {
 #pragma unroll
@@ -372,9 +678,16 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
     float bsum[TS];
 #pragma unroll
     for (int i = 0; i < TS; i++) bsum[i] = 0.f;
+    bool chained = false;
+    if constexpr (TS == 4 && ALIGNED) {
+      if (chain && c0 > 0) {
+        pp_chain_pass(p, wb, we, c0, D, xs, delta, c0 + 64 < p.K, acc, bsum);
+        chained = true;
+      }
+    }
     if (single)
       pp_rank_update<TS, ALIGNED, true>(p, wb, we, c0, D, acc, bsum, xs);
-    else
+    else if (!chained)
       pp_rank_update<TS, ALIGNED>(p, wb, we, c0, D, acc, bsum);
     if (wid > 0) {
       float *dst = parts + (wid - 1) * L::PART;
@@ -399,7 +712,7 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
       float b4[TS];
 #pragma unroll
       for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bnat[TS * m + i];
-      solve_row_cholesky<TS>(acc, b4, reg, sm, delta, D, p.ignored_flag);
+      solve_row_cholesky16<TS>(acc, b4, reg, sm, delta, D, p.ignored_flag);
       __threadfence_block();
       if (lane < D) {  // hpp:498
         const float nx = xs[c0 + lane] - delta[lane];
@@ -408,7 +721,7 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
       }
     }
     __syncthreads();
-    if (c0 + p.sub < p.K) {  // see ialspp_kernel: the last correction is never read
+    if (c0 + p.sub < p.K && !chain) {  // see ialspp_kernel: the last correction is never read
       pp_pred_update<ALIGNED>(p, delta, c0, D, wb, we);
       __threadfence();
       __syncthreads();

@@ -37,7 +37,10 @@ def solvers(sub, iters):
 
 @pytest.mark.parametrize("K,sub", [(4, 1), (4, 3), (16, 16), (16, 5), (20, 8), (32, 32), (48, 16),
                                    (64, 64), (64, 16), (64, 24), (64, 33), (40, 64), (128, 64),
-                                   (130, 32)])
+                                   (130, 32),
+                                   # 64-dim blocks of longer rows: the chained passes (2, 3 and 4
+                                   # blocks, a 2-dim and a 36-dim last block)
+                                   (130, 64), (192, 64), (228, 64), (256, 64)])
 @pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
 @pytest.mark.parametrize("direct", ["1", "0"])
 def test_epoch_matches_oracle(K, sub, loss, direct, monkeypatch):
@@ -128,3 +131,25 @@ def test_rows_above_the_workgroup_threshold(K, sub):
     o.step(osc)
     assert rel_err(t.user, o.user) < RTOL
     assert rel_err(t.item, o.item) < 10 * RTOL
+
+
+@pytest.mark.parametrize("K", [128, 200])
+def test_chained_passes_match_the_three_pass_form(K, monkeypatch):
+    """64-dim blocks: the merged passes (coalesced prediction pass, cache correction inside the
+    next block's rank update, packed P blocks; ``IRSPACK_AMD_IALSPP_CHAIN``) against the plain
+    three-pass form of the same kernel, rows above the workgroup threshold included."""
+    rng = np.random.default_rng(5)
+    X = random_csr(300, 260, 0.08, 11, empty_rows=(3,))
+    X = sps.vstack([X, sps.csr_matrix((rng.random((2, 260)) < 0.95).astype(np.float32))]).tocsr()
+    Xl = sps.hstack([X, sps.csr_matrix((rng.random((302, 2400)) < 0.9).astype(np.float32))]).tocsr()
+    mc, _ = build(K)
+    sc, _ = solvers(64, 2)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("IRSPACK_AMD_IALSPP_CHAIN", flag)
+        t = IALSTrainer(mc, Xl)
+        for _ in range(2):
+            t.step(sc)
+        out[flag] = (t.user, t.item)
+    assert rel_err(out["1"][0], out["0"][0]) < RTOL
+    assert rel_err(out["1"][1], out["0"][1]) < RTOL
