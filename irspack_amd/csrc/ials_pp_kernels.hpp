@@ -251,17 +251,31 @@ __device__ __forceinline__ void pp_chain_pass(const PpParams &p, int begin, int 
         }
     }
   };
-  // two-deep pipeline of 16-entry groups, unconditional loads (padded arrays)
+  // two-deep pipeline of 16-entry groups, unconditional loads (padded arrays).  The (index,
+  // confidence, prediction) triple of a group is requested one whole consume() before its
+  // gather needs the index; the gather takes a copy of the two values so that the triple's
+  // registers can be refilled at once.
+  float xa[4], xb[4], qa[4], qb[4];
+  auto keep = [&](const float (&cx)[4], const float (&px)[4], float (&xc)[4], float (&qc)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      xc[u] = cx[u];
+      qc[u] = px[u];
+    }
+  };
   load_idx(0, ia, ca, pa);
   gather(ia, va);
-  load_idx(1, ib, cb, pb);
+  keep(ca, pa, xa, qa);
+  load_idx(1, ia, ca, pa);
   for (int it = 0; it < nit; it += 2) {
-    gather(ib, vb);
-    consume(it, va, ca, pa);
-    load_idx(it + 2, ia, ca, pa);
-    gather(ia, va);
-    consume(it + 1, vb, cb, pb);  // an all-masked group when nit is odd
-    load_idx(it + 3, ib, cb, pb);
+    load_idx(it + 2, ib, cb, pb);
+    gather(ia, vb);
+    keep(ca, pa, xb, qb);
+    consume(it, va, xa, qa);
+    load_idx(it + 3, ia, ca, pa);
+    gather(ib, va);
+    keep(cb, pb, xa, qa);
+    consume(it + 1, vb, xb, qb);  // an all-masked group when nit is odd
   }
 #pragma unroll
   for (int i = 0; i < TS; i++) {
@@ -319,14 +333,14 @@ __device__ __forceinline__ void pp_predict16(const PpParams &p, const float *xs,
   };
   load_idx(0, ia);
   gather(ia, va);
-  load_idx(1, ib);
-  for (int it = 0; it < nit; it += 2) {
-    gather(ib, vb);
+  load_idx(1, ia);
+  for (int it = 0; it < nit; it += 2) {  // indices one consume() ahead of their gather
+    load_idx(it + 2, ib);
+    gather(ia, vb);
     consume(it, va);
-    load_idx(it + 2, ia);
-    gather(ia, va);
+    load_idx(it + 3, ia);
+    gather(ib, va);
     consume(it + 1, vb);
-    load_idx(it + 3, ib);
   }
 }
 

@@ -17,3 +17,6 @@ ls gpurun_out/prof | head -40
 # fused iALS evaluator (quick_eval_fused.py: 4 calls over all users at K = 64 and K = 256)
 bash scripts/prof_eval_fused.sh > gpurun_out/prof/ef.log 2>&1
 ls gpurun_out/prof | head -40
+# iALS++ with 64-dim blocks at K = 128 (chained passes)
+rm -rf gpurun_out/prof/pp_kt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/pp_kt -- python3 scripts/quick_ials.py --shape ml20m --K 128 --solvers IALSPP --epochs 3 > gpurun_out/prof/pp_kt.log 2>&1
