@@ -201,6 +201,29 @@ def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
     }
 
 
+def ialspp_leg(trainer, X, K, steps, warmup):
+    """iALS++ (the reference's subspace solver, hpp:387-630) with its default 64-dim blocks,
+    one sweep per half-step.  Algorithmic flops of a half-step: per block the 64 x 64 system
+    (nnz * 64 * 65 + R * (64^3 / 3 + 2 * 64^2)) plus the prediction work (nnz * 2 K once, nnz * 2 * 64
+    per later block)."""
+    from irspack_amd.recommenders._ials_core import IALSSolverConfigBuilder, SolverType
+
+    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType.IALSPP)
+          .set_ialspp_subspace_dimension(64).set_ialspp_iteration(1).build())
+    dt, kernels = time_epochs(trainer, sc, steps, warmup)
+    U, I = X.shape
+    nb = -(-K // 64)
+    flops = 0.0
+    for R in (U, I):
+        flops += nb * (X.nnz * 64.0 * 65.0 + R * (64.0 ** 3 / 3 + 2 * 64.0 ** 2))
+        flops += X.nnz * 2.0 * K + (nb - 1) * X.nnz * 2.0 * 64
+    return {"solver": "IALSPP subspace=64 iteration=1", "ms_per_epoch": dt * 1e3,
+            "updates_per_s": (U + I) / dt, "steps": steps, "warmup": warmup,
+            "kernels_ms_per_launch": kernels,
+            "f32_tflops": flops / dt / 1e12, "frac_f32": flops / dt / 1e12 / PEAK_F32_TFLOPS,
+            "algorithmic_gflop_per_epoch": flops / 1e9}
+
+
 def bf16x3_leg(X, K, steps, ceilings):
     """NOT the headline path: the same Cholesky epoch with the opt-in rank update on the bf16
     matrix cores (IRSPACK_AMD_IALS_BF16X3=1: every fp32 factor value split exactly into three
@@ -351,6 +374,7 @@ def k256_leg(X, ceilings):
            "create_s": time.perf_counter() - t0}
     out["cholesky"] = ials_leg(tr, X, K, "CHOLESKY", 3, 1, ceilings)
     out["cg"] = ials_leg(tr, X, K, "CG", 5, 1, ceilings)
+    out["ialspp"] = ialspp_leg(tr, X, K, 3, 1)
     out["evaluator"] = evaluator_leg(X, tr, K, ceilings)
     return out
 
