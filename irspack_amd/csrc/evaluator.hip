@@ -642,6 +642,24 @@ __global__ __launch_bounds__(256) void rank_cand_kernel(EvalParams p, EmitParams
   const float NEG_INF = -std::numeric_limits<float>::infinity();
   const float *cs = f.cand_score + static_cast<size_t>(row) * EM_CAP;
   const int32_t *ci = f.cand_item + static_cast<size_t>(row) * EM_CAP;
+  if (n <= 64) {
+    // The usual case after pruning (a few dozen candidates): one candidate per lane, its rank
+    // = the number of candidates that go before it (score desc, index asc: a strict order, so
+    // the ranks are a permutation), counted against every candidate by v_readlane; the item
+    // of rank r is then pushed to lane r.
+    const float s = ln < n ? cs[ln] : NEG_INF;
+    const int32_t i = ln < n ? ci[ln] : 0x7fffffff;
+    int rank = 0;
+    for (int k = 0; k < n; k++) {  // n is wave-uniform
+      const float sk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), k));
+      const int32_t ik = __builtin_amdgcn_readlane(i, k);
+      rank += (sk > s || (sk == s && ik < i)) ? 1 : 0;
+    }
+    if (ln >= n) rank = ln;  // lanes without a candidate keep to themselves
+    const int32_t mi = __builtin_amdgcn_ds_permute(rank << 2, i);
+    wave_metrics_tail(p, row, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
+    return;
+  }
   float bs[M];
   int32_t bi[M];
 #pragma unroll
@@ -942,19 +960,35 @@ __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
   wave_metrics_tail(p, orow, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
 }
 
+// First level of the sum for large calls: workgroup b folds the rows [b * chunk, (b + 1) * chunk)
+// into one RowOut-like partial with the SAME code as reduce_rows_kernel, so that the second
+// level (reduce over the partials) keeps a fixed order.  See reduce_rows_kernel.
+struct RowPartial {
+  long long valid;
+  double hit, recall, ndcg, precision, map;
+};
+
 // Sum of the per-user terms of one call (one 1024-thread workgroup) in a fixed order, so the
 // fp64 result is reproducible run to run; it is not the strict user order of a
 // single-threaded reference run (the reference's own order depends on n_threads,
 // evaluator.cpp:280-312).
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const RowOut *rows, int64_t n,
-                                                           irs_metrics *out) {
+                                                           irs_metrics *out,
+                                                           RowPartial *partials = nullptr,
+                                                           int64_t chunk = 0) {
   // thread t adds rows t, t + 1024, ... in that order; the 64 lanes of a wave fold by a fixed
-  // butterfly and wave 0 adds the 16 wave sums in wave order
+  // butterfly and wave 0 adds the 16 wave sums in wave order.  With `partials` workgroup b does
+  // that for its chunk of rows only and leaves the sums there (reduce_partials_kernel adds the
+  // chunks in order): one workgroup walking 138 k rows alone took 0.11 ms.
   __shared__ double part[16][5];
   __shared__ long long part_valid[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   long long valid = 0;
   double hit = 0, recall = 0, ndcg = 0, precision = 0, map = 0;
+  if (partials) {
+    rows += static_cast<int64_t>(blockIdx.x) * chunk;
+    n = min(chunk, n - static_cast<int64_t>(blockIdx.x) * chunk);
+  }
   for (int64_t i = tid; i < n; i += 1024) {
     const RowOut r = rows[i];
     if (r.valid) {
@@ -991,6 +1025,10 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const RowOut *rows, i
       v += part_valid[w];
       for (int c = 0; c < 5; c++) acc[c] += part[w][c];
     }
+    if (partials) {
+      partials[blockIdx.x] = RowPartial{v, acc[0], acc[1], acc[2], acc[3], acc[4]};
+      return;
+    }
     out->valid_user += v;
     out->total_user += n;
     out->hit += acc[0];
@@ -999,6 +1037,27 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const RowOut *rows, i
     out->precision += acc[3];
     out->map += acc[4];
   }
+}
+
+__global__ void reduce_partials_kernel(const RowPartial *partials, int nb, int64_t n, irs_metrics *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long v = 0;
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < nb; b++) {  // chunk order
+    v += partials[b].valid;
+    acc[0] += partials[b].hit;
+    acc[1] += partials[b].recall;
+    acc[2] += partials[b].ndcg;
+    acc[3] += partials[b].precision;
+    acc[4] += partials[b].map;
+  }
+  out->valid_user += v;
+  out->total_user += n;
+  out->hit += acc[0];
+  out->recall += acc[1];
+  out->ndcg += acc[2];
+  out->precision += acc[3];
+  out->map += acc[4];
 }
 
 // item_cnt[i] += how often item i stands in the recommended lists of a call (Metrics::update,
@@ -1099,6 +1158,7 @@ struct irs_evaluator {
   DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_ut, wg_prefix;
   DeviceBuffer<char> sort_tmp;
   DeviceBuffer<unsigned long long> tiles_scored;
+  DeviceBuffer<RowPartial> row_partials;  // chunk sums of the two-level reduction
   DeviceBuffer<int32_t> mask_row;         // row of every mask entry (built with the bitmap)
   std::vector<int64_t> mask_ptr_host;     // host copy of the mask's row pointers
   irs_eval_stats stats{};  // of the last irs_eval_get_metrics_ials call
@@ -1634,8 +1694,18 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
     IRS_HIP(hipGetLastError());
   }
   launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
-                     e->metrics.ptr);
+  if (rows >= 32768) {  // two levels: 4096-row chunks, then the chunks in order
+    const int64_t chunk = 4096;
+    const int nb = static_cast<int>(ceil_div(rows, chunk));
+    e->row_partials.alloc(nb);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(nb), dim3(1024), 0, s, e->row_out.ptr, rows,
+                       e->metrics.ptr, e->row_partials.ptr, chunk);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, s, e->row_partials.ptr, nb, rows,
+                       e->metrics.ptr);
+  } else {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
+                       e->metrics.ptr, static_cast<RowPartial *>(nullptr), int64_t(0));
+  }
   IRS_HIP(hipGetLastError());
   return true;
 }
