@@ -330,3 +330,64 @@ def test_ials_k64_bf16x3_rank_update_is_fp32_accurate(X20, X20t, monkeypatch):
         e16 = np.linalg.norm(got16[sub] - ref, axis=1) / nref
         assert e16.max() < 2 * e32.max() + 1e-6, (side, float(e16.max()), float(e32.max()))
         assert np.median(e16) < 2 * np.median(e32) + 1e-7, (side, float(np.median(e16)), float(np.median(e32)))
+
+
+def ialspp_float64(Xs, rows, tgt0, oth0, sub, alpha0=ALPHA0, reg=REG):
+    """One iALS++ sweep (hpp:423-514) in float64 for a few rows: unit confidences, loss IALSPP
+    (observation bias 0).  With one block it is the exact solve."""
+    K = oth0.shape[1]
+    O64 = oth0.astype(np.float64)
+    P = alpha0 * O64.T @ O64
+    out = np.empty((len(rows), K))
+    for j, r in enumerate(rows):
+        sl = slice(Xs.indptr[r], Xs.indptr[r + 1])
+        V = O64[Xs.indices[sl]]
+        reg_r = float(np.float32(reg) * (np.float32(alpha0) * np.float32(Xs.shape[1]) + np.float32(sl.stop - sl.start)))
+        x = tgt0[r].astype(np.float64).copy()
+        pred = V @ x
+        for c0 in range(0, K, sub):
+            b = slice(c0, min(c0 + sub, K))
+            Vb = V[:, b]
+            A = P[b, b] + Vb.T @ Vb + reg_r * np.eye(b.stop - b.start)
+            B = P[b, :] @ x + reg_r * x[b] + Vb.T @ (pred - 1.0)
+            d = np.linalg.solve(A, B)
+            x[b] -= d
+            pred -= Vb @ d
+        out[j] = x
+    return out
+
+
+@pytest.mark.parametrize("K,direct", [(64, "1"), (64, "0"), (128, "1")])
+def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
+    """iALS++ with the default 64-dim blocks at benchmark size: K = 64 is one block (computed as
+    the direct solve, and with IRSPACK_AMD_IALSPP_DIRECT=0 by the block kernel), K = 128 two
+    blocks (coalesced prediction pass + chained cache correction, rows above 2048 entries on the
+    workgroup kernel).  One half-step per side from identical factors; rows farther than RTOL
+    from the oracle are arbitrated by the float64 sweep."""
+    monkeypatch.setenv("IRSPACK_AMD_IALSPP_DIRECT", direct)
+    mc, _, omc, _ = configs(K, "CHOLESKY")
+    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType.IALSPP)
+          .set_ialspp_subspace_dimension(64).set_ialspp_iteration(1).build())
+    osc = O.solver_config(CORES, "IALSPP", 3, ialspp_subspace_dimension=64, ialspp_iteration=1)
+    t = IALSTrainer(mc, X20)
+    t.step(sc)
+    user0, item0 = t.user, t.item
+    for side, (Xs, tgt0, oth0) in enumerate(((X20, user0, item0), (X20t, item0, user0))):
+        t.user, t.item = user0, item0
+        half_step(t, side, sc)
+        got = t.user if side == 0 else t.item
+        rows, _ = row_sample(Xs, 1500, seed=10 + side)
+        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+        num = np.linalg.norm(got[rows].astype(np.float64) - want, axis=1)
+        den = np.linalg.norm(want.astype(np.float64), axis=1)
+        err = num / np.maximum(den, 1e-6 * den.max())
+        far = np.flatnonzero(~(err < RTOL))
+        assert far.size <= 0.05 * len(rows), (K, side, far.size, float(err.max()))
+        if far.size:
+            ref = ialspp_float64(Xs, rows[far], tgt0, oth0, 64)
+            nref = np.linalg.norm(ref, axis=1)
+            e_gpu = np.linalg.norm(got[rows][far] - ref, axis=1) / nref
+            e_orc = np.linalg.norm(want[far] - ref, axis=1) / nref
+            assert np.all(e_gpu <= np.maximum(2 * e_orc, RTOL)), (K, side, float(e_gpu.max()), float(e_orc.max()))
+            assert e_gpu.max() < 3 * RTOL, (K, side, float(e_gpu.max()))
+        assert np.isfinite(got).all()
