@@ -392,3 +392,34 @@ def test_norm_bound_pruning_keeps_the_lists(K, monkeypatch):
     monkeypatch.setenv("IRSPACK_AMD_EVAL_SAMPLE", "64")
     part = core.get_metrics_ials(t, 3, 1203, sps.csr_matrix(mask[3:1203]), cutoff, 3, True)
     compare(part, ocore.get_metrics_f32(scores[3:1203], cutoff, 3, 4, True))
+
+
+@pytest.mark.parametrize("rows", [1, 5, 64, 65, 130])
+def test_bounded_path_on_a_handful_of_users(rows):
+    """User blocks smaller than, equal to and just above one 64-user tile (the second-chance
+    buffer, the work list and the sorts are all sized by the block)."""
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, IALSTrainer)
+
+    rng2 = np.random.default_rng(rows)
+    U, I, K, cutoff = 200, 8300, 32, 10
+    mc = IALSModelConfigBuilder().set_K(K).build()
+    sc = IALSSolverConfigBuilder().build()
+    t = IALSTrainer(mc, sps.csr_matrix((U, I), dtype=np.float32))
+    scale = ((1.0 + np.arange(I)) ** -0.5).astype(np.float32)
+    t.user = rng2.standard_normal((U, K)).astype(np.float32)
+    t.item = rng2.standard_normal((I, K)).astype(np.float32) * scale[:, None]
+    mask = sps.random(U, I, density=0.02, format="csr", random_state=rng2, dtype=np.float32)
+    mask.data[:] = 1.0
+    gt = sps.random(U, I, density=0.004, format="csr", random_state=rng2, dtype=np.float64)
+    gt.data[:] = 1.0
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    b = 17
+    m = core.get_metrics_ials(t, b, b + rows, sps.csr_matrix(mask[b:b + rows]), cutoff, b, False)
+    assert core.last_call_stats()["path"] == "emit_bounded"
+    scores = t.user_scores(b, b + rows, sc)
+    scores[mask[b:b + rows].nonzero()] = -np.inf
+    compare(m, ocore.get_metrics_f32(scores, cutoff, b, 4, False))
+    # no mask at all
+    m2 = core.get_metrics_ials(t, b, b + rows, None, cutoff, b, True)
+    compare(m2, ocore.get_metrics_f32(t.user_scores(b, b + rows, sc), cutoff, b, 4, True))
