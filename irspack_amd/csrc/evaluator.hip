@@ -1274,7 +1274,7 @@ bool fused_enabled() {
 // when the call is outside its domain (candidate lists, cutoff > 32, a bitmap that would not
 // fit, a non-finite score met on the way): the caller then runs the two-pass path.
 bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int64_t *d_mptr,
-                        const int32_t *d_midx, hipStream_t s);
+                        const int32_t *d_midx, hipStream_t s, bool cacheable = true);
 
 bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t rows,
                        const int64_t *d_mptr, const int32_t *d_midx, int64_t cutoff,
@@ -1401,9 +1401,9 @@ bool bound_enabled() {
 
 // Builds (or reuses) the bitmap + per-row count of the mask CSR; false when it would not fit.
 bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int64_t *d_mptr,
-                        const int32_t *d_midx, hipStream_t s) {
+                        const int32_t *d_midx, hipStream_t s, bool cacheable) {
   if (static_cast<double>(rows) * words * 8.0 > 2147483648.0) return false;
-  const bool cached = d_mptr == e->mask_ptr.ptr && e->mask_bits_rows == rows;
+  const bool cached = cacheable && d_mptr == e->mask_ptr.ptr && e->mask_bits_rows == rows;
   if (!cached) {
     e->mask_bits.alloc(static_cast<size_t>(rows) * words);
     e->mask_count.alloc(rows);
@@ -1420,7 +1420,8 @@ bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int
     e->mask_row.alloc(static_cast<size_t>(std::max<int64_t>(e->mask_ptr_host[rows], 1)));
     hipLaunchKernelGGL(mask_row_ids_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, d_mptr, rows,
                        e->mask_row.ptr);
-    e->mask_bits_rows = d_mptr == e->mask_ptr.ptr ? rows : -1;  // only the resident mask is cached
+    // only the resident mask, covered by ONE pass, is cached
+    e->mask_bits_rows = (cacheable && d_mptr == e->mask_ptr.ptr) ? rows : -1;
   }
   return true;
 }
@@ -1428,9 +1429,12 @@ bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int
 // The threshold-filtered path of irs_eval_get_metrics_ials (eval_fused_kernels.hpp, second
 // half).  Returns false when the call is outside its domain or had to be abandoned; the caller
 // then runs the two-pass path.
-bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t rows,
-               const int64_t *d_mptr, const int32_t *d_midx, int64_t cutoff, int64_t offset,
-               bool rwc, hipStream_t s) {
+// One pass of the path over the users [begin, begin + rows): `first` = the first pass of a call
+// (it prepares the item side: norms, order, sample rows), `single` = the only one (the mask
+// bitmap of a resident mask may then be kept for the next call).
+bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t rows,
+                const int64_t *d_mptr, const int32_t *d_midx, int64_t cutoff, int64_t offset,
+                bool rwc, hipStream_t s, bool first, bool single) {
   if (!emit_enabled() || e->rec_mode != 0 || cutoff > FZ_MAX_CUTOFF || rows <= 0) return false;
   const float *user = nullptr, *item = nullptr;
   int32_t KP = 0, dev = 0;
@@ -1455,7 +1459,7 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
   const uint64_t *bits = nullptr;
   const int32_t *n_masked = nullptr;
   if (d_mptr) {
-    if (!ensure_mask_bitmap(e, rows, words, d_mptr, d_midx, s)) return false;
+    if (!ensure_mask_bitmap(e, rows, words, d_mptr, d_midx, s, single)) return false;
     bits = e->mask_bits.ptr;
     n_masked = e->mask_count.ptr;
   }
@@ -1470,7 +1474,12 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
   // ---- 0. bounded variant: items in order of decreasing norm (the sample is then the items
   //         of largest norm, which hold most of every user's final list)
   const float norm_c = 1.0f + (KP + 16) * 2.5e-7f;
-  if (bounded) {
+  if (bounded && !first) {  // (the item side is ready; iota must still cover this pass's rows)
+    e->iota.alloc(std::max(ni, rows));
+    hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(std::max(ni, rows), 256)), dim3(256), 0, s,
+                       e->iota.ptr, std::max(ni, rows));
+  }
+  if (bounded && first) {
     e->iota.alloc(std::max(ni, rows));
     hipLaunchKernelGGL(iota_kernel, dim3(ceil_div(std::max(ni, rows), 256)), dim3(256), 0, s,
                        e->iota.ptr, std::max(ni, rows));
@@ -1654,11 +1663,14 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
   IRS_HIP(hipMemcpyAsync(bad, e->bad_flag.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
   IRS_HIP(hipMemcpyAsync(&tiles_scored, e->tiles_scored.ptr, sizeof(tiles_scored), hipMemcpyDeviceToHost, s));
   IRS_HIP(hipStreamSynchronize(s));
-  e->stats.path = bounded ? 2 : 1;
-  e->stats.hard_rows = bad[1];
-  e->stats.tiles_total = ceil_div(rows, 64) * ceil_div(ni, 64);
-  e->stats.tiles_scored = bounded ? static_cast<int64_t>(tiles_scored) : e->stats.tiles_total;
-  e->stats.sample_items = n_sample;
+  {
+    const int64_t total = ceil_div(rows, 64) * ceil_div(ni, 64);
+    const int64_t scored = bounded ? static_cast<int64_t>(tiles_scored) : total;
+    if (first) e->stats = irs_eval_stats{bounded ? 2 : 1, 0, 0, 0, n_sample};
+    e->stats.hard_rows += bad[1];
+    e->stats.tiles_total += total;
+    e->stats.tiles_scored += scored;
+  }
   static const bool debug = std::getenv("IRSPACK_AMD_EVAL_DEBUG") != nullptr;
   if (debug)
     fprintf(stderr, "eval emit: flags %d, hard rows %d (after the first sample %d) of %lld, tiles scored %.4f\n",
@@ -1707,6 +1719,32 @@ bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t row
                        e->metrics.ptr, static_cast<RowPartial *>(nullptr), int64_t(0));
   }
   IRS_HIP(hipGetLastError());
+  return true;
+}
+
+
+// The threshold-filtered path over all users of a call, in passes that keep the scratch bounded:
+// the candidate lists take 8 KB per user and the mask bitmap n_items / 8 bytes per user (at most
+// 2 GiB per pass), so a call over millions of users or a catalogue of a million items runs as
+// several passes (IRSPACK_AMD_EVAL_PASS_ROWS overrides the pass size).  False: outside the
+// path's domain or abandoned - the caller resets the sums and runs the two-pass path.
+bool emit_path(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t rows,
+               const int64_t *d_mptr, const int32_t *d_midx, int64_t cutoff, int64_t offset,
+               bool rwc, hipStream_t s) {
+  if (rows <= 0) return false;
+  const char *env_v = std::getenv("IRSPACK_AMD_EVAL_PASS_ROWS");
+  const int64_t env_rows = env_v ? std::max<int64_t>(64, std::atoll(env_v) / 64 * 64) : int64_t(0);
+  const int64_t words = ceil_div(std::max<int64_t>(e->n_items, 1), 64);
+  int64_t pass = std::min<int64_t>(524288, (int64_t(1) << 31) / (words * 8) / 64 * 64);
+  if (env_rows) pass = std::min(pass, env_rows);
+  if (pass < 64) return false;
+  if (rows <= pass) return emit_block(e, t, begin, rows, d_mptr, d_midx, cutoff, offset, rwc, s, true, true);
+  for (int64_t b = 0; b < rows; b += pass) {
+    const int64_t m = std::min(pass, rows - b);
+    if (!emit_block(e, t, begin + b, m, d_mptr ? d_mptr + b : nullptr, d_midx, cutoff, offset + b, rwc,
+                    s, b == 0, false))
+      return false;
+  }
   return true;
 }
 

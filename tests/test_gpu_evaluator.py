@@ -387,6 +387,19 @@ def test_norm_bound_pruning_keeps_the_lists(K, monkeypatch):
     assert core.last_call_stats()["path"] == "emit"
     compare(b, want)
     np.testing.assert_array_equal(a.item_cnt, b.item_cnt)
+    # the same call in passes of 256 users (what a call over millions of users, or a catalogue
+    # of a million items, does to keep its scratch bounded)
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_BOUND", "1")
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_PASS_ROWS", "256")
+    c = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)
+    stc = core.last_call_stats()
+    assert stc["path"] == "emit_bounded" and stc["tiles_total"] == st["tiles_total"], stc
+    assert stc["hard_rows"] == st["hard_rows"]
+    compare(c, want)
+    np.testing.assert_array_equal(a.item_cnt, c.item_cnt)
+    monkeypatch.delenv("IRSPACK_AMD_EVAL_PASS_ROWS")
+    again = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)  # the bitmap cache is rebuilt
+    np.testing.assert_array_equal(a.item_cnt, again.item_cnt)
     # a sub-block with an offset, and the tiny first sample (more second chances)
     monkeypatch.setenv("IRSPACK_AMD_EVAL_BOUND", "1")
     monkeypatch.setenv("IRSPACK_AMD_EVAL_SAMPLE", "64")
