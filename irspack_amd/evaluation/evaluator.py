@@ -135,7 +135,12 @@ class Evaluator:
             elif block_start == 0 and block_end == model.X_train_all.shape[0]:
                 mask = model.X_train_all  # the whole matrix: no copy, and the device copy is reused
             else:
-                mask = model.X_train_all[block_start:block_end]
+                # the slice is kept: a new object per call would re-upload the mask every time
+                key = (id(model.X_train_all), block_start, block_end)
+                if getattr(self, "_mask_slice_key", None) != key:
+                    self._mask_slice_key = key
+                    self._mask_slice = (model.X_train_all, model.X_train_all[block_start:block_end])
+                mask = self._mask_slice[1]
             for i, c in enumerate(cutoffs):
                 metrics[i].merge(self.core.get_metrics_ials(trainer, block_start, block_end, mask, c,
                                                             0, self.recall_with_cutoff))
