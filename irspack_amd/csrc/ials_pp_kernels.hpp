@@ -512,9 +512,11 @@ __device__ __forceinline__ void pp_rhs_of_p16(const PpParams &p, const float *xs
   }
 }
 
-// One wave per row, four independent rows per workgroup.
+// One wave per row, four independent rows per workgroup.  (launch bound: without it the compiler
+// takes 256 VGPRs + 96 AGPRs, i.e. ONE wave per SIMD and every latency exposed - K = 128
+// epoch 15.0 ms; two waves per SIMD: 12.3 ms; forcing three spills 600 bytes per lane: 15.6 ms.)
 template <int TS, bool ALIGNED>
-__global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
+__global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
   using G = PpGeo<TS>;
   extern __shared__ __attribute__((aligned(16))) float pp_lds[];
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -546,7 +548,9 @@ __global__ __launch_bounds__(256) void ialspp_kernel(PpParams p) {
 #endif
   }
   if (chain) {
+#ifndef IRS_PP_SKIP_PRED
     pp_predict16(p, xs, begin, end);
+#endif
     __threadfence_block();
   }
 
