@@ -129,6 +129,10 @@ static HostCsr transpose_cols(int64_t rows, int64_t cols, const int64_t *indptr,
 }
 
 // X.transpose() as compressed row-major (hpp:713)
+// A counting sort by column on several host threads: thread k counts the columns of its row
+// range, a prefix over (column, thread) gives every thread its first slot in every column, and
+// the threads scatter their rows - the entries of a column stay in row order, so the result is
+// the sequential one (it was 120 ms of the 270 ms trainer construction on the ML-20M shape).
 static HostCsr transpose(const HostCsr &x) {
   HostCsr t;
   t.rows = x.cols;
@@ -137,15 +141,45 @@ static HostCsr transpose(const HostCsr &x) {
   const int64_t nnz = x.indptr[x.rows];
   t.indices.resize(nnz);
   t.data.resize(nnz);
-  for (int64_t p = 0; p < nnz; p++) t.indptr[x.indices[p] + 1]++;
-  for (int64_t c = 0; c < t.rows; c++) t.indptr[c + 1] += t.indptr[c];
-  std::vector<int64_t> cur(t.indptr.begin(), t.indptr.end() - 1);
-  for (int64_t r = 0; r < x.rows; r++)
-    for (int64_t p = x.indptr[r]; p < x.indptr[r + 1]; p++) {
-      const int64_t d = cur[x.indices[p]]++;
-      t.indices[d] = static_cast<int32_t>(r);
-      t.data[d] = x.data[p];
+  const int64_t cols = x.cols;
+  // threads: bounded by the counter memory (cols x threads x 8 B <= 256 MB) and the work
+  int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                            nnz / 500000 + 1, (int64_t(1) << 25) / std::max<int64_t>(cols, 1)})));
+  std::vector<int64_t> rb(n_thr + 1, x.rows);
+  for (int k = 0; k < n_thr; k++)  // row ranges of about equal entry counts
+    rb[k] = std::lower_bound(x.indptr.begin(), x.indptr.begin() + x.rows, nnz * k / n_thr) - x.indptr.begin();
+  rb[0] = 0;
+  std::vector<std::vector<int64_t>> cnt(n_thr);
+  auto run = [&](auto &&body) {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &q : th) q.join();
+  };
+  run([&](int k) {
+    cnt[k].assign(cols, 0);
+    for (int64_t p = x.indptr[rb[k]]; p < x.indptr[rb[k + 1]]; p++) cnt[k][x.indices[p]]++;
+  });
+  int64_t run_sum = 0;
+  for (int64_t c = 0; c < cols; c++) {  // slot of (column c, thread k) = prefix in that order
+    t.indptr[c] = run_sum;
+    for (int k = 0; k < n_thr; k++) {
+      const int64_t n = cnt[k][c];
+      cnt[k][c] = run_sum;
+      run_sum += n;
     }
+  }
+  t.indptr[cols] = run_sum;
+  run([&](int k) {
+    std::vector<int64_t> &cur = cnt[k];
+    for (int64_t r = rb[k]; r < rb[k + 1]; r++)
+      for (int64_t p = x.indptr[r]; p < x.indptr[r + 1]; p++) {
+        const int64_t d = cur[x.indices[p]]++;
+        t.indices[d] = static_cast<int32_t>(r);
+        t.data[d] = x.data[p];
+      }
+  });
   return t;
 }
 
