@@ -243,9 +243,16 @@ struct Side {
         tk.push_back(Task{static_cast<int32_t>(r), b, e, -1});
       }
     }
-    std::stable_sort(tk.begin(), tk.end(), [](const Task &a, const Task &b) {
-      return (a.end - a.begin) > (b.end - b.begin);
-    });
+    {  // longest first, ties in list order: a counting sort by length (stable, O(n + max length))
+      int32_t max_len = 0;
+      for (const Task &a : tk) max_len = std::max(max_len, a.end - a.begin);
+      std::vector<int32_t> start(static_cast<size_t>(max_len) + 2, 0);
+      for (const Task &a : tk) start[max_len - (a.end - a.begin) + 1]++;
+      for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
+      std::vector<Task> sorted(tk.size());
+      for (const Task &a : tk) sorted[start[max_len - (a.end - a.begin)]++] = a;
+      tk.swap(sorted);
+    }
     // (dealing length strata round-robin so that neighbouring waves sit in different phases
     // was tried: 3-5 % slower, and 2x slower when the stratum count shares a factor with the
     // 8 XCDs the dispatcher deals workgroups to - longest-first keeps the XCDs balanced)
@@ -262,21 +269,30 @@ struct Side {
     n_slots = slots;
     indptr.upload(ip32, s);
     {
-      // the gather pipeline loads whole 64-entry blocks up to two blocks past a row's end
-      std::vector<int32_t> idx_pad(m.indices);
-      std::vector<float> data_pad(m.data);
-      idx_pad.resize(m.indices.size() + 320, 0);
-      data_pad.resize(m.data.size() + 320, 0.0f);
-      indices.upload(idx_pad, s);
-      data.upload(data_pad, s);
+      // the gather pipeline loads whole 64-entry blocks up to two blocks past a row's end:
+      // 320 zero entries behind the arrays (set on the device; no padded host copies)
+      const size_t ne = m.indices.size();
+      indices.alloc(ne + 320);
+      data.alloc(ne + 320);
+      if (ne) {
+        IRS_HIP(hipMemcpyAsync(indices.ptr, m.indices.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        IRS_HIP(hipMemcpyAsync(data.ptr, m.data.data(), ne * sizeof(float), hipMemcpyHostToDevice, s));
+      }
+      IRS_HIP(hipMemsetAsync(indices.ptr + ne, 0, 320 * sizeof(int32_t), s));
+      IRS_HIP(hipMemsetAsync(data.ptr + ne, 0, 320 * sizeof(float), s));
       IRS_HIP(hipStreamSynchronize(s));
     }
     {
       std::vector<int32_t> order(re - rb);
-      for (int64_t r = rb; r < re; r++) order[r - rb] = static_cast<int32_t>(r);
-      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-        return (ip32[a + 1] - ip32[a]) > (ip32[b + 1] - ip32[b]);
-      });
+      {  // rows by length, longest first, ties in row order (counting sort)
+        int32_t max_len = 0;
+        for (int64_t r = rb; r < re; r++) max_len = std::max(max_len, ip32[r + 1] - ip32[r]);
+        std::vector<int32_t> start(static_cast<size_t>(max_len) + 2, 0);
+        for (int64_t r = rb; r < re; r++) start[max_len - (ip32[r + 1] - ip32[r]) + 1]++;
+        for (size_t i = 1; i < start.size(); i++) start[i] += start[i - 1];
+        for (int64_t r = rb; r < re; r++)
+          order[start[max_len - (ip32[r + 1] - ip32[r])]++] = static_cast<int32_t>(r);
+      }
       rows_by_len.upload(order, s);
       n_long = 0;  // rows long enough for a whole workgroup (ialspp_long_kernel)
       while (n_long < static_cast<int32_t>(order.size()) &&
