@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -86,5 +88,21 @@ void sort_pairs_f32(bool descending, const float *keys_in, float *keys_out, cons
                     int32_t *vals_out, size_t n, DeviceBuffer<char> &tmp, hipStream_t s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the big
+// host staging arrays (hundreds of MB) are written once right after they are sized, and the
+// value-initialising resize touched every page on one thread first (40 ms per 240 MB).
+template <class T> struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+  template <class U, class... A> void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0)
+      ::new (static_cast<void *>(p)) U;
+    else
+      ::new (static_cast<void *>(p)) U(std::forward<A>(a)...);
+  }
+};
+template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
 
 }  // namespace irs

@@ -24,6 +24,7 @@
 #include <thread>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <numeric>
 
@@ -838,8 +839,8 @@ __global__ __launch_bounds__(256) void knn_compact_kernel(const int32_t *__restr
 struct HostCsrD {
   int64_t rows = 0, cols = 0;
   std::vector<int64_t> indptr;
-  std::vector<int32_t> indices;
-  std::vector<double> data;
+  RawVector<int32_t> indices;  // (sized, then written by several threads: no zero fill)
+  RawVector<double> data;
 };
 
 static HostCsrD host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
@@ -851,10 +852,32 @@ static HostCsrD host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
   m.indptr.assign(indptr, indptr + rows + 1);
   const int64_t nnz = indptr[rows];
   check_arg(indptr[0] == 0 && nnz >= 0, "malformed indptr.");
-  m.indices.assign(indices, indices + nnz);
-  m.data.assign(data, data + nnz);
-  for (int64_t q = 0; q < nnz; q++)
-    check_arg(m.indices[q] >= 0 && m.indices[q] < cols, "column index out of range.");
+  // the two copies and the index check, on a few host threads (240 MB for 20 M entries)
+  m.indices.resize(nnz);
+  m.data.resize(nnz);
+  const int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({8, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz / 1000000 + 1})));
+  std::atomic<int> bad(0);
+  auto body = [&](int k) {
+    const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
+    if (e > b) {
+      std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
+      std::memcpy(m.data.data() + b, data + b, (e - b) * sizeof(double));
+    }
+    int32_t lo = 0, hi = 0;
+    for (int64_t q = b; q < e; q++) {
+      lo = std::min(lo, indices[q]);
+      hi = std::max(hi, indices[q]);
+    }
+    if (e > b && (lo < 0 || hi >= cols)) bad.store(1);
+  };
+  {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &w : th) w.join();
+  }
+  check_arg(bad.load() == 0, "column index out of range.");
   return m;
 }
 
@@ -870,8 +893,8 @@ static HostCsrD transpose(const HostCsrD &x) {
   t.indices.resize(nnz);
   t.data.resize(nnz);
   const int n_thr = static_cast<int>(std::max<int64_t>(
-      1, std::min<int64_t>({8, static_cast<int64_t>(std::thread::hardware_concurrency()),
-                            nnz / 1000000 + 1})));
+      1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                            nnz / 1000000 + 1, (int64_t(1) << 25) / std::max<int64_t>(x.cols, 1)})));
   std::vector<int64_t> row_lo(n_thr + 1, x.rows);
   row_lo[0] = 0;
   for (int k = 1; k < n_thr; k++)
@@ -1052,20 +1075,51 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     c->normalize = normalize != 0;
     HostCsrD Xt = transpose(X);
     pt.mark("create: transpose");
+    // the per-row and per-entry passes below run on several host threads over row blocks of
+    // about equal entry counts
+    const int64_t xt_nnz = Xt.indptr[Xt.rows];
+    const int n_thr = static_cast<int>(std::max<int64_t>(
+        1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                              xt_nnz / 500000 + 1})));
+    std::vector<int64_t> blk(n_thr + 1, Xt.rows);
+    for (int k = 0; k < n_thr; k++)
+      blk[k] = std::lower_bound(Xt.indptr.begin(), Xt.indptr.begin() + Xt.rows, xt_nnz * k / n_thr) -
+               Xt.indptr.begin();
+    blk[0] = 0;
+    auto on_threads = [&](auto &&body) {
+      std::vector<std::thread> th;
+      for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+      body(0);
+      for (auto &w : th) w.join();
+    };
     c->xt_row_len.resize(Xt.rows);
     c->xt_rowmax.assign(Xt.rows, 0.0);
-    for (int64_t u = 0; u < Xt.rows; u++) {
-      c->xt_row_len[u] = Xt.indptr[u + 1] - Xt.indptr[u];
-      double mx = 0.0;
-      for (int64_t q = Xt.indptr[u]; q < Xt.indptr[u + 1]; q++) mx = std::max(mx, std::fabs(Xt.data[q]));
-      c->xt_rowmax[u] = mx;
-    }
     hipStream_t s = nullptr;
-    {
-      const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
-      check_arg(Xt.indptr[Xt.rows] < (int64_t(1) << 31) - 1024, "nnz must be below 2^31.");
-      std::vector<uint32_t> tptr(static_cast<size_t>(Xt.rows) * (n_tiles + 1));
-      for (int64_t u = 0; u < Xt.rows; u++) {
+    const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
+    check_arg(xt_nnz < (int64_t(1) << 31) - 1024, "nnz must be below 2^31.");
+    std::vector<uint32_t> tptr(static_cast<size_t>(Xt.rows) * (n_tiles + 1));
+    // columns relative to their tile as 16-bit LDS byte offsets (column * 4), two per dword;
+    // 256 padding entries: the accumulate loop reads whole 128-entry strips from the (even)
+    // start of a slice
+    static_assert(TILE * 4 <= 65536, "tile-relative column offsets are stored in 16 bits");
+    const size_t nnz = Xt.indices.size(), padded = (nnz + 256 + 1) & ~size_t(1);
+    std::vector<uint32_t> idx_p(padded / 2, 0u);
+    uint16_t *idx16 = reinterpret_cast<uint16_t *>(idx_p.data());  // little endian: entry e = half e
+    std::atomic<int> not_ones(0), not_safe(0), not_pos(0);
+    on_threads([&](int k) {
+      bool ones = true, safe = true, pos = true;
+      for (int64_t u = blk[k]; u < blk[k + 1]; u++) {
+        c->xt_row_len[u] = Xt.indptr[u + 1] - Xt.indptr[u];
+        double mx = 0.0;
+        for (int64_t q = Xt.indptr[u]; q < Xt.indptr[u + 1]; q++) {
+          const double v = Xt.data[q], a = std::fabs(v);
+          mx = std::max(mx, a);
+          ones &= v == 1.0;
+          safe &= a > 1e-150 && a < 1e150;
+          pos &= v > 0.0;
+          idx16[q] = static_cast<uint16_t>((Xt.indices[q] % TILE) * 4);
+        }
+        c->xt_rowmax[u] = mx;
         const int32_t *b = Xt.indices.data() + Xt.indptr[u], *e = Xt.indices.data() + Xt.indptr[u + 1];
         uint32_t *dst = tptr.data() + u * (n_tiles + 1);
         for (int64_t t = 0; t < n_tiles; t++)
@@ -1073,28 +1127,21 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
                                          (std::lower_bound(b, e, static_cast<int32_t>(t * TILE)) - b));
         dst[n_tiles] = static_cast<uint32_t>(Xt.indptr[u + 1]);
       }
-      c->xt_tptr.upload(tptr, s);
-    }
+      if (!ones) not_ones.store(1);
+      if (!safe) not_safe.store(1);
+      if (!pos) not_pos.store(1);
+    });
+    c->xt_tptr.upload(tptr, s);
     pt.mark("create: slices");
-    {  // columns relative to their tile as 16-bit LDS byte offsets (column * 4), two per
-       // dword; 256 padding entries: the accumulate loop reads whole 128-entry strips from
-       // the (even) start of a slice
-      static_assert(TILE * 4 <= 65536, "tile-relative column offsets are stored in 16 bits");
-      const size_t nnz = Xt.indices.size(), padded = (nnz + 256 + 1) & ~size_t(1);
-      std::vector<uint32_t> idx_p(padded / 2, 0u);
-      for (size_t e = 0; e < nnz; e++)
-        idx_p[e >> 1] |= static_cast<uint32_t>((Xt.indices[e] % TILE) * 4) << (16 * (e & 1));
+    {
       c->xt_idx16.upload(idx_p, s);
-      c->xt_all_ones = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) { return v == 1.0; });
-      c->xt_nonzero = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) {
-        const double a = std::fabs(v);
-        return a > 1e-150 && a < 1e150;
-      });
-      c->xt_positive = std::all_of(Xt.data.begin(), Xt.data.end(), [](double v) { return v > 0.0; });
+      c->xt_all_ones = not_ones.load() == 0;
+      c->xt_nonzero = not_safe.load() == 0;
+      c->xt_positive = not_pos.load() == 0;
       if (c->xt_all_ones) {  // the ONES kernels never read the value stream
         c->xt_val.alloc(2);
       } else {
-        std::vector<double> val_p(Xt.data);
+        std::vector<double> val_p(Xt.data.begin(), Xt.data.end());
         val_p.resize(padded, 0.0);
         c->xt_val.upload(val_p, s);
       }
@@ -1103,6 +1150,19 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     c->norms.upload(norms, s);
     IRS_HIP(hipStreamSynchronize(s));
     pt.mark("create: pack+upload");
+    // (the host staging - half a gigabyte for 20 M entries - is released here rather than at
+    // scope exit so that the phase shows up in the timing)
+    // and on a thread of its own: returning 480 MB to the kernel (munmap) takes 56 ms, nothing
+    // waits for it
+    {
+      auto *junk = new std::pair<HostCsrD, HostCsrD>();
+      junk->first.indices.swap(X.indices);
+      junk->first.data.swap(X.data);
+      junk->second.indices.swap(Xt.indices);
+      junk->second.data.swap(Xt.data);
+      std::thread([junk] { delete junk; }).detach();
+    }
+    pt.mark("create: release host");
     *out = c.release();
   });
 }
