@@ -76,7 +76,9 @@ template <class T> struct DeviceBuffer {
     alloc(n);
     if (n) IRS_HIP(hipMemcpyAsync(ptr, host, n * sizeof(T), hipMemcpyHostToDevice, s));
   }
-  void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
+  template <class A> void upload(const std::vector<T, A> &v, hipStream_t s) {
+    upload(v.data(), v.size(), s);
+  }
   void zero(hipStream_t s) {
     if (ptr) IRS_HIP(hipMemsetAsync(ptr, 0, count * sizeof(T), s));
   }

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -53,8 +54,8 @@ static int padded_k(int64_t K) {
 struct HostCsr {
   int64_t rows = 0, cols = 0;
   std::vector<int64_t> indptr;
-  std::vector<int32_t> indices;
-  std::vector<float> data;
+  RawVector<int32_t> indices;  // (sized, then written: no zero fill of hundreds of MB)
+  RawVector<float> data;
 };
 
 static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
@@ -69,10 +70,31 @@ static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
   check_arg(indptr[0] == 0 && nnz >= 0, "malformed indptr.");
   check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31 (32-bit CSR like Eigen's).");
   for (int64_t r = 0; r < rows; r++) check_arg(indptr[r + 1] >= indptr[r], "malformed indptr.");
-  m.indices.assign(indices, indices + nnz);
-  m.data.assign(data, data + nnz);
-  for (int64_t p = 0; p < nnz; p++)
-    check_arg(m.indices[p] >= 0 && m.indices[p] < cols, "column index out of range.");
+  // the two copies and the index check on a few host threads
+  m.indices.resize(nnz);
+  m.data.resize(nnz);
+  const int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({8, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz / 1000000 + 1})));
+  std::atomic<int> bad(0);
+  auto body = [&](int k) {
+    const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
+    if (e <= b) return;
+    std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
+    std::memcpy(m.data.data() + b, data + b, (e - b) * sizeof(float));
+    int32_t lo = 0, hi = 0;
+    for (int64_t q = b; q < e; q++) {
+      lo = std::min(lo, indices[q]);
+      hi = std::max(hi, indices[q]);
+    }
+    if (lo < 0 || hi >= cols) bad.store(1);
+  };
+  {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &w : th) w.join();
+  }
+  check_arg(bad.load() == 0, "column index out of range.");
   return m;
 }
 
@@ -1093,6 +1115,14 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     upload_factor(t.get(), 0, init_draw.data());  // hpp:718-719: both sides from the same seed
     upload_factor(t.get(), 1, init_draw.data());
     mark("upload factors");
+    {  // the host staging goes back to the kernel on a thread of its own (munmap of ~0.3 GB)
+      auto *junk = new std::pair<HostCsr, HostCsr>();
+      junk->first.indices.swap(X.indices);
+      junk->first.data.swap(X.data);
+      junk->second.indices.swap(Xt.indices);
+      junk->second.data.swap(Xt.data);
+      std::thread([junk] { delete junk; }).detach();
+    }
     *out = t.release();
   });
 }
