@@ -726,29 +726,33 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
       t->prof.end(t->stream);
     }
   };
+  // the form of the sweep is a template parameter (each form gets its own register budget)
+  const bool single = p.sub >= p.K;
+  const bool chained = !single && TS == 4 && aligned && p.chain && p.sub == 64 && p.K > 64;
+#define IRS_PP_LAUNCH(TSV, AL)                                                                        \
+  do {                                                                                                \
+    if (single)                                                                                       \
+      launch(ialspp_long_kernel<TSV, AL, 1>, PpLongGeo<TSV>::LDS_FLOATS, ialspp_kernel<TSV, AL, 1>,   \
+             PpGeo<TSV>::LDS_FLOATS);                                                                 \
+    else                                                                                              \
+      launch(ialspp_long_kernel<TSV, AL, 0>, PpLongGeo<TSV>::LDS_FLOATS, ialspp_kernel<TSV, AL, 0>,   \
+             PpGeo<TSV>::LDS_FLOATS);                                                                 \
+  } while (0)
   switch (TS * 2 + (aligned ? 1 : 0)) {
     case 2:  // TS = 1 is always aligned
-    case 3:
-      launch(ialspp_long_kernel<1, true>, PpLongGeo<1>::LDS_FLOATS, ialspp_kernel<1, true>,
-             PpGeo<1>::LDS_FLOATS);
-      break;
-    case 4:
-      launch(ialspp_long_kernel<2, false>, PpLongGeo<2>::LDS_FLOATS, ialspp_kernel<2, false>,
-             PpGeo<2>::LDS_FLOATS);
-      break;
-    case 5:
-      launch(ialspp_long_kernel<2, true>, PpLongGeo<2>::LDS_FLOATS, ialspp_kernel<2, true>,
-             PpGeo<2>::LDS_FLOATS);
-      break;
-    case 8:
-      launch(ialspp_long_kernel<4, false>, PpLongGeo<4>::LDS_FLOATS, ialspp_kernel<4, false>,
-             PpGeo<4>::LDS_FLOATS);
-      break;
+    case 3: IRS_PP_LAUNCH(1, true); break;
+    case 4: IRS_PP_LAUNCH(2, false); break;
+    case 5: IRS_PP_LAUNCH(2, true); break;
+    case 8: IRS_PP_LAUNCH(4, false); break;
     default:
-      launch(ialspp_long_kernel<4, true>, PpLongGeo<4>::LDS_FLOATS, ialspp_kernel<4, true>,
-             PpGeo<4>::LDS_FLOATS);
+      if (chained)
+        launch(ialspp_long_kernel<4, true, 2>, PpLongGeo<4>::LDS_FLOATS, ialspp_kernel<4, true, 2>,
+               PpGeo<4>::LDS_FLOATS);
+      else
+        IRS_PP_LAUNCH(4, true);
       break;
   }
+#undef IRS_PP_LAUNCH
   IRS_HIP(hipGetLastError());
 }
 

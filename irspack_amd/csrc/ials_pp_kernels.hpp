@@ -515,7 +515,9 @@ __device__ __forceinline__ void pp_rhs_of_p16(const PpParams &p, const float *xs
 // One wave per row, four independent rows per workgroup.  (launch bound: without it the compiler
 // takes 256 VGPRs + 96 AGPRs, i.e. ONE wave per SIMD and every latency exposed - K = 128
 // epoch 15.0 ms; two waves per SIMD: 12.3 ms; forcing three spills 600 bytes per lane: 15.6 ms.)
-template <int TS, bool ALIGNED>
+// MODE 0: several blocks, three passes per block; 1: one block covers the row (no cache);
+// 2: 64-dim blocks, chained passes.  Compile-time so that each form gets its own registers.
+template <int TS, bool ALIGNED, int MODE>
 __global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
   using G = PpGeo<TS>;
   extern __shared__ __attribute__((aligned(16))) float pp_lds[];
@@ -538,16 +540,17 @@ __global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
     if (p.zero_start) xrow[i] = 0.f;
   }
   __threadfence_block();
-  const bool single = p.sub >= p.K;  // one block = the whole row: no prediction cache needed
+  constexpr bool single = MODE == 1;  // one block = the whole row: no prediction cache needed
   // 64-dim blocks of a longer row: the prediction passes ride in the rank-update passes
-  const bool chain = TS == 4 && ALIGNED && p.chain && p.sub == 64 && p.K > 64;
-  if (!single && !chain) {
+  constexpr bool chain = MODE == 2;
+  static_assert(!chain || (TS == 4 && ALIGNED), "chained passes: 64-dim aligned blocks");
+  if constexpr (!single && !chain) {
 #ifndef IRS_PP_SKIP_PRED
     pp_predict(p, xs, begin, end);
     __threadfence();  // the cache is re-read through other lanes' addresses below
 #endif
   }
-  if (chain) {
+  if constexpr (chain) {
 #ifndef IRS_PP_SKIP_PRED
     pp_predict16(p, xs, begin, end);
 #endif
@@ -559,13 +562,11 @@ __global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
     f32x4 acc[G::NT];
 #ifndef IRS_PP_SKIP_P
     float bp[TS];  // chain: the P part of the rhs, already in the layout of bsum
-    if constexpr (TS == 4 && ALIGNED) {
-      if (chain) {
-        pp_block_of_p_packed(p, c0, acc);
-        pp_rhs_of_p16(p, xs, reg, c0, bp);
-      }
+    if constexpr (chain) {
+      pp_block_of_p_packed(p, c0, acc);
+      pp_rhs_of_p16(p, xs, reg, c0, bp);
     }
-    if (!chain) {
+    if constexpr (!chain) {
       pp_block_of_p<TS>(p, c0, D, acc);
       pp_rhs_of_p<TS>(p, xs, reg, c0, D, bnat);
     }
@@ -579,13 +580,13 @@ __global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
     for (int i = 0; i < TS; i++) bsum[i] = 0.f;
 #ifndef IRS_PP_SKIP_RANK
     bool chained = false;
-    if constexpr (TS == 4 && ALIGNED) {
-      if (chain && c0 > 0) {
+    if constexpr (chain) {
+      if (c0 > 0) {
         pp_chain_pass(p, begin, end, c0, D, xs, delta, c0 + 64 < p.K, acc, bsum);
         chained = true;
       }
     }
-    if (single)
+    if constexpr (single)
       pp_rank_update<TS, ALIGNED, true>(p, begin, end, c0, D, acc, bsum, xs);
     else if (!chained)
       pp_rank_update<TS, ALIGNED>(p, begin, end, c0, D, acc, bsum);
@@ -595,11 +596,9 @@ __global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
 #pragma unroll
     for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bnat[TS * m + i];
 #ifndef IRS_PP_SKIP_P
-    if constexpr (TS == 4 && ALIGNED) {
-      if (chain) {
+    if constexpr (chain) {
 #pragma unroll
-        for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bp[i];
-      }
+      for (int i = 0; i < TS; i++) b4[i] = bsum[i] + bp[i];
     }
 #endif
     // ---- delta = (A + reg I)^-1 B   (hpp:490-497)
@@ -638,7 +637,7 @@ template <int TS> struct PpLongGeo {
   static constexpr int LDS_FLOATS = G::LDS_FLOATS + (PP_LONG_WAVES - 1) * PART;
 };
 
-template <int TS, bool ALIGNED>
+template <int TS, bool ALIGNED, int MODE>
 __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParams p) {
   using G = PpGeo<TS>;
   using L = PpLongGeo<TS>;
@@ -664,14 +663,14 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
     if (p.zero_start) xrow[i] = 0.f;
   }
   __syncthreads();
-  const bool single = p.sub >= p.K;  // see ialspp_kernel
-  const bool chain = TS == 4 && ALIGNED && p.chain && p.sub == 64 && p.K > 64;
-  if (!single && !chain) {
+  constexpr bool single = MODE == 1;  // see ialspp_kernel
+  constexpr bool chain = MODE == 2;
+  if constexpr (!single && !chain) {
     pp_predict(p, xs, wb, we);
     __threadfence();
     __syncthreads();
   }
-  if (chain) {
+  if constexpr (chain) {
     pp_predict16(p, xs, wb, we);
     __threadfence_block();
   }
@@ -681,11 +680,9 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
     f32x4 acc[G::NT];
     if (wid == 0) {
       bool packed = false;
-      if constexpr (TS == 4 && ALIGNED) {
-        if (chain) {
-          pp_block_of_p_packed(p, c0, acc);
-          packed = true;
-        }
+      if constexpr (chain) {
+        pp_block_of_p_packed(p, c0, acc);
+        packed = true;
       }
       if (!packed) pp_block_of_p<TS>(p, c0, D, acc);
       pp_rhs_of_p<TS>(p, xs, reg, c0, D, bnat);
@@ -697,13 +694,13 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
 #pragma unroll
     for (int i = 0; i < TS; i++) bsum[i] = 0.f;
     bool chained = false;
-    if constexpr (TS == 4 && ALIGNED) {
-      if (chain && c0 > 0) {
+    if constexpr (chain) {
+      if (c0 > 0) {
         pp_chain_pass(p, wb, we, c0, D, xs, delta, c0 + 64 < p.K, acc, bsum);
         chained = true;
       }
     }
-    if (single)
+    if constexpr (single)
       pp_rank_update<TS, ALIGNED, true>(p, wb, we, c0, D, acc, bsum, xs);
     else if (!chained)
       pp_rank_update<TS, ALIGNED>(p, wb, we, c0, D, acc, bsum);
