@@ -379,6 +379,8 @@ struct irs_ials_trainer {
   int KP = 0, T = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // iALS++: the short-row launch beside the long-row launch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool has_X = false;
   bool whole = true;  // unsharded: both CSR orientations are complete on this device
   irs_ials_shard shard{0, 0, 0, 0};
@@ -403,6 +405,7 @@ struct irs_ials_trainer {
   bool opt_short2 = true;  // two short rows per wave (IRSPACK_AMD_IALS_SHORT2)
   bool opt_pp_direct = true;  // iALS++ with one block = the direct solve (IRSPACK_AMD_IALSPP_DIRECT)
   bool opt_pp_chain = true;   // iALS++ prediction passes merged into the rank updates (IRSPACK_AMD_IALSPP_CHAIN)
+  bool opt_pp_fork = true;    // iALS++ short-row launch on a second stream (IRSPACK_AMD_IALSPP_FORK)
   bool opt_bf16x3 = false;
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
@@ -709,8 +712,23 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
     IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(long_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(lds_long)));
+    // The two launches touch different rows.  The long-row launch ends with a tail (a few rows
+    // of 10^5 entries on a few CUs), so the one-wave-per-row launch runs beside it on a second
+    // stream (fork / join by events) instead of behind it.
+    const bool fork = n_long > 0 && n_rows > n_long && t->opt_pp_fork;
+    if (fork && !t->stream2) {
+      IRS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+      IRS_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+      IRS_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    }
     for (uint64_t it = 0; it < sc->ialspp_iteration; it++) {
       t->prof.begin(kNames[pidx], t->stream);
+      hipStream_t s2 = t->stream;
+      if (fork) {
+        s2 = t->stream2;
+        IRS_HIP(hipEventRecord(t->ev_fork, t->stream));
+        IRS_HIP(hipStreamWaitEvent(s2, t->ev_fork, 0));
+      }
       if (n_long > 0) {
         PpParams pl = p;
         pl.n_rows = n_long;
@@ -721,7 +739,11 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
         PpParams ps = p;
         ps.rows = p.rows + n_long;
         ps.n_rows = n_rows - n_long;
-        hipLaunchKernelGGL(kernel, dim3(ceil_div(ps.n_rows, 4)), dim3(256), lds, t->stream, ps);
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(ps.n_rows, 4)), dim3(256), lds, s2, ps);
+      }
+      if (fork) {
+        IRS_HIP(hipEventRecord(t->ev_join, s2));
+        IRS_HIP(hipStreamWaitEvent(t->stream, t->ev_join, 0));
       }
       t->prof.end(t->stream);
     }
@@ -775,6 +797,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_short2 = env_flag("IRSPACK_AMD_IALS_SHORT2", true);
   t->opt_pp_direct = env_flag("IRSPACK_AMD_IALSPP_DIRECT", true);
   t->opt_pp_chain = env_flag("IRSPACK_AMD_IALSPP_CHAIN", true);
+  t->opt_pp_fork = env_flag("IRSPACK_AMD_IALSPP_FORK", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
   t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
 }
@@ -1160,6 +1183,12 @@ irs_status irs_ials_destroy(irs_ials_trainer *t) {
     if (t) {
       (void)hipSetDevice(t->device);
       t->prof.clear();
+      if (t->stream2) {
+        (void)hipStreamSynchronize(t->stream2);
+        (void)hipStreamDestroy(t->stream2);
+        (void)hipEventDestroy(t->ev_fork);
+        (void)hipEventDestroy(t->ev_join);
+      }
       delete t;
     }
   });
