@@ -59,7 +59,10 @@ def _free_port():
 @pytest.mark.parametrize("kind,equal,K", [("CHOLESKY", False, 64), ("CHOLESKY", True, 64),
                                           ("CG", False, 64), ("CG", True, 64), ("IALSPP", True, 64),
                                           # BASELINE configs[3] is K = 128, sharded
-                                          ("CG", True, 128), ("CHOLESKY", True, 128)])
+                                          ("CG", True, 128), ("CHOLESKY", True, 128),
+                                          # iALS++ with two 64-dim blocks (chained passes, the
+                                          # second stream of the short-row launch) on a shard
+                                          ("IALSPP", True, 128)])
 def test_two_ranks_match_single_gpu(tmp_path, kind, equal, K):
     import torch.multiprocessing as mp
 
