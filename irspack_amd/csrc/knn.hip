@@ -843,6 +843,26 @@ struct HostCsrD {
   RawVector<double> data;
 };
 
+// f(i) for every row i of a CSR on several host threads (row blocks of about equal entry
+// counts); f must only touch its own row
+template <class F>
+static void for_rows_parallel(const std::vector<int64_t> &indptr, int64_t rows, F &&f) {
+  const int64_t nnz = rows > 0 ? indptr[rows] : 0;
+  const int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                            nnz / 500000 + 1})));
+  auto body = [&](int k) {
+    const int64_t lo = std::lower_bound(indptr.begin(), indptr.begin() + rows, nnz * k / n_thr) - indptr.begin();
+    const int64_t hi = k + 1 == n_thr ? rows
+                                      : std::lower_bound(indptr.begin(), indptr.begin() + rows, nnz * (k + 1) / n_thr) - indptr.begin();
+    for (int64_t i = (k == 0 ? 0 : lo); i < hi; i++) f(i);
+  };
+  std::vector<std::thread> th;
+  for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+  body(0);
+  for (auto &w : th) w.join();
+}
+
 static HostCsrD host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
                          const int32_t *indices, const double *data) {
   check_arg(rows >= 0 && cols >= 0 && indptr, "bad matrix.");
@@ -1018,30 +1038,31 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     std::vector<double> norms(rows, 0.0);
     switch (sim_type) {
       case IRS_SIM_COSINE:  // similarities.hpp:20-28
-        for (int64_t i = 0; i < rows; i++) {
+        for_rows_parallel(X.indptr, rows, [&](int64_t i) {
           double s = 0;
           for (int64_t q = X.indptr[i]; q < X.indptr[i + 1]; q++) s += X.data[q] * X.data[q];
           norms[i] = std::sqrt(s);
-        }
+        });
         break;
       case IRS_SIM_ASYMMETRIC:  // similarities.hpp:61-72
         check_lower(alpha, 0, "alpha");
         if (alpha > 1)
           throw std::invalid_argument("alpha must be less than or equal to  " + std::to_string(1.0));
-        for (int64_t i = 0; i < rows; i++) {
+        for_rows_parallel(X.indptr, rows, [&](int64_t i) {
           double s = 0;
           for (int64_t q = X.indptr[i]; q < X.indptr[i + 1]; q++) s += X.data[q] * X.data[q];
           norms[i] = std::pow(s, 1 - alpha);
-        }
+        });
         break;
       case IRS_SIM_TVERSKY:  // similarities.hpp:143-159
         check_lower(alpha, 0, "alpha");
         check_lower(beta, 0, "beta");
         [[fallthrough]];
       case IRS_SIM_JACCARD:  // similarities.hpp:96-107: stored entries become 1
-        for (auto &v : X.data) v = 1;
-        for (int64_t i = 0; i < rows; i++)
+        for_rows_parallel(X.indptr, rows, [&](int64_t i) {
+          for (int64_t q = X.indptr[i]; q < X.indptr[i + 1]; q++) X.data[q] = 1;
           norms[i] = static_cast<double>(X.indptr[i + 1] - X.indptr[i]);
+        });
         break;
       case IRS_SIM_RP3BETA:  // similarities.hpp:265-292
         check_lower(alpha, 0, "alpha");
@@ -1049,14 +1070,14 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         [[fallthrough]];
       case IRS_SIM_P3ALPHA:  // similarities.hpp:198-222: rows pow-ed and normalised to sum 1
         check_lower(alpha, 0, "alpha");
-        for (int64_t i = 0; i < rows; i++) {
+        for_rows_parallel(X.indptr, rows, [&](int64_t i) {
           double s = 0;
           for (int64_t q = X.indptr[i]; q < X.indptr[i + 1]; q++) {
             X.data[q] = std::pow(X.data[q], alpha);
             s += X.data[q];
           }
           for (int64_t q = X.indptr[i]; q < X.indptr[i + 1]; q++) X.data[q] /= s;
-        }
+        });
         break;
       default:
         throw std::invalid_argument("unknown similarity type.");
@@ -1198,22 +1219,27 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     if (as_w) {  // similarities.hpp:224-240, 294-324
       T = host_csr(rows, cols, indptr, indices, data);
       std::vector<double> norm_temp(cols, 0.0), pop(rows, 0.0);
+      // (the pow calls and the divisions run on several host threads; the column sums are
+      // added in entry order on one, like the reference's loop, so they are the same numbers)
       if (c->sim_type == IRS_SIM_RP3BETA) {
-        for (int64_t i = 0; i < rows; i++)
-          for (int64_t q = T.indptr[i]; q < T.indptr[i + 1]; q++) pop[i] += T.data[q];
-        for (auto &v : pop) v = std::pow(v, c->beta);
+        for_rows_parallel(T.indptr, rows, [&](int64_t i) {
+          double sum = 0;
+          for (int64_t q = T.indptr[i]; q < T.indptr[i + 1]; q++) sum += T.data[q];
+          pop[i] = std::pow(sum, c->beta);
+        });
       }
-      for (int64_t q = 0; q < T.indptr[rows]; q++) {
-        T.data[q] = std::pow(T.data[q], c->alpha);
-        norm_temp[T.indices[q]] += T.data[q];
-      }
-      for (int64_t i = 0; i < rows; i++)
+      for_rows_parallel(T.indptr, rows, [&](int64_t i) {
+        for (int64_t q = T.indptr[i]; q < T.indptr[i + 1]; q++) T.data[q] = std::pow(T.data[q], c->alpha);
+      });
+      for (int64_t q = 0; q < T.indptr[rows]; q++) norm_temp[T.indices[q]] += T.data[q];
+      for_rows_parallel(T.indptr, rows, [&](int64_t i) {
         for (int64_t q = T.indptr[i]; q < T.indptr[i + 1]; q++) {
           if (c->sim_type == IRS_SIM_RP3BETA)
             T.data[q] /= (norm_temp[T.indices[q]] * pop[i]);
           else
             T.data[q] /= norm_temp[T.indices[q]];
         }
+      });
       ip = T.indptr.data();
       ix = T.indices.data();
       dv = T.data.data();
