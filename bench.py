@@ -523,8 +523,6 @@ def main():
             "roofline": roofline,
             "ceilings": ceilings,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(X, K, args.solver, args.cpu_seconds)
         if world == 1 and not args.no_secondary:
             legs = [s for s in args.legs.split(",") if s]
             sec = {}
@@ -555,6 +553,9 @@ def main():
                 run("k256", lambda: k256_leg(X, ceilings))
                 run("c4", lambda: c4_leg(not args.c4_small, ceilings))
             result["secondary"] = sec
+        # last: 256 busy host threads just before a GPU leg disturb its (host-clocked) timing
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(X, K, args.solver, args.cpu_seconds)
     if world > 1:
         dist.barrier()
     if rank == 0:
