@@ -393,9 +393,10 @@ struct EmitParams {
   // bounded variant (below): sorted position -> item id / row of the call, and per 64-user
   // tile the number of leading item tiles that can still hold a candidate
   const int32_t *iperm, *uperm, *limit_tiles;
-  // the work list of the bounded variant: workgroup b scores item tiles 4 (b - wg_prefix[ut])
-  // .. + 3 of user tile ut = wg_ut[b] (only workgroups with a live tile are launched)
-  const int32_t *wg_ut, *wg_prefix;
+  // the work list of the bounded variant: workgroup b scores the item tiles wg_desc[b].y ..
+  // + wg_desc[b].z - 1 (at most four) of user tile wg_desc[b].x - one 16-byte load instead of
+  // a chain of three (only workgroups with a live tile are launched)
+  const int4 *wg_desc;
   // rows the path cannot finish (no threshold from the sample, candidate list overflow): set
   // to 1 here, ranked one by one from their full score rows afterwards
   int32_t *hard;
@@ -488,9 +489,10 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
   const int64_t item_tiles = (p.n_items + 63) / 64;
   int64_t ut, it;
   if constexpr (BOUNDED) {
-    ut = p.wg_ut[blockIdx.x];
-    it = static_cast<int64_t>(blockIdx.x - p.wg_prefix[ut]) * 4 + wid;
-    if (it >= p.limit_tiles[ut]) return;
+    const int4 d = p.wg_desc[blockIdx.x];
+    ut = d.x;
+    it = static_cast<int64_t>(d.y) + wid;
+    if (wid >= d.z) return;
   } else {
     const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wid;
     ut = w / item_tiles;
@@ -789,13 +791,18 @@ __global__ __launch_bounds__(1024) void wg_scan_kernel(const int32_t *__restrict
   }
 }
 
-// wg_ut[b] = ut for the workgroups b of user tile ut (one wave per user tile)
-__global__ __launch_bounds__(256) void wg_fill_kernel(const int32_t *__restrict__ wg_prefix, int64_t n_ut,
-                                                      int32_t *__restrict__ wg_ut) {
+// wg_desc[b] = (ut, first item tile, live tiles of the workgroup) for the workgroups b of user
+// tile ut (one wave per user tile)
+__global__ __launch_bounds__(256) void wg_fill_kernel(const int32_t *__restrict__ wg_prefix,
+                                                      const int32_t *__restrict__ limit_tiles,
+                                                      int64_t n_ut, int4 *__restrict__ wg_desc) {
   const int64_t ut = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (ut >= n_ut) return;
-  const int32_t b = wg_prefix[ut], e = wg_prefix[ut + 1];
-  for (int32_t i = b + (threadIdx.x & 63); i < e; i += 64) wg_ut[i] = static_cast<int32_t>(ut);
+  const int32_t b = wg_prefix[ut], e = wg_prefix[ut + 1], lim = limit_tiles[ut];
+  for (int32_t i = b + (threadIdx.x & 63); i < e; i += 64) {
+    const int32_t it0 = 4 * (i - b);
+    wg_desc[i] = int4{static_cast<int32_t>(ut), it0, min(4, lim - it0), 0};
+  }
 }
 
 // list[0 .. min(*count, cap)) = hard rows that have ground truth (any order); *count = all of them

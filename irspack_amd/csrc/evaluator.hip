@@ -1155,7 +1155,8 @@ struct irs_evaluator {
   DeviceBuffer<int32_t> cand_item, cand_cnt, tau_hint, bad_flag;
   // bounded variant of the emit path: norms, the two sort permutations, per-tile limits
   DeviceBuffer<float> inorm, inorm_sorted, unorm, radius, radius_sorted, sample_item, hard_user;
-  DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_ut, wg_prefix;
+  DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_prefix;
+  DeviceBuffer<int4> wg_desc;
   DeviceBuffer<char> sort_tmp;
   DeviceBuffer<unsigned long long> tiles_scored;
   DeviceBuffer<RowPartial> row_partials;  // chunk sums of the two-level reduction
@@ -1568,7 +1569,8 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
   f.cand_item = e->cand_item.ptr;
   f.cand_cnt = e->cand_cnt.ptr;
   f.bad_flag = e->bad_flag.ptr;
-  f.iperm = f.uperm = f.limit_tiles = f.wg_ut = f.wg_prefix = nullptr;
+  f.iperm = f.uperm = f.limit_tiles = nullptr;
+  f.wg_desc = nullptr;
   f.hard = e->hard.ptr;
   int32_t n_wg = 0;
   if (bounded) {
@@ -1598,11 +1600,10 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
                        e->wg_prefix.ptr, e->bad_flag.ptr + 3);
     IRS_HIP(hipMemcpyAsync(&n_wg, e->bad_flag.ptr + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     IRS_HIP(hipStreamSynchronize(s));
-    e->wg_ut.alloc(std::max<int64_t>(n_wg, 1));
-    hipLaunchKernelGGL(wg_fill_kernel, dim3(ceil_div(n_ut, 4)), dim3(256), 0, s, e->wg_prefix.ptr, n_ut,
-                       e->wg_ut.ptr);
-    f.wg_ut = e->wg_ut.ptr;
-    f.wg_prefix = e->wg_prefix.ptr;
+    e->wg_desc.alloc(std::max<int64_t>(n_wg, 1));
+    hipLaunchKernelGGL(wg_fill_kernel, dim3(ceil_div(n_ut, 4)), dim3(256), 0, s, e->wg_prefix.ptr,
+                       e->limit_tiles.ptr, n_ut, e->wg_desc.ptr);
+    f.wg_desc = e->wg_desc.ptr;
   }
   if (!bounded || n_wg > 0) {
     const int64_t tiles = bounded ? int64_t(n_wg) * 4 : ceil_div(rows, 64) * ceil_div(ni, 64);
