@@ -41,6 +41,15 @@ def main():
     stats = newest(os.path.join(SRC, "kt", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
+    # the JSON line bench.py printed in that same (traced) process: its HIP-event durations are
+    # the ones that have to agree with the trace
+    ktlog = os.path.join(SRC, "kt.log")
+    if os.path.exists(ktlog):
+        for line in open(ktlog):
+            if line.startswith('{"metric"'):
+                json.dump(json.loads(line),
+                          open(os.path.join(DST, f"{TAG}_bench_line_under_rocprofv3_kernel_trace.json"), "w"),
+                          indent=1)
     # the user and the item half-step launch the SAME kernel symbol with different grids:
     # split the trace by grid so that each average can be set against bench.py's per-side
     # HIP-event numbers (the larger MODE-0 grid is the user side)
