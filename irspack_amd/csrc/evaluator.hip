@@ -74,6 +74,14 @@ struct EvalParams {
   int32_t *todo;             // per row: 1 = left to rank_rows_kernel by rank_wave_kernel (or null)
   // score row r stands for row row_map[r] of the call (ground truth, outputs); null: r itself
   const int32_t *row_map = nullptr;
+  // cutoff > SEL_CAP (rank_rows_kernel<..., BIG>): the selected (key, index, hit) lists live in
+  // global scratch, `big_cap` (a power of two >= cutoff) entries per workgroup of the launch;
+  // the launch covers the rows row_base + blockIdx.x
+  int64_t row_base = 0;
+  uint64_t *big_key = nullptr;
+  int32_t *big_idx = nullptr;
+  uint8_t *big_hit = nullptr;
+  int32_t big_cap = 0;
 };
 
 // key value no score maps to (it is the image of a negative NaN pattern, and NaNs are
@@ -94,7 +102,11 @@ template <> struct KeyStore<double> { using type = uint64_t; };
 //   MODE 0 (NT = 256): nowhere, every pass re-reads the scores.
 constexpr int RANK_MAXQ = 32;
 
-template <class T, int NT, int MODE, int MAXQ = RANK_MAXQ>
+// BIG (cutoff > SEL_CAP, any cutoff up to n_items like the reference, evaluator.cpp:263-268):
+// the selected lists are kept in global scratch instead of LDS (a workgroup's own global stores
+// are visible to its other waves after __syncthreads: they share the CU's L1), everything else
+// is the same code.
+template <class T, int NT, int MODE, int MAXQ = RANK_MAXQ, bool BIG = false>
 __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalParams p) {
   using KeyT = typename KeyStore<T>::type;
   constexpr int NWV = NT / 64;
@@ -102,16 +114,20 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
   extern __shared__ __attribute__((aligned(16))) unsigned char rank_dyn[];
   KeyT *keys = reinterpret_cast<KeyT *>(rank_dyn);
   __shared__ uint32_t hist[256];
-  __shared__ uint64_t sel_key[SEL_CAP];
-  __shared__ int32_t sel_idx[SEL_CAP];
-  __shared__ uint8_t sel_hit[SEL_CAP];
+  __shared__ uint64_t sel_key_lds[BIG ? 1 : SEL_CAP];
+  __shared__ int32_t sel_idx_lds[BIG ? 1 : SEL_CAP];
+  __shared__ uint8_t sel_hit_lds[BIG ? 1 : SEL_CAP];
   __shared__ int32_t scan_buf[NWV > 4 ? NWV : 4];
   __shared__ uint64_t sh_prefix;
   __shared__ int32_t sh_need, sh_count;
+  const int sel_cap = BIG ? p.big_cap : SEL_CAP;
+  uint64_t *sel_key = BIG ? p.big_key + static_cast<size_t>(blockIdx.x) * p.big_cap : sel_key_lds;
+  int32_t *sel_idx = BIG ? p.big_idx + static_cast<size_t>(blockIdx.x) * p.big_cap : sel_idx_lds;
+  uint8_t *sel_hit = BIG ? p.big_hit + static_cast<size_t>(blockIdx.x) * p.big_cap : sel_hit_lds;
 
   const int tid = threadIdx.x;
   const int wv = tid >> 6, ln = tid & 63;
-  const int64_t row = blockIdx.x;
+  const int64_t row = p.row_base + blockIdx.x;
   if (p.todo != nullptr && p.todo[row] == 0) return;  // ranked by rank_wave_kernel
   const int64_t orow = p.row_map ? p.row_map[row] : row;
   const int64_t u = orow + p.offset;
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
     for_each_slot([&](int64_t j, uint64_t k) {
       if (k != KEY_SKIP && k >= L) {
         const int pos = atomicAdd(&sh_count, 1);
-        if (pos < SEL_CAP) {
+        if (pos < sel_cap) {
           sel_key[pos] = k;
           sel_idx[pos] = item_of(j);
         }
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
     });
     __syncthreads();
     n_sel = sh_count;
-    fast = n_sel <= SEL_CAP;
+    fast = n_sel <= sel_cap;
     __syncthreads();  // sh_count is reset by the general selection
   }
   if (!fast) {
@@ -514,11 +530,16 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
     sel_hit[i] = (lo < ge && p.gt_idx[lo] == it) ? 1 : 0;
   }
   __syncthreads();
-  if (tid == 0) {  // Metrics::update :136-165, same sequential order
+  if (wv == 0) {
+    // Metrics::update :136-165 in the same sequential order: the wave reads 64 hit flags at a
+    // time and walks the set bits in ascending rank (every lane carries the same sums)
     double dcg = 0, ap = 0;
     int cum_hit = 0;
-    for (int i = 0; i < n_rec; i++) {
-      if (sel_hit[i]) {
+    for (int base = 0; base < n_rec; base += 64) {
+      unsigned long long hits = __ballot(base + ln < n_rec && sel_hit[base + ln] != 0);
+      while (hits) {
+        const int i = base + __ffsll(static_cast<long long>(hits)) - 1;
+        hits &= hits - 1;
         dcg += p.disc[i];
         cum_hit++;
         ap += static_cast<double>(cum_hit) / (i + 1);
@@ -531,7 +552,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 4 : 1) void rank_rows_kernel(EvalPa
                                p.recall_with_cutoff ? (n_gt > n_rec ? n_rec : n_gt) : n_gt);
     res.ndcg = dcg / idcg;
     res.map = ap / n_gt;
-    p.out[orow] = res;
+    if (ln == 0) p.out[orow] = res;
   }
 }
 
@@ -1175,12 +1196,50 @@ void validate_call(irs_evaluator *e, int64_t rows, int64_t cutoff, int64_t offse
   check_arg(offset + rows <= e->n_users, "offset + scores.shape[0] exceeds n_users");
   check_arg(cutoff > 0, "cutoff must be strictly greather than 0.");
   check_arg(cutoff <= e->n_items, "cutoff must not exeeed the number of items.");
-  if (cutoff > SEL_CAP)
-    throw std::invalid_argument("irspack_amd: cutoff above " + std::to_string(SEL_CAP) +
-                                " is not supported by the device ranking kernel.");
+}
+
+// cutoff > SEL_CAP: the lists of a launch's workgroups in global scratch (13 bytes per entry,
+// big_cap entries per row), at most ~1 GiB of it: the rows go through in launches of
+// `per` rows.  Rare (the reference's callers use cutoffs of 5..100), so the goal is only to be
+// correct for every cutoff the reference accepts and not slower than its partial_sort.
+template <class T> void launch_rank_big(EvalParams p, int64_t max_cand, hipStream_t s) {
+  int64_t cap = 1;
+  while (cap < p.cutoff) cap <<= 1;
+  const int64_t per = std::max<int64_t>(1, std::min<int64_t>(p.rows, (int64_t(1) << 30) / (cap * 13)));
+  DeviceBuffer<uint64_t> bk;
+  DeviceBuffer<int32_t> bi;
+  DeviceBuffer<uint8_t> bh;
+  bk.alloc(static_cast<size_t>(per) * cap);
+  bi.alloc(static_cast<size_t>(per) * cap);
+  bh.alloc(static_cast<size_t>(per) * cap);
+  p.big_key = bk.ptr;
+  p.big_idx = bi.ptr;
+  p.big_hit = bh.ptr;
+  p.big_cap = static_cast<int32_t>(cap);
+  p.todo = nullptr;
+  const size_t key_bytes = static_cast<size_t>(std::max<int64_t>(max_cand, 1)) * sizeof(typename KeyStore<T>::type);
+  for (int64_t b = 0; b < p.rows; b += per) {
+    const unsigned m = static_cast<unsigned>(std::min<int64_t>(per, p.rows - b));
+    p.row_base = b;
+    if (key_bytes <= 128 * 1024) {
+      auto kernel = rank_rows_kernel<T, 1024, 1, RANK_MAXQ, true>;
+      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(key_bytes)));
+      hipLaunchKernelGGL(kernel, dim3(m), dim3(1024), key_bytes, s, p);
+    } else {
+      hipLaunchKernelGGL((rank_rows_kernel<T, 256, 0, RANK_MAXQ, true>), dim3(m), dim3(256), 0, s, p);
+    }
+  }
+  IRS_HIP(hipGetLastError());
+  IRS_HIP(hipStreamSynchronize(s));  // the scratch is released on return
 }
 
 template <class T> void launch_rank(EvalParams p, int64_t max_cand, hipStream_t s, int32_t *todo) {
+  if (p.cutoff > SEL_CAP) {
+    launch_rank_big<T>(p, max_cand, s);
+    return;
+  }
   // the usual case first (all items are candidates, cutoff <= 64): one wave per row; the
   // rows it flags (and every row otherwise) go through the general kernel
   p.todo = nullptr;
@@ -1812,7 +1871,7 @@ irs_status irs_eval_create(int64_t n_users, int64_t n_items, const int64_t *indp
     e->rec_ptr.upload(rp, s);
     e->rec_items.upload(ri, s);
     // prepare_dcg_discount (:42-48) and its sequential prefix sums (std::accumulate, :137-139)
-    const int64_t nd = std::min<int64_t>(n_items, SEL_CAP);
+    const int64_t nd = std::max<int64_t>(n_items, 1);  // any cutoff up to n_items (:263-268)
     std::vector<double> disc(nd), pre(nd + 1, 0.0);
     for (int64_t i = 0; i < nd; i++) disc[i] = 1 / std::log2(2 + i);
     for (int64_t i = 0; i < nd; i++) pre[i + 1] = pre[i] + disc[i];
@@ -1966,9 +2025,6 @@ irs_status irs_retrieve_recommend(int32_t is_f64, const void *scores, int64_t ro
               "allowed_indices, if not empty, must have a size equal to X.rows()");
     check_arg(out_idx != nullptr && (rows == 0 || scores != nullptr), "null argument.");
     if (rows == 0 || cutoff <= 0) return;
-    if (cutoff > SEL_CAP)
-      throw std::invalid_argument("irspack_amd: cutoff above " + std::to_string(SEL_CAP) +
-                                  " is not supported by the device ranking kernel.");
     require_device(device);
     hipStream_t s = nullptr;
     // candidate lists keep their order and duplicates; out-of-range ids are dropped (:468-472)

@@ -467,17 +467,12 @@ __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float 
       return;
     }
   }
-  // diagonal: + reg (hpp:312-314); padded dims get 1 so that they decouple
-  {
-    int t = 0;
-#pragma unroll
-    for (int i = 0; i < T; i++) {
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (4 * g + r == m) acc[t][r] += (T * m + i < K) ? reg : 1.0f;
-      t += T - i;
-    }
-  }
+  // The regulariser stays OUT of the matrix: the product is (P + sum c v v^T) vec summed at its
+  // own magnitude, + reg vec in one last fma (the reference's order, hpp:222-223 / 241-242: P x,
+  // then reg x).  With reg on the diagonal every partial sum behind the diagonal term is
+  // rounded at the magnitude of reg vec - visible when reg_r dominates (10^6 items: reg_r = 100)
+  // and the solution is orders of magnitude smaller than the warm start.  Padded dims never
+  // enter (act is false for them).
   {
     int t = 0;
 #pragma unroll
@@ -527,7 +522,7 @@ __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float 
         s = fmaf(a[4 * q + 2], v4.z, s);
         s = fmaf(a[4 * q + 3], v4.w, s);
       }
-      return s;
+      return fmaf(reg, vec, s);
     };
     float r = act ? bv - matvec(x) : 0.f;
     float p = r;
@@ -790,11 +785,7 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
     xrow[64 + lane] = 0.f;
     return;
   }
-#pragma unroll
-  for (int i = 0; i < T; i++)
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-      if (4 * g + r == m) acc[C::tix(i, i)][r] += (T * m + i < K) ? reg : 1.0f;
+  // (the regulariser is not added to the diagonal: see solve_row<T, 1>)
   float *bbuf = sm + C::NT * C::TS;
 #pragma unroll
   for (int i = 0; i < T; i++) {
@@ -840,8 +831,8 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
       s0 = fmaf(a[0][k], vk, s0);
       s1 = fmaf(a[1][k], vk, s1);
     }
-    out[0] = s0;
-    out[1] = s1;
+    out[0] = fmaf(reg, vec[0], s0);
+    out[1] = fmaf(reg, vec[1], s1);
   };
 #pragma unroll
   for (int q = 0; q < 2; q++) x[q] = (warm_start && act[q]) ? xrow[dim[q]] : 0.f;

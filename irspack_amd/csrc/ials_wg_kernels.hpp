@@ -443,7 +443,7 @@ __device__ __forceinline__ void wg_cholesky_tiles(f32x4 (&acc)[WgGeo<T>::TPW], c
 // broadcast vector in LDS.
 template <int T>
 __device__ __forceinline__ void wg_cg_rows(const float *A, const float *bvec, float *pbuf, float *red,
-                                           int K, int nnz, int max_cg_steps, float *xrow,
+                                           float reg, int K, int nnz, int max_cg_steps, float *xrow,
                                            int32_t *err_flag) {
   constexpr int KP = WgGeo<T>::KP;
   const int tid = threadIdx.x;
@@ -486,7 +486,8 @@ __device__ __forceinline__ void wg_cg_rows(const float *A, const float *bvec, fl
       s0 = fmaf(a[4 * q + 2], v.z, s0);
       s1 = fmaf(a[4 * q + 3], v.w, s1);
     }
-    return s0 + s1;
+    // + reg vec last: the regulariser is kept out of the matrix (see solve_row<T, 1>)
+    return fmaf(reg, mine, s0 + s1);
   };
   float x = act ? xrow[dim] : 0.f;  // warm start (hpp:199); zero for fold-in (hpp:132)
   const float Ax = matvec(x);  // barriers inside: every thread calls it the same number of times
@@ -530,7 +531,7 @@ __device__ __forceinline__ void wg_row(const SolveParams &p, int item, float *ld
   // chunk of a split row: the same decision in all four waves, nobody reaches a barrier
   if (!wg_gather<T, W, MODE>(p, item, acc, bsum, row, nnz)) return;
   float *xrow = p.target + static_cast<size_t>(row) * G::KP;
-  wg_add_reg<T, W>(acc, p.reg[row], p.K);
+  if constexpr (SOLVER == 0) wg_add_reg<T, W>(acc, p.reg[row], p.K);
   if constexpr (W == 0) add_prior<T>(p, row, bsum);
   if (p.prior) nnz = max(nnz, 1);  // with a prior an empty row is solved like any other
   if constexpr (SOLVER == 0) {
@@ -542,7 +543,7 @@ __device__ __forceinline__ void wg_row(const SolveParams &p, int item, float *ld
       for (int i = 0; i < T; i++) ybuf[16 * i + (threadIdx.x & 15)] = bsum[i];
     }
     __syncthreads();
-    wg_cg_rows<T>(tiles, ybuf, xbuf, scal + 16, p.K, nnz, p.max_cg_steps, xrow, p.err_flag);
+    wg_cg_rows<T>(tiles, ybuf, xbuf, scal + 16, p.reg[row], p.K, nnz, p.max_cg_steps, xrow, p.err_flag);
   }
 }
 

@@ -200,7 +200,23 @@ class ShardedIALSTrainer:
     """``IALSTrainer.step`` over ``world_size`` ranks (see the module docstring)."""
 
     def __init__(self, local: LocalSolver, user_bounds: Sequence[int], item_bounds: Sequence[int],
-                 group=None, overlap: bool = True):
+                 group=None, overlap: bool = False, gram_group=None, timing: bool = False):
+        """``overlap=True`` issues the NEXT half-epoch's K x K all-reduce on a second
+        communicator while the all-gather of the solved rows is in flight.  It is OFF by
+        default: the two concurrent collectives have only ever run on RCCL at world size 1
+        (no multi-GPU hardware was available to this build; the gloo world-2 tests cover the
+        logic), so the default is the plain sequential exchange until a world >= 2 RCCL run has
+        passed ``tests/test_gpu_sharding.py``.
+
+        ``gram_group``: the second communicator, built by the caller.  When it is None and
+        ``overlap`` is set the constructor calls ``dist.new_group`` - a collective over the
+        DEFAULT group: every rank of the default group must construct the trainer (passing a
+        strict sub-group as ``group`` without a ready-made ``gram_group`` would hang).  A group
+        created here is destroyed by ``close()``.
+
+        ``timing=True`` records per half-epoch the time spent in the Gramian (partial sum +
+        all-reduce), the solve and the row exchange (``last_timing()``; device events on the
+        current stream for CUDA tensors, the host clock otherwise)."""
         import torch
         import torch.distributed as dist
 
@@ -215,13 +231,20 @@ class ShardedIALSTrainer:
         self.exchange = ["none", "none"]
         self._stage = [None, None]
         self.gram_group = group
+        self._owns_gram_group = False
+        self.timing = bool(timing)
+        self._marks = []  # (label, event or host time) of the current epoch
         if self.world > 1:
             # a second communicator: the K x K all-reduce of the next half-epoch's Gramian must
             # not queue behind the all-gather of the solved rows
             if self.overlap:
-                ranks = (list(range(self.world)) if group is None
-                         else [dist.get_global_rank(group, r) for r in range(self.world)])
-                self.gram_group = dist.new_group(ranks=ranks)
+                if gram_group is not None:
+                    self.gram_group = gram_group
+                else:
+                    ranks = (list(range(self.world)) if group is None
+                             else [dist.get_global_rank(group, r) for r in range(self.world)])
+                    self.gram_group = dist.new_group(ranks=ranks)
+                    self._owns_gram_group = True
             gather_ok = self._probe_gather(local.factor_view(0))
             for side in (0, 1):
                 view, b = local.factor_view(side), self.bounds[side]
@@ -238,6 +261,56 @@ class ShardedIALSTrainer:
                     smax = max(b[r + 1] - b[r] for r in range(self.world))
                     self._stage[side] = torch.zeros((self.world * max(smax, 1), view.shape[1]),
                                                     dtype=view.dtype, device=view.device)
+
+    def close(self) -> None:
+        """Destroys the communicator this trainer created (idempotent)."""
+        if self._owns_gram_group and self.gram_group is not None:
+            try:
+                self.dist.destroy_process_group(self.gram_group)
+            except Exception:  # the default group may already be gone at interpreter exit
+                pass
+        self._owns_gram_group = False
+        self.gram_group = self.group
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- phase timing ------------------------------------------------------------------
+    def _mark(self, label: str) -> None:
+        if not self.timing:
+            return
+        view = self.local.factor_view(0)
+        if view.device.type == "cuda":
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record(self.torch.cuda.current_stream(view.device))
+            self._marks.append((label, ev))
+        else:
+            import time
+
+            self._marks.append((label, time.perf_counter()))
+
+    def last_timing(self) -> dict:
+        """ms per phase summed over the marks since the last call: ``gramian_ms`` (own-row
+        partial sum + finish), ``allreduce_ms``, ``solve_ms``, ``allgather_ms`` (the row
+        exchange, with the overlapped all-reduce inside it when ``overlap``),
+        ``exposed_comm_ms`` = all-reduce + exchange time on the critical path, ``total_ms``."""
+        out = {"gramian_ms": 0.0, "allreduce_ms": 0.0, "solve_ms": 0.0, "allgather_ms": 0.0}
+        marks, self._marks = self._marks, []
+        if len(marks) < 2:
+            out.update(exposed_comm_ms=0.0, total_ms=0.0)
+            return out
+        if not isinstance(marks[0][1], float):
+            marks[-1][1].synchronize()
+        for (_, a), (label, b) in zip(marks, marks[1:]):
+            dt = (b - a) * 1e3 if isinstance(a, float) else a.elapsed_time(b)
+            if label in out:
+                out[label] += dt
+        out["exposed_comm_ms"] = out["allreduce_ms"] + out["allgather_ms"]
+        out["total_ms"] = sum(out[k] for k in ("gramian_ms", "allreduce_ms", "solve_ms", "allgather_ms"))
+        return out
 
     def _probe_gather(self, like) -> bool:
         """Can this backend all-gather tensors on the factors' device in ONE call?  Decided
@@ -290,6 +363,8 @@ class ShardedIALSTrainer:
 
     def _reduce_gramian(self, side: int, async_op: bool):
         self.local.partial_gramian(side)
+        if not async_op:
+            self._mark("gramian_ms")
         if self.world > 1:
             return self.dist.all_reduce(self.local.gramian_view(side), op=self.dist.ReduceOp.SUM,
                                         group=self.gram_group, async_op=async_op)
@@ -297,14 +372,19 @@ class ShardedIALSTrainer:
 
     def half_epoch(self, side: int, solver_config) -> None:
         local = self.local
+        if self.timing and not self._marks:
+            self._mark("start")
         # (1) Gramian of the other side: own rows, summed over ranks (K x K, latency bound) -
         #     unless the previous half-epoch already prefetched it
         if not self._gram_ready[side]:
             self._reduce_gramian(side, async_op=False)
+            self._mark("allreduce_ms")
         self._gram_ready[side] = False
         local.finish_gramian(side)
+        self._mark("gramian_ms")
         # (2) solve this rank's rows of `side`
         local.half_step(side, solver_config)
+        self._mark("solve_ms")
         if self.world == 1:
             return
         # (3) all-gather of the freshly solved rows; meanwhile (4) the next half-epoch's
@@ -318,6 +398,7 @@ class ShardedIALSTrainer:
             self._gram_ready[1 - side] = True
         else:
             self._finish_exchange(side, works)
+        self._mark("allgather_ms")
 
     def invalidate(self) -> None:
         """Call after changing the factors from outside (the prefetched Gramian is stale)."""

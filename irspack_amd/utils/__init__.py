@@ -79,11 +79,9 @@ def _retrieve(score: np.ndarray, allowed_item_indices: Sequence[Sequence[int]], 
     for i, l in enumerate(allowed_item_indices):
         litems[lptr[i]:lptr[i + 1]] = np.asarray(l, dtype=np.int64)
     # the reference clamps the list length to the candidate count (util.hpp:476-481): a cutoff
-    # of n_items ("rank everything") needs n_items slots at most.  The device ranking kernel
-    # holds at most 2048 slots per row: refuse a longer request BEFORE allocating rows x cutoff
+    # of n_items ("rank everything") needs n_items slots at most (above 2048 the device keeps
+    # the selected lists in global scratch instead of LDS: rank_rows_kernel<..., BIG>)
     width = max(min(int(cutoff), int(n_items)), 0)
-    if width > 2048:
-        raise ValueError("irspack_amd: cutoff above 2048 is not supported by the device ranking kernel.")
     out = np.full((rows, max(width, 1)), -1, dtype=np.int32)
     check(lib().irs_retrieve_recommend(
         C.c_int32(1 if score.dtype == np.float64 else 0), score.ctypes.data_as(C.c_void_p),

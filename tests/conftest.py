@@ -103,3 +103,31 @@ def row_rel_err(a, b, floor: float = 1e-6) -> float:
     den = np.maximum(np.linalg.norm(b2, axis=1), floor * np.linalg.norm(b2, axis=1).max())
     err = np.where(den > 0, num / np.where(den > 0, den, 1.0), np.where(num > 0, np.inf, 0.0))
     return float(err.max())
+
+
+PARITY_LOG = os.environ.get("IRSPACK_AMD_PARITY_LOG",
+                            os.path.join(ROOT, "gpurun_out", "parity_gpu.jsonl"))
+
+
+def record_parity(test: str, config: str, **fields) -> None:
+    """Appends one JSON line per parity comparison - the ACHIEVED errors, not just pass / fail -
+    to ``gpurun_out/parity_gpu.jsonl`` (``IRSPACK_AMD_PARITY_LOG`` overrides), which a GPU run
+    leaves behind; ``scripts/collect_parity.py`` folds it into the tracked
+    ``profiles/parity_rNN.json``.  Keys used by the factor tests: ``n_rows``,
+    ``worst_row_err`` (max over rows of ||gpu_r - oracle_r|| / ||oracle_r||),
+    ``n_rows_over_1e-4``, ``worst_vs_float64`` (of the arbitrated rows: GPU against the float64
+    evaluation; null when no row needed it) and ``oracle_vs_float64`` beside it."""
+    import json
+
+    rec = {"test": test, "config": config}
+    for k, v in fields.items():
+        if isinstance(v, (np.floating, np.integer)):
+            v = v.item()
+        rec[k] = v
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError as exc:  # a read-only checkout must not fail the parity test itself
+        print(f"record_parity: {exc}", file=sys.stderr)
+    print("PARITY", json.dumps(rec))

@@ -34,7 +34,7 @@ def test_random_blocks_match_oracle(U, I, dtype, cutoff_kind):
     rns = np.random.RandomState(42)
     scores = rns.randn(U, I).astype(dtype)
     gt = sps.csr_matrix((rns.rand(U, I) >= 0.7).astype(np.float64))
-    cutoff = min(I, 2048) if cutoff_kind == "full" else max(1, min(I // 2, 20))
+    cutoff = I if cutoff_kind == "full" else max(1, min(I // 2, 20))  # 5000 > 2048: the BIG lists
     core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
     f = "get_metrics_f64" if dtype == "float64" else "get_metrics_f32"
     for rwc in (False, True):
@@ -436,3 +436,42 @@ def test_bounded_path_on_a_handful_of_users(rows):
     # no mask at all
     m2 = core.get_metrics_ials(t, b, b + rows, None, cutoff, b, True)
     compare(m2, ocore.get_metrics_f32(t.user_scores(b, b + rows, sc), cutoff, b, 4, True))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_cutoff_above_2048_with_ties_masks_and_lists(dtype):
+    """evaluator.cpp:263-268 accepts any 0 < cutoff <= n_items.  Above 2048 the selected lists
+    are kept in global scratch (rank_rows_kernel<..., BIG>): counters and histogram bit-exact
+    against the oracle with heavy ties (integer scores), -inf masks, a global candidate list and
+    per-user lists, offsets, both recall conventions."""
+    rns = np.random.RandomState(7)
+    U, I = 40, 7000
+    scores = rns.randint(0, 50, size=(U, I)).astype(dtype)  # ~140 ties per value
+    scores[rns.rand(U, I) < 0.05] = -np.inf
+    scores[3, :] = -np.inf
+    scores[4, 100:] = -np.inf  # fewer rankable items than the cutoff
+    gt = sps.csr_matrix((rns.rand(U + 5, I) >= 0.98).astype(np.float64))
+    f = "get_metrics_f64" if dtype == "float64" else "get_metrics_f32"
+    glob = [sorted(rns.choice(I, size=5500, replace=False).tolist())]
+    per = [sorted(rns.choice(I, size=int(n), replace=False).tolist())
+           for n in rns.randint(0, 6000, size=U + 5)]
+    for lists in ([], glob, per):
+        core, ocore = EvaluatorCore(gt, lists), O.EvaluatorCore(gt, lists)
+        for cutoff in (2049, 4096, 5000, I):
+            for rwc in (False, True):
+                compare(getattr(core, f)(scores, cutoff, 5, 2, rwc),
+                        getattr(ocore, f)(scores, cutoff, 5, 2, rwc))
+
+
+def test_cutoff_5000_at_ml20m_width():
+    """The shape named by the round-2 review: cutoff = 5,000 at I = 26,744 (float keys in
+    registers do not apply: the BIG kernel keeps them in LDS), counters bit-exact."""
+    rns = np.random.RandomState(3)
+    U, I = 96, 26_744
+    scores = rns.randn(U, I).astype(np.float32)
+    scores[:, ::11] = np.round(scores[:, ::11], 1)  # ties
+    scores[rns.rand(U, I) < 0.01] = -np.inf
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.995).astype(np.float64))
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    for cutoff in (5000, 20_000, I):
+        compare(core.get_metrics_f32(scores, cutoff, 0, 1), ocore.get_metrics_f32(scores, cutoff, 0, 4))

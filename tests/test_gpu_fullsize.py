@@ -2,10 +2,12 @@
 
 Everything here runs the product on the full ML-20M-shaped matrix (138,493 x 26,744,
 20.0 M stored entries) - the unit-confidence rank update with split rows, the two kNN column
-tiles, the 16,384-user evaluator blocks, the fused evaluator at K = 256 - and compares a ROW
-SAMPLE of the result with the CPU oracle, which would need minutes for the whole matrix.
-The sample always contains every row the kernels treat specially (all split rows, the longest
-unsplit rows, the heaviest kNN rows).
+tiles, the 16,384-user evaluator blocks, the fused evaluator at K = 256 - and, round 3, on the
+full configs[3] matrix (10 M x 1 M, 95 M stored entries, K = 128).  On the ML-20M shape EVERY
+row is compared with the CPU oracle (K = 64 and K = 256 factors, all 26,744 kNN rows); on the
+10 M-user matrix every row the kernels treat specially (all split rows, the longest unsplit
+rows) plus 20,000 random ones.  Every comparison appends its ACHIEVED errors to
+gpurun_out/parity_gpu.jsonl (conftest.record_parity; tracked copy profiles/parity_r03.json).
 
 Bars: factors per row ``||gpu_r - oracle_r|| / ||oracle_r|| < 1e-4`` (north_star); kNN indices
 bit-exact, values 1e-12; evaluator counters and histogram bit-exact, fp64 sums 1e-12.
@@ -19,7 +21,7 @@ import pytest
 import scipy.sparse as sps
 
 import oracle as O
-from conftest import row_rel_err
+from conftest import record_parity, row_rel_err
 from irspack_amd.evaluation._core_evaluator import EvaluatorCore
 from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder, IALSSolverConfigBuilder,
                                                   IALSTrainer, SolverType)
@@ -109,26 +111,42 @@ def rows_float64(kind, Xs, rows, tgt0, oth0, alpha0=ALPHA0, reg=REG):
     return out
 
 
-def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what):
+FAR_FRACTION = 1e-3  # at most 0.1 % of the compared rows may need the float64 arbiter
+
+
+def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alpha0=ALPHA0, reg=REG):
     """Per row: within RTOL of the oracle.  Where it is not, the float64 evaluation of the same
-    algorithm arbitrates: on rows with thousands of stored entries the CPU restatement's own
-    float32 rounding (sequential accumulation of the matrix-free product over the row, like the
-    reference's loop hpp:222-247) is up to 6e-4 away from exact arithmetic under truncated CG,
-    so two correct float32 implementations cannot agree to 1e-4 there.  Such a row must be
-    within 3 RTOL of float64 and no farther from it than twice the oracle's own distance (the
-    GPU's MFMA partial sums are usually the closer ones: scripts/debug/cg_fullsize_probe.py)."""
+    algorithm arbitrates: under truncated CG (and for rows with thousands of stored entries) a
+    float32 implementation's own rounding - the CPU restatement's sequential accumulation of the
+    matrix-free product like the reference's loop hpp:222-247, the GPU's MFMA partial sums - is
+    up to ~3e-4 away from exact arithmetic on the worst few rows in 10^5, so two correct
+    float32 implementations cannot agree to 1e-4 on every row.  Rules, with EVERY row compared:
+      * at most FAR_FRACTION of the rows may differ from the oracle by more than RTOL;
+      * on those rows the GPU must be within 3 RTOL of the float64 result, and its worst row
+        must be no farther from float64 than twice the oracle's worst row (the two tails are
+        different rows: the comparison is between the distributions, not row by row).
+    The achieved figures go to the parity log whatever the outcome."""
     num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
     den = np.linalg.norm(want.astype(np.float64), axis=1)
     err = num / np.maximum(den, 1e-6 * den.max())
     far = np.flatnonzero(~(err < RTOL))
-    assert far.size <= 0.05 * len(rows), (what, far.size, float(err.max()))
-    if far.size:
-        ref = rows_float64(kind, Xs, rows[far], tgt0, oth0)
+    rec = dict(n_rows=int(len(rows)), worst_row_err=float(err.max()), median_row_err=float(np.median(err)),
+               p999_row_err=float(np.quantile(err, 0.999)), worst_row=int(rows[int(np.argmax(err))]),
+               worst_row_nnz=int(np.diff(Xs.indptr)[rows[int(np.argmax(err))]]),
+               n_rows_over_1e_4=int(far.size), worst_vs_float64=None, oracle_vs_float64=None)
+    e_gpu = e_orc = None
+    if 0 < far.size <= max(50, 0.05 * len(rows)):
+        ref = rows_float64(kind, Xs, rows[far], tgt0, oth0, alpha0, reg)
         nref = np.linalg.norm(ref, axis=1)
         e_gpu = np.linalg.norm(got[far] - ref, axis=1) / nref
         e_orc = np.linalg.norm(want[far] - ref, axis=1) / nref
-        assert np.all(e_gpu <= np.maximum(2 * e_orc, RTOL)), (what, float(e_gpu.max()), float(e_orc.max()))
+        rec.update(worst_vs_float64=float(e_gpu.max()), oracle_vs_float64=float(e_orc.max()),
+                   n_rows_gpu_closer_to_float64=int((e_gpu <= e_orc).sum()))
+    record_parity(test or "fullsize", str(what), **rec)
+    assert far.size <= max(2, FAR_FRACTION * len(rows)), (what, far.size, float(err.max()))
+    if far.size:
         assert e_gpu.max() < 3 * RTOL, (what, float(e_gpu.max()))
+        assert e_gpu.max() <= max(2 * e_orc.max(), RTOL), (what, float(e_gpu.max()), float(e_orc.max()))
     return float(err.max()), int(far.size)
 
 
@@ -143,7 +161,8 @@ def oracle_rows(target0, Xs, rows, other0, omc, osc):
 def test_ials_k64_ml20m_benchmarked_kernels_vs_oracle(X20, X20t, kind):
     """configs[1]: K = 64, binary data -> ials_solve_kernel<4, *, 0, UNIT> with split rows
     (the 116 k-entry item row runs as 32 chunks) + the MODE 1 reduction.  One half-step per
-    side from identical factors; sample = all split rows + 64 longest unsplit + 2,000 random."""
+    side from identical factors; EVERY row of both sides is compared with the oracle (138,493
+    user rows, 26,744 item rows; the oracle does both in about a second on the box's cores)."""
     K = 64
     mc, sc, omc, osc = configs(K, kind)
     t = IALSTrainer(mc, X20)
@@ -154,10 +173,13 @@ def test_ials_k64_ml20m_benchmarked_kernels_vs_oracle(X20, X20t, kind):
         t.user, t.item = user0, item0
         half_step(t, side, sc)
         got = t.user if side == 0 else t.item
-        rows, split = row_sample(Xs, 2000, seed=side)
-        assert split.size > 1000  # the split path is really exercised
-        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
-        worst[side] = assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0, (kind, side))
+        rows = np.arange(Xs.shape[0])
+        assert (np.diff(Xs.indptr) > 1024).sum() > 1000  # the split path is really exercised
+        P = O.ials_gramian(oth0, omc.alpha0, CORES)
+        want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
+        worst[side] = assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
+                                        f"ml20m K=64 {kind} {'user' if side == 0 else 'item'} half, all rows",
+                                        test="test_ials_k64_ml20m_benchmarked_kernels_vs_oracle")
         assert np.isfinite(got).all()
     # the general (non-unit) rank update on the same inputs: with loss = IALSPP (bias 0) the
     # two code paths perform the same float operations
@@ -178,8 +200,8 @@ def test_ials_k64_ml20m_benchmarked_kernels_vs_oracle(X20, X20t, kind):
 @pytest.mark.parametrize("name,normalize", [("cosine", True), ("cosine", False), ("jaccard", False)])
 def test_knn_top100_ml20m_rows_vs_oracle(X20t, name, normalize):
     """configs[2]: the whole 26,744 x 26,744 top-100 call bench.py times (two column tiles,
-    16-bit tile-relative offsets, persistent workgroups), checked on the 100 heaviest target
-    rows + 400 random ones.  `normalize=False` is the reference's default: raw co-occurrence
+    16-bit tile-relative offsets, persistent workgroups), every one of the 26,744 target rows
+    against the oracle.  `normalize=False` is the reference's default: raw co-occurrence
     counts, where the (value desc, column asc) rule decides most rows (knn.hpp:119-125)."""
     from irspack_amd.recommenders._knn import CosineSimilarityComputer, JaccardSimilarityComputer
 
@@ -192,17 +214,17 @@ def test_knn_top100_ml20m_rows_vs_oracle(X20t, name, normalize):
         ocomp = O.KNNComputer("jaccard", Xt, 0.0, n_threads=CORES, max_chunk_size=4)
     got = comp.compute_similarity(Xt, 100)
     got.sort_indices()
-    nnz = np.diff(Xt.indptr)
-    heavy = np.argsort(-nnz, kind="stable")[:100]
-    rnd = np.random.default_rng(9).choice(Xt.shape[0], size=400, replace=False)
-    rows = np.unique(np.concatenate([heavy, rnd]))
-    want = ocomp.compute_similarity(Xt[rows], 100)
+    want = ocomp.compute_similarity(Xt, 100)  # EVERY target row (round 2 compared 500)
     want.sort_indices()
-    sub = got[rows]
-    sub.sort_indices()
-    assert np.array_equal(sub.indptr, want.indptr)
-    assert np.array_equal(sub.indices, want.indices)  # bit-exact top-k sets
-    np.testing.assert_allclose(sub.data, want.data, rtol=1e-12, atol=0)
+    same_ptr = np.array_equal(got.indptr, want.indptr)
+    same_idx = same_ptr and np.array_equal(got.indices, want.indices)
+    rel = (np.abs(got.data - want.data) / np.maximum(np.abs(want.data), 1e-300)).max() if same_idx else None
+    record_parity("test_knn_top100_ml20m_rows_vs_oracle", f"ml20m {name} normalize={normalize} top_k=100, all rows",
+                  n_rows=int(Xt.shape[0]), indptr_equal=bool(same_ptr), indices_bit_exact=bool(same_idx),
+                  n_entries=int(want.nnz), worst_value_rel_err=None if rel is None else float(rel))
+    assert same_ptr
+    assert same_idx  # bit-exact top-k sets
+    np.testing.assert_allclose(got.data, want.data, rtol=1e-12, atol=0)
     assert np.diff(got.indptr).max() <= 100
 
 
@@ -282,7 +304,8 @@ def test_fused_evaluator_ml20m_vs_oracle(X20, K, path, monkeypatch):
 def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
     """configs[3] shape at 1/50 scale: 200 k x 20 k, geometric degrees (mean 9), Zipf items whose
     head rows are split (107 k entries); K = 128.  CG takes the matrix-free short-row kernels
-    for <= 32 entries, the wave kernel above; every row is compared."""
+    for <= 32 entries, the wave kernel above; Cholesky the low-rank (Woodbury) kernel for short
+    rows; every row is compared."""
     X = make_interactions("c4_small")
     Xt = X.T.tocsr()
     Xt.sort_indices()
@@ -295,10 +318,81 @@ def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
         t.user, t.item = user0, item0
         half_step(t, side, sc)
         got = t.user if side == 0 else t.item
-        rows, _ = row_sample(Xs, 20_000, seed=10 + side)
-        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
-        assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0, (kind, side))
+        rows = np.arange(Xs.shape[0])
+        P = O.ials_gramian(oth0, omc.alpha0, CORES)
+        want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
+        assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
+                          f"c4_small (200k x 20k) K=128 {kind} {'user' if side == 0 else 'item'} half, all rows",
+                          test="test_ials_k128_c4_like_short_rows_vs_oracle")
         assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_ials_k256_ml20m_vs_oracle(X20, X20t, kind):
+    """configs[4]'s trainer: K = 256 on the ML-20M shape - the four-wave 16-row block Cholesky
+    (ials_wg16_cholesky_kernel<16, *>, split rows up to 116 k entries through MODE 1) and the
+    K > 128 CG path.  One half-step per side from frozen factors; EVERY row against the oracle
+    (hpp:273-331, 170-271)."""
+    K = 256
+    mc, sc, omc, osc = configs(K, kind)
+    t = IALSTrainer(mc, X20)
+    t.step(sc)
+    user0, item0 = t.user, t.item
+    for side, (Xs, tgt0, oth0) in enumerate(((X20, user0, item0), (X20t, item0, user0))):
+        t.user, t.item = user0, item0
+        half_step(t, side, sc)
+        got = t.user if side == 0 else t.item
+        rows = np.arange(Xs.shape[0])
+        P = O.ials_gramian(oth0, omc.alpha0, CORES)
+        want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
+        assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
+                          f"ml20m K=256 {kind} {'user' if side == 0 else 'item'} half, all rows",
+                          test="test_ials_k256_ml20m_vs_oracle")
+        assert np.isfinite(got).all()
+
+
+@pytest.fixture(scope="module")
+def XC4():
+    """BASELINE configs[3], the FULL matrix: 10 M users x 1 M items, 95 M stored entries
+    (geometric user degrees, Zipf items: one item row of 4.4 M entries), and its transpose."""
+    X = make_interactions("c4")
+    assert X.shape == (10_000_000, 1_000_000)
+    Xt = X.T.tocsr()
+    Xt.sort_indices()
+    return X, Xt
+
+
+@pytest.mark.parametrize("kind", ["CG", "CHOLESKY"])
+def test_ials_k128_c4_full_matrix_vs_oracle(XC4, kind):
+    """configs[3] at FULL size on one GPU, K = 128: int32 entry offsets near 1e8, the
+    4.4 M-entry item row (the <= 32-chunks-per-row split + the MODE 1 reduction at T = 8), the
+    short-row kernels over 10 M user rows.  One half-step per side from frozen factors (one
+    trained CG epoch), against the oracle on: every split row (> 1024 entries), the 64 longest
+    unsplit rows and 20,000 random rows of each side."""
+    X, Xt = XC4
+    K = 128
+    mc, sc, omc, osc = configs(K, kind)
+    _, sc_cg, _, _ = configs(K, "CG")
+    t = IALSTrainer(mc, X)
+    t.step(sc_cg)
+    user0, item0 = t.user, t.item
+    assert np.isfinite(user0).all() and np.isfinite(item0).all()
+    for side, (Xs, tgt0, oth0) in enumerate(((X, user0, item0), (Xt, item0, user0))):
+        if side == 1:
+            t.user = user0  # the item half reads the frozen user factors
+        half_step(t, side, sc)
+        got = t.user if side == 0 else t.item
+        assert np.isfinite(got).all()
+        rows, split = row_sample(Xs, 20_000, seed=40 + side)
+        if side == 1:
+            assert split.size > 1000 and np.diff(Xs.indptr).max() > 4_000_000
+        got = got[rows]
+        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+        assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
+                          f"c4 FULL (10M x 1M, nnz={X.nnz}) K=128 {kind} {'user' if side == 0 else 'item'} half, "
+                          f"{split.size} split rows + 64 longest + 20k random",
+                          test="test_ials_k128_c4_full_matrix_vs_oracle")
+        del got, want
 
 
 def test_ials_k64_bf16x3_rank_update_is_fp32_accurate(X20, X20t, monkeypatch):
@@ -322,7 +416,9 @@ def test_ials_k64_bf16x3_rank_update_is_fp32_accurate(X20, X20t, monkeypatch):
         got16 = b.user if side == 0 else b.item
         rows, split = row_sample(Xs, 2000, seed=20 + side)
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
-        assert_rows_match(kind, got16[rows], want, Xs, rows, tgt0, oth0, ("bf16x3", side))
+        assert_rows_match(kind, got16[rows], want, Xs, rows, tgt0, oth0,
+                          f"ml20m K=64 bf16x3 rank update {'user' if side == 0 else 'item'} half, sample",
+                          test="test_ials_k64_bf16x3_rank_update_is_fp32_accurate")
         sub = rows[:: max(1, len(rows) // 300)]  # ~300 rows against float64
         ref = rows_float64(kind, Xs, sub, tgt0, oth0)
         nref = np.linalg.norm(ref, axis=1)
@@ -376,18 +472,26 @@ def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
         t.user, t.item = user0, item0
         half_step(t, side, sc)
         got = t.user if side == 0 else t.item
-        rows, _ = row_sample(Xs, 1500, seed=10 + side)
-        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
-        num = np.linalg.norm(got[rows].astype(np.float64) - want, axis=1)
+        rows = np.arange(Xs.shape[0])
+        P = O.ials_gramian(oth0, omc.alpha0, CORES)
+        want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
+        num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
         den = np.linalg.norm(want.astype(np.float64), axis=1)
         err = num / np.maximum(den, 1e-6 * den.max())
         far = np.flatnonzero(~(err < RTOL))
-        assert far.size <= 0.05 * len(rows), (K, side, far.size, float(err.max()))
-        if far.size:
+        rec = dict(n_rows=int(len(rows)), worst_row_err=float(err.max()), median_row_err=float(np.median(err)),
+                   n_rows_over_1e_4=int(far.size), worst_vs_float64=None, oracle_vs_float64=None)
+        e_gpu = e_orc = None
+        if 0 < far.size <= max(50, 0.05 * len(rows)):
             ref = ialspp_float64(Xs, rows[far], tgt0, oth0, 64)
             nref = np.linalg.norm(ref, axis=1)
-            e_gpu = np.linalg.norm(got[rows][far] - ref, axis=1) / nref
+            e_gpu = np.linalg.norm(got[far] - ref, axis=1) / nref
             e_orc = np.linalg.norm(want[far] - ref, axis=1) / nref
-            assert np.all(e_gpu <= np.maximum(2 * e_orc, RTOL)), (K, side, float(e_gpu.max()), float(e_orc.max()))
+            rec.update(worst_vs_float64=float(e_gpu.max()), oracle_vs_float64=float(e_orc.max()))
+        record_parity("test_ialspp_ml20m_vs_oracle",
+                      f"ml20m K={K} iALS++ sub=64 direct={direct} {'user' if side == 0 else 'item'} half, all rows", **rec)
+        assert far.size <= max(2, FAR_FRACTION * len(rows)), (K, side, far.size, float(err.max()))
+        if far.size:
             assert e_gpu.max() < 3 * RTOL, (K, side, float(e_gpu.max()))
+            assert e_gpu.max() <= max(2 * e_orc.max(), RTOL), (K, side, float(e_gpu.max()), float(e_orc.max()))
         assert np.isfinite(got).all()

@@ -35,22 +35,24 @@ def solvers(sub, iters):
                                ialspp_iteration=iters)
 
 
-@pytest.mark.parametrize("K,sub", [(4, 1), (4, 3), (16, 16), (16, 5), (20, 8), (32, 32), (48, 16),
-                                   (64, 64), (64, 16), (64, 24), (64, 33), (40, 64), (128, 64),
-                                   (130, 32),
-                                   # 64-dim blocks of longer rows: the chained passes (2, 3 and 4
-                                   # blocks, a 2-dim and a 36-dim last block)
-                                   (130, 64), (192, 64), (228, 64), (256, 64)])
+_KSUB = [(4, 1), (4, 3), (16, 16), (16, 5), (20, 8), (32, 32), (48, 16),
+         (64, 64), (64, 16), (64, 24), (64, 33), (40, 64), (128, 64), (130, 32),
+         # 64-dim blocks of longer rows: the chained passes (2, 3 and 4 blocks, a 2-dim and
+         # a 36-dim last block)
+         (130, 64), (192, 64), (228, 64), (256, 64)]
+# IRSPACK_AMD_IALSPP_DIRECT only matters when one block covers the row (sub >= K): the
+# "0" form is generated for those shapes only (no skipped combinations)
+_KSUB_DIRECT = [(K, sub, "1") for K, sub in _KSUB] + [(K, sub, "0") for K, sub in _KSUB if sub >= K]
+
+
+@pytest.mark.parametrize("K,sub,direct", _KSUB_DIRECT)
 @pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
-@pytest.mark.parametrize("direct", ["1", "0"])
 def test_epoch_matches_oracle(K, sub, loss, direct, monkeypatch):
     """Every epoch starts from the oracle's factors (teacher forcing), so the comparison is one
     iALS++ epoch (user half then item half) for the same input.  ``direct``: when one block
     covers every dimension (sub >= K) the library computes the block Newton step as the exact
     solve it is (``IRSPACK_AMD_IALSPP_DIRECT``, default on); both forms must match the oracle's
     two-step restatement of hpp:436-502."""
-    if direct == "0" and sub < K:
-        pytest.skip("the switch only matters when one block covers the row")
     monkeypatch.setenv("IRSPACK_AMD_IALSPP_DIRECT", direct)
     X = random_csr(150, 110, 0.1, 3, empty_rows=(7, 40))
     mc, omc = build(K, loss=loss)

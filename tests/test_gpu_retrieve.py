@@ -95,13 +95,26 @@ def test_ml100k_width_rows_with_list_longer_than_items():
     assert_same(retrieve_recommend_from_score(score, lst, 20, 1), restated(score, lst, 20))
 
 
-def test_cutoff_is_clamped_to_the_candidate_count_before_allocating():
-    """cutoff = n_items ("rank everything") is clamped like util.hpp:476-481; a request the
-    device kernel cannot hold is refused up front instead of after a rows x cutoff allocation."""
+def test_cutoff_is_clamped_to_the_candidate_count():
+    """cutoff = n_items ("rank everything") is clamped like util.hpp:476-481."""
     rng = np.random.default_rng(1)
     score = rng.standard_normal((6, 40)).astype(np.float32)
     got = retrieve_recommend_from_score(score, [], 10 ** 9, 1)
     assert_same(got, restated(score, [], 40))
-    big = np.zeros((2, 3000), dtype=np.float32)
-    with pytest.raises(ValueError, match="2048"):
-        retrieve_recommend_from_score(big, [], 3000, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cutoff_above_2048(dtype):
+    """Any cutoff the reference accepts (util.hpp:426-504 has no limit): above 2048 the
+    selected lists live in global scratch (rank_rows_kernel<..., BIG>).  Distinct scores, so
+    the order is fully determined; all items, one global list and per-row lists."""
+    rng = np.random.default_rng(5)
+    rows, I = 5, 6000
+    score = rng.permutation(rows * I).reshape(rows, I).astype(dtype)  # distinct, exact in float32
+    score[1, ::7] = -np.inf
+    for cutoff in (2049, 3000, 5000, I, I + 10):
+        assert_same(retrieve_recommend_from_score(score, [], cutoff, 1), restated(score, [], cutoff))
+    lst = [sorted(rng.choice(I, size=4500, replace=False).tolist())]
+    assert_same(retrieve_recommend_from_score(score, lst, 4000, 1), restated(score, lst, 4000))
+    per = [sorted(rng.choice(I, size=n, replace=False).tolist()) for n in (3000, 10, 5999, 2500, 0)]
+    assert_same(retrieve_recommend_from_score(score, per, 2600, 2), restated(score, per, 2600))

@@ -225,3 +225,125 @@ def test_ialspp_half_step_matches_float64_block_newton(K, sub, loss):
     want = ialspp_half_step_float64(X.astype(np.float32), user0, item0, alpha0, reg, nu, bias, sub, 2)
     err = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
     assert err.max() < 2e-5, err.max()
+
+
+def cg_half_step_float64(X, target, other, alpha0, reg, nu, bias, steps, warm=True):
+    """float64 restatement of Solver::step_cg (hpp:199-264), matrix free like the reference:
+    warm start from the row's current value (:199), `nnz == 0` zeroes the row (:207-210),
+    b (:212-221), r = b - P x - reg x - sum c (v.x) v (:222-228), at most `steps` iterations
+    (0 means K, :232-234) with the two absolute exits at ||r||^2 <= 1e-20 (:238, :258) and
+    beta = new ||r||^2 / old (:261).  Returns the rows and the number of iterations each ran."""
+    X = sps.csr_matrix(X).astype(np.float64)
+    V = other.astype(np.float64)
+    K = V.shape[1]
+    P = alpha0 * V.T @ V
+    out = np.zeros((X.shape[0], K))
+    iters = np.zeros(X.shape[0], dtype=np.int64)
+    for r_ in range(X.shape[0]):
+        sl = slice(X.indptr[r_], X.indptr[r_ + 1])
+        nnz = sl.stop - sl.start
+        if nnz == 0:
+            continue
+        Vr, c = V[X.indices[sl]], X.data[sl]
+        reg_r = float(np.float32(reg) * np.float32(np.float32(alpha0) * V.shape[0] + nnz) ** np.float32(nu))
+        x = target[r_].astype(np.float64).copy() if warm else np.zeros(K)
+        b = ((c + bias)[:, None] * Vr).sum(axis=0)
+        r = b - P @ x - reg_r * x - Vr.T @ (c * (Vr @ x))
+        p = r.copy()
+        for _ in range(K if steps == 0 else steps):
+            r2 = r @ r
+            if r2 <= 1e-20:
+                break
+            Ap = P @ p + reg_r * p + Vr.T @ (c * (Vr @ p))
+            alpha = r2 / (p @ Ap)
+            x += alpha * p
+            r -= alpha * Ap
+            iters[r_] += 1
+            if r @ r <= 1e-20:
+                break
+            p = r + ((r @ r) / r2) * p
+        out[r_] = x
+    return out, iters
+
+
+@pytest.mark.parametrize("steps", [1, 3, 5])
+@pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
+def test_truncated_cg_half_step_matches_float64(steps, loss):
+    """Pins the oracle's TRUNCATED CG - the reference default (max_cg_steps = 3,
+    IALSLearningConfig.hpp:117) and the CG legs of bench.py - to 2e-5 per row; the
+    converged-CG == Cholesky check above cannot see a wrong beta, a wrong warm start or a
+    wrong step count.  Rows with stored entries start from a random row (the warm start,
+    hpp:199); one row is empty (zeroed, hpp:207-210)."""
+    rng = np.random.default_rng(11 + steps)
+    X = sps.random(70, 50, density=0.15, format="csr", random_state=8, dtype=np.float64)
+    X.data = rng.uniform(0.5, 3.0, X.nnz)
+    X = X.tolil()
+    X.rows[5], X.data[5] = [], []
+    X = X.tocsr()
+    K, alpha0, reg, nu = 12, 0.25, 0.05, 0.5
+    mc = O.model_config(K, alpha0=alpha0, reg=reg, nu=nu, loss_type=loss)
+    sc = O.solver_config(2, "CG", steps)
+    user0 = (rng.standard_normal((70, K)) * 0.3).astype(np.float32)
+    item0 = (rng.standard_normal((50, K)) * 0.3).astype(np.float32)
+    P = O.ials_gramian(item0, alpha0, 1)
+    got = O.ials_solver_step(user0, X, item0, P, mc, sc)
+    bias = 0.0 if loss == "IALSPP" else alpha0
+    want, iters = cg_half_step_float64(X.astype(np.float32), user0, item0, alpha0, reg, nu, bias, steps)
+    assert np.all(got[5] == 0) and np.all(want[5] == 0)
+    live = np.flatnonzero(np.diff(X.indptr) > 0)
+    assert iters[live].min() == steps  # truncated: no row converged early
+    err = np.linalg.norm(got[live] - want[live], axis=1) / np.linalg.norm(want[live], axis=1)
+    assert err.max() < 2e-5, err.max()
+    # a different step count must be visibly different at this bar (the pin has teeth)
+    other_steps, _ = cg_half_step_float64(X.astype(np.float32), user0, item0, alpha0, reg, nu, bias, steps + 1)
+    gap = np.linalg.norm(other_steps[live] - want[live], axis=1) / np.linalg.norm(want[live], axis=1)
+    assert np.median(gap) > 1e-3
+
+
+def test_cg_early_exit_and_zero_means_K_steps():
+    """`max_cg_steps = 0` runs up to K iterations (hpp:232-234) and the absolute
+    ||r||^2 <= 1e-20 exits stop a row that has converged (hpp:238, 258): a warm start AT the
+    solution must come back unchanged to float rounding, and the K-step run must equal the
+    float64 normal-equation solve."""
+    rng = np.random.default_rng(4)
+    X = sps.random(40, 30, density=0.2, format="csr", random_state=2, dtype=np.float64)
+    X.data = rng.uniform(0.5, 2.0, X.nnz)
+    K, alpha0, reg = 6, 0.2, 0.5
+    mc = O.model_config(K, alpha0=alpha0, reg=reg, nu=0.0, loss_type="IALSPP")
+    user0 = (rng.standard_normal((40, K)) * 0.3).astype(np.float32)
+    item0 = (rng.standard_normal((30, K)) * 0.3).astype(np.float32)
+    P = O.ials_gramian(item0, alpha0, 1)
+    full = O.ials_solver_step(user0, X, item0, P, mc, O.solver_config(1, "CG", 0))
+    want, iters = cg_half_step_float64(X.astype(np.float32), user0, item0, alpha0, reg, 0.0, 0.0, 0)
+    live = np.flatnonzero(np.diff(X.indptr) > 0)
+    assert iters[live].max() <= K
+    err = np.linalg.norm(full[live] - want[live], axis=1) / np.linalg.norm(want[live], axis=1)
+    assert err.max() < 2e-5, err.max()
+    chol = O.ials_solver_step(user0, X, item0, P, mc, O.solver_config(1, "CHOLESKY", 0))
+    np.testing.assert_allclose(full[live], chol[live], rtol=2e-4, atol=2e-6)
+    # warm start at the converged point: further steps stay there (per row, float32 rounding)
+    again = O.ials_solver_step(full, X, item0, P, mc, O.solver_config(1, "CG", 3))
+    err = np.linalg.norm(again[live] - full[live], axis=1) / np.linalg.norm(full[live], axis=1)
+    assert err.max() < 2e-5, err.max()
+    # the exit at ||r||^2 <= 1e-20 BEFORE the first step (hpp:238): a row whose only item has a
+    # zero factor and that starts at zero has b = 0, r = 0; without the exit the step would
+    # divide 0 / 0 and the denominator test (hpp:250-254) would throw
+    item1 = item0.copy()
+    item1[7] = 0.0
+    X1 = sps.csr_matrix((np.ones(1), ([0], [7])), shape=(3, 30))
+    P1 = O.ials_gramian(item1, alpha0, 1)
+    z = O.ials_solver_step(np.zeros((3, K), dtype=np.float32), X1, item1, P1, mc, O.solver_config(1, "CG", 3))
+    assert np.all(z == 0)
+
+
+def test_cg_fold_in_starts_from_zero(X_small):
+    """transform_user (X_to_vector, hpp:122-141) starts CG from zeros, not from the trained row
+    (hpp:132): equal to the float64 CG from a zero start."""
+    t, mc, _ = train(X_small, 4, 3, "CG", alpha0=0.3, reg=0.2, nu=0.0)
+    got = t.transform_user(X_small, O.solver_config(1, "CG", 2))
+    want, _ = cg_half_step_float64(X_small.astype(np.float32), np.zeros_like(t.user), t.item,
+                                   0.3, 0.2, 0.0, 0.0, 2, warm=False)
+    live = np.flatnonzero(np.diff(X_small.indptr) > 0)
+    err = np.linalg.norm(got[live] - want[live], axis=1) / np.linalg.norm(want[live], axis=1)
+    assert err.max() < 2e-5, err.max()
+    assert np.all(got[3] == 0)

@@ -74,7 +74,7 @@ class OracleLocalSolver(LocalSolver):
         pass
 
 
-def _worker(rank, world, port, kind, out_dir, equal=False):
+def _worker(rank, world, port, kind, out_dir, equal=False, overlap=True):
     import torch
     import torch.distributed as dist
 
@@ -91,13 +91,22 @@ def _worker(rank, world, port, kind, out_dir, equal=False):
     ub, ib = equal_shard_bounds(X, world) if equal else shard_bounds(X, K, kind, world)
     local = OracleLocalSolver(omc, X, (ub[rank], ub[rank + 1], ib[rank], ib[rank + 1]), K,
                               pad=equal)
-    tr = ShardedIALSTrainer(local, ub, ib)
+    # the default is the sequential exchange (overlap off until RCCL has run it at world >= 2)
+    assert ShardedIALSTrainer(local, ub, ib).overlap is False
+    tr = ShardedIALSTrainer(local, ub, ib, overlap=overlap, timing=True)
     for _ in range(2):
         tr.step(sc)
     # one collective per half-epoch either way: in place for equal blocks, through the
     # padded staging rows for the cost-balanced uneven shards
     assert tr.exchange == (["inplace", "inplace"] if equal else ["padded", "padded"])
-    assert tr.gram_group is not None and tr.overlap
+    assert tr.overlap == overlap and (tr.gram_group is not None) == overlap
+    assert tr._owns_gram_group == overlap
+    tm = tr.last_timing()
+    assert set(tm) == {"gramian_ms", "allreduce_ms", "solve_ms", "allgather_ms", "exposed_comm_ms", "total_ms"}
+    assert tm["solve_ms"] > 0 and tm["allgather_ms"] > 0 and tm["total_ms"] >= tm["exposed_comm_ms"]
+    tr.close()
+    tr.close()  # idempotent
+    assert not tr._owns_gram_group
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), user=local.factor[0], item=local.factor[1])
     dist.barrier()
     dist.destroy_process_group()
@@ -111,16 +120,17 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("equal", [False, True])
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
-def test_world2_matches_single_process(tmp_path, kind, equal):
+def test_world2_matches_single_process(tmp_path, kind, equal, overlap):
     import torch.multiprocessing as mp
 
     import oracle as O
     from conftest import random_csr
 
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, kind, str(tmp_path), equal), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, kind, str(tmp_path), equal, overlap), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     # replicas agree bit for bit (solved rows are broadcast; the reduced Gramian is shared)
     np.testing.assert_array_equal(r0["user"], r1["user"])
