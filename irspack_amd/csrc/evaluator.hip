@@ -1346,6 +1346,7 @@ bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int
   void *sv = nullptr;
   if (irs_ials_factors_device_(t, &user, &item, &KP, &nu, &ni, &sv, &dev) != IRS_OK)
     throw std::runtime_error(irs_last_error());
+  if (KP > 256) return false;  // K > 256: the two-pass path (run-time-sized scoring kernel)
   if (ni != e->n_items || ni < 64) return false;
   const int64_t words = ceil_div(ni, 64);
   const int64_t item_tiles = words;
@@ -1502,6 +1503,7 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
   void *sv = nullptr;
   if (irs_ials_factors_device_(t, &user, &item, &KP, &nu, &ni, &sv, &dev) != IRS_OK)
     throw std::runtime_error(irs_last_error());
+  if (KP > 256) return false;  // K > 256: the two-pass path (run-time-sized scoring kernel)
   // worth it only when the sample is a small part of the catalogue
   if (ni != e->n_items || ni < 4 * EM_SAMPLE || rows > (int64_t(1) << 31) / EM_CAP) return false;
   const bool bounded = bound_enabled() && ni < (int64_t(1) << 31) && rows < (int64_t(1) << 31);

@@ -24,6 +24,7 @@
 #include "ials_pp_kernels.hpp"
 #include "ials_feature_kernels.hpp"
 #include "ials_short_kernels.hpp"
+#include "ials_gk_kernels.hpp"
 
 namespace irs {
 
@@ -417,6 +418,8 @@ struct irs_ials_trainer {
   DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   DeviceBuffer<float> pp_pblk;         // iALS++ chain path: blocks of P in accumulator layout
+  DeviceBuffer<float> gk_sys, gk_delta;  // general-size path (ials_gk_kernels.hpp): scratch systems
+  bool gk() const { return KP > 256; }   // K > 256: every size is a run-time value
   Profiler prof;
   bool opt_wave128 = true, opt_unit = true, opt_short = true, opt_wg16 = true;  // read_switches()
   bool opt_short2 = true;  // two short rows per wave (IRSPACK_AMD_IALS_SHORT2)
@@ -471,7 +474,9 @@ namespace {
 
 void validate_config(const irs_ials_model_config &c) {
   check_arg(c.K >= 1, "K must be positive.");
-  check_arg(c.K <= 256, "irspack_amd: n_components above 256 is not supported.");
+  // (no upper limit, like the reference: above 256 the general-size kernels of
+  // ials_gk_kernels.hpp take over; 2^15 keeps K * K and the tile offsets inside int32)
+  check_arg(c.K <= 32768, "irspack_amd: n_components above 32768 is not supported.");
   check_arg(c.loss_type == IRS_LOSS_ORIGINAL || c.loss_type == IRS_LOSS_IALSPP,
             "unknown loss_type.");
 }
@@ -617,6 +622,24 @@ void init_factor(irs_ials_trainer *t, int which) {
 // Gramian of `which` factors over rows [rb, re) into P_raw[dst] (unscaled).
 void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t re, int dst) {
   const int64_t n = std::max<int64_t>(re - rb, 0);
+  if (t->gk()) {  // K > 256: (64 x 64 block pair, row slab) units, slabs summed in order
+    const int KP = t->KP, nb = KP / 64, nbp = nb * (nb + 1) / 2;
+    const int n_slabs = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(64, ceil_div(n, 256))));
+    const int64_t per = ceil_div(ceil_div(std::max<int64_t>(n, 1), n_slabs), 4) * 4;
+    t->gram_partial.alloc(static_cast<size_t>(n_slabs) * KP * KP);
+    t->prof.begin("gramian_partial", t->stream);
+    hipLaunchKernelGGL(gk_gramian_partial_kernel, dim3(ceil_div(static_cast<int64_t>(n_slabs) * nbp, 4)),
+                       dim3(256), 0, t->stream, static_cast<const float *>(t->factor[which].ptr), KP, rb,
+                       re, per, n_slabs, t->gram_partial.ptr);
+    t->prof.end(t->stream);
+    t->prof.begin("gramian_reduce", t->stream);
+    hipLaunchKernelGGL(gk_gramian_reduce_kernel, dim3(ceil_div(static_cast<int64_t>(KP) * KP, 256)),
+                       dim3(256), 0, t->stream, static_cast<const float *>(t->gram_partial.ptr), KP,
+                       n_slabs, t->P_raw[dst].ptr);
+    t->prof.end(t->stream);
+    IRS_HIP(hipGetLastError());
+    return;
+  }
   int64_t n_waves = std::min<int64_t>(1024, std::max<int64_t>(1, ceil_div(n, 64)));
   n_waves = ceil_div(n_waves, 4) * 4;
   int64_t per = ceil_div(std::max<int64_t>(n, 1), n_waves);
@@ -654,6 +677,15 @@ void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t 
 }
 
 void launch_finish_gramian(irs_ials_trainer *t, int dst) {
+  if (t->gk()) {
+    const int64_t n = static_cast<int64_t>(t->KP) * t->KP;
+    t->prof.begin("gramian_finish", t->stream);
+    hipLaunchKernelGGL(gk_gramian_finish_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, t->stream,
+                       static_cast<const float *>(t->P_raw[dst].ptr), t->cfg.alpha0, n, t->P[dst].ptr);
+    t->prof.end(t->stream);
+    IRS_HIP(hipGetLastError());
+    return;
+  }
   IRS_DISPATCH_ANY(t->T, {
     using G = Geo<TT>;
     t->prof.launch("gramian_finish", gramian_finish_kernel<TT>, dim3(ceil_div(G::KP * G::KP, 256)),
@@ -669,9 +701,142 @@ void check_solver(const irs_ials_solver_config *sc) {
   check_arg(sc->solver_type == IRS_SOLVER_CHOLESKY || sc->solver_type == IRS_SOLVER_CG ||
                 sc->solver_type == IRS_SOLVER_IALSPP,
             "unknown solver_type.");
-  if (sc->solver_type == IRS_SOLVER_IALSPP && sc->ialspp_subspace_dimension > 64)
-    throw std::invalid_argument(
-        "irspack_amd: ialspp_subspace_dimension above 64 is not supported by the device solver.");
+}
+
+// ---- general-size path (ials_gk_kernels.hpp): K > 256 and iALS++ blocks wider than 64 ----
+GkParams gk_params(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
+                   const float *prior) {
+  GkParams p{};
+  p.rows = sd.rows_by_len.ptr;
+  p.row_first = 0;
+  p.n_rows = static_cast<int32_t>(sd.row_end - sd.row_begin);
+  p.indptr = sd.indptr.ptr;
+  p.indices = sd.indices.ptr;
+  p.data = sd.data.ptr;
+  p.pred = nullptr;
+  p.other = other;
+  p.ld_other = t->KP;
+  p.target = target;
+  p.ld_target = t->KP;
+  p.reg = sd.reg.ptr;
+  p.P = t->P[pidx].ptr;
+  p.ldP = t->KP;
+  p.prior = prior;
+  p.c0 = 0;
+  p.D = static_cast<int32_t>(t->K);
+  p.Np = static_cast<int32_t>(ceil_div(t->K, 64) * 64);
+  p.K = static_cast<int32_t>(t->K);
+  p.bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;
+  p.mode = 0;
+  p.err_flag = t->err_flag.ptr;
+  return p;
+}
+
+// rows of one pass through the scratch systems (at most IRSPACK_AMD_GK_SCRATCH_MB, default 2048)
+int32_t gk_batch_rows(irs_ials_trainer *t, GkParams &p) {
+  const int64_t nt = p.Np / 16;
+  p.sys_floats = nt * (nt + 1) / 2 * 256 + p.Np;
+  static const int64_t budget_mb = [] {
+    const char *e = std::getenv("IRSPACK_AMD_GK_SCRATCH_MB");
+    return e ? std::max<int64_t>(1, std::atoll(e)) : int64_t(2048);
+  }();
+  const int64_t fit = (budget_mb << 20) / (p.sys_floats * static_cast<int64_t>(sizeof(float)));
+  const int32_t B = static_cast<int32_t>(std::max<int64_t>(1, std::min<int64_t>(p.n_rows, fit)));
+  t->gk_sys.alloc(static_cast<size_t>(B) * p.sys_floats);
+  p.sys = t->gk_sys.ptr;
+  return B;
+}
+
+// rank update + blocked Cholesky of the rows [first, first + m) of the launch order
+void gk_build_and_solve(irs_ials_trainer *t, GkParams p, int32_t first, int32_t m) {
+  p.row_first = first;
+  p.n_rows = m;
+  const int nb = p.Np / 64, nbp = nb * (nb + 1) / 2;
+  if (p.mode == 1)
+    hipLaunchKernelGGL(gk_block_rhs0_kernel, dim3(m), dim3(256), static_cast<size_t>(p.ldP) * sizeof(float),
+                       t->stream, p);
+  hipLaunchKernelGGL(gk_syrk_kernel, dim3(ceil_div(static_cast<int64_t>(m) * nbp, 4)), dim3(256), 0,
+                     t->stream, p);
+  const size_t lds = (4 * 2 * 16 * 17 + p.Np + 16) * sizeof(float);
+  hipLaunchKernelGGL(gk_chol_kernel, dim3(m), dim3(256), lds, t->stream, p);
+}
+
+// Solver::step_cholesky / step_cg for K > 256
+void launch_gk_solve(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
+                     const irs_ials_solver_config *sc, const float *prior, int32_t *err_flag) {
+  GkParams p = gk_params(t, sd, other, target, pidx, prior);
+  p.err_flag = err_flag;
+  const int32_t n = p.n_rows;
+  if (n <= 0) return;
+  if (sc->solver_type == IRS_SOLVER_CG) {
+    const int steps = sc->max_cg_steps == 0 ? static_cast<int>(t->K)
+                                            : static_cast<int>(std::min<uint64_t>(sc->max_cg_steps, 1u << 20));
+    const size_t lds = (8 * static_cast<size_t>(t->KP) + 8) * sizeof(float);
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gk_cg_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    t->prof.begin(pidx == 0 ? "ials_solve_cg_user" : "ials_solve_cg_item", t->stream);
+    hipLaunchKernelGGL(gk_cg_kernel, dim3(n), dim3(256), lds, t->stream, p, steps, 1);
+    t->prof.end(t->stream);
+  } else {
+    const int32_t B = gk_batch_rows(t, p);
+    t->prof.begin(pidx == 0 ? "ials_solve_cholesky_user" : "ials_solve_cholesky_item", t->stream);
+    for (int32_t first = 0; first < n; first += B) gk_build_and_solve(t, p, first, std::min(B, n - first));
+    t->prof.end(t->stream);
+  }
+  IRS_HIP(hipGetLastError());
+}
+
+// Solver::step_ialspp (hpp:516-535) with blocks wider than 64 dims, or at K > 256: per block the
+// Newton step of _step_dimrange (hpp:436-502) through the scratch systems; the prediction cache
+// (hpp:410-413) is corrected after every block but the last (hpp:500-506).
+void launch_ialspp_general(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
+                           const irs_ials_solver_config *sc) {
+  GkParams base = gk_params(t, sd, other, target, pidx, nullptr);
+  if (!t->pp_llt_sink.ptr) {
+    t->pp_llt_sink.alloc(1);
+    t->pp_llt_sink.zero(t->stream);
+  }
+  base.err_flag = t->pp_llt_sink.ptr;  // the reference does not test the LLT status here (hpp:495-497)
+  const int32_t n = base.n_rows;
+  if (n <= 0) return;
+  t->pp_pred.alloc(static_cast<size_t>(sd.nnz) + 320);
+  const int32_t K = static_cast<int32_t>(t->K);
+  const int32_t sub = static_cast<int32_t>(std::min<uint64_t>(std::max<uint64_t>(1, sc->ialspp_subspace_dimension), t->K));
+  base.mode = 1;
+  base.pred = t->pp_pred.ptr;
+  for (uint64_t it = 0; it < sc->ialspp_iteration; it++) {
+    t->prof.begin(pidx == 0 ? "ials_ialspp_user" : "ials_ialspp_item", t->stream);
+    hipLaunchKernelGGL(gk_pred_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, t->stream, base, nullptr,
+                       t->pp_pred.ptr, 0);
+    for (int32_t c0 = 0; c0 < K; c0 += sub) {
+      GkParams p = base;
+      p.c0 = c0;
+      p.D = std::min(sub, K - c0);
+      p.Np = static_cast<int32_t>(ceil_div(p.D, 64) * 64);
+      const int32_t B = gk_batch_rows(t, p);
+      const bool last = c0 + sub >= K;
+      if (!last) t->gk_delta.alloc(static_cast<size_t>(B) * p.D);
+      for (int32_t first = 0; first < n; first += B) {
+        const int32_t m = std::min(B, n - first);
+        GkParams q = p;
+        q.row_first = first;
+        q.n_rows = m;
+        const int64_t nd = static_cast<int64_t>(m) * p.D;
+        if (!last)
+          hipLaunchKernelGGL(gk_block_delta_kernel, dim3(ceil_div(nd, 256)), dim3(256), 0, t->stream, q,
+                             t->gk_delta.ptr, 0);
+        gk_build_and_solve(t, p, first, m);
+        if (!last) {
+          hipLaunchKernelGGL(gk_block_delta_kernel, dim3(ceil_div(nd, 256)), dim3(256), 0, t->stream, q,
+                             t->gk_delta.ptr, 1);
+          hipLaunchKernelGGL(gk_pred_kernel, dim3(ceil_div(m, 4)), dim3(256), 0, t->stream, q,
+                             static_cast<const float *>(t->gk_delta.ptr), t->pp_pred.ptr, 1);
+        }
+      }
+    }
+    t->prof.end(t->stream);
+  }
+  IRS_HIP(hipGetLastError());
 }
 
 // Solver::step_ialspp / step_icd (hpp:516-630): `ialspp_iteration` sweeps, one wave per row.
@@ -680,6 +845,10 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
   static const char *kNames[2] = {"ials_ialspp_user", "ials_ialspp_item"};
   const int32_t n_rows = static_cast<int32_t>(sd.row_end - sd.row_begin);
   if (n_rows <= 0) return;
+  if (t->gk() || sc->ialspp_subspace_dimension > 64) {  // run-time sizes: ials_gk_kernels.hpp
+    launch_ialspp_general(t, sd, other, target, pidx, sc);
+    return;
+  }
   t->pp_pred.alloc(static_cast<size_t>(sd.nnz) + 320);
   if (!t->pp_llt_sink.ptr) {
     t->pp_llt_sink.alloc(1);
@@ -841,6 +1010,20 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       launch_ialspp(t, sd, other, target, pidx, sc);
       return;
     }
+  }
+  if (t->gk()) {
+    int32_t *flag = t->err_flag.ptr;
+    if (pp_direct) {
+      if (!t->pp_llt_sink.ptr) {
+        t->pp_llt_sink.alloc(1);
+        t->pp_llt_sink.zero(t->stream);
+      }
+      flag = t->pp_llt_sink.ptr;
+    }
+    irs_ials_solver_config eff = *sc;
+    if (pp_direct) eff.solver_type = IRS_SOLVER_CHOLESKY;
+    launch_gk_solve(t, sd, other, target, pidx, &eff, prior, flag);
+    return;
   }
   SolveParams p;
   p.prior = prior;
@@ -1355,11 +1538,18 @@ irs_status irs_ials_scores_device_(irs_ials_trainer *t, int64_t begin, int64_t e
     check_arg(device_out != nullptr, "null output.");
     const int64_t waves = ceil_div(m, 64) * ceil_div(t->n_items, 64);
     t->prof.begin("user_scores", t->stream);
-    IRS_DISPATCH_ANY(t->T, {
-      hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
-                         t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m, t->n_items,
+    if (t->gk()) {
+      hipLaunchKernelGGL(gk_user_scores_kernel, dim3(ceil_div(waves, 4)), dim3(256), 0, t->stream,
+                         static_cast<const float *>(t->factor[0].ptr),
+                         static_cast<const float *>(t->factor[1].ptr), t->KP, begin, m, t->n_items,
                          device_out);
-    });
+    } else {
+      IRS_DISPATCH_ANY(t->T, {
+        hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
+                           t->stream, t->factor[0].ptr, t->factor[1].ptr, begin, m, t->n_items,
+                           device_out);
+      });
+    }
     t->prof.end(t->stream);
     IRS_HIP(hipGetLastError());
   });
@@ -1381,12 +1571,19 @@ irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, in
     if (m == 0) return;
     const int64_t waves = ceil_div(m, 64) * ceil_div(n_prefix, 64);
     t->prof.begin("user_scores", t->stream);
-    IRS_DISPATCH_ANY(t->T, {
-      hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
-                         t->stream, user_rows ? user_rows : t->factor[0].ptr,
-                         item_rows ? item_rows : t->factor[1].ptr,
+    if (t->gk()) {
+      hipLaunchKernelGGL(gk_user_scores_kernel, dim3(ceil_div(waves, 4)), dim3(256), 0, t->stream,
+                         user_rows ? user_rows : static_cast<const float *>(t->factor[0].ptr),
+                         item_rows ? item_rows : static_cast<const float *>(t->factor[1].ptr), t->KP,
                          begin, m, n_prefix, device_out);
-    });
+    } else {
+      IRS_DISPATCH_ANY(t->T, {
+        hipLaunchKernelGGL((user_scores_kernel<16 * TT>), dim3(ceil_div(waves, 4)), dim3(256), 0,
+                           t->stream, user_rows ? user_rows : t->factor[0].ptr,
+                           item_rows ? item_rows : t->factor[1].ptr,
+                           begin, m, n_prefix, device_out);
+      });
+    }
     t->prof.end(t->stream);
     IRS_HIP(hipGetLastError());
   });
@@ -1538,7 +1735,7 @@ irs_status irs_ials_apply_feature_prior(irs_ials_trainer *t, int32_t which, cons
     t->f_W[which].upload(padded, t->stream);
     t->prior[which].alloc(static_cast<size_t>(ceil_div(n, 8) * 8) * t->KP);
     t->prof.begin(which == 0 ? "feature_prior_user" : "feature_prior_item", t->stream);
-    hipLaunchKernelGGL(feature_prior_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, t->stream,
+    hipLaunchKernelGGL(feature_prior_kernel, dim3(ceil_div(n, 4), ceil_div(t->KP, 256)), dim3(256), 0, t->stream,
                        t->f_indptr[which].ptr, t->f_indices[which].ptr, t->f_data[which].ptr,
                        t->f_W[which].ptr, n, t->KP, t->prior[which].ptr);
     t->prof.end(t->stream);
@@ -1557,7 +1754,7 @@ irs_status irs_ials_feature_rhs(irs_ials_trainer *t, int32_t which, float *out) 
     const int64_t F = t->n_feat[which];
     t->prof.begin(which == 0 ? "feature_rhs_user" : "feature_rhs_item", t->stream);
     const int nc = t->f_chunks[which];
-    hipLaunchKernelGGL(feature_rhs_kernel, dim3(F, nc), dim3(256), 0, t->stream,
+    hipLaunchKernelGGL(feature_rhs_kernel, dim3(F, nc, ceil_div(t->KP, 256)), dim3(256), 0, t->stream,
                        t->ft_indptr[which].ptr, t->ft_indices[which].ptr, t->ft_data[which].ptr,
                        t->side[which].reg.ptr, t->factor[which].ptr, t->KP,
                        static_cast<int>(FEATURE_RHS_CHUNK), static_cast<int>(F),
@@ -1601,14 +1798,27 @@ irs_status irs_ials_compute_loss(irs_ials_trainer *t, const irs_ials_solver_conf
     for (int s = 0; s < 2; s++) {
       const int64_t n = t->rows_of(s);
       if (n == 0) continue;
-      IRS_DISPATCH_ANY(t->T, {
+      if (t->gk()) {
         t->prof.begin("loss_rows", t->stream);
-        hipLaunchKernelGGL((loss_rows_kernel<TT>), dim3(ceil_div(n, 4)), dim3(256), 0,
-                           t->stream, t->factor[s].ptr, t->factor[1 - s].ptr,
-                           t->side[s].indptr.ptr, t->side[s].indices.ptr, t->side[s].data.ptr,
-                           t->side[s].reg.ptr, n, bias, s == 0 ? 1 : 0, t->row_loss.ptr);
+        hipLaunchKernelGGL(gk_loss_rows_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, t->stream,
+                           static_cast<const float *>(t->factor[s].ptr),
+                           static_cast<const float *>(t->factor[1 - s].ptr), t->KP,
+                           static_cast<const int32_t *>(t->side[s].indptr.ptr),
+                           static_cast<const int32_t *>(t->side[s].indices.ptr),
+                           static_cast<const float *>(t->side[s].data.ptr),
+                           static_cast<const float *>(t->side[s].reg.ptr), n, bias, s == 0 ? 1 : 0,
+                           t->row_loss.ptr);
         t->prof.end(t->stream);
-      });
+      } else {
+        IRS_DISPATCH_ANY(t->T, {
+          t->prof.begin("loss_rows", t->stream);
+          hipLaunchKernelGGL((loss_rows_kernel<TT>), dim3(ceil_div(n, 4)), dim3(256), 0,
+                             t->stream, t->factor[s].ptr, t->factor[1 - s].ptr,
+                             t->side[s].indptr.ptr, t->side[s].indices.ptr, t->side[s].data.ptr,
+                             t->side[s].reg.ptr, n, bias, s == 0 ? 1 : 0, t->row_loss.ptr);
+          t->prof.end(t->stream);
+        });
+      }
       hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, t->stream, t->row_loss.ptr, n,
                          t->loss_sum.ptr + s);
       IRS_HIP(hipGetLastError());

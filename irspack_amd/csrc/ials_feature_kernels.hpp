@@ -19,17 +19,18 @@ __global__ __launch_bounds__(256) void feature_prior_kernel(const int32_t *__res
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};  // KP <= 256
+  const int k0 = 256 * blockIdx.y + lane;  // blockIdx.y: block of 256 latent dims (K > 256)
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int q = indptr[row]; q < indptr[row + 1]; q++) {
     const float v = data[q];
     const float *w = W + static_cast<size_t>(indices[q]) * KP;
 #pragma unroll
     for (int c = 0; c < 4; c++)
-      if (lane + 64 * c < KP) acc[c] = fmaf(v, w[lane + 64 * c], acc[c]);
+      if (k0 + 64 * c < KP) acc[c] = fmaf(v, w[k0 + 64 * c], acc[c]);
   }
 #pragma unroll
   for (int c = 0; c < 4; c++)
-    if (lane + 64 * c < KP) prior[row * KP + lane + 64 * c] = acc[c];
+    if (k0 + 64 * c < KP) prior[row * KP + k0 + 64 * c] = acc[c];
 }
 
 // part[c, f, :] = sum over chunk c of the rows r that store feature f of  val * reg_r *
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void feature_rhs_kernel(const int32_t *__restr
   __shared__ float sh[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int f = blockIdx.x, c = blockIdx.y;
+  const int kb = 256 * blockIdx.z;  // block of 256 latent dims (K > 256)
   const int qb = t_indptr[f] + c * chunk;
   const int qe = min(qb + chunk, t_indptr[f + 1]);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -57,14 +59,16 @@ __global__ __launch_bounds__(256) void feature_rhs_kernel(const int32_t *__restr
     const float *x = factor + static_cast<size_t>(r) * KP;
 #pragma unroll
     for (int cc = 0; cc < 4; cc++)
-      if (lane + 64 * cc < KP) acc[cc] = fmaf(s, x[lane + 64 * cc], acc[cc]);
+      if (kb + lane + 64 * cc < KP) acc[cc] = fmaf(s, x[kb + lane + 64 * cc], acc[cc]);
   }
 #pragma unroll
   for (int cc = 0; cc < 4; cc++) sh[wv][lane + 64 * cc] = acc[cc];
   __syncthreads();
   float *dst = part + (static_cast<size_t>(c) * n_feat + f) * KP;
-  for (int k = threadIdx.x; k < KP; k += 256)
-    dst[k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
+  {
+    const int k = threadIdx.x;
+    if (kb + k < KP) dst[kb + k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
+  }
 }
 
 __global__ void feature_rhs_reduce_kernel(const float *__restrict__ part, int n_chunks,

@@ -111,7 +111,7 @@ def rows_float64(kind, Xs, rows, tgt0, oth0, alpha0=ALPHA0, reg=REG):
     return out
 
 
-FAR_FRACTION = 1e-3  # at most 0.1 % of the compared rows may need the float64 arbiter
+FAR_FRACTION = 1e-3  # at most 0.1 % of the compared rows may be farther than RTOL from float64
 
 
 def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alpha0=ALPHA0, reg=REG):
@@ -119,11 +119,14 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
     algorithm arbitrates: under truncated CG (and for rows with thousands of stored entries) a
     float32 implementation's own rounding - the CPU restatement's sequential accumulation of the
     matrix-free product like the reference's loop hpp:222-247, the GPU's MFMA partial sums - is
-    up to ~3e-4 away from exact arithmetic on the worst few rows in 10^5, so two correct
-    float32 implementations cannot agree to 1e-4 on every row.  Rules, with EVERY row compared:
-      * at most FAR_FRACTION of the rows may differ from the oracle by more than RTOL;
-      * on those rows the GPU must be within 3 RTOL of the float64 result, and its worst row
-        must be no farther from float64 than twice the oracle's worst row (the two tails are
+    up to ~3e-4 (the oracle on rows of 10^4 entries: 2e-3) away from exact arithmetic on the
+    worst rows, so two correct float32 implementations cannot agree to 1e-4 on every row.
+    Rules, with EVERY row compared:
+      * the rows that differ from the oracle by more than RTOL (at most 5 %: the arbiter must
+        stay affordable) are evaluated in float64;
+      * on those rows the GPU must be within 3 RTOL of the float64 result, at most
+        FAR_FRACTION of all rows may be farther than RTOL from it, and its worst row must be
+        no farther from float64 than twice the oracle's worst row (the two tails are
         different rows: the comparison is between the distributions, not row by row).
     The achieved figures go to the parity log whatever the outcome."""
     num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
@@ -141,11 +144,13 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
         e_gpu = np.linalg.norm(got[far] - ref, axis=1) / nref
         e_orc = np.linalg.norm(want[far] - ref, axis=1) / nref
         rec.update(worst_vs_float64=float(e_gpu.max()), oracle_vs_float64=float(e_orc.max()),
-                   n_rows_gpu_closer_to_float64=int((e_gpu <= e_orc).sum()))
+                   n_rows_gpu_over_1e_4_vs_float64=int((e_gpu >= RTOL).sum()),
+                   n_rows_oracle_over_1e_4_vs_float64=int((e_orc >= RTOL).sum()))
     record_parity(test or "fullsize", str(what), **rec)
-    assert far.size <= max(2, FAR_FRACTION * len(rows)), (what, far.size, float(err.max()))
+    assert far.size <= max(50, 0.05 * len(rows)), (what, far.size, float(err.max()))
     if far.size:
         assert e_gpu.max() < 3 * RTOL, (what, float(e_gpu.max()))
+        assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows)), (what, int((e_gpu >= RTOL).sum()))
         assert e_gpu.max() <= max(2 * e_orc.max(), RTOL), (what, float(e_gpu.max()), float(e_orc.max()))
     return float(err.max()), int(far.size)
 
@@ -490,8 +495,9 @@ def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
             rec.update(worst_vs_float64=float(e_gpu.max()), oracle_vs_float64=float(e_orc.max()))
         record_parity("test_ialspp_ml20m_vs_oracle",
                       f"ml20m K={K} iALS++ sub=64 direct={direct} {'user' if side == 0 else 'item'} half, all rows", **rec)
-        assert far.size <= max(2, FAR_FRACTION * len(rows)), (K, side, far.size, float(err.max()))
+        assert far.size <= max(50, 0.05 * len(rows)), (K, side, far.size, float(err.max()))
         if far.size:
             assert e_gpu.max() < 3 * RTOL, (K, side, float(e_gpu.max()))
+            assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows)), (K, side, int((e_gpu >= RTOL).sum()))
             assert e_gpu.max() <= max(2 * e_orc.max(), RTOL), (K, side, float(e_gpu.max()), float(e_orc.max()))
         assert np.isfinite(got).all()

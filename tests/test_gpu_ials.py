@@ -353,10 +353,12 @@ def test_ml100k_shape_parity_c1():
         assert rel_err(t2.user, o2.user) < 1e-2
 
 
-@pytest.mark.parametrize("K", [65, 100, 128, 160, 192, 256])
+@pytest.mark.parametrize("K", [65, 100, 128, 160, 192, 256, 257, 300, 320, 512, 600])
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
 def test_large_k_matches_oracle(K, kind):
-    # 64 < K <= 256: workgroup-per-row kernels (KP = 128 / 192 / 256), BASELINE configs[3], [4]
+    # 64 < K <= 256: workgroup-per-row kernels (KP = 128 / 192 / 256), BASELINE configs[3], [4];
+    # K > 256 (the reference has no limit; its tune range reaches 300, ials.py:358): the
+    # general-size kernels of ials_gk_kernels.hpp (scratch systems in HBM, run-time sizes)
     X = random_csr(90, 260, 0.25, 21, empty_rows=(7,))
     mc, omc = build(K, alpha0=0.1, reg=2e-2)
     sc, osc = solver(kind, steps=3)
@@ -402,10 +404,10 @@ def test_large_k_split_rows():
         assert rel_err(t.user, o.user) < RTOL
 
 
-@pytest.mark.parametrize("K", [20, 100, 200])
+@pytest.mark.parametrize("K", [20, 100, 200, 300])
 def test_loss_user_scores_transform_at_every_kernel_family(K):
-    """compute_loss / user_scores / transform on the K <= 64, K <= 128 and K <= 256 code paths
-    against float64 numpy on the same factors."""
+    """compute_loss / user_scores / transform on the K <= 64, K <= 128, K <= 256 and K > 256 code
+    paths against float64 numpy on the same factors."""
     X = random_csr(60, 45, 0.2, 21, empty_rows=(3,))
     alpha0, reg = 0.1, 0.2
     mc, omc = build(K, alpha0=alpha0, reg=reg, nu=0.0, loss="ORIGINAL")
@@ -444,9 +446,51 @@ def test_cg_short_and_general_rows_mixed(K, loss):
     sc, osc = solver("CG", steps=3)
     t, o = IALSTrainer(mc, X), O.IALSTrainer(omc, X)
     for _ in range(2):
+        t.user, t.item = o.user, o.item  # every epoch from the oracle's factors (same input)
         t.step(sc)
         o.step(osc)
-    assert rel_err(t.user, o.user) < RTOL and rel_err(t.item, o.item) < RTOL
+        assert rel_err(t.user, o.user) < RTOL and rel_err(t.item, o.item) < RTOL
     # fold-in of short and long rows (zero start, hpp:132)
     got, want = t.transform_user(X[:50], sc), o.transform_user(X[:50], osc)
     assert rel_err(got, want) < RTOL
+
+
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_k320_long_rows_batches_and_both_losses(kind, monkeypatch):
+    """K > 256 with rows of thousands of entries (no row splitting on this path), non-binary
+    confidences, loss ORIGINAL (observation bias), and the scratch budget forced so small that
+    the rows go through in several batches (IRSPACK_AMD_GK_SCRATCH_MB)."""
+    monkeypatch.setenv("IRSPACK_AMD_GK_SCRATCH_MB", "2")  # 320 x 320: 0.2 MB per system
+    rng = np.random.default_rng(6)
+    n_u, n_i = 30, 3000
+    lens = [2600, 1500, 1025, 300, 64, 5, 0, 1, 2, 3, 700] + [int(v) for v in rng.integers(1, 200, size=19)]
+    rows = [np.sort(rng.choice(n_i, size=d, replace=False)) for d in lens]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    X = sps.csr_matrix((rng.uniform(0.5, 2.0, size=indptr[-1]).astype(np.float32),
+                        np.concatenate(rows).astype(np.int32), indptr), shape=(n_u, n_i))
+    mc, omc = build(320, alpha0=0.05, reg=1e-2, loss="ORIGINAL")
+    sc, osc = solver(kind)
+    t, o = IALSTrainer(mc, X), O.IALSTrainer(omc, X)
+    t.partial_gramian_async(0)
+    t.finish_gramian_async(0)
+    t.half_step_async(0, sc)
+    t.synchronize()
+    o.step(osc)
+    assert rel_err(t.user, o.user) < RTOL
+    t.user = o.user
+    t.partial_gramian_async(1)
+    t.finish_gramian_async(1)
+    t.half_step_async(1, sc)
+    t.synchronize()
+    # (the item systems are 320 x 320 of rank <= 30 + the regulariser: three CG steps on them
+    # amplify the rounding of either float32 implementation; Cholesky keeps the 1e-4 bar)
+    assert rel_err(t.item, o.item) < (RTOL if kind == "CHOLESKY" else 3 * RTOL)
+
+
+def test_k300_cholesky_failure_is_reported(X_small):
+    """alpha0 = 0 and an empty row: A = 0, the reference throws from LLT (hpp:316-318)"""
+    mc, _ = build(300, alpha0=0.0, reg=1e-3)
+    sc, _ = solver("CHOLESKY")
+    t = IALSTrainer(mc, X_small)
+    with pytest.raises(RuntimeError, match="Cholesky"):
+        t.step(sc)

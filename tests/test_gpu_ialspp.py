@@ -109,13 +109,46 @@ def test_transform_with_ialspp(X_small):
     assert rel_err(u, ou) < RTOL
 
 
-def test_subspace_above_64_is_rejected(X_small):
-    mc, _ = build(128)
-    sc = (IALSSolverConfigBuilder().set_solver_type(SolverType.IALSPP)
-          .set_ialspp_subspace_dimension(128).build())
-    t = IALSTrainer(mc, X_small)
-    with pytest.raises(ValueError, match="ialspp_subspace_dimension"):
+@pytest.mark.parametrize("K,sub", [(128, 100), (130, 65), (200, 128), (256, 128), (256, 200), (256, 255),
+                                   (300, 64), (300, 128), (320, 150), (300, 7), (270, 1), (300, 300), (300, 1000)])
+@pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
+def test_wide_blocks_and_large_k_match_oracle(K, sub, loss):
+    """ialspp_subspace_dimension has no limit in the reference (IALSLearningConfig.hpp:119,
+    139-141; _step_dimrange loops over any block width, hpp:516-535): blocks wider than 64 dims
+    and every block width at K > 256 run on the general-size kernels (ials_gk_kernels.hpp:
+    scratch systems, prediction cache corrected after each block); sub >= K is the direct
+    solve; sub = 1 the iCD branch.  Two sweeps per half-step, teacher-forced epochs."""
+    X = random_csr(150, 110, 0.1, 3, empty_rows=(7, 40))
+    mc, omc = build(K, loss=loss)
+    sc, osc = solvers(sub, 2)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    np.testing.assert_array_equal(t.user, o.user)
+    for _ in range(2):
+        t.user, t.item = o.user, o.item
         t.step(sc)
+        o.step(osc)
+        assert rel_err(t.user, o.user) < RTOL
+        assert rel_err(t.item, o.item) < 10 * RTOL  # the item half sees the user half's rounding
+
+
+def test_wide_blocks_long_rows_and_weights(monkeypatch):
+    """128-dim blocks at K = 256 over rows of thousands of weighted entries, in several scratch
+    batches."""
+    monkeypatch.setenv("IRSPACK_AMD_GK_SCRATCH_MB", "1")
+    rng = np.random.default_rng(8)
+    X = random_csr(24, 6000, 0.5, 13)
+    X.data[:] = rng.uniform(0.5, 2.0, size=X.nnz).astype(np.float32)
+    mc, omc = build(256, alpha0=0.02, reg=1e-2)
+    sc, osc = solvers(128, 1)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    t.partial_gramian_async(0)
+    t.finish_gramian_async(0)
+    t.half_step_async(0, sc)
+    t.synchronize()
+    o.step(osc)
+    assert rel_err(t.user, o.user) < RTOL
 
 
 @pytest.mark.parametrize("K,sub", [(64, 64), (32, 16), (20, 7)])
