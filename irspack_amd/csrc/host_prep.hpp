@@ -1,0 +1,265 @@
+// Multi-threaded host preparation of the iALS trainer (no HIP dependency): the CSR copy with
+// validation, the counting-sort transpose (X^T, hpp:713) and the parallel but bit-identical
+// libstdc++ random stream of Solver::initialize (hpp:64-76).  Included by ials.hip; compiled on
+// its own under ThreadSanitizer / AddressSanitizer by tests/test_host_sanitizers.py.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <thread>
+
+#include "host_util.hpp"
+
+namespace irs {
+namespace ials {
+
+struct HostCsr {
+  int64_t rows = 0, cols = 0;
+  std::vector<int64_t> indptr;
+  RawVector<int32_t> indices;  // (sized, then written: no zero fill of hundreds of MB)
+  RawVector<float> data;
+};
+
+static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
+                        const int32_t *indices, const float *data) {
+  check_arg(rows >= 0 && cols >= 0, "negative matrix shape.");
+  check_arg(indptr != nullptr, "indptr is null.");
+  HostCsr m;
+  m.rows = rows;
+  m.cols = cols;
+  m.indptr.assign(indptr, indptr + rows + 1);
+  const int64_t nnz = indptr[rows];
+  check_arg(indptr[0] == 0 && nnz >= 0, "malformed indptr.");
+  check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31 (32-bit CSR like Eigen's).");
+  for (int64_t r = 0; r < rows; r++) check_arg(indptr[r + 1] >= indptr[r], "malformed indptr.");
+  // the two copies and the index check on a few host threads
+  m.indices.resize(nnz);
+  m.data.resize(nnz);
+  const int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({8, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz / 1000000 + 1})));
+  std::atomic<int> bad(0);
+  auto body = [&](int k) {
+    const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
+    if (e <= b) return;
+    std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
+    std::memcpy(m.data.data() + b, data + b, (e - b) * sizeof(float));
+    int32_t lo = 0, hi = 0;
+    for (int64_t q = b; q < e; q++) {
+      lo = std::min(lo, indices[q]);
+      hi = std::max(hi, indices[q]);
+    }
+    if (lo < 0 || hi >= cols) bad.store(1);
+  };
+  {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &w : th) w.join();
+  }
+  check_arg(bad.load() == 0, "column index out of range.");
+  return m;
+}
+
+// Rows [rb, re) of a CSR as a matrix of the same shape whose other rows are empty: what a
+// rank of a sharded run needs of X (its user rows).  Only the slice is copied and validated.
+static HostCsr host_csr_rows(int64_t rows, int64_t cols, const int64_t *indptr,
+                             const int32_t *indices, const float *data, int64_t rb, int64_t re) {
+  check_arg(rows >= 0 && cols >= 0, "negative matrix shape.");
+  check_arg(indptr != nullptr, "indptr is null.");
+  const int64_t nnz = indptr[rows];
+  check_arg(indptr[0] == 0 && nnz >= 0, "malformed indptr.");
+  check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31 (32-bit CSR like Eigen's).");
+  for (int64_t r = 0; r < rows; r++) check_arg(indptr[r + 1] >= indptr[r], "malformed indptr.");
+  HostCsr m;
+  m.rows = rows;
+  m.cols = cols;
+  m.indptr.assign(rows + 1, 0);
+  const int64_t b = indptr[rb], e = indptr[re];
+  for (int64_t r = rb; r <= rows; r++) m.indptr[r] = std::min(indptr[r], e) - b;
+  m.indices.assign(indices + b, indices + e);
+  m.data.assign(data + b, data + e);
+  for (int64_t p = 0; p < e - b; p++)
+    check_arg(m.indices[p] >= 0 && m.indices[p] < cols, "column index out of range.");
+  return m;
+}
+
+// Rows [cb, ce) of X^T (the columns [cb, ce) of X), other rows empty: a rank's item rows.
+// One scan of X; every column index is validated on the way.
+static HostCsr transpose_cols(int64_t rows, int64_t cols, const int64_t *indptr,
+                              const int32_t *indices, const float *data, int64_t cb, int64_t ce) {
+  HostCsr t;
+  t.rows = cols;
+  t.cols = rows;
+  t.indptr.assign(cols + 1, 0);
+  const int64_t nnz = indptr[rows];
+  for (int64_t p = 0; p < nnz; p++) {
+    const int32_t c = indices[p];
+    check_arg(c >= 0 && c < cols, "column index out of range.");
+    if (c >= cb && c < ce) t.indptr[c + 1]++;
+  }
+  for (int64_t c = 0; c < cols; c++) t.indptr[c + 1] += t.indptr[c];
+  t.indices.resize(t.indptr[cols]);
+  t.data.resize(t.indptr[cols]);
+  std::vector<int64_t> cur(t.indptr.begin() + cb, t.indptr.begin() + ce);
+  for (int64_t r = 0; r < rows; r++)
+    for (int64_t p = indptr[r]; p < indptr[r + 1]; p++) {
+      const int32_t c = indices[p];
+      if (c < cb || c >= ce) continue;
+      const int64_t d = cur[c - cb]++;
+      t.indices[d] = static_cast<int32_t>(r);
+      t.data[d] = data[p];
+    }
+  return t;
+}
+
+// X.transpose() as compressed row-major (hpp:713)
+// A counting sort by column on several host threads: thread k counts the columns of its row
+// range, a prefix over (column, thread) gives every thread its first slot in every column, and
+// the threads scatter their rows - the entries of a column stay in row order, so the result is
+// the sequential one (it was 120 ms of the 270 ms trainer construction on the ML-20M shape).
+static HostCsr transpose(const HostCsr &x) {
+  HostCsr t;
+  t.rows = x.cols;
+  t.cols = x.rows;
+  t.indptr.assign(t.rows + 1, 0);
+  const int64_t nnz = x.indptr[x.rows];
+  t.indices.resize(nnz);
+  t.data.resize(nnz);
+  const int64_t cols = x.cols;
+  // threads: bounded by the counter memory (cols x threads x 8 B <= 256 MB) and the work
+  int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                            nnz / 500000 + 1, (int64_t(1) << 25) / std::max<int64_t>(cols, 1)})));
+  std::vector<int64_t> rb(n_thr + 1, x.rows);
+  for (int k = 0; k < n_thr; k++)  // row ranges of about equal entry counts
+    rb[k] = std::lower_bound(x.indptr.begin(), x.indptr.begin() + x.rows, nnz * k / n_thr) - x.indptr.begin();
+  rb[0] = 0;
+  std::vector<std::vector<int64_t>> cnt(n_thr);
+  auto run = [&](auto &&body) {
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto &q : th) q.join();
+  };
+  run([&](int k) {
+    cnt[k].assign(cols, 0);
+    for (int64_t p = x.indptr[rb[k]]; p < x.indptr[rb[k + 1]]; p++) cnt[k][x.indices[p]]++;
+  });
+  int64_t run_sum = 0;
+  for (int64_t c = 0; c < cols; c++) {  // slot of (column c, thread k) = prefix in that order
+    t.indptr[c] = run_sum;
+    for (int k = 0; k < n_thr; k++) {
+      const int64_t n = cnt[k][c];
+      cnt[k][c] = run_sum;
+      run_sum += n;
+    }
+  }
+  t.indptr[cols] = run_sum;
+  run([&](int k) {
+    std::vector<int64_t> &cur = cnt[k];
+    for (int64_t r = rb[k]; r < rb[k + 1]; r++)
+      for (int64_t p = x.indptr[r]; p < x.indptr[r + 1]; p++) {
+        const int64_t d = cur[x.indices[p]]++;
+        t.indices[d] = static_cast<int32_t>(r);
+        t.data[d] = x.data[p];
+      }
+  });
+  return t;
+}
+
+// Solver::initialize, hpp:64-76: libstdc++ mt19937 + normal_distribution<float>
+// on the host, so a libstdc++ build of the reference draws the same stream.
+// Both matrices are drawn from generators with the SAME seed (hpp:718-719), so the shorter one
+// is a prefix of the longer one's stream: `n` rows are drawn once.
+static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int64_t K, int64_t n) {
+  std::vector<float> h(static_cast<size_t>(n) * K, 0.0f);
+  if (!(init_stdev > 0)) return h;  // the reference leaves the matrix uninitialised; we zero it
+  // std::sqrt(factor.cols()) takes the integral overload (hpp:68-69): the quotient is formed
+  // in double and rounded to float once
+  const float sd = static_cast<float>(static_cast<double>(init_stdev) / std::sqrt(static_cast<double>(K)));
+  std::mt19937 gen(random_seed);
+  const size_t total = h.size();
+  if (total < (size_t(1) << 18)) {
+    std::normal_distribution<float> dist(0.0, sd);
+    for (size_t i = 0; i < total; i++) h[i] = dist(gen);
+    return h;
+  }
+  // Large matrices (1.3 G values at the 10 M x 1 M shape: 56 s of sequential
+  // std::normal_distribution): the SAME stream, bit for bit, in parallel.  libstdc++'s
+  // normal_distribution<float> (bits/random.tcc) is Marsaglia's polar method on
+  // generate_canonical<float, 24>: every attempt consumes exactly two 32-bit words of the
+  // engine, accepted or not, and an accepted attempt yields two variates (y * m first, the
+  // saved x * m next).  So attempt j owns the words 2 j, 2 j + 1 whatever happened before it,
+  // and the output position of an accepted attempt is twice the number of accepted attempts
+  // before it: the engine's words are generated sequentially (the only serial part, ~2.5 ns a
+  // word) and the attempts are evaluated by all host threads with a prefix count.
+  auto canonical = [](uint32_t w) {
+    const float r = static_cast<float>(w) / 4294967296.0f;
+    return r >= 1.0f ? std::nextafter(1.0f, 0.0f) : r;
+  };
+  struct Attempt {
+    float x, y, r2;
+    bool ok;
+  };
+  auto attempt = [&](uint32_t w0, uint32_t w1) {
+    Attempt a;
+    a.x = static_cast<float>(2.0f * canonical(w0) - 1.0);
+    a.y = static_cast<float>(2.0f * canonical(w1) - 1.0);
+    a.r2 = a.x * a.x + a.y * a.y;
+    a.ok = !(a.r2 > 1.0f || a.r2 == 0.0f);
+    return a;
+  };
+  const size_t BLK = size_t(1) << 24;  // attempts per block (128 MB of words)
+  const int n_thr = static_cast<int>(std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
+  // (sized to what the call needs, no zero fill: a 2^18-value factor used to allocate and clear
+  // 128 MB per trainer)
+  RawVector<uint32_t> words;
+  words.resize(2 * std::min(BLK, static_cast<size_t>(((total + 1) / 2) * 1.3) + 4096));
+  std::vector<size_t> cnt(n_thr + 1);
+  size_t produced = 0;
+  while (produced < total) {
+    const size_t want_pairs = (total - produced + 1) / 2;
+    // ~78.5 % of the attempts are accepted; a short block at the end
+    const size_t na = std::min(BLK, static_cast<size_t>(want_pairs * 1.3) + 4096);
+    for (size_t i = 0; i < 2 * na; i++) words[i] = static_cast<uint32_t>(gen());
+    auto range = [&](int th, size_t &b, size_t &e) {
+      b = na * th / n_thr;
+      e = na * (th + 1) / n_thr;
+    };
+    auto count = [&](int th) {
+      size_t b, e, c = 0;
+      range(th, b, e);
+      for (size_t j = b; j < e; j++) c += attempt(words[2 * j], words[2 * j + 1]).ok ? 1 : 0;
+      cnt[th + 1] = c;
+    };
+    auto emit = [&](int th) {
+      size_t b, e;
+      range(th, b, e);
+      size_t pos = produced + 2 * cnt[th];
+      for (size_t j = b; j < e && pos < total; j++) {
+        const Attempt a = attempt(words[2 * j], words[2 * j + 1]);
+        if (!a.ok) continue;
+        const float mult = std::sqrt(-2 * std::log(a.r2) / a.r2);
+        h[pos] = a.y * mult * sd + 0.0f;
+        if (pos + 1 < total) h[pos + 1] = a.x * mult * sd + 0.0f;
+        pos += 2;
+      }
+    };
+    auto run = [&](auto fn) {
+      std::vector<std::thread> th;
+      for (int k = 1; k < n_thr; k++) th.emplace_back(fn, k);
+      fn(0);
+      for (auto &t : th) t.join();
+    };
+    cnt[0] = 0;
+    run(count);
+    for (int k = 0; k < n_thr; k++) cnt[k + 1] += cnt[k];
+    run(emit);
+    produced = std::min(total, produced + 2 * cnt[n_thr]);
+  }
+  return h;
+}
+}  // namespace ials
+}  // namespace irs

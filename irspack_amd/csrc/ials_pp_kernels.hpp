@@ -35,6 +35,7 @@ struct PpParams {
   int32_t *ignored_flag;   // sink for the LLT status bits
   float bias;              // observation_bias (hpp:431-432)
   int32_t K, KP;
+  int32_t xs_extra;        // LDS floats of the x row beyond PpGeo::XS (KP > 256: KP - 256, else 0)
   int32_t sub;             // subspace dimension, >= 1
   int32_t zero_start;      // fold-in: the row starts from 0 (hpp:132)
   int32_t chain;           // 64-dim blocks: prediction passes merged into the rank updates
@@ -44,7 +45,7 @@ struct PpParams {
 template <int TS> struct PpGeo {
   static constexpr int DP = 16 * TS;
   static constexpr int NT = TS * (TS + 1) / 2;
-  static constexpr int XS = 256;  // largest padded K
+  static constexpr int XS = 256;  // x row of a padded K up to 256; PpParams::xs_extra floats more above it
   static constexpr int CHOL_FLOATS = Chol16Geo<TS>::LDS_FLOATS;  // scratch of solve_row_cholesky16
   // Cholesky scratch | x (whole row) | P-part of the rhs | delta
   static constexpr int LDS_FLOATS = CHOL_FLOATS + XS + 2 * DP;
@@ -294,6 +295,40 @@ __device__ __forceinline__ void pp_predict16(const PpParams &p, const float *xs,
   const int nj = p.KP >> 6;  // 64-float segments of a row (KP is a multiple of 64 when K > 64)
   const int32_t *ip = p.indices + begin + g;
   float *pp = p.pred + begin + g;
+  if (nj > 4) {
+    // K > 256: more than four segments per row - the same layout, four segments of an entry in
+    // flight at a time (the two-deep pipeline below keeps a whole row in registers)
+    for (int it = 0; it < nit; it++) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int e = 8 * it + 4 * u + g;
+        const int ix = ip[8 * it + 4 * u];  // (padded arrays)
+        const float *row = p.other + static_cast<size_t>(static_cast<unsigned>(ix)) * p.KP + 4 * m;
+        float dot = 0.f;
+        for (int j0 = 0; j0 < nj; j0 += 4) {
+          f32x4 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = *reinterpret_cast<const f32x4 *>(row + 64 * min(j0 + j, nj - 1));
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (j0 + j < nj) {
+              const f32x4 x4 = *reinterpret_cast<const f32x4 *>(xs + 64 * (j0 + j) + 4 * m);
+              dot = fmaf(x4.x, v[j].x, dot);
+              dot = fmaf(x4.y, v[j].y, dot);
+              dot = fmaf(x4.z, v[j].z, dot);
+              dot = fmaf(x4.w, v[j].w, dot);
+            }
+          }
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        dot += __shfl_xor(dot, 8, 64);
+        if (m == 0 && e < n) pp[8 * it + 4 * u] = dot;
+      }
+    }
+    return;
+  }
   f32x4 xw[4];
 #pragma unroll
   for (int j = 0; j < 4; j++)
@@ -525,9 +560,9 @@ __global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
   const int m = lane & 15;
   const int w = blockIdx.x * 4 + wid;
   if (w >= p.n_rows) return;  // the kernel uses no workgroup barrier
-  float *sm = pp_lds + wid * G::LDS_FLOATS;
+  float *sm = pp_lds + wid * (G::LDS_FLOATS + p.xs_extra);
   float *xs = sm + G::CHOL_FLOATS;
-  float *bnat = xs + G::XS;
+  float *bnat = xs + G::XS + p.xs_extra;
   float *delta = bnat + G::DP;
 
   const int row = p.rows[w];
@@ -646,7 +681,7 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
   const int m = lane & 15;
   float *sm = pp_lds;
   float *xs = sm + G::CHOL_FLOATS;
-  float *bnat = xs + G::XS;
+  float *bnat = xs + G::XS + p.xs_extra;
   float *delta = bnat + G::DP;
   float *parts = delta + G::DP;
 

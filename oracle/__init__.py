@@ -36,19 +36,43 @@ def build(force: bool = False) -> str:
 _lib: Optional[C.CDLL] = None
 
 
-def lib() -> C.CDLL:
+def use_fast_build() -> str:
+    """bench.py's cpu_baseline only: (re)builds ``oracle/_fast/liboracle_fast.so`` ON THIS BOX
+    (``make fast``: -O3 -march=native -ffp-contract=fast, register-blocked rank update - the
+    same algorithm tuned like a CPU BLAS would be, NOT the parity oracle) and makes this
+    process's oracle calls go to it.  Never call it from a parity test."""
     global _lib
+    subprocess.check_call(["make", "-s", "-C", _HERE, "fast"])
+    so = os.path.join(_HERE, "_fast", "liboracle_fast.so")
+    _lib = None
+    _load(so)
+    return so
+
+
+def lib() -> C.CDLL:
     if _lib is None:
         build()
-        _lib = C.CDLL(_SO)
-        _lib.orc_last_error.restype = C.c_char_p
-        _lib.orc_knn_last_error.restype = C.c_char_p
-        _lib.orc_eval_last_error.restype = C.c_char_p
-        _lib.orc_ials_create.restype = C.c_void_p
-        _lib.orc_ials_user_ptr.restype = C.POINTER(C.c_float)
-        _lib.orc_ials_item_ptr.restype = C.POINTER(C.c_float)
-        _lib.orc_metrics_create.restype = C.c_void_p
+        _load(_SO)
     return _lib
+
+
+def _load(so: str) -> None:
+    global _lib
+    _lib = C.CDLL(so)
+    _lib.orc_last_error.restype = C.c_char_p
+    _lib.orc_knn_last_error.restype = C.c_char_p
+    _lib.orc_eval_last_error.restype = C.c_char_p
+    _lib.orc_ials_create.restype = C.c_void_p
+    _lib.orc_ials_user_ptr.restype = C.POINTER(C.c_float)
+    _lib.orc_ials_item_ptr.restype = C.POINTER(C.c_float)
+    _lib.orc_metrics_create.restype = C.c_void_p
+
+
+def use_parity_build() -> None:
+    """back to ``liboracle.so`` (the parity oracle) after ``use_fast_build``"""
+    global _lib
+    _lib = None
+    lib()
 
 
 class ModelConfig(C.Structure):

@@ -198,6 +198,46 @@ void step_cholesky(float *target, int64_t n_rows, const Csr &X,
     auto consume = [&](int64_t n_batch) {
       // target.rankUpdate(buffer^T): upper triangle += buffer^T buffer (hpp:48).
       // The batch product is summed first and then added, like Eigen's kernel.
+#ifdef ORACLE_FAST
+      // cpu_baseline build only (make fast): the same batch product as a register-blocked
+      // 4 x 16 micro-kernel (4 rows of the triangle x 16 columns accumulate over the batch in
+      // registers; with -march=native -ffp-contract=fast the column loop is 1-2 vector FMAs),
+      // what a tuned CPU SYRK does.  Not used for parity: the sum order is the same, the
+      // contraction of a * b + c into one FMA is not.
+      for (int64_t i0 = 0; i0 < K; i0 += 4) {
+        const int64_t ni = std::min<int64_t>(4, K - i0);
+        for (int64_t j0 = i0 & ~int64_t(15); j0 < K; j0 += 16) {
+          const int64_t nj = std::min<int64_t>(16, K - j0);
+          float a4[4][16];
+          for (int a = 0; a < 4; a++)
+            for (int c = 0; c < 16; c++) a4[a][c] = 0.0f;
+          if (ni == 4 && nj == 16) {
+            for (int64_t r = 0; r < n_batch; r++) {
+              const float *br = buffer.data() + r * K;
+              const float b0 = br[i0], b1 = br[i0 + 1], b2 = br[i0 + 2], b3 = br[i0 + 3];
+#pragma GCC unroll 16
+              for (int c = 0; c < 16; c++) {
+                const float bj = br[j0 + c];
+                a4[0][c] += b0 * bj;
+                a4[1][c] += b1 * bj;
+                a4[2][c] += b2 * bj;
+                a4[3][c] += b3 * bj;
+              }
+            }
+          } else {
+            for (int64_t r = 0; r < n_batch; r++) {
+              const float *br = buffer.data() + r * K;
+              for (int64_t a = 0; a < ni; a++)
+                for (int64_t c = 0; c < nj; c++) a4[a][c] += br[i0 + a] * br[j0 + c];
+            }
+          }
+          for (int64_t a = 0; a < ni; a++)
+            for (int64_t c = 0; c < nj; c++)
+              if (j0 + c >= i0 + a) P_local[(i0 + a) * K + j0 + c] += a4[a][c];
+        }
+      }
+      return;
+#endif
       for (int64_t i = 0; i < K; i++) {
         float *a = acc.data();
         for (int64_t j = i; j < K; j++) a[j] = 0.0f;

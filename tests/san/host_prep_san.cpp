@@ -1,0 +1,124 @@
+// Sanitizer harness of the multi-threaded HOST preparation of libirspack_amd.so (no GPU): the
+// validated CSR copy, the counting-sort transposes and the parallel libstdc++ random stream of
+// irspack_amd/csrc/host_prep.hpp, and the kNN target pass helpers of knn_host_prep.hpp.  Built
+// and run by tests/test_host_sanitizers.py with -fsanitize=thread and -fsanitize=address,undefined.
+// Every multi-threaded result is compared with a sequential evaluation.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "../../irspack_amd/csrc/host_prep.hpp"
+#include "../../irspack_amd/csrc/knn_host_prep.hpp"
+
+using namespace irs;
+
+#define CHECK(cond)                                                       \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      std::exit(1);                                                       \
+    }                                                                     \
+  } while (0)
+
+int main() {
+  // ---- a random CSR large enough for every helper to take several threads
+  const int64_t rows = 30000, cols = 4000;
+  std::mt19937_64 rng(7);
+  std::vector<int64_t> indptr(rows + 1, 0);
+  std::vector<int32_t> indices;
+  std::vector<float> data;
+  for (int64_t r = 0; r < rows; r++) {
+    const int deg = static_cast<int>(rng() % 200);
+    std::vector<char> seen(cols, 0);
+    std::vector<int32_t> row;
+    for (int d = 0; d < deg; d++) {
+      const int32_t c = static_cast<int32_t>(rng() % cols);
+      if (!seen[c]) {
+        seen[c] = 1;
+        row.push_back(c);
+      }
+    }
+    std::sort(row.begin(), row.end());
+    for (int32_t c : row) {
+      indices.push_back(c);
+      data.push_back(static_cast<float>(rng() % 1000) / 100.0f + 0.5f);
+    }
+    indptr[r + 1] = static_cast<int64_t>(indices.size());
+  }
+  const int64_t nnz = indptr[rows];
+  CHECK(nnz > 2500000);
+  // ---- iALS: copy + validation, transpose (counting sort on several threads)
+  const ials::HostCsr X = ials::host_csr(rows, cols, indptr.data(), indices.data(), data.data());
+  CHECK(X.indptr == indptr);
+  CHECK(std::equal(indices.begin(), indices.end(), X.indices.begin()));
+  const ials::HostCsr Xt = ials::transpose(X);
+  {  // sequential transpose
+    std::vector<int64_t> tp(cols + 1, 0);
+    for (int64_t p = 0; p < nnz; p++) tp[indices[p] + 1]++;
+    for (int64_t c = 0; c < cols; c++) tp[c + 1] += tp[c];
+    CHECK(Xt.indptr == tp);
+    std::vector<int64_t> cur(tp.begin(), tp.end() - 1);
+    std::vector<int32_t> ti(nnz);
+    std::vector<float> td(nnz);
+    for (int64_t r = 0; r < rows; r++)
+      for (int64_t p = indptr[r]; p < indptr[r + 1]; p++) {
+        const int64_t d = cur[indices[p]]++;
+        ti[d] = static_cast<int32_t>(r);
+        td[d] = data[p];
+      }
+    CHECK(std::equal(ti.begin(), ti.end(), Xt.indices.begin()));
+    CHECK(std::equal(td.begin(), td.end(), Xt.data.begin()));
+  }
+  {  // a rank's shard: rows [rb, re) of X and the columns [cb, ce) of X as rows of X^T
+    const int64_t rb = 1000, re = 17000, cb = 100, ce = 2100;
+    const ials::HostCsr S = ials::host_csr_rows(rows, cols, indptr.data(), indices.data(), data.data(), rb, re);
+    CHECK(S.indptr[rows] == indptr[re] - indptr[rb] && S.indptr[rb] == 0);
+    const ials::HostCsr T = ials::transpose_cols(rows, cols, indptr.data(), indices.data(), data.data(), cb, ce);
+    for (int64_t c = cb; c < ce; c++) {
+      CHECK(T.indptr[c + 1] - T.indptr[c] == Xt.indptr[c + 1] - Xt.indptr[c]);
+      CHECK(std::equal(T.indices.begin() + T.indptr[c], T.indices.begin() + T.indptr[c + 1],
+                       Xt.indices.begin() + Xt.indptr[c]));
+    }
+    CHECK(T.indptr[cb] == 0 && T.indptr[cols] == T.indptr[ce]);
+  }
+  // ---- the parallel random stream is the sequential libstdc++ one, bit for bit (> 2^18 values)
+  for (const int64_t K : {int64_t(64), int64_t(10)}) {
+    const int64_t n = K == 64 ? 6000 : 40000;
+    const float stdev = 0.1f;
+    const std::vector<float> par = ials::draw_factor(stdev, 42, K, n);
+    CHECK(par.size() == static_cast<size_t>(n * K) && par.size() >= (size_t(1) << 18));
+    std::mt19937 gen(42);
+    const float sd = static_cast<float>(static_cast<double>(stdev) / std::sqrt(static_cast<double>(K)));
+    std::normal_distribution<float> dist(0.0, sd);
+    for (size_t i = 0; i < par.size(); i++) {
+      const float want = dist(gen);
+      if (par[i] != want) {
+        std::fprintf(stderr, "stream differs at %zu: %a vs %a\n", i, par[i], want);
+        return 1;
+      }
+    }
+  }
+  // ---- kNN: parallel fp64 CSR copy, transpose, per-row pass
+  {
+    std::vector<double> dd(data.begin(), data.end());
+    const knn::HostCsrD D = knn::host_csr(rows, cols, indptr.data(), indices.data(), dd.data());
+    const knn::HostCsrD Dt = knn::transpose(D);
+    CHECK(Dt.indptr == Xt.indptr);
+    CHECK(std::equal(Dt.indices.begin(), Dt.indices.end(), Xt.indices.begin()));
+    for (int64_t p = 0; p < nnz; p++) CHECK(Dt.data[p] == static_cast<double>(Xt.data[p]));
+    std::vector<double> norms(rows, 0.0);
+    knn::for_rows_parallel(D.indptr, rows, [&](int64_t r) {
+      double s = 0;
+      for (int64_t p = D.indptr[r]; p < D.indptr[r + 1]; p++) s += D.data[p] * D.data[p];
+      norms[r] = s;
+    });
+    for (int64_t r = 0; r < rows; r += 997) {
+      double s = 0;
+      for (int64_t p = indptr[r]; p < indptr[r + 1]; p++) s += dd[p] * dd[p];
+      CHECK(norms[r] == s);
+    }
+  }
+  std::puts("host_prep_san ok");
+  return 0;
+}

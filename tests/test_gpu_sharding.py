@@ -87,9 +87,15 @@ def test_two_ranks_match_single_gpu(tmp_path, kind, equal, K):
     assert row_rel_err(r0["item"], ref.item) < 5e-4
 
 
-def test_bench_two_ranks_control_flow():
-    """bench.py's N > 1 path (process group, equal shards, barrier + max-over-ranks timing,
-    one JSON line from rank 0) with two ranks on one device over gloo."""
+@pytest.mark.parametrize("extra", [["--shape", "small"],
+                                   ["--shape", "small", "--balance", "cost", "--solver", "CG"],
+                                   ["--shape", "c4_small", "--K", "128", "--solver", "CG"]])
+def test_bench_two_ranks_control_flow(extra):
+    """bench.py's N > 1 path (process group, shards, barrier + max-over-ranks timing, the
+    per-phase compute / all-reduce / all-gather split, one JSON line from rank 0) with two ranks
+    on one device over gloo: equal shards, cost-balanced shards, and the configs[3] invocation
+    (`--shape c4 --K 128 --solver CG`, here its 1/50-scale matrix), whose longest row selects
+    the cost balance by itself."""
     import json
     import os
     import subprocess
@@ -100,14 +106,20 @@ def test_bench_two_ranks_control_flow():
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
-         "--gpus", "2", "--steps", "2", "--warmup", "1", "--shape", "small"],
-        env=env, capture_output=True, text=True, timeout=600, cwd=root)
+         "--gpus", "2", "--steps", "2", "--warmup", "1", *extra],
+        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert "roofline" in d and d["roofline"]["frac"] > 0
+    want_balance = "equal" if extra == ["--shape", "small"] else "cost"
+    assert d["config"]["balance"] == want_balance
+    c = d["comm"]
+    assert c["compute_ms"] > 0 and c["allgather_ms"] > 0 and c["allreduce_ms"] >= 0
+    assert 0 < c["exposed_comm_ms"] <= c["allreduce_ms"] + c["allgather_ms"] + 1e-6
+    assert len(c["exchange"]) == 2 and c["overlap"] is False
 
 
 def _knn_eval_worker(rank, world, port, out_dir):
