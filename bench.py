@@ -255,7 +255,9 @@ def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
         "ms_per_epoch": dt * 1e3, "updates_per_s": (U + I) / dt, "steps": steps, "warmup": warmup,
         "kernels_ms_per_launch": kernels,
         "roofline": both_terms(priced, byts, dt, ceilings,
-                               bound="mfma" if kind == "CHOLESKY" else None,
+                               # CG: when most of the executed flops are the explicit K x K build
+                               # (rows above 32 entries) the kernel is issue-bound like Cholesky
+                               bound="mfma" if kind == "CHOLESKY" or priced > 1.5 * flops else None,
                                scope="whole epoch (all kernels)",
                                algorithmic_gflop_per_epoch=flops / 1e9,
                                algorithmic_gbyte_per_epoch=byts / 1e9,

@@ -26,6 +26,7 @@
 #include "ials_feature_kernels.hpp"
 #include "ials_short_kernels.hpp"
 #include "ials_gk_kernels.hpp"
+#include "ials_eig_kernels.hpp"
 
 namespace irs {
 
@@ -77,6 +78,8 @@ struct Side {
   // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
   int32_t n_short = 0, n_short16 = 0;
   bool unit = false;  // every stored confidence is exactly 1 (UNIT kernels)
+  bool positive = false;  // every stored confidence is > 0 (eigenbasis short-row kernels)
+  float reg_min = 0.f;    // smallest per-row regulariser of the rows [row_begin, row_end)
 
   void build(const HostCsr &m, int64_t rb, int64_t re, const irs_ials_model_config &cfg,
              hipStream_t s) {
@@ -86,6 +89,7 @@ struct Side {
     row_end = re;
     nnz = m.indptr[m.rows];
     unit = std::all_of(m.data.begin(), m.data.end(), [](float v) { return v == 1.0f; });
+    positive = unit || std::all_of(m.data.begin(), m.data.end(), [](float v) { return v > 0.0f; });
     std::vector<int32_t> ip32(m.rows + 1);
     for (int64_t r = 0; r <= m.rows; r++) ip32[r] = static_cast<int32_t>(m.indptr[r]);
     std::vector<float> regs(m.rows);
@@ -94,6 +98,8 @@ struct Side {
       const int64_t nz = m.indptr[r + 1] - m.indptr[r];
       regs[r] = cfg.reg * std::pow(cfg.alpha0 * m.cols + nz, cfg.nu);
     }
+    reg_min = 0.f;
+    for (int64_t r = rb; r < re; r++) reg_min = r == rb ? regs[r] : std::min(reg_min, regs[r]);
     const int CH = chunk_size();
     std::vector<Task> tk;
     std::vector<SplitRow> sp;
@@ -266,6 +272,13 @@ struct irs_ials_trainer {
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   DeviceBuffer<float> pp_pblk;         // iALS++ chain path: blocks of P in accumulator layout
   DeviceBuffer<float> gk_sys, gk_delta;  // general-size path (ials_gk_kernels.hpp): scratch systems
+  // eigenbasis short-row path (ials_eig_kernels.hpp)
+  DeviceBuffer<float> eig_Qrows, eig_Qcols, eig_lam, eig_stats, eig_table, eig_xt;
+  DeviceBuffer<double> eig_Qd[2];   // per solved side: float64 eigenvectors, the next call's warm start
+  bool eig_warm[2] = {false, false};
+  float eig_stats_host[4] = {0, 0, 0, 0};
+  bool opt_eig = true;  // IRSPACK_AMD_IALS_EIG
+  int32_t eig_last = 0; // 1: the last half-step took the eigenbasis path (diagnostics)
   bool gk() const { return KP > 256; }   // K > 256: every size is a run-time value
   Profiler prof;
   bool opt_wave128 = true, opt_unit = true, opt_short = true, opt_wg16 = true;  // read_switches()
@@ -744,6 +757,178 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_pp_fork = env_flag("IRSPACK_AMD_IALSPP_FORK", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
   t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
+  t->opt_eig = env_flag("IRSPACK_AMD_IALS_EIG", true);
+}
+
+// Eigen-decomposition of P[pidx] (row-major [KP, KP]) into the trainer's eig_* buffers.
+void launch_eigen(irs_ials_trainer *t, int pidx, hipStream_t stream) {
+  const int KP = t->KP;
+  t->eig_Qrows.alloc(static_cast<size_t>(KP) * KP);
+  t->eig_Qcols.alloc(static_cast<size_t>(KP) * KP);
+  t->eig_lam.alloc(KP);
+  t->eig_stats.alloc(4);
+  t->eig_Qd[pidx].alloc(static_cast<size_t>(KP) * KP);
+  EigOut o{t->eig_Qrows.ptr, t->eig_Qcols.ptr, t->eig_lam.ptr, t->eig_stats.ptr, t->eig_Qd[pidx].ptr};
+  const int warm = t->eig_warm[pidx] ? 1 : 0;
+  t->eig_warm[pidx] = true;
+  const size_t lds = static_cast<size_t>(KP) * KP * sizeof(double);
+  auto launch = [&](auto kernel) {
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    t->prof.begin("eig_jacobi", stream);
+    hipLaunchKernelGGL(kernel, dim3(1), dim3(1024), lds, stream,
+                       static_cast<const float *>(t->P[pidx].ptr), static_cast<int>(t->K), o, warm);
+    t->prof.end(stream);
+  };
+  if (KP == 128) launch(eig_jacobi_kernel<128>);
+  else launch(eig_jacobi_kernel<64>);
+  IRS_HIP(hipGetLastError());
+}
+
+// Short rows (<= 32 stored entries, the tail of the task list) in the eigenbasis of P
+// (ials_eig_kernels.hpp), on a SECOND stream beside the kernels of the longer rows: the
+// eigen-decomposition is one workgroup (1 - 3 ms of one CU) and must not leave the other 255 idle.
+//   eig_begin   decides from host-side facts whether the path is a candidate and, if so, forks the
+//               second stream and starts the decomposition + the copy of its statistics;
+//   eig_finish  (after the caller has launched the long rows on the main stream) waits for the
+//               statistics, checks the conditioning, runs table product / short-row kernels /
+//               rotation on the second stream and joins it.  Returns false - nothing launched
+//               that changes the factors - when the path declines; the caller then runs its
+//               usual kernels over those rows.
+bool eig_begin(irs_ials_trainer *t, Side &sd, int pidx) {
+  t->eig_last = 0;
+  const int KP = t->KP;
+  if (!t->opt_eig || (KP != 64 && KP != 128) || !sd.positive || sd.n_short <= 0) return false;
+  // worth one eigen-decomposition (milliseconds of ONE compute unit) and the product that takes
+  // every gathered row into the eigenbasis (n_other x KP x KP multiply-adds, 8 KP bytes per row)?
+  // configs[3]: the user side (9.7 M short rows, 10^6 gathered rows) yes, the item side (0.8 M
+  // short rows, 10^7 gathered rows: the product alone would cost more than those rows) no.
+  if (static_cast<double>(sd.n_short) * KP * KP * KP < 3e11) return false;
+  if (static_cast<double>(sd.n_short) * KP < 64.0 * static_cast<double>(sd.n_other)) return false;
+  if (!t->stream2) {
+    IRS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+    IRS_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+    IRS_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+  }
+  IRS_HIP(hipEventRecord(t->ev_fork, t->stream));  // (the Gramian of this half-step is on t->stream)
+  IRS_HIP(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+  launch_eigen(t, pidx, t->stream2);
+  IRS_HIP(hipMemcpyAsync(t->eig_stats_host, t->eig_stats.ptr, 3 * sizeof(float), hipMemcpyDeviceToHost,
+                         t->stream2));
+  return true;
+}
+
+bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx, bool cg,
+                int max_cg_steps, int32_t *err_flag) {
+  const int KP = t->KP;
+  hipStream_t s2 = t->stream2;
+  IRS_HIP(hipStreamSynchronize(s2));
+  const float *st = t->eig_stats_host;
+  if (env_flag("IRSPACK_AMD_EIG_DEBUG", false))
+    std::fprintf(stderr, "eig: side %d lambda [%g, %g] sweeps %g reg_min %g n_short %d\n", pidx, st[1], st[0],
+                 st[2], sd.reg_min, sd.n_short);
+  // M = P + reg_r I must be well conditioned for EVERY row: float32 carries Q and 1 / (lambda + reg)
+  const double lo = std::max(0.0, static_cast<double>(st[1])) + sd.reg_min;
+  const double hi = static_cast<double>(st[0]) + sd.reg_min;
+  if (!(lo > 0.0) || !(hi <= 1e4 * lo) || !std::isfinite(hi)) return false;
+  // V~ = other Q  (every gathered row once per half-step)
+  const int64_t n_other = sd.n_other;
+  t->eig_table.alloc(static_cast<size_t>(std::max<int64_t>(n_other, 1)) * KP);
+  {
+    const int64_t waves = ceil_div(n_other, 64) * ceil_div(KP, 64);
+    t->prof.begin("eig_table", s2);
+    if (KP == 128)
+      hipLaunchKernelGGL((user_scores_kernel<128>), dim3(ceil_div(waves, 4)), dim3(256), 0, s2, other,
+                         static_cast<const float *>(t->eig_Qrows.ptr), int64_t(0), n_other, int64_t(KP),
+                         t->eig_table.ptr);
+    else
+      hipLaunchKernelGGL((user_scores_kernel<64>), dim3(ceil_div(waves, 4)), dim3(256), 0, s2, other,
+                         static_cast<const float *>(t->eig_Qrows.ptr), int64_t(0), n_other, int64_t(KP),
+                         t->eig_table.ptr);
+    t->prof.end(s2);
+  }
+  const int32_t first = sd.n_tasks - sd.n_short;
+  const int32_t B = std::min<int32_t>(sd.n_short, 1 << 20);  // rows per pass: x~ scratch of B x KP floats
+  t->eig_xt.alloc(static_cast<size_t>(B) * KP);
+  EigShortParams p{};
+  p.indices = sd.indices.ptr;
+  p.data = sd.data.ptr;
+  p.table = t->eig_table.ptr;
+  p.lam = t->eig_lam.ptr;
+  p.reg = sd.reg.ptr;
+  p.xt = t->eig_xt.ptr;
+  p.bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;
+  p.K = static_cast<int32_t>(t->K);
+  p.max_cg_steps = max_cg_steps;
+  p.warm_start = 1;
+  p.err_flag = err_flag;
+  auto rotate = [&](const float *src, const Task *src_rows, float *dst, const Task *dst_rows, const float *M,
+                    int n) {
+    if (KP == 128)
+      hipLaunchKernelGGL((rows_times_matT_kernel<128>), dim3(ceil_div(n, 256)), dim3(256), 0, s2, src,
+                         src_rows, dst, dst_rows, M, n);
+    else
+      hipLaunchKernelGGL((rows_times_matT_kernel<64>), dim3(ceil_div(n, 256)), dim3(256), 0, s2, src,
+                         src_rows, dst, dst_rows, M, n);
+  };
+  const char *kname = cg ? (pidx == 0 ? "ials_short_cg_user" : "ials_short_cg_item")
+                         : (pidx == 0 ? "ials_short_cholesky_user" : "ials_short_cholesky_item");
+  // the list is longest first: [17..32 entries | <= 16 entries]
+  const int32_t n32 = sd.n_short - sd.n_short16;
+  for (int32_t b0 = 0; b0 < sd.n_short; b0 += B) {
+    const int32_t m = std::min(B, sd.n_short - b0);
+    const Task *tasks = sd.tasks.ptr + first + b0;
+    p.tasks = tasks;
+    p.n_tasks = m;
+    // rows of this pass with 17..32 entries: [0, m2) (one row per wave), the rest have <= 16
+    // (four rows per wave, 16 lanes each)
+    const int32_t m2 = std::max(0, std::min(b0 + m, n32) - b0);
+    auto part = [&](auto kernel, int32_t off, int32_t cnt, int rows_per_block, size_t lds) {
+      if (cnt <= 0) return;
+      EigShortParams q = p;
+      q.tasks = tasks + off;
+      q.n_tasks = cnt;
+      q.xt = t->eig_xt.ptr + static_cast<size_t>(off) * KP;
+      hipLaunchKernelGGL(kernel, dim3(ceil_div(cnt, rows_per_block)), dim3(256), lds, s2, q);
+    };
+    static const bool rows16 = env_flag("IRSPACK_AMD_IALS_EIG16", true);  // A/B: one row per wave everywhere
+    if (cg) {
+      t->prof.begin("eig_rotate", s2);
+      rotate(target, tasks, t->eig_xt.ptr, nullptr, t->eig_Qrows.ptr, m);  // x~0 = Q^T x0
+      t->prof.end(s2);
+    }
+    t->prof.begin(kname, s2);
+    if (cg) {
+      if (KP == 128) {
+        part(ials_cg_eig_short_kernel<128>, 0, rows16 ? m2 : m, 4, 0);
+        if (rows16) part(ials_cg_eig16_kernel<128>, m2, m - m2, 16, 0);
+      } else {
+        part(ials_cg_eig_short_kernel<64>, 0, rows16 ? m2 : m, 4, 0);
+        if (rows16) part(ials_cg_eig16_kernel<64>, m2, m - m2, 16, 0);
+      }
+    } else {
+      const size_t lds1 = 4 * (Chol16Geo<1>::LDS_FLOATS + 32) * sizeof(float);
+      const size_t lds2 = 4 * (Chol16Geo<2>::LDS_FLOATS + 64) * sizeof(float);
+      if (KP == 128) {
+        part(ials_wb_short_kernel<128, 2>, 0, m2, 4, lds2);
+        if (rows16) part(ials_wb_eig16_kernel<128>, m2, m - m2, 16, 0);
+        else part(ials_wb_short_kernel<128, 1>, m2, m - m2, 4, lds1);
+      } else {
+        part(ials_wb_short_kernel<64, 2>, 0, m2, 4, lds2);
+        if (rows16) part(ials_wb_eig16_kernel<64>, m2, m - m2, 16, 0);
+        else part(ials_wb_short_kernel<64, 1>, m2, m - m2, 4, lds1);
+      }
+    }
+    t->prof.end(s2);
+    t->prof.begin("eig_rotate", s2);
+    rotate(t->eig_xt.ptr, nullptr, target, tasks, t->eig_Qcols.ptr, m);  // x = Q x~
+    t->prof.end(s2);
+  }
+  IRS_HIP(hipGetLastError());
+  IRS_HIP(hipEventRecord(t->ev_join, s2));
+  IRS_HIP(hipStreamWaitEvent(t->stream, t->ev_join, 0));
+  t->eig_last = 1;
+  return true;
 }
 
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
@@ -821,8 +1006,11 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
   // CG, short rows: the matrix-free kernel takes the tail of the longest-first task list
   int n_regular = sd.n_tasks;
-  if (cg && prior == nullptr && sd.n_short > 0 && (t->T <= 4 || t->T == 8) && t->opt_short) {
-    n_regular = sd.n_tasks - sd.n_short;
+  // short rows (<= 32 entries) of a side that has enough of them: Cholesky in its low-rank form /
+  // CG with a diagonal P, both in the eigenbasis of P (ials_eig_kernels.hpp)
+  const bool short_cg_ok = cg && prior == nullptr && sd.n_short > 0 && (t->T <= 4 || t->T == 8) && t->opt_short;
+  auto launch_short_cg = [&]() {  // the matrix-free short-row CG kernels over the tail of the task list
+    const int n_regular = sd.n_tasks - sd.n_short;
     int n_cu = 0;
     IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device));
     t->prof.begin(pidx == 0 ? "ials_short_cg_user" : "ials_short_cg_item", t->stream);
@@ -849,8 +1037,19 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       }
     });
     t->prof.end(t->stream);
-    p.n_tasks = n_regular;
+  };
+  const bool eig_cand = prior == nullptr && other == t->factor[1 - pidx].ptr && eig_begin(t, sd, pidx);
+  if (eig_cand) {
+    n_regular = sd.n_tasks - sd.n_short;  // (the long rows start now, beside the decomposition)
+  } else if (short_cg_ok) {
+    launch_short_cg();
+    n_regular = sd.n_tasks - sd.n_short;
   }
+  // the kernels of the K x K systems over `count` tasks starting at `tasks_begin`
+  auto launch_dense = [&](const Task *tasks_begin, int count, bool with_split) {
+  const int n_regular = count;
+  p.tasks = tasks_begin;
+  p.n_tasks = count;
   if (!cg && (t->T >= 12 || (t->T == 8 && !t->opt_wave128)) && t->opt_wg16) {
     // 128 < K <= 256, Cholesky: one workgroup per row, 16-row block steps on the matrix cores
     // (ials_wg16_kernels.hpp).  K <= 128 stays on the one-wave-per-row kernel, whose solve is the
@@ -871,7 +1070,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         t->prof.end(t->stream);
       };
       launch(ials_wg16_cholesky_kernel<TT, 0>, n_regular, kNames[0][0][pidx]);
-      launch(ials_wg16_cholesky_kernel<TT, 1>, sd.n_split, kNames[0][1][pidx]);
+      if (with_split) launch(ials_wg16_cholesky_kernel<TT, 1>, sd.n_split, kNames[0][1][pidx]);
     });
   } else if (t->T == 8 && t->opt_wave128) {
     // 64 < K <= 128: the 36 tiles still fit one wave's 512 registers (144 of them
@@ -892,7 +1091,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0>), dim3(n_regular), dim3(64), 0, t->stream, p);
       t->prof.end(t->stream);
     }
-    if (sd.n_split > 0) {
+    if (with_split && sd.n_split > 0) {
       t->prof.begin(kNames[cg][1][pidx], t->stream);
       if (cg)
         hipLaunchKernelGGL((ials_solve_kernel<8, 1, 1>), dim3(sd.n_split), dim3(64), 0, t->stream, p);
@@ -919,7 +1118,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         else
           t->prof.launch(name, ials_solve_kernel<TT, 0, 0>, grid, block, 0, t->stream, p);
       }
-      if (sd.n_split > 0) {
+      if (with_split && sd.n_split > 0) {
         const dim3 grid(ceil_div(sd.n_split, SOLVE_WAVES)), block(64 * SOLVE_WAVES);
         if (cg)
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 1, 1>, grid, block, 0, t->stream, p);
@@ -947,7 +1146,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         else
           launch(ials_wg_solve_kernel<TT, 0, 0>, n_regular, kNames[0][0][pidx]);
       }
-      if (sd.n_split > 0) {
+      if (with_split && sd.n_split > 0) {
         if (cg)
           launch(ials_wg_solve_kernel<TT, 1, 1>, sd.n_split, kNames[1][1][pidx]);
         else
@@ -956,6 +1155,15 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     });
   }
   IRS_HIP(hipGetLastError());
+  };  // launch_dense
+  launch_dense(sd.tasks.ptr, n_regular, true);
+  if (eig_cand && !eig_finish(t, sd, other, target, pidx, cg, p.max_cg_steps, p.err_flag)) {
+    // the eigenbasis path declined (ill-conditioned P + reg I): the short rows through the usual kernels
+    p.tasks = sd.tasks.ptr;
+    p.n_tasks = sd.n_tasks;
+    if (short_cg_ok) launch_short_cg();
+    else launch_dense(sd.tasks.ptr + n_regular, sd.n_short, false);
+  }
 }
 
 // Raise what the reference would have thrown from inside the worker threads.
@@ -1591,6 +1799,69 @@ irs_status irs_ials_compute_loss(irs_ials_trainer *t, const irs_ials_solver_conf
     *out = static_cast<float>((loss + h[0] + h[1]) / 2.0);  // hpp:939
   });
 }
+
+// Internal hook for the tests (not part of the public ABI): the eigen-decomposition kernel of
+// ials_eig_kernels.hpp on a host matrix.  P: [K, K] row-major symmetric; out: Qrows [K, K] (row k
+// = eigenvector k), lam [K], stats [3] (largest, smallest eigenvalue, sweeps).
+irs_status irs_ials_eigen_debug_(const float *P, int64_t K, int32_t device, float *Qrows, float *lam,
+                                 float *stats, const float *P_prev) {
+  return guard([&] {
+    check_arg(P && Qrows && lam && stats && K >= 1 && K <= 128, "bad argument.");
+    require_device(device);
+    const int KP = K <= 64 ? 64 : 128;
+    std::vector<float> padded(static_cast<size_t>(KP) * KP, 0.0f);
+    for (int64_t r = 0; r < K; r++) std::copy(P + r * K, P + (r + 1) * K, padded.begin() + r * KP);
+    DeviceBuffer<float> dP, dQr, dQc, dl, ds;
+    DeviceBuffer<double> dQd;
+    hipStream_t s = nullptr;
+    dP.upload(padded, s);
+    dQr.alloc(padded.size());
+    dQc.alloc(padded.size());
+    dl.alloc(KP);
+    ds.alloc(4);
+    dQd.alloc(padded.size());
+    EigOut o{dQr.ptr, dQc.ptr, dl.ptr, ds.ptr, dQd.ptr};
+    const size_t lds = padded.size() * sizeof(double);
+    // P_prev given: decompose it first, then P warm-started from its eigenvectors
+    for (int pass = P_prev ? 0 : 1; pass < 2; pass++) {
+    const int warm = (pass == 1 && P_prev) ? 1 : 0;
+    if (pass == 0) {
+      std::vector<float> prev(padded.size(), 0.0f);
+      for (int64_t r = 0; r < K; r++) std::copy(P_prev + r * K, P_prev + (r + 1) * K, prev.begin() + r * KP);
+      dP.upload(prev, s);
+      IRS_HIP(hipStreamSynchronize(s));
+    } else if (P_prev) {
+      dP.upload(padded, s);
+    }
+    if (KP == 128) {
+      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eig_jacobi_kernel<128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL(eig_jacobi_kernel<128>, dim3(1), dim3(1024), lds, s,
+                         static_cast<const float *>(dP.ptr), static_cast<int>(K), o, warm);
+    } else {
+      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(eig_jacobi_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+      hipLaunchKernelGGL(eig_jacobi_kernel<64>, dim3(1), dim3(1024), lds, s,
+                         static_cast<const float *>(dP.ptr), static_cast<int>(K), o, warm);
+    }
+    IRS_HIP(hipGetLastError());
+    IRS_HIP(hipStreamSynchronize(s));
+    }
+    std::vector<float> q(padded.size()), l(KP);
+    IRS_HIP(hipMemcpyAsync(q.data(), dQr.ptr, q.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    IRS_HIP(hipMemcpyAsync(l.data(), dl.ptr, KP * sizeof(float), hipMemcpyDeviceToHost, s));
+    IRS_HIP(hipMemcpyAsync(stats, ds.ptr, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    IRS_HIP(hipStreamSynchronize(s));
+    for (int64_t k = 0; k < K; k++) {
+      std::copy(q.begin() + k * KP, q.begin() + k * KP + K, Qrows + k * K);
+      lam[k] = l[k];
+    }
+  });
+}
+
+// Internal hook (diagnostics / tests): 1 when the last half-step solved its short rows in the
+// eigenbasis of the Gramian (ials_eig_kernels.hpp).
+int32_t irs_ials_eig_last_(irs_ials_trainer *t) { return t ? t->eig_last : 0; }
 
 irs_status irs_ials_profile(irs_ials_trainer *t, int32_t enable) {
   return guard([&] {

@@ -189,12 +189,14 @@ __global__ __launch_bounds__(64 * SHORT_WAVES, CAP == 16 ? 4 : (NR == 1 ? 3 : 2)
 #pragma unroll
           for (int c = 0; c < DPL; c++) vsh[rr * KP + DPL * dl + c] = vec[rr][c];
       }
-      // Order of the reference (hpp:222-228, 240-247): P vec first (summed from zero, at its own
-      // magnitude), THEN + reg vec, then the gathered terms.  Starting the accumulator at
-      // reg vec rounds every one of the KP products of P at the magnitude of reg vec: with
-      // reg_r = 100 (10^6 items) and a solution 5,000 times smaller than the warm start that
-      // was 8 x the oracle's error on the full configs[3] matrix (2.4e-3 against 3e-4 of a
-      // 2e-7-norm row; tests/test_gpu_fullsize.py::test_ials_k128_c4_full_matrix_vs_oracle).
+      // P vec and the gathered terms are summed from zero, at their own magnitude, and reg vec
+      // is added LAST in one fma (the reference adds it between the two, hpp:222-228, 240-247).
+      // Starting the accumulator at reg vec rounds every one of the KP products of P at the
+      // magnitude of reg vec: with reg_r = 100 (10^6 items) and a solution 5,000 times smaller
+      // than the warm start that was 8 x the oracle's error on the full configs[3] matrix
+      // (2.4e-3 against 3e-4 of a 2e-7-norm row; tests/test_gpu_fullsize.py::
+      // test_ials_k128_c4_full_matrix_vs_oracle): the error of the FIRST residual r0 = b - A x0
+      // is never seen by the recursively updated residual and survives into x as A^-1 e(r0).
 #pragma unroll
       for (int rr = 0; rr < NR; rr++)
 #pragma unroll
@@ -232,10 +234,6 @@ __global__ __launch_bounds__(64 * SHORT_WAVES, CAP == 16 ? 4 : (NR == 1 ? 3 : 2)
         }
       }
 #pragma unroll
-      for (int rr = 0; rr < NR; rr++)
-#pragma unroll
-        for (int c = 0; c < DPL; c++) out[rr][c] = fmaf(reg[rr], vec[rr][c], out[rr][c]);
-#pragma unroll
       for (int rr = 0; rr < NR; rr++) {
 #pragma unroll
         for (int j0 = 0; j0 < CAP; j0 += 16) {
@@ -264,6 +262,10 @@ __global__ __launch_bounds__(64 * SHORT_WAVES, CAP == 16 ? 4 : (NR == 1 ? 3 : 2)
           }
         }
       }
+#pragma unroll
+      for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+        for (int c = 0; c < DPL; c++) out[rr][c] = fmaf(reg[rr], vec[rr][c], out[rr][c]);
     };
     auto dotw = [&](const float (&a)[DPL], const float (&b)[DPL]) {
       float s = 0.f;

@@ -685,6 +685,13 @@ class IALSTrainer:
     def synchronize(self) -> None:
         check(lib().irs_ials_synchronize(self._h))
 
+    def last_half_step_used_eigenbasis(self) -> bool:
+        """diagnostics: the last half-step solved its short rows (<= 32 stored entries) in the
+        eigenbasis of the Gramian (csrc/ials_eig_kernels.hpp)"""
+        f = lib().irs_ials_eig_last_
+        f.restype = C.c_int32
+        return bool(f(self._h))
+
     def profile(self, enable: bool) -> None:
         check(lib().irs_ials_profile(self._h, C.c_int32(1 if enable else 0)))
 

@@ -125,9 +125,10 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
       * the rows that differ from the oracle by more than RTOL (at most 5 %: the arbiter must
         stay affordable) are evaluated in float64;
       * on those rows the GPU must be within 3 RTOL of the float64 result, at most
-        FAR_FRACTION of all rows may be farther than RTOL from it, and its worst row must be
-        no farther from float64 than twice the oracle's worst row (the two tails are
-        different rows: the comparison is between the distributions, not row by row).
+        FAR_FRACTION of all rows - or as many as the oracle itself has - may be farther than
+        RTOL from it, and its worst row must be no farther from float64 than twice the oracle's
+        worst row (the two tails are different rows: the comparison is between the
+        distributions, not row by row).
     The achieved figures go to the parity log whatever the outcome."""
     num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
     den = np.linalg.norm(want.astype(np.float64), axis=1)
@@ -150,7 +151,10 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
     assert far.size <= max(50, 0.05 * len(rows)), (what, far.size, float(err.max()))
     if far.size:
         assert e_gpu.max() < 3 * RTOL, (what, float(e_gpu.max()))
-        assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows)), (what, int((e_gpu >= RTOL).sum()))
+        # (rows of norm ~1e-7 next to a warm start of norm ~1e-3 lose 3-4 digits to cancellation
+        # in ANY float32 evaluation: the oracle's own count is the yardstick there)
+        assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows), (e_orc >= RTOL).sum()), (
+            what, int((e_gpu >= RTOL).sum()), int((e_orc >= RTOL).sum()))
         assert e_gpu.max() <= max(2 * e_orc.max(), RTOL), (what, float(e_gpu.max()), float(e_orc.max()))
     return float(err.max()), int(far.size)
 
