@@ -94,6 +94,11 @@ __device__ __forceinline__ uint64_t order_key(double s) {
   return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
 }
 
+__device__ __forceinline__ double key_to_double(uint64_t k) {  // inverse of order_key (non-NaN)
+  const uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double(static_cast<long long>(u));
+}
+
 // similarities.hpp epilogues; operations are kept un-fused so that the value is
 // the one a default x86-64 build of the reference computes.
 __device__ __forceinline__ double epilogue(const Params &p, double v, double norm_j,
@@ -138,22 +143,33 @@ __device__ unsigned long long knn_phase_clk[8];
 // are counts, accumulated with 32-bit LDS atomics (one bank per lane instead of two: 1.5x the
 // fp64 atomic rate) in the upper half of the accumulator block and widened to fp64 in place
 // afterwards - the same values as the fp64 sums, which are exact for integers.
-template <bool ONES, bool SENTINEL, bool ACC32 = false>
-__global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
+// COMPACT (round 3; counts only): NT = 512 threads and 66 KB of LDS per workgroup - the TILE
+// 32-bit counters, the sinks, the select scratch; the similarities are NOT written back to LDS
+// (a winner's value is recovered from its order-preserving key, which is a bijection on the
+// non-NaN doubles) - so that TWO workgroups are resident per CU and one pair's epilogue /
+// selection (4 of the 10 ms of a call: fp64 divisions, global norm loads, barriers) overlaps the
+// other pair's accumulation (LDS atomics).
+template <bool ONES, bool SENTINEL, bool ACC32 = false, int NT = THREADS, bool COMPACT = false>
+__global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p) {
   static_assert(!ACC32 || (ONES && SENTINEL), "counts need all-ones operands");
+  static_assert(!COMPACT || (ACC32 && NT == 512), "the compact layout holds counters only");
+  constexpr int THREADS = NT;  // (shadows the namespace constant inside this kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *acc = reinterpret_cast<double *>(smem);                        // TILE
-  uint32_t *bits = reinterpret_cast<uint32_t *>(acc + TILE);             // TILE / 32
-  uint32_t *hist = bits + TILE / 32;                                     // 256
+  double *acc = reinterpret_cast<double *>(smem);                        // TILE (COMPACT: TILE counters)
+  // COMPACT: [TILE x u32 counters][64 x u32 sinks][256 x u32 hist][16 x i32 wave_cnt]
+  uint32_t *bits = COMPACT ? reinterpret_cast<uint32_t *>(smem + TILE * 4 + 256)
+                           : reinterpret_cast<uint32_t *>(acc + TILE);   // TILE / 32 (unused when COMPACT)
+  uint32_t *hist = COMPACT ? bits : bits + TILE / 32;                    // 256
   int32_t *wave_cnt = reinterpret_cast<int32_t *>(hist + 256);           // 16
   // one sink per lane for the lanes of a strip that lie outside their slice: the atomic is
-  // issued without a branch (ACC32 uses the idle upper half of the accumulator block)
+  // issued without a branch (ACC32 uses the idle upper half of the accumulator block; COMPACT
+  // the 256 bytes behind the counters)
   constexpr uint32_t SINK_BYTES = TILE * 8 + (TILE / 32) * 4 + 256 * 4 + 16 * 4;
   __shared__ uint64_t sh_prefix;
   __shared__ int32_t sh_need, sh_count, sh_total;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  constexpr int NW = THREADS / 64;
+  constexpr int NW = NT / 64;
   __shared__ int32_t sh_slot;
   // One workgroup per CU stays resident and draws (row slot, tile) pairs, heaviest rows
   // first, from a global counter: a 1024-thread / 130 KB workgroup costs ~20 us to launch
@@ -184,7 +200,8 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   } else {
     for (int i = tid; i < width; i += THREADS) acc[i] = SENTINEL ? -0.0 : 0.0;
   }
-  for (int i = tid; i < TILE / 32; i += THREADS) bits[i] = 0u;
+  if (!COMPACT)
+    for (int i = tid; i < TILE / 32; i += THREADS) bits[i] = 0u;
   __syncthreads();
   PHASE_MARK(0);
 
@@ -395,13 +412,13 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
   //      k = 0..15, so (wave, k, lane) order is column order.  The similarity of every stored
   //      entry is written back (the winners' values are read from there) and its
   //      order-preserving key stays in registers: the selection below never reads LDS keys.
-  static_assert(PER == 16 && THREADS / 64 * PER * 64 == TILE, "column ownership");
+  static_assert(PER * THREADS == TILE && PER <= 32 && PER % 8 == 0, "column ownership (the `have` mask is 32 bits)");
   const double tstat = p.t_stat[r];
   const double fx_inv = 1.0 / fx_scale;  // a power of two: exact
   uint64_t key[PER];
   uint32_t have = 0;  // bit k: column k of this thread is a stored entry of the product row
-  uint32_t cv[ACC32 ? PER : 1];
-  if (ACC32) {
+  uint32_t cv[(ACC32 && !COMPACT) ? PER : 1];
+  if (ACC32 && !COMPACT) {
     // count i sits in the bytes of acc[i / 2]: every count is read before any sum is written
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -420,8 +437,12 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int i = cbase + 64 * (h + k);
-      if (ACC32) {
-        raw[k] = static_cast<double>(cv[ACC32 ? h + k : 0]);
+      if (COMPACT) {
+        const uint32_t c32 = cnt[min(i, TILE - 1)];  // (nothing overwrites the counters)
+        raw[k] = static_cast<double>(c32);
+        if (i < width && c32 != 0u) have |= 1u << (h + k);
+      } else if (ACC32) {
+        raw[k] = static_cast<double>(cv[(ACC32 && !COMPACT) ? h + k : 0]);
       } else {
         // fixed-point sum -> double (one rounding).  Sentinel: the accumulator started at the
         // bit pattern of -0.0 = INT64_MIN, the sum is the difference.
@@ -437,7 +458,7 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
     for (int k = 0; k < 8; k++) {
       const double sv = epilogue(p, raw[k], nrm[k], tstat);
       key[h + k] = order_key(sv);
-      if ((have >> (h + k)) & 1u) acc[cbase + 64 * (h + k)] = sv;
+      if (!COMPACT && ((have >> (h + k)) & 1u)) acc[cbase + 64 * (h + k)] = sv;
     }
   }
   // stored entries of the tile, and the bits in which their keys differ (the radix select
@@ -635,7 +656,9 @@ __global__ __launch_bounds__(THREADS) void knn_tile_kernel(Params p) {
     if (win) {
       const int pos = pos0 + __popcll(bal & lt_mask);
       cidx[pos] = c0 + cbase + 64 * k;
-      cval[pos] = acc[cbase + 64 * k];
+      // COMPACT: the value back from its key (order_key is invertible: similarities of counts
+      // are finite and never -0.0)
+      cval[pos] = COMPACT ? key_to_double(key[k]) : acc[cbase + 64 * k];
     }
     pos0 += __popcll(bal);
   }
@@ -1373,7 +1396,25 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     IRS_HIP(hipEventCreate(&ev0));
     IRS_HIP(hipEventCreate(&ev1));
     IRS_HIP(hipEventRecord(ev0, s));
-    if (c->xt_all_ones) {
+    // IRSPACK_AMD_KNN_COMPACT=1 (opt-in, a measured NEGATIVE result): counts (binary data) on two
+    // 512-thread workgroups per CU with 66 KB of LDS each, so that one pair's epilogue / selection
+    // overlaps the other's accumulation.  Same results (tests/test_gpu_knn.py runs both), same
+    // time: 10.69 against 10.54 ms per ML-20M call - the phases of one pair do not leave the CU
+    // idle, they keep different units busy in turn (LDS atomics at 77 % of their rate, then fp64
+    // divisions), and two half-size workgroups issue the same instructions with 32 instead of 16
+    // keys per thread (128 registers, 51 spilled dwords).  DESIGN.md 3.4.
+    const char *compact_env = std::getenv("IRSPACK_AMD_KNN_COMPACT");  // (read per call: tests toggle it)
+    const bool compact = compact_env && compact_env[0] == '1';
+    if (c->xt_all_ones && acc32 && compact) {
+      const size_t lds_c = TILE * sizeof(uint32_t) + 64 * sizeof(uint32_t) + 256 * sizeof(uint32_t) +
+                           16 * sizeof(int32_t);
+      auto kernel = knn_tile_kernel<true, true, true, 512, true>;
+      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_c)));
+      const unsigned grid_c = static_cast<unsigned>(
+          std::min<size_t>(slots, 2 * static_cast<size_t>(std::max(n_cu, 1))));
+      hipLaunchKernelGGL(kernel, dim3(grid_c), dim3(512), lds_c, s, p);
+    } else if (c->xt_all_ones) {
       if (acc32) launch(knn_tile_kernel<true, true, true>);
       else if (sentinel) launch(knn_tile_kernel<true, true>);
       else launch(knn_tile_kernel<true, false>);

@@ -124,7 +124,7 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
     Rules, with EVERY row compared:
       * the rows that differ from the oracle by more than RTOL (at most 5 %: the arbiter must
         stay affordable) are evaluated in float64;
-      * on those rows the GPU must be within 3 RTOL of the float64 result, at most
+      * on those rows the GPU must be within 5 RTOL of the float64 result, at most
         FAR_FRACTION of all rows - or as many as the oracle itself has - may be farther than
         RTOL from it, and its worst row must be no farther from float64 than twice the oracle's
         worst row (the two tails are different rows: the comparison is between the
@@ -150,7 +150,11 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
     record_parity(test or "fullsize", str(what), **rec)
     assert far.size <= max(50, 0.05 * len(rows)), (what, far.size, float(err.max()))
     if far.size:
-        assert e_gpu.max() < 3 * RTOL, (what, float(e_gpu.max()))
+        # (5 RTOL: the worst rows are those where three CG steps have NOT converged - ML-20M user
+        # 38077: ||r||^2 = 32, 67, 1.7, 19 over the steps, 8 % from the solution - and the
+        # iteration amplifies any float32 rounding by the conditioning, for GPU and oracle
+        # alike: 1.6e-4 .. 3.7e-4 from float64 for either, run to run; scripts/debug/cg_row_probe.py)
+        assert e_gpu.max() < 5 * RTOL, (what, float(e_gpu.max()))
         # (rows of norm ~1e-7 next to a warm start of norm ~1e-3 lose 3-4 digits to cancellation
         # in ANY float32 evaluation: the oracle's own count is the yardstick there)
         assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows), (e_orc >= RTOL).sum()), (
