@@ -1161,6 +1161,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     const int64_t e_begin = ip[row_begin], e_end = ip[row_end];
     check_arg(e_begin >= 0 && e_end >= e_begin, "malformed indptr.");
     check_arg(e_end < (int64_t(1) << 31), "nnz must be below 2^31.");
+    // the row pointers of the call must be monotone BEFORE anything walks or uploads them: the
+    // threads below cut [e_begin, e_end) by lower_bound, which on a non-monotone array yields
+    // rows whose entries lie outside that range (an out-of-bounds host read instead of this error)
+    for (int64_t i = row_begin; i < row_end; i++) check_arg(ip[i + 1] >= ip[i], "malformed indptr.");
     std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0);
     // The row pointers and column indices of the call's rows travel to the device on a second
     // host thread while this one walks them (the values follow later, and only if the kernel

@@ -136,7 +136,9 @@ class Evaluator:
                 mask = model.X_train_all  # the whole matrix: no copy, and the device copy is reused
             else:
                 # the slice is kept: a new object per call would re-upload the mask every time
-                key = (id(model.X_train_all), block_start, block_end)
+                # (keyed on the content fingerprint too: an edited training matrix gets a new slice)
+                key = (id(model.X_train_all), block_start, block_end,
+                       self.core._mask_fingerprint(model.X_train_all))
                 if getattr(self, "_mask_slice_key", None) != key:
                     self._mask_slice_key = key
                     self._mask_slice = (model.X_train_all, model.X_train_all[block_start:block_end])

@@ -179,6 +179,29 @@ def test_argument_validation():
         remove_diagonal(sps.csr_matrix(np.ones((2, 3))))
 
 
+def test_non_monotone_indptr_through_the_c_abi_is_an_error_not_a_wild_read():
+    """irs_knn_compute validates the row pointers of the call before any host thread walks them
+    (a C-ABI caller may hand over anything; scipy would never build such a matrix)."""
+    import ctypes as C
+
+    from irspack_amd import _lib
+
+    rng2 = np.random.default_rng(0)
+    X = sps.random(400, 300, density=0.05, format="csr", random_state=rng2, dtype=np.float64)
+    X.data[:] = 1.0
+    comp = K.CosineSimilarityComputer(sps.csr_matrix(X.T), 0.0, False)
+    good = comp.compute_similarity(sps.csr_matrix(X.T), 5)
+    assert good.shape == (300, 300)
+    Xt = sps.csr_matrix(X.T)
+    indptr = Xt.indptr.astype(np.int64).copy()
+    indptr[100], indptr[101] = indptr[101] + 50, indptr[100]  # non-monotone in the middle
+    bad = sps.csr_matrix(Xt.shape, dtype=np.float64)
+    bad.indices, bad.data, bad.indptr = Xt.indices, Xt.data, indptr  # bypass scipy's own checks
+    bad.has_sorted_indices = True  # (the wrapper would otherwise ask scipy to sort the garbage)
+    with pytest.raises(ValueError, match="malformed indptr"):
+        comp.compute_similarity(bad, 5)
+
+
 def test_weighting_helpers_match_oracle():
     for X in (X_small, X_many_dense):
         for mine, ref in ((tf_idf_weight(X), O.tf_idf_weight(X)),
