@@ -364,6 +364,31 @@ def test_ials_k256_ml20m_vs_oracle(X20, X20t, kind):
         assert np.isfinite(got).all()
 
 
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_ials_k320_ml20m_general_size_kernels_vs_oracle(X20, X20t, kind):
+    """K = 320 (above the register / LDS kernels: ials_gk_kernels.hpp - scratch systems in HBM,
+    MFMA rank update per 64 x 64 block pair, blocked Cholesky; matrix-free CG) on the ML-20M shape,
+    rows of up to 116 k entries in one piece, several scratch batches.  One half-step per side
+    from frozen factors, EVERY row against the oracle."""
+    K = 320
+    mc, sc, omc, osc = configs(K, kind)
+    t = IALSTrainer(mc, X20)
+    _, sc_pp, _, _ = configs(K, "CG")
+    t.step(sc_pp)
+    user0, item0 = t.user, t.item
+    for side, (Xs, tgt0, oth0) in enumerate(((X20, user0, item0), (X20t, item0, user0))):
+        t.user, t.item = user0, item0
+        half_step(t, side, sc)
+        got = t.user if side == 0 else t.item
+        rows = np.arange(Xs.shape[0])
+        P = O.ials_gramian(oth0, omc.alpha0, CORES)
+        want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
+        assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
+                          f"ml20m K=320 (general-size kernels) {kind} {'user' if side == 0 else 'item'} half, all rows",
+                          test="test_ials_k320_ml20m_general_size_kernels_vs_oracle")
+        assert np.isfinite(got).all()
+
+
 @pytest.fixture(scope="module")
 def XC4():
     """BASELINE configs[3], the FULL matrix: 10 M users x 1 M items, 95 M stored entries
@@ -466,7 +491,7 @@ def ialspp_float64(Xs, rows, tgt0, oth0, sub, alpha0=ALPHA0, reg=REG):
     return out
 
 
-@pytest.mark.parametrize("K,direct", [(64, "1"), (64, "0"), (128, "1")])
+@pytest.mark.parametrize("K,direct", [(64, "1"), (64, "0"), (128, "1"), (320, "1")])
 def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
     """iALS++ with the default 64-dim blocks at benchmark size: K = 64 is one block (computed as
     the direct solve, and with IRSPACK_AMD_IALSPP_DIRECT=0 by the block kernel), K = 128 two

@@ -217,11 +217,13 @@ def test_recommender_level_features():
     assert rec.get_score_cold_user(X).shape == (3, 4)
 
 
-@pytest.mark.parametrize("K", [100, 200])
+@pytest.mark.parametrize("K", [100, 200, 300])
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
 def test_prior_on_the_large_k_kernels(K, kind):
-    """K in (64, 128] runs on the one-wave kernel with 36 tiles, K > 128 on the workgroup
-    kernels: the prior must reach their right-hand sides too (closed form, float64)."""
+    """K in (64, 128] runs on the one-wave kernel with 36 tiles, K in (128, 256] on the workgroup
+    kernels, K > 256 on the general-size kernels (scratch systems / matrix-free CG; the feature
+    products take the latent dims in blocks of 256): the prior must reach their right-hand
+    sides too (closed form, float64)."""
     rng = np.random.default_rng(K)
     Xd = (rng.random((30, 25)) < 0.3) * rng.uniform(0.5, 2.0, (30, 25))
     X = sps.csr_matrix(Xd.astype(np.float32))
