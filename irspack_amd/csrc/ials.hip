@@ -899,23 +899,32 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
     }
     t->prof.begin(kname, s2);
     if (cg) {
-      if (KP == 128) {
-        part(ials_cg_eig_short_kernel<128>, 0, rows16 ? m2 : m, 4, 0);
-        if (rows16) part(ials_cg_eig16_kernel<128>, m2, m - m2, 16, 0);
+      if (!rows16) {
+        if (KP == 128) part(ials_cg_eig_short_kernel<128>, 0, m, 4, 0);
+        else part(ials_cg_eig_short_kernel<64>, 0, m, 4, 0);
+      } else if (KP == 128) {
+        part(ials_cg_eig16_kernel<128, 32>, 0, m2, 8, 0);   // 17..32 entries: 32 lanes per row
+        part(ials_cg_eig16_kernel<128, 16>, m2, m - m2, 16, 0);
       } else {
-        part(ials_cg_eig_short_kernel<64>, 0, rows16 ? m2 : m, 4, 0);
-        if (rows16) part(ials_cg_eig16_kernel<64>, m2, m - m2, 16, 0);
+        part(ials_cg_eig16_kernel<64, 32>, 0, m2, 8, 0);
+        part(ials_cg_eig16_kernel<64, 16>, m2, m - m2, 16, 0);
       }
     } else {
       const size_t lds1 = 4 * (Chol16Geo<1>::LDS_FLOATS + 32) * sizeof(float);
       const size_t lds2 = 4 * (Chol16Geo<2>::LDS_FLOATS + 64) * sizeof(float);
+      // 17..32 entries: the MFMA kernel (one row per wave) by default; the 32-lanes-per-row form of
+      // the register kernel is slower for Cholesky (its n x n factorisation is n^2 / 2 lane
+      // broadcasts: configs[3] epoch 69 -> 77 ms) although it is the faster one for CG (68 -> 63)
+      static const bool rows32 = env_flag("IRSPACK_AMD_IALS_EIG32", false);
       if (KP == 128) {
-        part(ials_wb_short_kernel<128, 2>, 0, m2, 4, lds2);
-        if (rows16) part(ials_wb_eig16_kernel<128>, m2, m - m2, 16, 0);
+        if (rows16 && rows32) part(ials_wb_eig16_kernel<128, 32>, 0, m2, 8, 0);
+        else part(ials_wb_short_kernel<128, 2>, 0, m2, 4, lds2);
+        if (rows16) part(ials_wb_eig16_kernel<128, 16>, m2, m - m2, 16, 0);
         else part(ials_wb_short_kernel<128, 1>, m2, m - m2, 4, lds1);
       } else {
-        part(ials_wb_short_kernel<64, 2>, 0, m2, 4, lds2);
-        if (rows16) part(ials_wb_eig16_kernel<64>, m2, m - m2, 16, 0);
+        if (rows16 && rows32) part(ials_wb_eig16_kernel<64, 32>, 0, m2, 8, 0);
+        else part(ials_wb_short_kernel<64, 2>, 0, m2, 4, lds2);
+        if (rows16) part(ials_wb_eig16_kernel<64, 16>, m2, m - m2, 16, 0);
         else part(ials_wb_short_kernel<64, 1>, m2, m - m2, 4, lds1);
       }
     }

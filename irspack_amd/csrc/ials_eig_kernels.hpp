@@ -541,19 +541,49 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig_short_kernel(EigShortParam
 // of the CG vectors.  A dot product over K is DPL FMAs + four DPP adds (row16_sum: no LDS
 // crossbar, no 6-step 64-lane butterfly), and four rows' dependency chains interleave in one
 // instruction stream - the one-row-per-wave forms above spent their time waiting on both.
-template <int KP> struct Eig16 {
-  static constexpr int DPL = KP / 16;
+// LPR = lanes per row = most entries a row may have: 16 (four rows per wave) or 32 (two).
+template <int KP, int LPR = 16> struct Eig16 {
+  static constexpr int DPL = KP / LPR, NE = LPR;
+  static_assert((LPR == 16 || LPR == 32) && DPL >= 2, "lanes per row");
   // entry j of this lane's row: broadcast from lane (g, j)
   static __device__ __forceinline__ int bcast_i(int v, int j) {
-    return __builtin_amdgcn_ds_bpermute(((threadIdx.x & 48) | j) << 2, v);
+    return __builtin_amdgcn_ds_bpermute(((threadIdx.x & (64 - LPR)) | j) << 2, v);
+  }
+  // sum over the lanes of the row, result in every lane
+  static __device__ __forceinline__ float row_sum(float v) {
+    v = row16_sum(v);
+    if constexpr (LPR == 32) v += __shfl_xor(v, 16, 64);
+    return v;
+  }
+  // DPL consecutive floats (16-byte loads where the width allows)
+  static __device__ __forceinline__ void load_dpl(const float *src, float (&out)[DPL]) {
+    if constexpr (DPL % 4 == 0) {
+#pragma unroll
+      for (int c = 0; c < DPL; c += 4) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(src + c);
+        out[c] = t4.x; out[c + 1] = t4.y; out[c + 2] = t4.z; out[c + 3] = t4.w;
+      }
+    } else {
+      static_assert(DPL == 2, "two floats per lane");
+      const f32x2 t2 = *reinterpret_cast<const f32x2 *>(src);
+      out[0] = t2.x; out[1] = t2.y;
+    }
+  }
+  static __device__ __forceinline__ void store_dpl(float *dst, const float (&in)[DPL]) {
+    if constexpr (DPL % 4 == 0) {
+#pragma unroll
+      for (int c = 0; c < DPL; c += 4) *reinterpret_cast<f32x4 *>(dst + c) = f32x4{in[c], in[c + 1], in[c + 2], in[c + 3]};
+    } else {
+      *reinterpret_cast<f32x2 *>(dst) = f32x2{in[0], in[1]};
+    }
   }
   static __device__ __forceinline__ float bcast_f(float v, int j) {
     return __builtin_bit_cast(float, bcast_i(__builtin_bit_cast(int, v), j));
   }
   // v[j][:] = table[idx_j][DPL m ..] for j < nmax (rows past the group's own n read as zero)
   static __device__ __forceinline__ void gather(const EigShortParams &p, const Task &task, int n, int nmax,
-                                                float (&v)[16][DPL], float (&cj)[16]) {
-    const int m = threadIdx.x & 15;
+                                                float (&v)[NE][DPL], float (&cj)[NE]) {
+    const int m = threadIdx.x & (LPR - 1);
     const int qe = task.begin + min(m, max(n, 1) - 1);
     const int my_idx = n > 0 ? p.indices[qe] : 0;  // (lanes past the end repeat the last entry: a valid row)
     const float my_c = m < n ? p.data[qe] : 0.f;
@@ -561,53 +591,47 @@ template <int KP> struct Eig16 {
     // under ONE wave-uniform branch) and masked afterwards: a load under its own branch makes
     // the wave wait for it before the next one is issued - sixteen exposed cache / HBM latencies
     // per row (40 us per wave measured that way).
-    const float *src[16];
+    const float *src[NE];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < NE; j++) {
       cj[j] = bcast_f(my_c, j);
       const unsigned idx = static_cast<unsigned>(bcast_i(my_idx, j));
       src[j] = p.table + static_cast<size_t>(idx) * KP + DPL * m;
     }
     auto load8 = [&](int j0) {
 #pragma unroll
-      for (int j = j0; j < j0 + 8; j++)
-#pragma unroll
-        for (int c = 0; c < DPL; c += 4) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4 *>(src[j] + c);
-          v[j][c] = t4.x;
-          v[j][c + 1] = t4.y;
-          v[j][c + 2] = t4.z;
-          v[j][c + 3] = t4.w;
-        }
+      for (int j = j0; j < j0 + 8; j++) load_dpl(src[j], v[j]);
     };
     load8(0);
-    if (nmax > 8) load8(8);
+#pragma unroll
+    for (int j0 = 8; j0 < NE; j0 += 8)
+      if (nmax > j0) load8(j0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const bool ok = j < n && (j < 8 || nmax > 8);
+    for (int j = 0; j < NE; j++) {
+      const bool ok = j < n && (j < 8 || nmax > (j & ~7));
 #pragma unroll
       for (int c = 0; c < DPL; c++) v[j][c] = ok ? v[j][c] : 0.f;
     }
   }
 };
 
-template <int KP>
+template <int KP, int LPR = 16>
 __global__ __launch_bounds__(256, 2) void ials_cg_eig16_kernel(EigShortParams p) {
-  using E = Eig16<KP>;
-  constexpr int DPL = E::DPL;
-  const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
-  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + g;
+  using E = Eig16<KP, LPR>;
+  constexpr int DPL = E::DPL, NE = E::NE;
+  const int lane = threadIdx.x & 63, g = lane / LPR, m = lane % LPR;
+  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPR) + g;
   const bool exists = ti < p.n_tasks;
   const Task task = p.tasks[min(ti, p.n_tasks - 1)];
   const int n = exists ? task.end - task.begin : 0;
   int nmax = n;
-  nmax = max(nmax, __shfl_xor(nmax, 16, 64));
-  nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
   nmax = __builtin_amdgcn_readfirstlane(nmax);
   float *xrow = p.xt + static_cast<size_t>(min(ti, p.n_tasks - 1)) * KP + DPL * m;
   const float reg = p.reg[task.row];
-  float v[16][DPL], cj[16];
+  float v[NE][DPL], cj[NE];
   E::gather(p, task, n, nmax, v, cj);
   float dm[DPL], x[DPL], r[DPL], pv[DPL], Ap[DPL];
 #pragma unroll
@@ -618,7 +642,7 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig16_kernel(EigShortParams p)
   }
   // b = sum (bias + c) v   (hpp:212-219)
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
+  for (int j = 0; j < NE; j++) {
     if (j < nmax) {  // (wave-uniform guard, no `break`: the loop must unroll fully or v[][] goes to scratch)
       const float w = j < n ? p.bias + cj[j] : 0.f;
 #pragma unroll
@@ -633,12 +657,12 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig16_kernel(EigShortParams p)
 #pragma unroll
     for (int c = 0; c < DPL; c++) out[c] = dm[c] * vec[c];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < NE; j++) {
       if (j < nmax) {
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < DPL; c++) s = fmaf(v[j][c], vec[c], s);
-        const float w = cj[j] * row16_sum(s);
+        const float w = cj[j] * E::row_sum(s);
 #pragma unroll
         for (int c = 0; c < DPL; c++) out[c] = fmaf(w, v[j][c], out[c]);
       }
@@ -650,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig16_kernel(EigShortParams p)
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < DPL; c++) s = fmaf(a[c], b[c], s);
-    return row16_sum(s);
+    return E::row_sum(s);
   };
   if (p.warm_start) {
     matvec(x, Ap);
@@ -688,32 +712,33 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig16_kernel(EigShortParams p)
     if (lane == 0) atomicOr(p.err_flag, 4);
   }
   if (exists) {
+    if (n == 0) {  // hpp:207-210
 #pragma unroll
-    for (int c = 0; c < DPL; c += 4)
-      *reinterpret_cast<f32x4 *>(xrow + c) = n > 0 ? f32x4{x[c], x[c + 1], x[c + 2], x[c + 3]}
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};  // hpp:207-210
+      for (int c = 0; c < DPL; c++) x[c] = 0.f;
+    }
+    E::store_dpl(xrow, x);
   }
 }
 
 // Cholesky (low-rank form, see the header comment) of rows with at most 16 entries, four per
 // wave.  The n x n system I + G S G lives in registers, lane m of the row's 16 owning matrix row m;
 // it is factorised column by column with one lane broadcast per (column, row) pair.
-template <int KP>
+template <int KP, int LPR = 16>
 __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p) {
-  using E = Eig16<KP>;
-  constexpr int DPL = E::DPL;
-  const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
-  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + g;
+  using E = Eig16<KP, LPR>;
+  constexpr int DPL = E::DPL, NE = E::NE;
+  const int lane = threadIdx.x & 63, g = lane / LPR, m = lane % LPR;
+  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPR) + g;
   const bool exists = ti < p.n_tasks;
   const Task task = p.tasks[min(ti, p.n_tasks - 1)];
   const int n = exists ? task.end - task.begin : 0;
   int nmax = n;
-  nmax = max(nmax, __shfl_xor(nmax, 16, 64));
-  nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
   nmax = __builtin_amdgcn_readfirstlane(nmax);
   float *xrow = p.xt + static_cast<size_t>(min(ti, p.n_tasks - 1)) * KP + DPL * m;
   const float reg = p.reg[task.row];
-  float v[16][DPL], cj[16];
+  float v[NE][DPL], cj[NE];
   E::gather(p, task, n, nmax, v, cj);
   float d[DPL];
 #pragma unroll
@@ -721,25 +746,25 @@ __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p)
   // A = I + G S G (G = C^1/2), lane m keeps row m; rhs G^-1 w of entry m
   const float my_c = m < n ? p.data[task.begin + m] : 0.f;  // confidence of entry m (this lane's matrix row)
   const float my_sq = sqrtf(my_c);
-  float sqj[16];
+  float sqj[NE];
 #pragma unroll
-  for (int j = 0; j < 16; j++) sqj[j] = E::bcast_f(my_sq, j);
-  float A[16];
+  for (int j = 0; j < NE; j++) sqj[j] = E::bcast_f(my_sq, j);
+  float A[NE];
 #pragma unroll
-  for (int q = 0; q < 16; q++) A[q] = q == m ? 1.0f : 0.f;
+  for (int q = 0; q < NE; q++) A[q] = q == m ? 1.0f : 0.f;
 #pragma unroll
-  for (int pp = 0; pp < 16; pp++) {
+  for (int pp = 0; pp < NE; pp++) {
     if (pp < nmax) {  // (wave-uniform guards, no `break`: the loops must unroll fully)
       float dv[DPL];
 #pragma unroll
       for (int c = 0; c < DPL; c++) dv[c] = d[c] * v[pp][c] * sqj[pp];
 #pragma unroll
-      for (int q = pp; q < 16; q++) {
+      for (int q = pp; q < NE; q++) {
         if (q < nmax) {
           float s = 0.f;
 #pragma unroll
           for (int c = 0; c < DPL; c++) s = fmaf(dv[c], v[q][c], s);
-          s = row16_sum(s) * sqj[q];  // (G S G)[pp][q], in every lane of the row
+          s = E::row_sum(s) * sqj[q];  // (G S G)[pp][q], in every lane of the row
           A[q] += m == pp ? s : 0.f;
           if (q != pp) A[pp] += m == q ? s : 0.f;
         }
@@ -750,7 +775,7 @@ __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p)
   // ---- Cholesky A = L L^T by columns; lane m ends with row m of L in A[0 .. m]
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
+  for (int k = 0; k < NE; k++) {
     if (k < nmax) {
       const float piv = E::bcast_f(A[k], k);
       bad = bad || !(piv > 0.f);
@@ -758,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p)
       const float lmk = A[k] * rinv;  // L[m][k] for m >= k (lane k: sqrt(piv))
       A[k] = lmk;
 #pragma unroll
-      for (int q = k + 1; q < 16; q++) {
+      for (int q = k + 1; q < NE; q++) {
         if (q < nmax) {
           const float lqk = E::bcast_f(lmk, q);  // L[q][k]
           A[q] = fmaf(-lmk, lqk, A[q]);          // (only the part q <= m of row m is used below)
@@ -768,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p)
   }
   // ---- L z = rhs, then L^T s = z
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
+  for (int k = 0; k < NE; k++) {
     if (k < nmax) {
       const float zk = E::bcast_f(rhs * __builtin_amdgcn_rcpf(A[k]), k);  // lane k holds L[k][k] in A[k]
       rhs = m == k ? zk : (m > k ? fmaf(-A[k], zk, rhs) : rhs);
@@ -777,9 +802,9 @@ __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p)
   // s_k = (z_k - sum_{q > k} L[q][k] s_q) / L[k][k]: lane q holds L[q][k] and (once final) s_q, so
   // the sum is one product per lane and a row sum - no per-element hand-over between lanes
 #pragma unroll
-  for (int k = 15; k >= 0; k--) {
+  for (int k = NE - 1; k >= 0; k--) {
     if (k < nmax) {
-      const float part = row16_sum(m > k && m < nmax ? A[k] * rhs : 0.f);
+      const float part = E::row_sum(m > k && m < nmax ? A[k] * rhs : 0.f);
       rhs = m == k ? (rhs - part) * __builtin_amdgcn_rcpf(A[k]) : rhs;
     }
   }
@@ -792,7 +817,7 @@ __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p)
 #pragma unroll
   for (int c = 0; c < DPL; c++) acc[c] = 0.f;
 #pragma unroll
-  for (int j = 0; j < 16; j++) {
+  for (int j = 0; j < NE; j++) {
     if (j < nmax) {
       const float yj = E::bcast_f(ym, j);
 #pragma unroll
@@ -801,9 +826,8 @@ __global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p)
   }
   if (exists) {
 #pragma unroll
-    for (int c = 0; c < DPL; c += 4)
-      *reinterpret_cast<f32x4 *>(xrow + c) =
-          f32x4{acc[c] * d[c], acc[c + 1] * d[c + 1], acc[c + 2] * d[c + 2], acc[c + 3] * d[c + 3]};
+    for (int c = 0; c < DPL; c++) acc[c] *= d[c];
+    E::store_dpl(xrow, acc);
   }
 }
 
