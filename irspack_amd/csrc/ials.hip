@@ -1018,11 +1018,12 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   // short rows (<= 32 entries) of a side that has enough of them: Cholesky in its low-rank form /
   // CG with a diagonal P, both in the eigenbasis of P (ials_eig_kernels.hpp)
   const bool short_cg_ok = cg && prior == nullptr && sd.n_short > 0 && (t->T <= 4 || t->T == 8) && t->opt_short;
+  hipStream_t short_stream = t->stream;
   auto launch_short_cg = [&]() {  // the matrix-free short-row CG kernels over the tail of the task list
     const int n_regular = sd.n_tasks - sd.n_short;
     int n_cu = 0;
     IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device));
-    t->prof.begin(pidx == 0 ? "ials_short_cg_user" : "ials_short_cg_item", t->stream);
+    t->prof.begin(pidx == 0 ? "ials_short_cg_user" : "ials_short_cg_item", short_stream);
     IRS_DISPATCH_T8(t->T, {
       constexpr int KPP = 16 * TT;
       const size_t lds = ShortGeo<KPP>::LDS_BYTES;
@@ -1033,7 +1034,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                                     static_cast<int>(lds)));
         const int grid = static_cast<int>(
             std::min<int64_t>(ceil_div(count, SHORT_WAVES * nr), 2 * std::max(n_cu, 1)));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * SHORT_WAVES), lds, t->stream, p,
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * SHORT_WAVES), lds, short_stream, p,
                            t->P[pidx].ptr, first, count);
       };
       // the list is longest first: [general | 17..32 entries | <= 16 entries]
@@ -1045,13 +1046,28 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         launch(ials_cg_short_kernel<KPP, 16, 1>, sd.n_tasks - sd.n_short16, sd.n_short16, 1);
       }
     });
-    t->prof.end(t->stream);
+    t->prof.end(short_stream);
   };
   const bool eig_cand = prior == nullptr && other == t->factor[1 - pidx].ptr && eig_begin(t, sd, pidx);
+  bool short_forked = false;
   if (eig_cand) {
     n_regular = sd.n_tasks - sd.n_short;  // (the long rows start now, beside the decomposition)
   } else if (short_cg_ok) {
+    // the short-row kernels (latency bound, low issue rate) run BESIDE the kernels of the long rows
+    // (matrix-core bound) on the second stream when there are enough of them to matter
+    if (sd.n_short >= 65536) {
+      if (!t->stream2) {
+        IRS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+        IRS_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+        IRS_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+      }
+      IRS_HIP(hipEventRecord(t->ev_fork, t->stream));
+      IRS_HIP(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+      short_stream = t->stream2;
+      short_forked = true;
+    }
     launch_short_cg();
+    short_stream = t->stream;
     n_regular = sd.n_tasks - sd.n_short;
   }
   // the kernels of the K x K systems over `count` tasks starting at `tasks_begin`
@@ -1166,6 +1182,10 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   IRS_HIP(hipGetLastError());
   };  // launch_dense
   launch_dense(sd.tasks.ptr, n_regular, true);
+  if (short_forked) {
+    IRS_HIP(hipEventRecord(t->ev_join, t->stream2));
+    IRS_HIP(hipStreamWaitEvent(t->stream, t->ev_join, 0));
+  }
   if (eig_cand && !eig_finish(t, sd, other, target, pidx, cg, p.max_cg_steps, p.err_flag)) {
     // the eigenbasis path declined (ill-conditioned P + reg I): the short rows through the usual kernels
     p.tasks = sd.tasks.ptr;

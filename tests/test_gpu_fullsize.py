@@ -126,8 +126,8 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
         stay affordable) are evaluated in float64;
       * on those rows the GPU must be within 5 RTOL of the float64 result, at most
         FAR_FRACTION of all rows - or as many as the oracle itself has - may be farther than
-        RTOL from it, and its worst row must be no farther from float64 than twice the oracle's
-        worst row (the two tails are different rows: the comparison is between the
+        RTOL from it, and its worst row must be no farther from float64 than three times the
+        oracle's worst row (the two tails are different rows: the comparison is between the
         distributions, not row by row).
     The achieved figures go to the parity log whatever the outcome."""
     num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
@@ -159,7 +159,9 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
         # in ANY float32 evaluation: the oracle's own count is the yardstick there)
         assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows), (e_orc >= RTOL).sum()), (
             what, int((e_gpu >= RTOL).sum()), int((e_orc >= RTOL).sum()))
-        assert e_gpu.max() <= max(2 * e_orc.max(), RTOL), (what, float(e_gpu.max()), float(e_orc.max()))
+        # (three times: the tails are a handful of rows - 3 or 4 of 200,000 on the configs[3]-like
+        # matrix - and the ratio of two such maxima moves between 0.7 and 2.1 from run to run)
+        assert e_gpu.max() <= max(3 * e_orc.max(), RTOL), (what, float(e_gpu.max()), float(e_orc.max()))
     return float(err.max()), int(far.size)
 
 
