@@ -542,7 +542,8 @@ void launch_gk_solve(irs_ials_trainer *t, Side &sd, const float *other, float *t
   if (sc->solver_type == IRS_SOLVER_CG) {
     const int steps = sc->max_cg_steps == 0 ? static_cast<int>(t->K)
                                             : static_cast<int>(std::min<uint64_t>(sc->max_cg_steps, 1u << 20));
-    const size_t lds = (8 * static_cast<size_t>(t->KP) + 8) * sizeof(float);
+    const size_t lds = (4 * static_cast<size_t>(t->KP) + 8) * sizeof(float) +
+                       4 * static_cast<size_t>(t->KP) * sizeof(double);  // vectors + float64 partial sums
     IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gk_cg_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     t->prof.begin(pidx == 0 ? "ials_solve_cg_user" : "ials_solve_cg_item", t->stream);

@@ -414,8 +414,12 @@ __global__ void gk_block_delta_kernel(GkParams p, float *__restrict__ delta, int
 __global__ __launch_bounds__(256, 2) void gk_cg_kernel(GkParams p, int max_cg_steps, int warm_start) {
   extern __shared__ __attribute__((aligned(16))) float gk_cg_lds[];
   const int KP = p.ldP, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  float *x = gk_cg_lds, *r = x + KP, *pv = r + KP, *Ap = pv + KP, *wacc = Ap + KP;  // wacc: 4 x KP
-  float *red = wacc + 4 * KP;                                                       // 8 floats
+  float *x = gk_cg_lds, *r = x + KP, *pv = r + KP, *Ap = pv + KP;
+  // the gathered sums of a row (up to 10^5 terms per dim on this path: rows are not split) are
+  // accumulated in float64, one partial per wave: the float32 form was 7e-4 from the float64
+  // iterate on ML-20M item rows of 10^4 entries at K = 320 (the oracle's sequential float32 sums: 1.2e-3)
+  double *wacc = reinterpret_cast<double *>(Ap + KP);             // 4 x KP doubles
+  float *red = reinterpret_cast<float *>(wacc + 4 * KP);          // 8 floats
   const int row = p.rows[p.row_first + blockIdx.x];
   const int b = p.indptr[row], e = p.indptr[row + 1];
   float *trow = p.target + static_cast<size_t>(row) * p.ld_target;
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(256, 2) void gk_cg_kernel(GkParams p, int max_cg_st
   // out (+)= sum_q wgt_q (v_q . vec) v_q over the row; wgt = c.  `vec` may be null: out = sum w v
   // with the rhs weights (the right-hand side b, hpp:212-221)
   auto gather = [&](const float *vec, float *out, bool add) {
-    float *mine = wacc + wv * KP;
-    for (int k = lane; k < KP; k += 64) mine[k] = 0.f;
+    double *mine = wacc + wv * KP;
+    for (int k = lane; k < KP; k += 64) mine[k] = 0.0;
     // four stored entries of this wave at a time: their loads are issued together (one entry
     // after the other is a chain of exposed L2 latencies - the 116 k-entry item row of the
     // ML-20M shape alone took 60 ms per half-step that way)
@@ -463,16 +467,19 @@ __global__ __launch_bounds__(256, 2) void gk_cg_kernel(GkParams p, int max_cg_st
         for (int j = 0; j < 4; j++) s[j] = q0 + 4 * j < e ? p.bias + c[j] : 0.f;
       }
       for (int k = lane; k < KP; k += 64) {
-        float a = mine[k];
+        double a = mine[k];
 #pragma unroll
-        for (int j = 0; j < 4; j++) a = fmaf(s[j], v[j][k], a);  // ascending entry order
+        for (int j = 0; j < 4; j++)  // ascending entry order
+          a = fma(static_cast<double>(s[j]), static_cast<double>(v[j][k]), a);
         mine[k] = a;
       }
     }
     __syncthreads();
     for (int k = tid; k < KP; k += 256) {
-      const float s = (wacc[k] + wacc[KP + k]) + (wacc[2 * KP + k] + wacc[3 * KP + k]);
-      out[k] = add ? out[k] + s : s;
+      const double s = (wacc[k] + wacc[KP + k]) + (wacc[2 * KP + k] + wacc[3 * KP + k]);
+      // (`add`: out holds P vec; + reg vec comes last, see ials_short_kernels.hpp)
+      out[k] = add ? fmaf(reg, vec[k], static_cast<float>(static_cast<double>(out[k]) + s))
+                   : static_cast<float>(s);
     }
     __syncthreads();
   };
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void gk_cg_kernel(GkParams p, int max_cg_st
         s2 = fmaf(col[static_cast<size_t>(k + 2) * KP], vec[k + 2], s2);
         s3 = fmaf(col[static_cast<size_t>(k + 3) * KP], vec[k + 3], s3);
       }
-      out[t] = fmaf(reg, vec[t], (s0 + s1) + (s2 + s3));
+      out[t] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     gather(vec, out, true);

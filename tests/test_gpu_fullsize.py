@@ -154,7 +154,9 @@ def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alph
         # 38077: ||r||^2 = 32, 67, 1.7, 19 over the steps, 8 % from the solution - and the
         # iteration amplifies any float32 rounding by the conditioning, for GPU and oracle
         # alike: 1.6e-4 .. 3.7e-4 from float64 for either, run to run; scripts/debug/cg_row_probe.py)
-        assert e_gpu.max() < 5 * RTOL, (what, float(e_gpu.max()))
+        # (... and never asked to be closer to float64 than the oracle itself manages: its
+        # sequential float32 sums over rows of 10^4 entries reach 1e-3 .. 2e-3)
+        assert e_gpu.max() < max(5 * RTOL, e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))
         # (rows of norm ~1e-7 next to a warm start of norm ~1e-3 lose 3-4 digits to cancellation
         # in ANY float32 evaluation: the oracle's own count is the yardstick there)
         assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows), (e_orc >= RTOL).sum()), (
