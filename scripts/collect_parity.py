@@ -1,6 +1,6 @@
 """Folds gpurun_out/parity_gpu.jsonl (written by tests/conftest.py:record_parity during a
 `pytest -m gpu` run on the GPU box) into the tracked profiles/parity_rNN.json: the last
-record per (test, config), sorted, plus the worst figure per test.
+record per (test, config), sorted, plus a per-test summary.
 
     python scripts/collect_parity.py [gpurun_out/parity_gpu.jsonl] [profiles/parity_r03.json]
 """
@@ -22,13 +22,24 @@ def main() -> None:
                 rec = json.loads(line)
                 last[(rec["test"], rec["config"])] = rec
     recs = [last[k] for k in sorted(last)]
-    worst = {}
+    # per test: the worst row against the oracle and - on the rows that differ from it by more
+    # than 1e-4, which the float64 evaluation arbitrates - the worst GPU and the worst ORACLE
+    # distance from float64 (a large first figure with a small second one means the oracle's own
+    # float32 rounding is the far side)
+    summary = {}
     for r in recs:
-        e = r.get("worst_row_err")
-        if e is not None:
-            worst[r["test"]] = max(worst.get(r["test"], 0.0), e)
+        s = summary.setdefault(r["test"], {"n_comparisons": 0})
+        s["n_comparisons"] += 1
+        for key, name in (("worst_row_err", "worst_row_err_vs_oracle"), ("worst_vs_float64", "worst_gpu_vs_float64"),
+                          ("oracle_vs_float64", "worst_oracle_vs_float64"), ("n_rows_over_1e_4", "max_rows_over_1e-4_vs_oracle"),
+                          ("worst_value_rel_err", "worst_value_rel_err")):
+            v = r.get(key)
+            if v is not None:
+                s[name] = max(s.get(name, 0), v)
+        if "indices_bit_exact" in r:
+            s["indices_bit_exact"] = bool(s.get("indices_bit_exact", True) and r["indices_bit_exact"])
     out = {"source": os.path.relpath(src, ROOT), "n_records": len(recs),
-           "worst_row_err_by_test": worst, "records": recs}
+           "summary_by_test": summary, "records": recs}
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print(f"{len(recs)} records -> {dst}")

@@ -122,3 +122,32 @@ def test_ill_conditioned_gramian_falls_back():
     t.half_step_async(0, sc)
     t.synchronize()
     assert not t.last_half_step_used_eigenbasis()
+
+
+@pytest.mark.parametrize("K", [64, 128])
+def test_ialspp_with_one_block_takes_the_eigenbasis_cholesky(K):
+    """iALS++ whose one block covers every dimension is the direct solve (hpp:436-502 is a Newton
+    step of a quadratic): it goes through the same kernels as Cholesky, the eigenbasis path
+    included; equal to the oracle's two-step block form within 1e-4."""
+    X = short_row_matrix(160_000 if K > 64 else 1_200_000, 300, 9, True)
+    mc = (IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(2e-2).set_nu(1.0).set_init_stdev(0.1)
+          .set_random_seed(42).build())
+    omc = O.model_config(K, alpha0=0.1, reg=2e-2, nu=1.0, init_stdev=0.1, random_seed=42)
+    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType.IALSPP)
+          .set_ialspp_subspace_dimension(128).set_ialspp_iteration(1).build())
+    osc = O.solver_config(8, "IALSPP", 3, ialspp_subspace_dimension=128, ialspp_iteration=1)
+    t = IALSTrainer(mc, X)
+    user0, item0 = t.user, t.item
+    P = O.ials_gramian(item0, 0.1, 8)
+    want = O.ials_solver_step(user0, X, item0, P, omc, osc)
+    t.partial_gramian_async(0)
+    t.finish_gramian_async(0)
+    t.half_step_async(0, sc)
+    t.synchronize()
+    assert t.last_half_step_used_eigenbasis()
+    # (an empty row: the direct solve gives exactly 0, the oracle's Newton step x0 - A^-1 (A x0)
+    # leaves rounding noise of ~1e-9 there - compared in absolute terms)
+    live = np.diff(X.indptr) > 0
+    got = t.user
+    assert row_rel_err(got[live], want[live]) < RTOL
+    assert np.abs(got[~live]).max() == 0.0 and np.abs(want[~live]).max() < 1e-6
