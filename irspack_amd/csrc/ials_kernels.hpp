@@ -580,6 +580,16 @@ template <int T> struct CholGeo {
   static constexpr int PAN_FLOATS = 4 * PR;
   static constexpr int SPILL_FLOATS = NT * TS + KP;
   static constexpr int LDS_FLOATS = PAN_FLOATS > SPILL_FLOATS ? PAN_FLOATS : SPILL_FLOATS;
+  // solve_row_cg128 (T = 8): unpadded tile rows.  With the 20-float stride the spill is 46.6 KB per
+  // wave and only THREE one-wave workgroups fit a CU's 160 KB (one SIMD idle); at 16 floats it is
+  // 37.4 KB and four fit.  The price is a 4-way bank conflict on the b128 row reads that load the
+  // matrix into registers once per row (IRS_CG128_ROW_STRIDE=20 restores the padded layout).
+#ifndef IRS_CG128_ROW_STRIDE
+#define IRS_CG128_ROW_STRIDE 16
+#endif
+  static constexpr int RS_CG = IRS_CG128_ROW_STRIDE;
+  static constexpr int TS_CG = 16 * RS_CG;
+  static constexpr int SPILL_CG_FLOATS = NT * TS_CG + KP;
   static constexpr int tix(int i, int j) { return i * T - i * (i - 1) / 2 + (j - i); }
 };
 
@@ -786,13 +796,13 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
     return;
   }
   // (the regulariser is not added to the diagonal: see solve_row<T, 1>)
-  float *bbuf = sm + C::NT * C::TS;
+  float *bbuf = sm + C::NT * C::TS_CG;
 #pragma unroll
   for (int i = 0; i < T; i++) {
 #pragma unroll
     for (int j = i; j < T; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS + (4 * g + r) * C::RS + m] = acc[C::tix(i, j)][r];
+      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS_CG + (4 * g + r) * C::RS_CG + m] = acc[C::tix(i, j)][r];
     if (g == 0) bbuf[16 * i + m] = b4[i];
   }
   __threadfence_block();
@@ -805,7 +815,7 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
 #pragma unroll
     for (int J = 0; J < T; J++) {
       if (J >= Iq[q]) {  // row rk of tile (I, J)
-        const float *src = sm + tile_of(Iq[q], J) * C::TS + rk * C::RS;
+        const float *src = sm + tile_of(Iq[q], J) * C::TS_CG + rk * C::RS_CG;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
           const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * c);
@@ -813,9 +823,9 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
           a[q][16 * J + 4 * c + 2] = v.z; a[q][16 * J + 4 * c + 3] = v.w;
         }
       } else {  // column rk of tile (J, I)
-        const float *src = sm + tile_of(J, Iq[q]) * C::TS + rk;
+        const float *src = sm + tile_of(J, Iq[q]) * C::TS_CG + rk;
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[q][16 * J + c] = src[c * C::RS];
+        for (int c = 0; c < 16; c++) a[q][16 * J + c] = src[c * C::RS_CG];
       }
     }
   // virtual row 16 I + rk is latent dim T rk + I
@@ -903,7 +913,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : SOLV
   constexpr bool LOWER = SOLVER == 0;
   constexpr int RING = (T > 4 && SOLVER == 0) ? 4 : 8;  // gathered sub-steps in flight
   constexpr int LDS_PER_WAVE = SOLVER == 0 ? Chol16Geo<T>::LDS_FLOATS
-                                           : (T == 8 ? CholGeo<T>::LDS_FLOATS : G::LDS_FLOATS);
+                                           : (T == 8 ? CholGeo<T>::SPILL_CG_FLOATS : G::LDS_FLOATS);
   __shared__ __attribute__((aligned(16))) float lds[SOLVE_WAVES * LDS_PER_WAVE];
   const int wid = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
