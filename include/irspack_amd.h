@@ -301,7 +301,8 @@ irs_status irs_eval_last_stats(irs_evaluator *e, irs_eval_stats *out);
  * No reference counterpart: SURVEY.md 8(d) asks for ceilings MEASURED on the box next to the
  * spec peaks.  Runs a 1 GiB device copy and STREAM triad (HBM bytes moved / time), a loop of
  * nothing but v_mfma_f32_16x16x4_f32 on every SIMD, and a loop of random-bank ds_add_u32 on
- * every CU (the kNN count accumulation's instruction); all HIP-event timed, best of 5. */
+ * every CU (the kNN count accumulation's instruction), and a random whole-row gather out of a
+ * 1 GiB table (the iALS access pattern); all HIP-event timed, best of 3-5. */
 typedef struct irs_ceilings {
   double copy_gbs;            /* read + write bytes per second of dst = src, GB/s */
   double triad_gbs;           /* a = b + s c: 3 x bytes, GB/s */
@@ -309,6 +310,8 @@ typedef struct irs_ceilings {
   double lds_atomic_u32_gops; /* lane-level LDS atomic adds per second (whole device), G/s */
   double clock_mhz;           /* hipDeviceAttributeClockRate */
   int32_t n_cu;
+  double gather256_gbs;       /* uniformly random 256-byte rows of a 1 GiB table (16 lanes per row), GB/s */
+  double gather512_gbs;       /* the same with 512-byte rows (K = 128 factor rows) */
 } irs_ceilings;
 irs_status irs_measure_ceilings(int32_t device, irs_ceilings *out);
 

@@ -80,6 +80,8 @@ class CeilingsStruct(C.Structure):  # irs_ceilings
         ("lds_atomic_u32_gops", C.c_double),
         ("clock_mhz", C.c_double),
         ("n_cu", C.c_int32),
+        ("gather256_gbs", C.c_double),
+        ("gather512_gbs", C.c_double),
     ]
 
 

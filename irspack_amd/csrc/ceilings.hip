@@ -1,6 +1,6 @@
 // Measured ceilings of the device this process runs on ("a device copy / triad
 // GB/s and a pure-MFMA fp32 GEMM TF measured in the same run next to the spec peaks").
-// Three tiny kernels, HIP-event timed: bench.py prints fraction-of-spec and
+// A few tiny kernels, HIP-event timed: bench.py prints fraction-of-spec and
 // fraction-of-measured for its roofline objects.  No reference counterpart.
 #include <algorithm>
 
@@ -62,6 +62,34 @@ __global__ __launch_bounds__(1024) void lds_atomic_kernel(int n_per_thread, unsi
   if (s == 0xdeadbeefu) out[blockIdx.x] = s;
 }
 
+// Random gather of whole rows (ROW_F4 x 16 bytes each, 16 lanes per row) out of a 1 GiB table:
+// the access pattern of the iALS rank update and of its short-row kernels (one gathered factor
+// row per stored entry).  Eight row loads are in flight per lane group; the rows are drawn by a
+// per-group LCG, uniformly - no reuse beyond what 2 M random rows leave in the caches.
+template <int ROW_F4>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const f32x4 *__restrict__ table, unsigned row_mask,
+                                                          int rows_per_group, f32x4 *__restrict__ out) {
+  constexpr int PER_LANE = ROW_F4 / 16;  // float4 loads per lane and row (1: 256 B rows, 2: 512 B rows)
+  const unsigned group = (blockIdx.x * 256u + threadIdx.x) >> 4, m = threadIdx.x & 15;
+  unsigned st = group * 2654435761u + 12345u;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < rows_per_group; it += 8) {
+    f32x4 v[8][PER_LANE];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      st = st * 1664525u + 1013904223u;
+      const f32x4 *row = table + static_cast<size_t>((st >> 8) & row_mask) * ROW_F4;
+#pragma unroll
+      for (int q = 0; q < PER_LANE; q++) v[u][q] = row[16 * q + m];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int q = 0; q < PER_LANE; q++) acc += v[u][q];
+  }
+  if (acc.x == 12345.678f) out[threadIdx.x] = acc;  // never true (the table is zero): keeps the loads
+}
+
 template <class F> double best_ms(F &&launch, hipStream_t s, int reps) {
   hipEvent_t e0, e1;
   IRS_HIP(hipEventCreate(&e0));
@@ -118,6 +146,15 @@ extern "C" irs_status irs_measure_ceilings(int32_t device, irs_ceilings *out) {
     const int per = 4096;
     ms = best_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel, dim3(n_cu), dim3(1024), 0, s, per, reinterpret_cast<unsigned *>(a.ptr)); }, s, 3);
     out->lds_atomic_u32_gops = static_cast<double>(n_cu) * 1024 * per / (ms * 1e-3) / 1e9;
+    {
+      // 1 GiB table: 4 M rows of 256 B / 2 M rows of 512 B; 8 workgroups per CU, 16 row groups each
+      const int ggrid = n_cu * 8, per_group = 512;
+      const double rows = static_cast<double>(ggrid) * 16 * per_group;
+      ms = best_ms([&] { hipLaunchKernelGGL(gather_rows_kernel<16>, dim3(ggrid), dim3(256), 0, s, b.ptr, (1u << 22) - 1, per_group, a.ptr); }, s, 3);
+      out->gather256_gbs = rows * 256.0 / (ms * 1e-3) / 1e9;
+      ms = best_ms([&] { hipLaunchKernelGGL(gather_rows_kernel<32>, dim3(ggrid), dim3(256), 0, s, b.ptr, (1u << 21) - 1, per_group, a.ptr); }, s, 3);
+      out->gather512_gbs = rows * 512.0 / (ms * 1e-3) / 1e9;
+    }
     out->n_cu = n_cu;
     int clk_khz = 0;
     IRS_HIP(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, device));

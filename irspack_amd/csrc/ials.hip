@@ -66,6 +66,15 @@ static int chunk_size() {
   return v;
 }
 
+static int max_chunks() {
+  static int v = [] {
+    const char *e = std::getenv("IRSPACK_AMD_IALS_MAX_CHUNKS");
+    int c = e ? std::atoi(e) : 256;
+    return std::max(c, 1);
+  }();
+  return v;
+}
+
 // One CSR orientation resident on the device, with its longest-first task list.
 struct Side {
   int64_t n_rows = 0, n_other = 0, row_begin = 0, row_end = 0, nnz = 0;
@@ -73,6 +82,8 @@ struct Side {
   DeviceBuffer<float> data, reg;
   DeviceBuffer<Task> tasks;
   DeviceBuffer<SplitRow> split;
+  DeviceBuffer<FoldGroup> fold;  // groups of partial Gramians summed before the split rows are finished
+  int32_t n_fold = 0;
   DeviceBuffer<int32_t> rows_by_len;  // rows [row_begin, row_end) longest first (iALS++ launch order)
   int32_t n_tasks = 0, n_split = 0, n_slots = 0, n_long = 0;
   // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
@@ -103,18 +114,27 @@ struct Side {
     const int CH = chunk_size();
     std::vector<Task> tk;
     std::vector<SplitRow> sp;
+    std::vector<FoldGroup> fg;
     tk.reserve(re - rb);
     int32_t slots = 0;
     for (int64_t r = rb; r < re; r++) {
       const int32_t b = ip32[r], e = ip32[r + 1], nz = e - b;
       if (nz > CH) {
-        // at most 32 chunks per row: the second kernel adds a row's partials one after the other
-        const int32_t nch = std::min<int32_t>((nz + CH - 1) / CH, 32);
+        // a bounded number of chunks per row: the second kernel adds a row's partials one after
+        // the other, and a chunk is one wave's serial work (the longest chunk is the floor of
+        // the half-step: 4.4 M entries in 32 chunks were 16 ms of one wave at K = 128)
+        const int32_t nch = std::min<int32_t>((nz + CH - 1) / CH, max_chunks());
         const int32_t per = (((nz + nch - 1) / nch) + 3) & ~3;
-        SplitRow sr{static_cast<int32_t>(r), slots, 0, nz};
+        SplitRow sr{static_cast<int32_t>(r), slots, 0, nz, 1};
         for (int32_t c = b; c < e; c += per) {
           tk.push_back(Task{static_cast<int32_t>(r), c, std::min(c + per, e), slots++});
           sr.n_slots++;
+        }
+        if (sr.n_slots > FOLD_MIN) {
+          for (int32_t g = 0; g < sr.n_slots; g += FOLD_GROUP)
+            fg.push_back(FoldGroup{sr.first_slot + g, std::min(FOLD_GROUP, sr.n_slots - g)});
+          sr.n_slots = (sr.n_slots + FOLD_GROUP - 1) / FOLD_GROUP;
+          sr.slot_stride = FOLD_GROUP;
         }
         sp.push_back(sr);
       } else {
@@ -180,6 +200,8 @@ struct Side {
     reg.upload(regs, s);
     tasks.upload(tk, s);
     split.upload(sp, s);
+    n_fold = static_cast<int32_t>(fg.size());
+    fold.upload(fg, s);
     IRS_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
   }
 };
@@ -252,6 +274,8 @@ struct irs_ials_trainer {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;  // iALS++: the short-row launch beside the long-row launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream3 = nullptr;  // eigenbasis short rows: every other pass
+  hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;
   bool has_X = false;
   bool whole = true;  // unsharded: both CSR orientations are complete on this device
   irs_ials_shard shard{0, 0, 0, 0};
@@ -273,9 +297,11 @@ struct irs_ials_trainer {
   DeviceBuffer<float> pp_pblk;         // iALS++ chain path: blocks of P in accumulator layout
   DeviceBuffer<float> gk_sys, gk_delta;  // general-size path (ials_gk_kernels.hpp): scratch systems
   // eigenbasis short-row path (ials_eig_kernels.hpp)
-  DeviceBuffer<float> eig_Qrows, eig_Qcols, eig_lam, eig_stats, eig_table, eig_xt;
+  DeviceBuffer<float> eig_Qrows, eig_Qcols, eig_lam, eig_stats, eig_table, eig_xt, eig_xt2;
   DeviceBuffer<double> eig_Qd[2];   // per solved side: float64 eigenvectors, the next call's warm start
   bool eig_warm[2] = {false, false};
+  int *eig_resident = nullptr;  // host-pinned: the decomposition kernel reports that it has a CU
+  int eig_token = 0;
   float eig_stats_host[4] = {0, 0, 0, 0};
   bool opt_eig = true;  // IRSPACK_AMD_IALS_EIG
   int32_t eig_last = 0; // 1: the last half-step took the eigenbasis path (diagnostics)
@@ -428,7 +454,10 @@ void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t 
     });
   } else {
     // four waves of a block share a slab of rows and split the tiles between them
-    const int64_t n_blocks = std::min<int64_t>(256, std::max<int64_t>(1, ceil_div(n, 64)));
+    // (a wave has ONE 4-row load in flight per step: with one block per CU ten million rows took
+    // 5.6 ms, 0.9 TB/s; more resident blocks hide the latency - up to eight per CU for long sides)
+    const int64_t n_blocks = std::min<int64_t>(std::max<int64_t>(256, std::min<int64_t>(2048, n / 1024)),
+                                               std::max<int64_t>(1, ceil_div(n, 64)));
     int64_t per_block = ceil_div(std::max<int64_t>(n, 1), n_blocks);
     per_block = ceil_div(per_block, 4) * 4;
     IRS_DISPATCH_TW(t->T, {
@@ -769,7 +798,12 @@ void launch_eigen(irs_ials_trainer *t, int pidx, hipStream_t stream) {
   t->eig_lam.alloc(KP);
   t->eig_stats.alloc(4);
   t->eig_Qd[pidx].alloc(static_cast<size_t>(KP) * KP);
-  EigOut o{t->eig_Qrows.ptr, t->eig_Qcols.ptr, t->eig_lam.ptr, t->eig_stats.ptr, t->eig_Qd[pidx].ptr};
+  if (!t->eig_resident) {
+    IRS_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->eig_resident), sizeof(int), hipHostMallocCoherent));
+    *t->eig_resident = 0;
+  }
+  EigOut o{t->eig_Qrows.ptr, t->eig_Qcols.ptr, t->eig_lam.ptr, t->eig_stats.ptr, t->eig_Qd[pidx].ptr,
+           t->eig_resident, ++t->eig_token};
   const int warm = t->eig_warm[pidx] ? 1 : 0;
   t->eig_warm[pidx] = true;
   const size_t lds = static_cast<size_t>(KP) * KP * sizeof(double);
@@ -796,7 +830,7 @@ void launch_eigen(irs_ials_trainer *t, int pidx, hipStream_t stream) {
 //               rotation on the second stream and joins it.  Returns false - nothing launched
 //               that changes the factors - when the path declines; the caller then runs its
 //               usual kernels over those rows.
-bool eig_begin(irs_ials_trainer *t, Side &sd, int pidx) {
+bool eig_begin(irs_ials_trainer *t, Side &sd, int pidx, bool cg) {
   t->eig_last = 0;
   const int KP = t->KP;
   if (!t->opt_eig || (KP != 64 && KP != 128) || !sd.positive || sd.n_short <= 0) return false;
@@ -805,7 +839,16 @@ bool eig_begin(irs_ials_trainer *t, Side &sd, int pidx) {
   // configs[3]: the user side (9.7 M short rows, 10^6 gathered rows) yes, the item side (0.8 M
   // short rows, 10^7 gathered rows: the product alone would cost more than those rows) no.
   if (static_cast<double>(sd.n_short) * KP * KP * KP < 3e11) return false;
-  if (static_cast<double>(sd.n_short) * KP < 64.0 * static_cast<double>(sd.n_other)) return false;
+  // Cholesky saves a dense KP^3 / 3 factorisation per short row, CG only its products with P, and
+  // the table product competes with the long rows' kernels beside it.  configs[3], item side
+  // (0.8 M short rows, 10^7 gathered rows) on this path: Cholesky epoch 60.2 -> 52.1 ms, CG epoch
+  // 48.8 -> 50.9 ms.  IRSPACK_AMD_IALS_EIG_RATIO overrides both thresholds.
+  static const double ratio_env = [] {
+    const char *e = std::getenv("IRSPACK_AMD_IALS_EIG_RATIO");
+    return e ? std::atof(e) : 0.0;
+  }();
+  const double ratio = ratio_env > 0.0 ? ratio_env : (cg ? 64.0 : 8.0);
+  if (static_cast<double>(sd.n_short) * KP < ratio * static_cast<double>(sd.n_other)) return false;
   if (!t->stream2) {
     IRS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
     IRS_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
@@ -814,8 +857,14 @@ bool eig_begin(irs_ials_trainer *t, Side &sd, int pidx) {
   IRS_HIP(hipEventRecord(t->ev_fork, t->stream));  // (the Gramian of this half-step is on t->stream)
   IRS_HIP(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
   launch_eigen(t, pidx, t->stream2);
-  IRS_HIP(hipMemcpyAsync(t->eig_stats_host, t->eig_stats.ptr, 3 * sizeof(float), hipMemcpyDeviceToHost,
-                         t->stream2));
+  // the decomposition needs a CU to itself (its LDS): the long rows' kernels, which the caller
+  // launches next, must not reach the device before it is resident.  It reports that through a
+  // host-pinned word; the wait is the time the stream's earlier work (the Gramian) still needs,
+  // bounded so that a lost report costs speed, not progress.
+  const auto t0 = std::chrono::steady_clock::now();
+  while (__atomic_load_n(t->eig_resident, __ATOMIC_ACQUIRE) != t->eig_token &&
+         std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
+    ;
   return true;
 }
 
@@ -823,6 +872,7 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
                 int max_cg_steps, int32_t *err_flag) {
   const int KP = t->KP;
   hipStream_t s2 = t->stream2;
+  IRS_HIP(hipMemcpyAsync(t->eig_stats_host, t->eig_stats.ptr, 3 * sizeof(float), hipMemcpyDeviceToHost, s2));
   IRS_HIP(hipStreamSynchronize(s2));
   const float *st = t->eig_stats_host;
   if (env_flag("IRSPACK_AMD_EIG_DEBUG", false))
@@ -835,21 +885,21 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
   // V~ = other Q  (every gathered row once per half-step)
   const int64_t n_other = sd.n_other;
   t->eig_table.alloc(static_cast<size_t>(std::max<int64_t>(n_other, 1)) * KP);
-  {
-    const int64_t waves = ceil_div(n_other, 64) * ceil_div(KP, 64);
-    t->prof.begin("eig_table", s2);
-    if (KP == 128)
-      hipLaunchKernelGGL((user_scores_kernel<128>), dim3(ceil_div(waves, 4)), dim3(256), 0, s2, other,
-                         static_cast<const float *>(t->eig_Qrows.ptr), int64_t(0), n_other, int64_t(KP),
-                         t->eig_table.ptr);
-    else
-      hipLaunchKernelGGL((user_scores_kernel<64>), dim3(ceil_div(waves, 4)), dim3(256), 0, s2, other,
-                         static_cast<const float *>(t->eig_Qrows.ptr), int64_t(0), n_other, int64_t(KP),
-                         t->eig_table.ptr);
-    t->prof.end(s2);
-  }
+  check_arg(n_other < (int64_t(1) << 31) - 64, "eigenbasis table: too many gathered rows");
+  t->prof.begin("eig_table", s2);
+  if (KP == 128)
+    hipLaunchKernelGGL((rows_times_matT_kernel<128>), dim3(ceil_div(n_other, 256)), dim3(256), 0, s2, other,
+                       static_cast<const Task *>(nullptr), t->eig_table.ptr, static_cast<const Task *>(nullptr),
+                       static_cast<const float *>(t->eig_Qrows.ptr), static_cast<int>(n_other));
+  else
+    hipLaunchKernelGGL((rows_times_matT_kernel<64>), dim3(ceil_div(n_other, 256)), dim3(256), 0, s2, other,
+                       static_cast<const Task *>(nullptr), t->eig_table.ptr, static_cast<const Task *>(nullptr),
+                       static_cast<const float *>(t->eig_Qrows.ptr), static_cast<int>(n_other));
+  t->prof.end(s2);
   const int32_t first = sd.n_tasks - sd.n_short;
-  const int32_t B = std::min<int32_t>(sd.n_short, 1 << 20);  // rows per pass: x~ scratch of B x KP floats
+  // rows per pass: x~ scratch of B x KP floats (IRSPACK_AMD_IALS_EIG_PASS_ROWS: tests shrink it)
+  const char *pass_env = std::getenv("IRSPACK_AMD_IALS_EIG_PASS_ROWS");
+  const int32_t B = std::min<int32_t>(sd.n_short, pass_env ? std::max(64, std::atoi(pass_env)) : 1 << 20);
   t->eig_xt.alloc(static_cast<size_t>(B) * KP);
   EigShortParams p{};
   p.indices = sd.indices.ptr;
@@ -863,13 +913,28 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
   p.max_cg_steps = max_cg_steps;
   p.warm_start = 1;
   p.err_flag = err_flag;
+  // passes alternate between two streams (each with its own x~ scratch): the rotation of one pass
+  // (matrix cores, streaming) runs beside the short-row kernel of the next (gather latency)
+  const bool two = sd.n_short > B;
+  hipStream_t sb = s2;
+  float *xt = t->eig_xt.ptr;
+  if (two) {
+    t->eig_xt2.alloc(static_cast<size_t>(B) * KP);
+    if (!t->stream3) {
+      IRS_HIP(hipStreamCreateWithFlags(&t->stream3, hipStreamNonBlocking));
+      IRS_HIP(hipEventCreateWithFlags(&t->ev_fork3, hipEventDisableTiming));
+      IRS_HIP(hipEventCreateWithFlags(&t->ev_join3, hipEventDisableTiming));
+    }
+    IRS_HIP(hipEventRecord(t->ev_fork3, s2));  // (after the table product)
+    IRS_HIP(hipStreamWaitEvent(t->stream3, t->ev_fork3, 0));
+  }
   auto rotate = [&](const float *src, const Task *src_rows, float *dst, const Task *dst_rows, const float *M,
                     int n) {
     if (KP == 128)
-      hipLaunchKernelGGL((rows_times_matT_kernel<128>), dim3(ceil_div(n, 256)), dim3(256), 0, s2, src,
+      hipLaunchKernelGGL((rows_times_matT_kernel<128>), dim3(ceil_div(n, 256)), dim3(256), 0, sb, src,
                          src_rows, dst, dst_rows, M, n);
     else
-      hipLaunchKernelGGL((rows_times_matT_kernel<64>), dim3(ceil_div(n, 256)), dim3(256), 0, s2, src,
+      hipLaunchKernelGGL((rows_times_matT_kernel<64>), dim3(ceil_div(n, 256)), dim3(256), 0, sb, src,
                          src_rows, dst, dst_rows, M, n);
   };
   const char *kname = cg ? (pidx == 0 ? "ials_short_cg_user" : "ials_short_cg_item")
@@ -879,6 +944,9 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
   for (int32_t b0 = 0; b0 < sd.n_short; b0 += B) {
     const int32_t m = std::min(B, sd.n_short - b0);
     const Task *tasks = sd.tasks.ptr + first + b0;
+    const bool odd = two && ((b0 / B) & 1);
+    sb = odd ? t->stream3 : s2;
+    xt = odd ? t->eig_xt2.ptr : t->eig_xt.ptr;
     p.tasks = tasks;
     p.n_tasks = m;
     // rows of this pass with 17..32 entries: [0, m2) (one row per wave), the rest have <= 16
@@ -889,16 +957,16 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
       EigShortParams q = p;
       q.tasks = tasks + off;
       q.n_tasks = cnt;
-      q.xt = t->eig_xt.ptr + static_cast<size_t>(off) * KP;
-      hipLaunchKernelGGL(kernel, dim3(ceil_div(cnt, rows_per_block)), dim3(256), lds, s2, q);
+      q.xt = xt + static_cast<size_t>(off) * KP;
+      hipLaunchKernelGGL(kernel, dim3(ceil_div(cnt, rows_per_block)), dim3(256), lds, sb, q);
     };
     static const bool rows16 = env_flag("IRSPACK_AMD_IALS_EIG16", true);  // A/B: one row per wave everywhere
     if (cg) {
-      t->prof.begin("eig_rotate", s2);
-      rotate(target, tasks, t->eig_xt.ptr, nullptr, t->eig_Qrows.ptr, m);  // x~0 = Q^T x0
-      t->prof.end(s2);
+      t->prof.begin("eig_rotate", sb);
+      rotate(target, tasks, xt, nullptr, t->eig_Qrows.ptr, m);  // x~0 = Q^T x0
+      t->prof.end(sb);
     }
-    t->prof.begin(kname, s2);
+    t->prof.begin(kname, sb);
     if (cg) {
       if (!rows16) {
         if (KP == 128) part(ials_cg_eig_short_kernel<128>, 0, m, 4, 0);
@@ -929,10 +997,14 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
         else part(ials_wb_short_kernel<64, 1>, m2, m - m2, 4, lds1);
       }
     }
-    t->prof.end(s2);
-    t->prof.begin("eig_rotate", s2);
-    rotate(t->eig_xt.ptr, nullptr, target, tasks, t->eig_Qcols.ptr, m);  // x = Q x~
-    t->prof.end(s2);
+    t->prof.end(sb);
+    t->prof.begin("eig_rotate", sb);
+    rotate(xt, nullptr, target, tasks, t->eig_Qcols.ptr, m);  // x = Q x~
+    t->prof.end(sb);
+  }
+  if (two) {
+    IRS_HIP(hipEventRecord(t->ev_join3, t->stream3));
+    IRS_HIP(hipStreamWaitEvent(s2, t->ev_join3, 0));
   }
   IRS_HIP(hipGetLastError());
   IRS_HIP(hipEventRecord(t->ev_join, s2));
@@ -1049,7 +1121,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     });
     t->prof.end(short_stream);
   };
-  const bool eig_cand = prior == nullptr && other == t->factor[1 - pidx].ptr && eig_begin(t, sd, pidx);
+  const bool eig_cand = prior == nullptr && other == t->factor[1 - pidx].ptr && eig_begin(t, sd, pidx, cg);
   bool short_forked = false;
   if (eig_cand) {
     n_regular = sd.n_tasks - sd.n_short;  // (the long rows start now, beside the decomposition)
@@ -1072,6 +1144,12 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     n_regular = sd.n_tasks - sd.n_short;
   }
   // the kernels of the K x K systems over `count` tasks starting at `tasks_begin`
+  // rows cut into many chunks: their partial Gramians are summed in groups first (ials_kernels.hpp)
+  auto fold_partials = [&](int partial_floats) {
+    if (sd.n_fold <= 0) return;
+    t->prof.launch("ials_fold_partials", fold_partials_kernel, dim3(sd.n_fold, ceil_div(partial_floats / 4, 256)),
+                   dim3(256), 0, t->stream, t->split_partial.ptr, partial_floats, sd.fold.ptr);
+  };
   auto launch_dense = [&](const Task *tasks_begin, int count, bool with_split) {
   const int n_regular = count;
   p.tasks = tasks_begin;
@@ -1096,6 +1174,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         t->prof.end(t->stream);
       };
       launch(ials_wg16_cholesky_kernel<TT, 0>, n_regular, kNames[0][0][pidx]);
+      if (with_split) fold_partials(G::PARTIAL_FLOATS);
       if (with_split) launch(ials_wg16_cholesky_kernel<TT, 1>, sd.n_split, kNames[0][1][pidx]);
     });
   } else if (t->T == 8 && t->opt_wave128) {
@@ -1118,6 +1197,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       t->prof.end(t->stream);
     }
     if (with_split && sd.n_split > 0) {
+      fold_partials(G::PARTIAL_FLOATS);
       t->prof.begin(kNames[cg][1][pidx], t->stream);
       if (cg)
         hipLaunchKernelGGL((ials_solve_kernel<8, 1, 1>), dim3(sd.n_split), dim3(64), 0, t->stream, p);
@@ -1145,6 +1225,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
           t->prof.launch(name, ials_solve_kernel<TT, 0, 0>, grid, block, 0, t->stream, p);
       }
       if (with_split && sd.n_split > 0) {
+        fold_partials(G::PARTIAL_FLOATS);
         const dim3 grid(ceil_div(sd.n_split, SOLVE_WAVES)), block(64 * SOLVE_WAVES);
         if (cg)
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 1, 1>, grid, block, 0, t->stream, p);
@@ -1173,6 +1254,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
           launch(ials_wg_solve_kernel<TT, 0, 0>, n_regular, kNames[0][0][pidx]);
       }
       if (with_split && sd.n_split > 0) {
+        fold_partials(G::PARTIAL_FLOATS);
         if (cg)
           launch(ials_wg_solve_kernel<TT, 1, 1>, sd.n_split, kNames[1][1][pidx]);
         else
@@ -1377,6 +1459,13 @@ irs_status irs_ials_destroy(irs_ials_trainer *t) {
         (void)hipEventDestroy(t->ev_fork);
         (void)hipEventDestroy(t->ev_join);
       }
+      if (t->stream3) {
+        (void)hipStreamSynchronize(t->stream3);
+        (void)hipStreamDestroy(t->stream3);
+        (void)hipEventDestroy(t->ev_fork3);
+        (void)hipEventDestroy(t->ev_join3);
+      }
+      if (t->eig_resident) (void)hipHostFree(t->eig_resident);
       delete t;
     }
   });

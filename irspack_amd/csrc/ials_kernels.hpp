@@ -49,9 +49,40 @@ struct Task {
 struct SplitRow {
   int32_t row;
   int32_t first_slot;
-  int32_t n_slots;
+  int32_t n_slots;      // slots the second kernel adds: first_slot + i * slot_stride
   int32_t nnz;
+  int32_t slot_stride;  // 1, or FOLD_GROUP once fold_partials_kernel has summed each group into its first slot
 };
+
+// A row cut into more than FOLD_MIN chunks has its partial Gramians summed in groups of
+// FOLD_GROUP first (one thread per float4 of the partial, every group in parallel), so that the
+// one wave (or workgroup) that finishes the row adds at most FOLD_MIN partials one after another.
+constexpr int FOLD_GROUP = 16;
+constexpr int FOLD_MIN = 32;
+struct FoldGroup {
+  int32_t first_slot;
+  int32_t count;
+};
+
+__global__ __launch_bounds__(256) void fold_partials_kernel(float *__restrict__ partials, int partial_floats,
+                                                            const FoldGroup *__restrict__ groups) {
+  const FoldGroup g = groups[blockIdx.x];
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  if (4 * e >= partial_floats) return;
+  f32x4 *base = reinterpret_cast<f32x4 *>(partials + static_cast<size_t>(g.first_slot) * partial_floats) + e;
+  const size_t step = static_cast<size_t>(partial_floats) / 4;
+  f32x4 sum = base[0];
+  int s = 1;
+  for (; s + 4 <= g.count; s += 4) {  // ascending slot order, four loads in flight
+    const f32x4 a = base[s * step], b = base[(s + 1) * step], c = base[(s + 2) * step], d = base[(s + 3) * step];
+    sum += a;
+    sum += b;
+    sum += c;
+    sum += d;
+  }
+  for (; s < g.count; s++) sum += base[s * step];
+  base[0] = sum;
+}
 
 struct SolveParams {
   const Task *tasks;
@@ -986,7 +1017,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : SOLV
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int s = min(s0 + u, sr.n_slots - 1);  // clamped: the duplicate is not added
-        const float *src = p.partials + static_cast<size_t>(sr.first_slot + s) * G::PARTIAL_FLOATS;
+        const float *src = p.partials + static_cast<size_t>(sr.first_slot + s * sr.slot_stride) * G::PARTIAL_FLOATS;
         const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
         for (int t = 0; t < G::NT; t++) part[u][t] = s4[t * 64 + lane];

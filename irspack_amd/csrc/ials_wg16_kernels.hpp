@@ -156,7 +156,7 @@ __device__ __forceinline__ bool wg16_gather(const SolveParams &p, int item, f32x
       acc[s] = t < G::NT ? Pacc[t * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int sl = 0; sl < sr.n_slots; sl++) {
-      const float *src = p.partials + static_cast<size_t>(sr.first_slot + sl) * PARTIAL;
+      const float *src = p.partials + static_cast<size_t>(sr.first_slot + sl * sr.slot_stride) * PARTIAL;
       const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
       for (int s = 0; s < G::TPW; s++) {

@@ -404,6 +404,34 @@ def test_large_k_split_rows():
         assert rel_err(t.user, o.user) < RTOL
 
 
+@pytest.mark.parametrize("K", [32, 128, 200])
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_rows_of_many_chunks_fold_their_partials(K, kind):
+    """Rows cut into more than 32 chunks (here 40960 + 3 and 70001 entries: 41 and 69 chunks) have
+    their partial Gramians summed in groups of 16 before the row is finished
+    (fold_partials_kernel); a 33-chunk row is the smallest that folds, 32 chunks do not."""
+    rng = np.random.default_rng(11)
+    n_u, n_i = 9, 80000
+    lens = [40963, 70001, 32 * 1024 + 1, 32 * 1024, 5000, 64, 3, 0, 1500]
+    rows = [np.sort(rng.choice(n_i, size=d, replace=False)) for d in lens]
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    X = sps.csr_matrix((rng.uniform(0.5, 2.0, size=indptr[-1]).astype(np.float32),
+                        np.concatenate(rows).astype(np.int32), indptr), shape=(n_u, n_i))
+    mc, omc = build(K, alpha0=0.05, reg=1e-2)
+    sc, osc = solver(kind)
+    t, o = IALSTrainer(mc, X), O.IALSTrainer(omc, X)
+    t.partial_gramian_async(0)
+    t.finish_gramian_async(0)
+    t.half_step_async(0, sc)
+    t.synchronize()
+    o.step(osc)
+    # per row: the long rows' own float32 rounding in the sequential CPU sum is the larger part
+    num = np.linalg.norm(t.user.astype(np.float64) - o.user, axis=1)
+    den = np.maximum(np.linalg.norm(o.user.astype(np.float64), axis=1), 1e-12)
+    live = np.asarray(lens) > 0
+    assert (num[live] / den[live]).max() < 3 * RTOL, (num / den)
+
+
 @pytest.mark.parametrize("K", [20, 100, 200, 300])
 def test_loss_user_scores_transform_at_every_kernel_family(K):
     """compute_loss / user_scores / transform on the K <= 64, K <= 128, K <= 256 and K > 256 code

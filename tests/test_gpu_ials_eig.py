@@ -109,6 +109,31 @@ def test_short_rows_in_the_eigenbasis_match_oracle(K, weights, loss, kind, monke
     assert row_rel_err(d.user, want) < RTOL
 
 
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_eigenbasis_passes_alternate_between_two_streams(kind, monkeypatch):
+    """The short rows are taken in passes (2^20 rows by default, 30 000 here: six passes of mixed
+    17..32-entry and <= 16-entry rows) that alternate between two streams with their own scratch."""
+    monkeypatch.setenv("IRSPACK_AMD_IALS_EIG_PASS_ROWS", "30000")
+    K = 128
+    X = short_row_matrix(160_000, 300, 5, True)
+    mc = (IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(2e-2).set_nu(1.0).set_init_stdev(0.1)
+          .set_random_seed(7).set_loss_type(LossType.IALSPP).build())
+    omc = O.model_config(K, alpha0=0.1, reg=2e-2, nu=1.0, init_stdev=0.1, random_seed=7, loss_type="IALSPP")
+    sc = (IALSSolverConfigBuilder().set_n_threads(1).set_solver_type(SolverType[kind]).set_max_cg_steps(3).build())
+    osc = O.solver_config(8, kind, 3)
+    t = IALSTrainer(mc, X)
+    user0, item0 = t.user, t.item
+    want = O.ials_solver_step(user0, X, item0, O.ials_gramian(item0, 0.1, 8), omc, osc)
+    for _ in range(2):  # (the second call reuses streams and scratch)
+        t.user = user0
+        t.partial_gramian_async(0)
+        t.finish_gramian_async(0)
+        t.half_step_async(0, sc)
+        t.synchronize()
+        assert t.last_half_step_used_eigenbasis()
+        assert row_rel_err(t.user, want) < RTOL
+
+
 def test_ill_conditioned_gramian_falls_back():
     """lambda_max + reg > 1e4 (lambda_min + reg) - here 100 items at K = 128: P has 28 zero
     eigenvalues and reg_r = 1e-7 - the eigenbasis path declines, the dense kernels run"""
