@@ -87,7 +87,7 @@ struct Side {
   DeviceBuffer<int32_t> rows_by_len;  // rows [row_begin, row_end) longest first (iALS++ launch order)
   int32_t n_tasks = 0, n_split = 0, n_slots = 0, n_long = 0;
   // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
-  int32_t n_short = 0, n_short16 = 0;
+  int32_t n_short = 0, n_short16 = 0, n_short8 = 0;
   bool unit = false;  // every stored confidence is exactly 1 (UNIT kernels)
   bool positive = false;  // every stored confidence is > 0 (eigenbasis short-row kernels)
   float reg_min = 0.f;    // smallest per-row regulariser of the rows [row_begin, row_end)
@@ -158,10 +158,11 @@ struct Side {
                      [](const SplitRow &a, const SplitRow &b) { return a.n_slots > b.n_slots; });
     n_tasks = static_cast<int32_t>(tk.size());
     n_split = static_cast<int32_t>(sp.size());
-    n_short = n_short16 = 0;
+    n_short = n_short16 = n_short8 = 0;
     while (n_short < n_tasks && tk[n_tasks - 1 - n_short].slot < 0 &&
            tk[n_tasks - 1 - n_short].end - tk[n_tasks - 1 - n_short].begin <= SHORT_MAX) {
       if (tk[n_tasks - 1 - n_short].end - tk[n_tasks - 1 - n_short].begin <= 16) n_short16++;
+      if (tk[n_tasks - 1 - n_short].end - tk[n_tasks - 1 - n_short].begin <= 8) n_short8++;
       n_short++;
     }
     n_slots = slots;
@@ -939,8 +940,10 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
   };
   const char *kname = cg ? (pidx == 0 ? "ials_short_cg_user" : "ials_short_cg_item")
                          : (pidx == 0 ? "ials_short_cholesky_user" : "ials_short_cholesky_item");
-  // the list is longest first: [17..32 entries | <= 16 entries]
+  // the list is longest first: [17..32 entries | 9..16 entries | <= 8 entries]
   const int32_t n32 = sd.n_short - sd.n_short16;
+  static const bool rows8 = env_flag("IRSPACK_AMD_IALS_EIG8", true);  // A/B: the 8-entry forms
+  const int32_t n16 = sd.n_short - (rows8 ? sd.n_short8 : 0);         // rows before the <= 8 class
   for (int32_t b0 = 0; b0 < sd.n_short; b0 += B) {
     const int32_t m = std::min(B, sd.n_short - b0);
     const Task *tasks = sd.tasks.ptr + first + b0;
@@ -952,6 +955,7 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
     // rows of this pass with 17..32 entries: [0, m2) (one row per wave), the rest have <= 16
     // (four rows per wave, 16 lanes each)
     const int32_t m2 = std::max(0, std::min(b0 + m, n32) - b0);
+    const int32_t m3 = std::max(m2, std::min(b0 + m, n16) - b0);  // [m2, m3): 9..16 entries, [m3, m): <= 8
     auto part = [&](auto kernel, int32_t off, int32_t cnt, int rows_per_block, size_t lds) {
       if (cnt <= 0) return;
       EigShortParams q = p;
@@ -973,10 +977,12 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
         else part(ials_cg_eig_short_kernel<64>, 0, m, 4, 0);
       } else if (KP == 128) {
         part(ials_cg_eig16_kernel<128, 32>, 0, m2, 8, 0);   // 17..32 entries: 32 lanes per row
-        part(ials_cg_eig16_kernel<128, 16>, m2, m - m2, 16, 0);
+        part(ials_cg_eig16_kernel<128, 16>, m2, m3 - m2, 16, 0);
+        part(ials_cg_eig16_kernel<128, 16, 8>, m3, m - m3, 16, 0);
       } else {
         part(ials_cg_eig16_kernel<64, 32>, 0, m2, 8, 0);
-        part(ials_cg_eig16_kernel<64, 16>, m2, m - m2, 16, 0);
+        part(ials_cg_eig16_kernel<64, 16>, m2, m3 - m2, 16, 0);
+        part(ials_cg_eig16_kernel<64, 16, 8>, m3, m - m3, 16, 0);
       }
     } else {
       const size_t lds1 = 4 * (Chol16Geo<1>::LDS_FLOATS + 32) * sizeof(float);
@@ -988,13 +994,21 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
       if (KP == 128) {
         if (rows16 && rows32) part(ials_wb_eig16_kernel<128, 32>, 0, m2, 8, 0);
         else part(ials_wb_short_kernel<128, 2>, 0, m2, 4, lds2);
-        if (rows16) part(ials_wb_eig16_kernel<128, 16>, m2, m - m2, 16, 0);
-        else part(ials_wb_short_kernel<128, 1>, m2, m - m2, 4, lds1);
+        if (rows16) {
+          part(ials_wb_eig16_kernel<128, 16>, m2, m3 - m2, 16, 0);
+          part(ials_wb_eig16_kernel<128, 16, 8>, m3, m - m3, 16, 0);
+        } else {
+          part(ials_wb_short_kernel<128, 1>, m2, m - m2, 4, lds1);
+        }
       } else {
         if (rows16 && rows32) part(ials_wb_eig16_kernel<64, 32>, 0, m2, 8, 0);
         else part(ials_wb_short_kernel<64, 2>, 0, m2, 4, lds2);
-        if (rows16) part(ials_wb_eig16_kernel<64, 16>, m2, m - m2, 16, 0);
-        else part(ials_wb_short_kernel<64, 1>, m2, m - m2, 4, lds1);
+        if (rows16) {
+          part(ials_wb_eig16_kernel<64, 16>, m2, m3 - m2, 16, 0);
+          part(ials_wb_eig16_kernel<64, 16, 8>, m3, m - m3, 16, 0);
+        } else {
+          part(ials_wb_short_kernel<64, 1>, m2, m - m2, 4, lds1);
+        }
       }
     }
     t->prof.end(sb);

@@ -547,10 +547,13 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig_short_kernel(EigShortParam
 // of the CG vectors.  A dot product over K is DPL FMAs + four DPP adds (row16_sum: no LDS
 // crossbar, no 6-step 64-lane butterfly), and four rows' dependency chains interleave in one
 // instruction stream - the one-row-per-wave forms above spent their time waiting on both.
-// LPR = lanes per row = most entries a row may have: 16 (four rows per wave) or 32 (two).
-template <int KP, int LPR = 16> struct Eig16 {
-  static constexpr int DPL = KP / LPR, NE = LPR;
-  static_assert((LPR == 16 || LPR == 32) && DPL >= 2, "lanes per row");
+// LPR = lanes per row: 16 (four rows per wave) or 32 (two); NEV = most entries a row may have
+// (LPR, or 8 with LPR = 16: the gathered rows are NEV x DPL registers per lane - 128 of the ~200
+// at KP = 128 - and rows of <= 8 entries, more than half of configs[3]'s users, run at twice
+// the waves per SIMD with the 8-entry form).
+template <int KP, int LPR = 16, int NEV = LPR> struct Eig16 {
+  static constexpr int DPL = KP / LPR, NE = NEV;
+  static_assert((LPR == 16 || LPR == 32) && DPL >= 2 && (NEV == LPR || (NEV == 8 && LPR == 16)), "lanes per row");
   // entry j of this lane's row: broadcast from lane (g, j)
   static __device__ __forceinline__ int bcast_i(int v, int j) {
     return __builtin_amdgcn_ds_bpermute(((threadIdx.x & (64 - LPR)) | j) << 2, v);
@@ -622,9 +625,9 @@ template <int KP, int LPR = 16> struct Eig16 {
   }
 };
 
-template <int KP, int LPR = 16>
-__global__ __launch_bounds__(256, 2) void ials_cg_eig16_kernel(EigShortParams p) {
-  using E = Eig16<KP, LPR>;
+template <int KP, int LPR = 16, int NEV = LPR>
+__global__ __launch_bounds__(256, NEV == 8 ? 4 : 2) void ials_cg_eig16_kernel(EigShortParams p) {
+  using E = Eig16<KP, LPR, NEV>;
   constexpr int DPL = E::DPL, NE = E::NE;
   const int lane = threadIdx.x & 63, g = lane / LPR, m = lane % LPR;
   const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPR) + g;
@@ -729,9 +732,9 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig16_kernel(EigShortParams p)
 // Cholesky (low-rank form, see the header comment) of rows with at most 16 entries, four per
 // wave.  The n x n system I + G S G lives in registers, lane m of the row's 16 owning matrix row m;
 // it is factorised column by column with one lane broadcast per (column, row) pair.
-template <int KP, int LPR = 16>
-__global__ __launch_bounds__(256, 2) void ials_wb_eig16_kernel(EigShortParams p) {
-  using E = Eig16<KP, LPR>;
+template <int KP, int LPR = 16, int NEV = LPR>
+__global__ __launch_bounds__(256, NEV == 8 ? 4 : 2) void ials_wb_eig16_kernel(EigShortParams p) {
+  using E = Eig16<KP, LPR, NEV>;
   constexpr int DPL = E::DPL, NE = E::NE;
   const int lane = threadIdx.x & 63, g = lane / LPR, m = lane % LPR;
   const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPR) + g;
