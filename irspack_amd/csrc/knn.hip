@@ -62,6 +62,7 @@ struct Params {
   int32_t sim_type;
   int32_t normalize;
   double shrinkage, alpha, beta;
+  float shrink_f, alpha_f, beta_f;  // the same rounded to float32 (FAST path: scalar operands, no conversions)
   int32_t top_k;
   int32_t tile_k;      // winners one (row, tile) pair can hold: min(top_k, TILE)
   // per (row slot, tile) winners, in ascending column order
@@ -75,6 +76,11 @@ struct Params {
   // persistent launch: workgroups draw (row slot, tile) pairs from this counter
   int32_t *cursor;
   int32_t n_slots;     // n_rows * n_tiles
+  // FAST: pairs whose candidates did not fit are listed here and taken by a second launch of the
+  // exact kernel (redo != 0: the pairs are redo_list[0 .. *redo_count), drawn through cursor[1])
+  int32_t *redo_list;
+  int32_t *redo_count;
+  int32_t redo;
   int32_t merge_cap;   // entries of the merge buffer: power of two, >= 2 * top_k
 };
 
@@ -125,6 +131,27 @@ __device__ __forceinline__ double epilogue(const Params &p, double v, double nor
   }
 }
 
+// float32 approximation of `epilogue` for a COUNT v >= 1 (FAST path).  Every term of the
+// denominator is non-negative (the host checks shrinkage, alpha, beta >= 0) and the only
+// subtractions are of integers below 2^24 (exact in float32) or leave a result no smaller than
+// half of their operands' sum, so the relative error stays below ~12 roundings of 2^-24 < 2^-20.
+__device__ __forceinline__ float approx_epilogue(const Params &p, float v, float norm_j, float tstat,
+                                                 float shrink, float alpha, float beta) {
+  float d;
+  switch (p.sim_type) {
+    case IRS_SIM_JACCARD: d = (norm_j + tstat) - v; break;
+    case IRS_SIM_TVERSKY: d = v + beta * (norm_j - v) + alpha * (tstat - v); break;
+    default: d = norm_j * tstat; break;  // cosine (normalised), asymmetric cosine
+  }
+  d = d + shrink + 1e-6f;
+  return v * __builtin_amdgcn_rcpf(d);
+}
+constexpr int FAST_CAP = 2048;   // candidates the exact ranking of the FAST path holds (32 KB of LDS)
+#ifndef IRS_KNN_FAST_SLACK
+#define IRS_KNN_FAST_SLACK 96
+#endif
+constexpr int FAST_SLACK = IRS_KNN_FAST_SLACK;  // the approximate select stops once at most top_k + this many keys remain
+
 // touched-ness of a column without a bitmap atomic: accumulators start at -0.0, and
 // -0.0 + x is x for every x that is not itself -0.0, so a column stays at the bit
 // pattern of -0.0 exactly when nothing (or only -0.0 products) was added.  The host
@@ -133,6 +160,7 @@ __device__ __forceinline__ double epilogue(const Params &p, double v, double nor
 constexpr uint64_t NEG_ZERO_BITS = 0x8000000000000000ull;
 
 #ifdef IRS_KNN_PHASES
+__device__ unsigned long long knn_fast_stat[8];  // pairs, exact-path pairs, sum of candidates, pairs with <= 128 / 256 / 512 / 1024 candidates
 __device__ unsigned long long knn_phase_clk[8];
 #define PHASE_MARK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&knn_phase_clk[i], t_ - ph_t); ph_t = t_; } } while (0)
 #else
@@ -149,10 +177,20 @@ __device__ unsigned long long knn_phase_clk[8];
 // non-NaN doubles) - so that TWO workgroups are resident per CU and one pair's epilogue /
 // selection (4 of the 10 ms of a call: fp64 divisions, global norm loads, barriers) overlaps the
 // other pair's accumulation (LDS atomics).
-template <bool ONES, bool SENTINEL, bool ACC32 = false, int NT = THREADS, bool COMPACT = false>
+// FAST (round 3; counts only, the four similarities that end in a division): the selection runs
+// on float32 APPROXIMATIONS of the similarities (8 vector instructions per column instead of the
+// ~45 of the un-fused fp64 epilogue, 32-bit keys), and only the columns that can still be among
+// the top_k - approximation within 2^-18 of the top_k-th best approximation - get the exact
+// fp64 value and are ranked exactly (value desc, column asc).  With |approx - exact| <=
+// eps * exact for every stored column (eps < 2^-20, see approx_epilogue) a column of the exact
+// top_k has approx >= t (1 - eps) / (1 + eps), t = the top_k-th largest approximation, so the
+// candidate set is a superset of the exact winners whatever the ties; when it does not fit
+// FAST_CAP entries (thousands of near-ties) the pair takes the exact path below.
+template <bool ONES, bool SENTINEL, bool ACC32 = false, int NT = THREADS, bool COMPACT = false, bool FAST = false>
 __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p) {
   static_assert(!ACC32 || (ONES && SENTINEL), "counts need all-ones operands");
   static_assert(!COMPACT || (ACC32 && NT == 512), "the compact layout holds counters only");
+  static_assert(!FAST || (ACC32 && !COMPACT), "the approximate selection is built for the count path");
   constexpr int THREADS = NT;  // (shadows the namespace constant inside this kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double *acc = reinterpret_cast<double *>(smem);                        // TILE (COMPACT: TILE counters)
@@ -176,16 +214,18 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   // and retire, as much as the whole accumulation of a light row.  The draw for the next
   // pair is issued before the current one is processed, so its latency is hidden.
   int32_t next_slot = 0;
-  if (tid == 0) next_slot = atomicAdd(p.cursor, 1);
+  int32_t *const cursor = p.redo ? p.cursor + 1 : p.cursor;
+  const int n_draw = p.redo ? *p.redo_count : p.n_slots;
+  if (tid == 0) next_slot = atomicAdd(cursor, 1);
   for (;;) {
   __syncthreads();  // the previous pair is finished by every wave (LDS and sh_* reuse)
   if (tid == 0) {
     sh_slot = next_slot;
-    next_slot = atomicAdd(p.cursor, 1);
+    next_slot = atomicAdd(cursor, 1);
   }
   __syncthreads();
-  const int bid = sh_slot;
-  if (bid >= p.n_slots) break;
+  if (sh_slot >= n_draw) break;
+  const int bid = p.redo ? p.redo_list[sh_slot] : sh_slot;
   const int slot = bid / p.n_tiles, tile = bid % p.n_tiles;
   const int r = p.row_order[slot];
   const int c0 = tile * TILE, c1 = min(c0 + TILE, p.N);
@@ -403,10 +443,17 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   // (the column norms of this thread's first eight columns are fetched while the slower
   // waves finish accumulating)
   constexpr int PER = TILE / THREADS;  // 16
-  const int cbase = wv * (PER * 64) + lane;
-  double nrm0[8];
+  // (opaque to the optimiser: everything derived from it - 16 column offsets, their clamped
+  // forms, LDS addresses - would otherwise be hoisted out of the persistent loop and held in
+  // registers across the accumulation, which has none to spare)
+  int cbase_ = wv * (PER * 64) + lane;
+  asm volatile("" : "+v"(cbase_));
+  const int cbase = cbase_;
+  // (FAST: all sixteen - the accumulation's registers are dead by now - and the exact path of a
+  // FAST kernel reloads its own)
+  double nrm0[FAST ? PER : 8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) nrm0[k] = p.norms[c0 + min(cbase + 64 * k, width - 1)];
+  for (int k = 0; k < (FAST ? PER : 8); k++) nrm0[k] = p.norms[c0 + min(cbase + 64 * k, width - 1)];
   __syncthreads();
   PHASE_MARK(1);
 
@@ -417,8 +464,248 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   static_assert(PER * THREADS == TILE && PER <= 32 && PER % 8 == 0, "column ownership (the `have` mask is 32 bits)");
   const double tstat = p.t_stat[r];
   const double fx_inv = 1.0 / fx_scale;  // a power of two: exact
-  uint64_t key[PER];
   uint32_t have = 0;  // bit k: column k of this thread is a stored entry of the product row
+  int32_t *cidx = p.cand_idx + static_cast<size_t>(bid) * p.tile_k;
+  double *cval = p.cand_val + static_cast<size_t>(bid) * p.tile_k;
+  bool fast_done = false;
+  if constexpr (FAST) {
+    // ---- 2F. approximate similarities (float32) of the stored columns: positive, so their bit
+    //      patterns order like the values
+    //      (the counters stay where they are, in the lower half of the accumulator block: the
+    //      candidate list below lives in the upper half, and the exact path re-reads them)
+    uint32_t k32[PER];
+    {
+      const float tstat_f = static_cast<float>(tstat), shrink_f = p.shrink_f;
+      const float alpha_f = p.alpha_f, beta_f = p.beta_f;
+#pragma unroll
+      for (int k = 0; k < PER; k++) {
+        const int i = cbase + 64 * k;
+        const uint32_t c32 = cnt[min(i, TILE - 1)];
+        const bool st = i < width && c32 != 0u;
+        if (st) have |= 1u << k;
+        const float a = approx_epilogue(p, static_cast<float>(c32), static_cast<float>(nrm0[FAST ? k : 0]), tstat_f,
+                                        shrink_f, alpha_f, beta_f);
+        k32[k] = st ? __float_as_uint(a) : 0u;
+      }
+    }
+    uint32_t a_and = ~0u, a_or = 0u;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+      if ((have >> k) & 1u) {
+        a_and &= k32[k];
+        a_or |= k32[k];
+      }
+    }
+    int local = __popc(have);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      local += __shfl_xor(local, o, 64);
+      a_and &= __shfl_xor(a_and, o, 64);
+      a_or |= __shfl_xor(a_or, o, 64);
+    }
+    uint32_t *red32 = hist;  // 16 x (and, or); the counts in wave_cnt
+    if (lane == 0) {
+      red32[2 * wv] = a_and;
+      red32[2 * wv + 1] = a_or;
+      wave_cnt[wv] = local;
+    }
+    __syncthreads();
+    int n_stored = 0;
+    a_and = ~0u;
+    a_or = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      n_stored += wave_cnt[w];
+      a_and &= red32[2 * w];
+      a_or |= red32[2 * w + 1];
+    }
+    __syncthreads();  // red32 / wave_cnt are reused below
+    const int n_sel = min(p.top_k, n_stored);
+    if (n_sel == 0) {
+      if (tid == 0) p.cand_cnt[bid] = 0;
+      continue;
+    }
+    PHASE_MARK(3);
+    // ---- 3F. a lower bound `prefix` of the n_sel-th largest approximation: the radix select of
+    //      the exact path on 32-bit keys (it stops as soon as the bin of that key is known)
+    uint32_t prefix = 0;
+    const bool take_all = n_sel >= n_stored;
+    if (!take_all) {
+      int need = n_sel;
+      const uint32_t diff = a_and ^ a_or;
+      if (diff == 0) {
+        prefix = a_and;
+      } else {
+        // digits of up to 8 bits from the highest differing bit downwards (NOT byte aligned: the
+        // top byte of a positive float is 7 exponent bits - a handful of values, i.e. a
+        // same-address atomic storm in the histogram; starting at the first bit that differs
+        // spreads the first digit over exponent AND mantissa bits)
+        int top = 32 - __clz(static_cast<int>(diff));           // bits [top - 1 .. 0] may differ
+        const int low_bit = __ffs(static_cast<int>(a_or)) - 1;  // below it every key is zero
+        prefix = top >= 32 ? 0u : a_and & (~0u << top);
+        while (top > 0) {
+          const int lo = max(top - 8, 0);
+          const uint32_t dmask = (1u << (top - lo)) - 1u;
+          if (tid < 256) hist[tid] = 0;
+          __syncthreads();
+          const uint32_t hi_mask = top >= 32 ? 0u : (~0u << top);
+#pragma unroll
+          for (int k = 0; k < PER; k++) {
+            const bool in = ((have >> k) & 1u) && (k32[k] & hi_mask) == prefix;
+            const uint32_t digit = (k32[k] >> lo) & dmask;
+            const unsigned long long todo = __ballot(in);
+            if (todo) {
+              const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+              const uint32_t d = __builtin_amdgcn_readlane(digit, leader);
+              const unsigned long long same = __ballot(in && digit == d);
+              if (same == todo) {
+                if (lane == leader) atomicAdd(&hist[d], static_cast<uint32_t>(__popcll(same)));
+              } else if (in) {
+                atomicAdd(&hist[digit], 1u);
+              }
+            }
+          }
+          __syncthreads();
+          int bin = 0, incl = 0;
+          if (tid < 256) {
+            bin = static_cast<int>(hist[255 - tid]);
+            incl = bin;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const int t = __shfl_up(incl, o, 64);
+              if (lane >= o) incl += t;
+            }
+            if (lane == 63) wave_cnt[wv] = incl;
+          }
+          __syncthreads();
+          if (tid < 256) {
+            for (int w = 0; w < wv; w++) incl += wave_cnt[w];
+            const int excl = incl - bin;
+            if (excl < need && incl >= need) {
+              sh_prefix = prefix | ((255u - static_cast<uint32_t>(tid)) << lo);
+              sh_need = (incl == need) ? -1 : need - excl;
+              sh_total = n_sel - need + incl;  // keys >= the lower bound of this bin
+            }
+          }
+          __syncthreads();
+          prefix = static_cast<uint32_t>(sh_prefix);
+          need = sh_need;
+          const int above = sh_total;
+          __syncthreads();
+          top = lo;
+          // every key of the chosen bin is >= prefix, which is all a lower bound needs: stop when
+          // the bin is wanted as a whole, no lower digit differs, or few enough keys lie at or
+          // above it (they all become candidates)
+          if (need < 0 || top <= low_bit || above <= n_sel + FAST_SLACK) break;
+        }
+      }
+    }
+    // candidates: approximation >= prefix (1 - 2^-18), one more unit in the last place for the
+    // rounding of this very product
+    uint32_t thr = 0u;
+    if (!take_all) {
+      const float lf = __uint_as_float(prefix) * (1.0f - 0x1p-18f);
+      thr = __float_as_uint(lf);
+      thr = thr > 0u ? thr - 1u : 0u;
+    }
+    uint32_t candmask = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+      if (((have >> k) & 1u) && k32[k] >= thr) candmask |= 1u << k;
+    int n_cand = __popc(candmask);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n_cand += __shfl_xor(n_cand, o, 64);
+    if (lane == 0) wave_cnt[wv] = n_cand;
+    if (tid == 0) sh_count = 0;
+    __syncthreads();
+    n_cand = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) n_cand += wave_cnt[w];
+    PHASE_MARK(4);
+#ifdef IRS_KNN_PHASES
+    if (tid == 0) {
+      atomicAdd(&knn_fast_stat[0], 1ull);
+      if (n_cand > FAST_CAP) atomicAdd(&knn_fast_stat[1], 1ull);
+      atomicAdd(&knn_fast_stat[2], static_cast<unsigned long long>(n_cand));
+      if (n_cand <= 128) atomicAdd(&knn_fast_stat[3], 1ull);
+      if (n_cand <= 256) atomicAdd(&knn_fast_stat[4], 1ull);
+      if (n_cand <= 512) atomicAdd(&knn_fast_stat[5], 1ull);
+      if (n_cand <= 1024) atomicAdd(&knn_fast_stat[6], 1ull);
+    }
+#endif
+    if (n_cand <= FAST_CAP) {  // (block-uniform)
+      // ---- 4F. exact values of the candidates, ranked exactly (value desc, column asc)
+      // (upper half of the accumulator block, behind the 256 bytes of sinks: idle on the count path)
+      uint64_t *candK = reinterpret_cast<uint64_t *>(smem + TILE * 4 + 1024);
+      uint32_t *candC = reinterpret_cast<uint32_t *>(candK + FAST_CAP);
+      uint32_t *candV = candC + FAST_CAP;  // the count
+      // owners hand (column, count) to the list; thread t then takes candidate t: ONE gathered
+      // norm load and one fp64 epilogue per candidate, all of them side by side (under the
+      // owners' branches every load would expose its own latency)
+      {
+        // one returning atomic per wave: the wave's candidates take consecutive slots
+        int mine = __popc(candmask), total = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(total, o, 64);
+          if (lane >= o) total += t;
+        }
+        int base = 0;
+        if (lane == 63) base = total > 0 ? atomicAdd(&sh_count, total) : 0;
+        base = __shfl(base, 63, 64) + total - mine;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+          if ((candmask >> k) & 1u) {
+            candC[base] = static_cast<uint32_t>(cbase + 64 * k);
+            candV[base] = cnt[cbase + 64 * k];
+            base++;
+          }
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < n_cand; t += THREADS) {
+        const double sv = epilogue(p, static_cast<double>(candV[t]), p.norms[c0 + candC[t]], tstat);
+        candK[t] = order_key(sv);
+      }
+      __syncthreads();
+      // rank = candidates that go before (value desc, column asc): eight threads per candidate,
+      // each against every eighth entry of the list.  The winners leave in RANK order (the row
+      // merge sorts the tiles' lists anyway; calls whose merge relies on column-sorted lists,
+      // top_k > TOPK_CAP, do not take this path).
+      constexpr int TPC = 8, CPR = THREADS / TPC;  // candidates per round
+      int tid_ = tid;
+      asm volatile("" : "+v"(tid_));  // (nothing derived from it is worth a register across the accumulation)
+      const int sub = tid_ & (TPC - 1);
+      for (int t0 = 0; t0 < n_cand; t0 += CPR) {
+        const int t = t0 + tid_ / TPC;
+        const bool live = t < n_cand;
+        const uint64_t mk = candK[live ? t : 0];
+        const uint32_t mc = candC[live ? t : 0];
+        int before = 0;
+        for (int q = sub; q < n_cand; q += TPC) {
+          const uint64_t ok = candK[q];
+          const uint32_t oc = candC[q];
+          before += (ok > mk || (ok == mk && oc < mc)) ? 1 : 0;
+        }
+        before += __shfl_xor(before, 1, 64);
+        before += __shfl_xor(before, 2, 64);
+        before += __shfl_xor(before, 4, 64);
+        if (live && sub == 0 && before < n_sel) {
+          cidx[before] = c0 + static_cast<int>(mc);
+          cval[before] = key_to_double(mk);  // (order_key is invertible on the finite values)
+        }
+      }
+      if (tid == 0) p.cand_cnt[bid] = n_sel;
+      fast_done = true;
+      PHASE_MARK(5);
+    }
+  }
+  if constexpr (FAST) {
+    // (rare: thousands of near-ties at the threshold) the pair goes to the exact kernel's list
+    if (!fast_done && tid == 0) p.redo_list[atomicAdd(p.redo_count, 1)] = bid;
+  } else {
+  uint64_t key[PER];
+  have = 0;
   uint32_t cv[(ACC32 && !COMPACT) ? PER : 1];
   if (ACC32 && !COMPACT) {
     // count i sits in the bytes of acc[i / 2]: every count is read before any sum is written
@@ -498,8 +785,6 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   }
   __syncthreads();  // red / wave_cnt are reused below
   const int n_sel = min(p.top_k, n_stored);
-  int32_t *cidx = p.cand_idx + static_cast<size_t>(bid) * p.tile_k;
-  double *cval = p.cand_val + static_cast<size_t>(bid) * p.tile_k;
   if (tid == 0) p.cand_cnt[bid] = n_sel;
   if (n_sel == 0) continue;
   PHASE_MARK(3);
@@ -665,6 +950,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     pos0 += __popcll(bal);
   }
   PHASE_MARK(5);
+  }  // exact path
   }  // persistent loop
 }
 
@@ -900,7 +1186,7 @@ struct irs_knn_computer {
   // cost more than a millisecond, and hipFree synchronises the device)
   struct Scratch {
     DeviceBuffer<int64_t> t_ptr, res_ptr;
-    DeviceBuffer<int32_t> t_idx, order, cand_idx, cand_cnt, out_idx, out_cnt, cursor, slot_of;
+    DeviceBuffer<int32_t> t_idx, order, cand_idx, cand_cnt, out_idx, out_cnt, cursor, slot_of, redo_list;
     DeviceBuffer<double> t_val, t_stat, t_scale, cand_val, out_val;
   } scratch;
 };
@@ -1366,6 +1652,9 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     p.shrinkage = c->shrinkage;
     p.alpha = c->alpha;
     p.beta = c->beta;
+    p.shrink_f = static_cast<float>(c->shrinkage);
+    p.alpha_f = static_cast<float>(c->alpha);
+    p.beta_f = static_cast<float>(c->beta);
     p.top_k = static_cast<int32_t>(out_k);
     p.tile_k = static_cast<int32_t>(tile_k);
     p.cand_idx = cand_idx.ptr;
@@ -1380,9 +1669,12 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     int n_cu = 0;
     IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
     DeviceBuffer<int32_t> &cursor = sc.cursor;
-    cursor.alloc(1);
-    IRS_HIP(hipMemsetAsync(cursor.ptr, 0, sizeof(int32_t), s));
+    cursor.alloc(3);  // [0] pairs, [1] pairs of the redo list, [2] length of the redo list
+    IRS_HIP(hipMemsetAsync(cursor.ptr, 0, 3 * sizeof(int32_t), s));
     p.cursor = cursor.ptr;
+    p.redo_count = cursor.ptr + 2;
+    p.redo_list = nullptr;
+    p.redo = 0;
     {  // merge buffer: all tiles' candidates at once when they fit, else rounds of MERGE_CAP
       int64_t want = std::max<int64_t>(2 * out_k, std::min<int64_t>(int64_t(n_tiles) * out_k, MERGE_CAP));
       int cap = 64;
@@ -1421,7 +1713,24 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
           std::min<size_t>(slots, 2 * static_cast<size_t>(std::max(n_cu, 1))));
       hipLaunchKernelGGL(kernel, dim3(grid_c), dim3(512), lds_c, s, p);
     } else if (c->xt_all_ones) {
-      if (acc32) launch(knn_tile_kernel<true, true, true>);
+      // counts + a similarity that ends in a division: selection on float32 approximations, exact
+      // fp64 values for the candidates only (knn_tile_kernel, FAST).  The error bound of the
+      // approximation needs non-negative terms in the denominator.  IRSPACK_AMD_KNN_FAST=0: A/B.
+      const char *fast_env = std::getenv("IRSPACK_AMD_KNN_FAST");  // (read per call: tests toggle it)
+      const bool divides = (c->sim_type == IRS_SIM_COSINE && p.normalize) || c->sim_type == IRS_SIM_ASYMMETRIC ||
+                           c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
+      const bool tv_ok = c->sim_type != IRS_SIM_TVERSKY ||
+                         (p.alpha >= 0.0 && p.alpha <= 16.0 && p.beta >= 0.0 && p.beta <= 16.0);
+      const bool fast = acc32 && !big && divides && tv_ok && p.shrinkage >= 0.0 && p.shrinkage < 1e30 &&
+                        !(fast_env && fast_env[0] == '0');
+      if (fast) {
+        sc.redo_list.alloc(slots);
+        p.redo_list = sc.redo_list.ptr;
+        launch(knn_tile_kernel<true, true, true, THREADS, false, true>);
+        p.redo = 1;  // the pairs the approximate selection handed back (usually none), exactly
+        launch(knn_tile_kernel<true, true, true>);
+        p.redo = 0;
+      } else if (acc32) launch(knn_tile_kernel<true, true, true>);
       else if (sentinel) launch(knn_tile_kernel<true, true>);
       else launch(knn_tile_kernel<true, false>);
     } else {
@@ -1453,6 +1762,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       IRS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(knn_phase_clk), z, sizeof(z)));
       fprintf(stderr, "knn phases (10 ns ticks, sum over %lld WGs): init %llu acc %llu bitmap %llu epi %llu select %llu write %llu\n",
               static_cast<long long>(slots), h[0], h[1], h[2], h[3], h[4], h[5]);
+      IRS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(knn_fast_stat), sizeof(h)));
+      IRS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(knn_fast_stat), z, sizeof(z)));
+      fprintf(stderr, "knn fast path: pairs %llu exact-path %llu candidates %llu; pairs with <= 128 / 256 / 512 / 1024 candidates: %llu %llu %llu %llu\n",
+              h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
     }
 #endif
     // the CSR in target-row order (slots are work-ordered), compacted on the device

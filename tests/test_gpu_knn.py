@@ -119,6 +119,27 @@ def test_topk_ties_known_answer():
     np.testing.assert_array_equal(actual, expected)
 
 
+@pytest.mark.parametrize("kind,kw", [c for c in CASES if c[1].get("normalize", True)])
+def test_thousands_of_ties_at_the_threshold_go_to_the_exact_kernel(kind, kw, monkeypatch):
+    """Binary data with a similarity that ends in a division selects on float32 approximations and
+    ranks only the candidates exactly (knn_tile_kernel, FAST).  Here most of 3,000 items are
+    identical columns: every one of them ties at the top_k-th value, the candidates do not fit the
+    list (2,048) and the pair is handed to the exact kernel - the lowest columns must win
+    (knn.hpp:119-136).  A few distinct items keep some rows on the approximate path; both settings
+    of the switch must give the oracle's rows."""
+    r = np.random.RandomState(5)
+    n_users, n_items = 60, 3000
+    base = (r.rand(n_users) < 0.5).astype(float)
+    D = np.tile(base[:, None], (1, n_items))
+    D[:, ::97] = (r.rand(n_users, len(range(0, n_items, 97))) < 0.4).astype(float)
+    Xt = sps.csr_matrix(D.T)  # items x users
+    g, o = make(kind, Xt, **dict(kw))
+    want = o.compute_similarity(Xt, 10)
+    assert_same_csr(g.compute_similarity(Xt, 10), want)
+    monkeypatch.setenv("IRSPACK_AMD_KNN_FAST", "0")
+    assert_same_csr(g.compute_similarity(Xt, 10), want)
+
+
 def test_explicit_zero_products_are_stored_entries():
     # knn.hpp:111-118: candidates are the stored entries of the product, exact zeros included
     X = sps.csr_matrix(np.asarray([[1.0, -1.0, 0.0], [1.0, 1.0, 2.0], [0.0, 0.0, 3.0]]))
