@@ -488,6 +488,11 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
         k32[k] = st ? __float_as_uint(a) : 0u;
       }
     }
+    // (barriers are most of what is left of a pair's fixed cost: the statistics have their own
+    // LDS words, the histogram is returned to zero by the wave that scans it, and the candidates
+    // are counted by the compaction itself - two barriers per digit pass, five around them)
+    __shared__ uint32_t f_and[16], f_or[16];
+    __shared__ int32_t f_cnt[16];
     uint32_t a_and = ~0u, a_or = 0u;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -503,25 +508,25 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       a_and &= __shfl_xor(a_and, o, 64);
       a_or |= __shfl_xor(a_or, o, 64);
     }
-    uint32_t *red32 = hist;  // 16 x (and, or); the counts in wave_cnt
     if (lane == 0) {
-      red32[2 * wv] = a_and;
-      red32[2 * wv + 1] = a_or;
-      wave_cnt[wv] = local;
+      f_and[wv] = a_and;
+      f_or[wv] = a_or;
+      f_cnt[wv] = local;
     }
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) sh_count = 0;
     __syncthreads();
     int n_stored = 0;
     a_and = ~0u;
     a_or = 0u;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-      n_stored += wave_cnt[w];
-      a_and &= red32[2 * w];
-      a_or |= red32[2 * w + 1];
+      n_stored += f_cnt[w];
+      a_and &= f_and[w];
+      a_or |= f_or[w];
     }
-    __syncthreads();  // red32 / wave_cnt are reused below
     const int n_sel = min(p.top_k, n_stored);
-    if (n_sel == 0) {
+    if (n_sel == 0) {  // (block-uniform; the next pair starts with a barrier)
       if (tid == 0) p.cand_cnt[bid] = 0;
       continue;
     }
@@ -546,8 +551,6 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
         while (top > 0) {
           const int lo = max(top - 8, 0);
           const uint32_t dmask = (1u << (top - lo)) - 1u;
-          if (tid < 256) hist[tid] = 0;
-          __syncthreads();
           const uint32_t hi_mask = top >= 32 ? 0u : (~0u << top);
 #pragma unroll
           for (int k = 0; k < PER; k++) {
@@ -566,32 +569,36 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
             }
           }
           __syncthreads();
-          int bin = 0, incl = 0;
-          if (tid < 256) {
-            bin = static_cast<int>(hist[255 - tid]);
-            incl = bin;
+          if (wv == 0) {
+            // lane l scans the bins 255 - 4 l .. 252 - 4 l (descending digits) and clears them
+            int bn[4], sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              bn[j] = static_cast<int>(hist[255 - 4 * lane - j]);
+              hist[255 - 4 * lane - j] = 0u;
+              sum += bn[j];
+            }
+            int incl = sum;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
               const int t = __shfl_up(incl, o, 64);
               if (lane >= o) incl += t;
             }
-            if (lane == 63) wave_cnt[wv] = incl;
-          }
-          __syncthreads();
-          if (tid < 256) {
-            for (int w = 0; w < wv; w++) incl += wave_cnt[w];
-            const int excl = incl - bin;
-            if (excl < need && incl >= need) {
-              sh_prefix = prefix | ((255u - static_cast<uint32_t>(tid)) << lo);
-              sh_need = (incl == need) ? -1 : need - excl;
-              sh_total = n_sel - need + incl;  // keys >= the lower bound of this bin
+            int run = incl - sum;  // keys in higher bins
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              if (run < need && run + bn[j] >= need) {
+                sh_prefix = prefix | (static_cast<uint32_t>(255 - 4 * lane - j) << lo);
+                sh_need = (run + bn[j] == need) ? -1 : need - run;
+                sh_total = n_sel - need + run + bn[j];  // keys >= the lower bound of this bin
+              }
+              run += bn[j];
             }
           }
           __syncthreads();
           prefix = static_cast<uint32_t>(sh_prefix);
           need = sh_need;
           const int above = sh_total;
-          __syncthreads();
           top = lo;
           // every key of the chosen bin is >= prefix, which is all a lower bound needs: stop when
           // the bin is wanted as a whole, no lower digit differs, or few enough keys lie at or
@@ -612,29 +619,8 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
 #pragma unroll
     for (int k = 0; k < PER; k++)
       if (((have >> k) & 1u) && k32[k] >= thr) candmask |= 1u << k;
-    int n_cand = __popc(candmask);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) n_cand += __shfl_xor(n_cand, o, 64);
-    if (lane == 0) wave_cnt[wv] = n_cand;
-    if (tid == 0) sh_count = 0;
-    __syncthreads();
-    n_cand = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) n_cand += wave_cnt[w];
     PHASE_MARK(4);
-#ifdef IRS_KNN_PHASES
-    if (tid == 0) {
-      atomicAdd(&knn_fast_stat[0], 1ull);
-      if (n_cand > FAST_CAP) atomicAdd(&knn_fast_stat[1], 1ull);
-      atomicAdd(&knn_fast_stat[2], static_cast<unsigned long long>(n_cand));
-      if (n_cand <= 128) atomicAdd(&knn_fast_stat[3], 1ull);
-      if (n_cand <= 256) atomicAdd(&knn_fast_stat[4], 1ull);
-      if (n_cand <= 512) atomicAdd(&knn_fast_stat[5], 1ull);
-      if (n_cand <= 1024) atomicAdd(&knn_fast_stat[6], 1ull);
-    }
-#endif
-    if (n_cand <= FAST_CAP) {  // (block-uniform)
-      // ---- 4F. exact values of the candidates, ranked exactly (value desc, column asc)
+    {
       // (upper half of the accumulator block, behind the 256 bytes of sinks: idle on the count path)
       uint64_t *candK = reinterpret_cast<uint64_t *>(smem + TILE * 4 + 1024);
       uint32_t *candC = reinterpret_cast<uint32_t *>(candK + FAST_CAP);
@@ -656,13 +642,28 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
 #pragma unroll
         for (int k = 0; k < PER; k++) {
           if ((candmask >> k) & 1u) {
-            candC[base] = static_cast<uint32_t>(cbase + 64 * k);
-            candV[base] = cnt[cbase + 64 * k];
+            if (base < FAST_CAP) {
+              candC[base] = static_cast<uint32_t>(cbase + 64 * k);
+              candV[base] = cnt[cbase + 64 * k];
+            }
             base++;
           }
         }
       }
       __syncthreads();
+      const int n_cand = sh_count;  // (the compaction counted them)
+#ifdef IRS_KNN_PHASES
+      if (tid == 0) {
+        atomicAdd(&knn_fast_stat[0], 1ull);
+        if (n_cand > FAST_CAP) atomicAdd(&knn_fast_stat[1], 1ull);
+        atomicAdd(&knn_fast_stat[2], static_cast<unsigned long long>(n_cand));
+        if (n_cand <= 128) atomicAdd(&knn_fast_stat[3], 1ull);
+        if (n_cand <= 256) atomicAdd(&knn_fast_stat[4], 1ull);
+        if (n_cand <= 512) atomicAdd(&knn_fast_stat[5], 1ull);
+        if (n_cand <= 1024) atomicAdd(&knn_fast_stat[6], 1ull);
+      }
+#endif
+      if (n_cand <= FAST_CAP) {  // (block-uniform)
       for (int t = tid; t < n_cand; t += THREADS) {
         const double sv = epilogue(p, static_cast<double>(candV[t]), p.norms[c0 + candC[t]], tstat);
         candK[t] = order_key(sv);
@@ -697,6 +698,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       }
       if (tid == 0) p.cand_cnt[bid] = n_sel;
       fast_done = true;
+      }
       PHASE_MARK(5);
     }
   }
