@@ -37,6 +37,10 @@ typedef int32_t irs_status;
 #define IRS_INVALID_ARGUMENT 1
 #define IRS_RUNTIME_ERROR 2
 
+/* Layout version of the structs below: 2 since irs_ceilings grew the gather rates.  A binding
+ * compares irs_abi_version() with the header it was written against before passing structs. */
+#define IRS_ABI_VERSION 2
+
 const char *irs_last_error(void);
 /* Library / device probe.  irs_device_count() returns 0 when no GPU is visible. */
 int32_t irs_abi_version(void);

@@ -85,6 +85,8 @@ class CeilingsStruct(C.Structure):  # irs_ceilings
     ]
 
 
+ABI_VERSION = 2  # IRS_ABI_VERSION of include/irspack_amd.h
+
 # every symbol include/irspack_amd.h declares
 EXPORTED_SYMBOLS = [
     "irs_last_error",
@@ -145,6 +147,12 @@ def lib() -> C.CDLL:
         _lib.irs_last_error.restype = C.c_char_p
         _lib.irs_abi_version.restype = C.c_int32
         _lib.irs_device_count.restype = C.c_int32
+        if _lib.irs_abi_version() != ABI_VERSION:
+            found = _lib.irs_abi_version()
+            _lib = None
+            raise RuntimeError(
+                f"{LIB_PATH} has struct layout version {found}, this package was written against "
+                f"{ABI_VERSION} (include/irspack_amd.h): rebuild it with `make -C irspack_amd/csrc`.")
     return _lib
 
 

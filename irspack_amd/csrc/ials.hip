@@ -1334,7 +1334,7 @@ irs_status irs_ials_scores_prefix_device_(irs_ials_trainer *t, int64_t begin, in
                                           const float *user_rows, float *device_out);
 
 const char *irs_last_error(void) { return irs::last_error().c_str(); }
-int32_t irs_abi_version(void) { return 1; }
+int32_t irs_abi_version(void) { return IRS_ABI_VERSION; }
 int32_t irs_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
