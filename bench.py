@@ -574,7 +574,8 @@ def main():
                 "copy_frac_of_spec": ceilings["copy_gbs"] / PEAK_HBM_GBS,
                 "mfma_f32_frac_of_spec": ceilings["mfma_f32_tflops"] / PEAK_F32_TFLOPS,
                 "how": "irs_measure_ceilings: 1 GiB copy / triad, v_mfma_f32_16x16x4_f32 loop on "
-                       "every SIMD, random-bank ds_add_u32 loop on every CU; best of 5, HIP events"})
+                       "every SIMD, random-bank ds_add_u32 loop on every CU, random 256 / 512-byte row gather "
+                       "out of a 1 GiB table; best of 3-5, HIP events"})
         except Exception as exc:  # the headline line must still be printed
             ceilings = {"error": repr(exc)}
         value = (U + I) * args.steps / elapsed
