@@ -137,6 +137,7 @@ __device__ __forceinline__ double epilogue(const Params &p, double v, double nor
 // half of their operands' sum, so the relative error stays below ~12 roundings of 2^-24 < 2^-20.
 __device__ __forceinline__ float approx_epilogue(const Params &p, float v, float norm_j, float tstat,
                                                  float shrink, float alpha, float beta) {
+  if (p.sim_type == IRS_SIM_COSINE && !p.normalize) return v;  // the count itself (exact below 2^24)
   float d;
   switch (p.sim_type) {
     case IRS_SIM_JACCARD: d = (norm_j + tstat) - v; break;
@@ -1719,7 +1720,9 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       // fp64 values for the candidates only (knn_tile_kernel, FAST).  The error bound of the
       // approximation needs non-negative terms in the denominator.  IRSPACK_AMD_KNN_FAST=0: A/B.
       const char *fast_env = std::getenv("IRSPACK_AMD_KNN_FAST");  // (read per call: tests toggle it)
-      const bool divides = (c->sim_type == IRS_SIM_COSINE && p.normalize) || c->sim_type == IRS_SIM_ASYMMETRIC ||
+      // (un-normalised cosine: the similarity IS the count - no division to save, but the 32-bit
+      // select and the candidate ranking replace the 64-bit select over every column)
+      const bool divides = c->sim_type == IRS_SIM_COSINE || c->sim_type == IRS_SIM_ASYMMETRIC ||
                            c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
       const bool tv_ok = c->sim_type != IRS_SIM_TVERSKY ||
                          (p.alpha >= 0.0 && p.alpha <= 16.0 && p.beta >= 0.0 && p.beta <= 16.0);

@@ -119,7 +119,7 @@ def test_topk_ties_known_answer():
     np.testing.assert_array_equal(actual, expected)
 
 
-@pytest.mark.parametrize("kind,kw", [c for c in CASES if c[1].get("normalize", True)])
+@pytest.mark.parametrize("kind,kw", CASES)
 def test_thousands_of_ties_at_the_threshold_go_to_the_exact_kernel(kind, kw, monkeypatch):
     """Binary data with a similarity that ends in a division selects on float32 approximations and
     ranks only the candidates exactly (knn_tile_kernel, FAST).  Here most of 3,000 items are
