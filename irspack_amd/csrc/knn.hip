@@ -475,6 +475,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     //      (the counters stay where they are, in the lower half of the accumulator block: the
     //      candidate list below lives in the upper half, and the exact path re-reads them)
     uint32_t k32[PER];
+    int local_bad = 0;
     {
       const float tstat_f = static_cast<float>(tstat), shrink_f = p.shrink_f;
       const float alpha_f = p.alpha_f, beta_f = p.beta_f;
@@ -487,6 +488,10 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
         const float a = approx_epilogue(p, static_cast<float>(c32), static_cast<float>(nrm0[FAST ? k : 0]), tstat_f,
                                         shrink_f, alpha_f, beta_f);
         k32[k] = st ? __float_as_uint(a) : 0u;
+        // (safety net behind the host's checks: a stored column whose approximation is not a
+        // positive normal number - the error bound does not cover it - sends the pair to the
+        // exact kernel)
+        if (st && !(a >= 1.17549435e-38f && a <= 3.0e38f)) local_bad = 1;
       }
     }
     // (barriers are most of what is left of a pair's fixed cost: the statistics have their own
@@ -509,10 +514,11 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       a_and &= __shfl_xor(a_and, o, 64);
       a_or |= __shfl_xor(a_or, o, 64);
     }
+    local_bad = __any(local_bad) ? 1 : 0;
     if (lane == 0) {
       f_and[wv] = a_and;
       f_or[wv] = a_or;
-      f_cnt[wv] = local;
+      f_cnt[wv] = local | (local_bad << 30);
     }
     if (tid < 256) hist[tid] = 0;
     if (tid == 0) sh_count = 0;
@@ -520,11 +526,17 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     int n_stored = 0;
     a_and = ~0u;
     a_or = 0u;
+    int any_bad = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-      n_stored += f_cnt[w];
+      n_stored += f_cnt[w] & 0x3fffffff;
+      any_bad |= f_cnt[w] >> 30;
       a_and &= f_and[w];
       a_or |= f_or[w];
+    }
+    if (any_bad) {  // (block-uniform)
+      if (tid == 0) p.redo_list[atomicAdd(p.redo_count, 1)] = bid;
+      continue;
     }
     const int n_sel = min(p.top_k, n_stored);
     if (n_sel == 0) {  // (block-uniform; the next pair starts with a barrier)
@@ -1726,7 +1738,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
       const bool tv_ok = c->sim_type != IRS_SIM_TVERSKY ||
                          (p.alpha >= 0.0 && p.alpha <= 16.0 && p.beta >= 0.0 && p.beta <= 16.0);
-      const bool fast = acc32 && !big && divides && tv_ok && p.shrinkage >= 0.0 && p.shrinkage < 1e30 &&
+      // (asymmetric cosine: norms are s^(1 - alpha) and s^alpha - inside [1, s] only for alpha in
+      // [0, 1]; outside, a float32 norm may underflow where the float64 one does not)
+      const bool as_ok = c->sim_type != IRS_SIM_ASYMMETRIC || (p.alpha >= 0.0 && p.alpha <= 1.0);
+      const bool fast = acc32 && !big && divides && tv_ok && as_ok && p.shrinkage >= 0.0 && p.shrinkage < 1e30 &&
                         !(fast_env && fast_env[0] == '0');
       if (fast) {
         sc.redo_list.alloc(slots);

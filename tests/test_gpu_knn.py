@@ -140,6 +140,20 @@ def test_thousands_of_ties_at_the_threshold_go_to_the_exact_kernel(kind, kw, mon
     assert_same_csr(g.compute_similarity(Xt, 10), want)
 
 
+@pytest.mark.parametrize("kind,kw", [("cosine", dict(shrinkage=1e31, normalize=True)),
+                                     ("jaccard", dict(shrinkage=1e31)),
+                                     ("tversky", dict(shrinkage=0.0, alpha=40.0, beta=0.5)),
+                                     ("tversky", dict(shrinkage=2.0, alpha=0.5, beta=1e3))])
+def test_parameters_outside_the_approximate_path_take_the_exact_kernel(kind, kw):
+    """The float32 approximations bound their error only for non-negative denominators in
+    float32 range (Tversky weights up to 16, shrinkage below 1e30; negative values are rejected at
+    construction like the reference does): larger ones - which the reference accepts - run the
+    exact fp64 kernel."""
+    Xb = sps.csr_matrix((X_many > 0).astype(float))
+    g, o = make(kind, Xb, **dict(kw))
+    assert_same_csr(g.compute_similarity(Xb, 20), o.compute_similarity(Xb, 20), rtol=1e-11)
+
+
 def test_explicit_zero_products_are_stored_entries():
     # knn.hpp:111-118: candidates are the stored entries of the product, exact zeros included
     X = sps.csr_matrix(np.asarray([[1.0, -1.0, 0.0], [1.0, 1.0, 2.0], [0.0, 0.0, 3.0]]))
