@@ -83,7 +83,8 @@ __global__ __launch_bounds__(1024) void eig_jacobi_kernel(const float *__restric
   constexpr int TPR = 1024 / KP, PPT = NP / TPR;            // phase 2: TPR threads per row, PPT pairs each
   static_assert(G <= 64 && (G & (G - 1)) == 0 && TPR * PPT == NP, "thread mapping");
   __shared__ double sh_cs[2][NP], sh_sn[2][NP];
-  __shared__ unsigned int sh_off;  // max |c| / sqrt(a b) of the sweep (float bits)
+  __shared__ unsigned int sh_off;   // the sweep's largest remaining coupling (float bits), see phase 1
+  __shared__ unsigned int sh_amax;  // largest squared column norm of W seen so far (float bits)
   __shared__ float sh_lam[KP];
   const int tid = threadIdx.x, pr = tid / G, l = tid % G;
   const int qr = tid / TPR, qt = tid % TPR;  // phase 2: row, part
@@ -106,15 +107,27 @@ __global__ __launch_bounds__(1024) void eig_jacobi_kernel(const float *__restric
     const int col = i / KP, row = i % KP;
     double s;
     if (warm) {
-      s = 0.0;
-      for (int d = 0; d < KP; d++)
-        s = fma(static_cast<double>(P[static_cast<size_t>(row) * KP + d]), Qd[col * KP + d], s);
+      // W = P Q_prev.  P[d][row] for P[row][d] (P is symmetric): the lanes of a wave are
+      // consecutive rows, so the load is one 256-byte line instead of 64 lines 512 bytes apart;
+      // Q_prev[col][d] is the same word for the whole wave.  Four partial sums, eight loads in
+      // flight: the product took 1.5 of the decomposition's 4 ms as a chain of 128 exposed loads.
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+      for (int d = 0; d < KP; d += 4) {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          s4[e] = fma(static_cast<double>(P[static_cast<size_t>(d + e) * KP + row]), Qd[col * KP + d + e], s4[e]);
+      }
+      s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     } else {
       s = static_cast<double>(P[static_cast<size_t>(row) * KP + col]);  // (P is symmetric)
     }
     W[i] = s;
   }
-  if (tid == 0) sh_off = 0u;
+  if (tid == 0) {
+    sh_off = 0u;
+    sh_amax = 0u;
+  }
   __syncthreads();
   int sweeps = 0;
   for (int sweep = 0; sweep < 16; sweep++) {
@@ -151,10 +164,21 @@ __global__ __launch_bounds__(1024) void eig_jacobi_kernel(const float *__restric
           // for the next sweep - so t comes from float division / square root (float64 ones are
           // ~30-instruction sequences at a quarter rate, a chain of seven per round) and only
           // cs = 1 / sqrt(1 + t^2) is refined to float64 by two Newton steps.
+          // The test is on the COUPLING the pair leaves in P, relative to the largest eigenvalue:
+          // c = q_i^T P^2 q_j ~ e_ij (lambda_i + lambda_j) with e_ij = q_i^T P q_j, and the
+          // column norms are |lambda|, so e_ij / lambda_max ~ |c| / (sqrt(max(a, b)) sqrt(a_max)).
+          // (|c| / sqrt(a b) alone never settles for a pair of near-null columns - a Gramian of
+          // rank-deficient factors has eigenvalues at 1e-7 of the largest, whose columns of W are
+          // rounding noise - and every call then ran all 16 sweeps.)
           const float cf = static_cast<float>(c);
-          const float rel = fabsf(cf) * __builtin_amdgcn_rsqf(fmaxf(static_cast<float>(a), 1e-37f)) *
-                            __builtin_amdgcn_rsqf(fmaxf(static_cast<float>(b), 1e-37f));
-          if (l == 0) atomicMax(&sh_off, __float_as_uint(rel));
+          const float mab = fmaxf(static_cast<float>(a), static_cast<float>(b));
+          const float amax = fmaxf(__uint_as_float(sh_amax), mab);  // (running maximum: never above lambda_max^2)
+          const float rel = fabsf(cf) * __builtin_amdgcn_rsqf(fmaxf(mab, 1e-37f)) *
+                            __builtin_amdgcn_rsqf(fmaxf(amax, 1e-37f));
+          if (l == 0) {
+            atomicMax(&sh_off, __float_as_uint(rel));
+            atomicMax(&sh_amax, __float_as_uint(mab));
+          }
           if (c * c > 1e-30 * ab) {
             const float zeta = static_cast<float>(b - a) / (2.0f * cf);
             const float tf = (zeta >= 0.f ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
