@@ -574,7 +574,8 @@ __global__ __launch_bounds__(256, 2) void ials_cg_eig_short_kernel(EigShortParam
 // LPR = lanes per row: 16 (four rows per wave) or 32 (two); NEV = most entries a row may have
 // (LPR, or 8 with LPR = 16: the gathered rows are NEV x DPL registers per lane - 128 of the ~200
 // at KP = 128 - and rows of <= 8 entries, more than half of configs[3]'s users, run at twice
-// the waves per SIMD with the 8-entry form).
+// the waves per SIMD with the 8-entry form; the 9..16 class on 32 lanes per row - half the
+// registers, three waves of two rows - was measured: CG equal, Cholesky 49.1 -> 51.1 ms).
 template <int KP, int LPR = 16, int NEV = LPR> struct Eig16 {
   static constexpr int DPL = KP / LPR, NE = NEV;
   static_assert((LPR == 16 || LPR == 32) && DPL >= 2 && (NEV == LPR || (NEV == 8 && LPR == 16)), "lanes per row");
