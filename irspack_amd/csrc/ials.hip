@@ -112,6 +112,9 @@ struct Side {
     reg_min = 0.f;
     for (int64_t r = rb; r < re; r++) reg_min = r == rb ? regs[r] : std::min(reg_min, regs[r]);
     const int CH = chunk_size();
+    // (read per build, not once per process: the tests lower it to fold rows of 10^4 entries)
+    const char *long_env = std::getenv("IRSPACK_AMD_IALS_CHUNK_LONG");
+    const int32_t chunk_long = std::max(CH, long_env ? std::atoi(long_env) : 16384);
     std::vector<Task> tk;
     std::vector<SplitRow> sp;
     std::vector<FoldGroup> fg;
@@ -123,7 +126,10 @@ struct Side {
         // a bounded number of chunks per row: the second kernel adds a row's partials one after
         // the other, and a chunk is one wave's serial work (the longest chunk is the floor of
         // the half-step: 4.4 M entries in 32 chunks were 16 ms of one wave at K = 128)
-        const int32_t nch = std::min<int32_t>((nz + CH - 1) / CH, max_chunks());
+        // (up to 32 chunks of any length, more only to keep a chunk below 16 K entries: the
+        // ML-20M shape's longest row - 116 k entries - stays at 32 chunks and needs no fold pass)
+        const int32_t nch = std::min<int32_t>(
+            (nz + CH - 1) / CH, std::max<int32_t>(32, std::min<int32_t>(max_chunks(), (nz + chunk_long - 1) / chunk_long)));
         const int32_t per = (((nz + nch - 1) / nch) + 3) & ~3;
         SplitRow sr{static_cast<int32_t>(r), slots, 0, nz, 1};
         for (int32_t c = b; c < e; c += per) {

@@ -406,10 +406,13 @@ def test_large_k_split_rows():
 
 @pytest.mark.parametrize("K", [32, 128, 200])
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
-def test_rows_of_many_chunks_fold_their_partials(K, kind):
-    """Rows cut into more than 32 chunks (here 40960 + 3 and 70001 entries: 41 and 69 chunks) have
-    their partial Gramians summed in groups of 16 before the row is finished
-    (fold_partials_kernel); a 33-chunk row is the smallest that folds, 32 chunks do not."""
+def test_rows_of_many_chunks_fold_their_partials(K, kind, monkeypatch):
+    """Rows cut into more than 32 chunks have their partial Gramians summed in groups of 16 before
+    the row is finished (fold_partials_kernel).  A row gets more than 32 chunks only to keep a
+    chunk below 16 K entries; the switch lowers that to the chunk size itself, so that here 40963
+    and 70001 entries are 41 and 69 chunks; a 33-chunk row is the smallest that folds, 32 chunks
+    do not."""
+    monkeypatch.setenv("IRSPACK_AMD_IALS_CHUNK_LONG", "1024")
     rng = np.random.default_rng(11)
     n_u, n_i = 9, 80000
     lens = [40963, 70001, 32 * 1024 + 1, 32 * 1024, 5000, 64, 3, 0, 1500]
