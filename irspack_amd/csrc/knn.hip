@@ -342,6 +342,8 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     const int sidx = m - (u > 0 ? before : 0);
     const uint32_t lo_u = __shfl(lo, u, 64);
     Batch bt;
+    // (strip loads that start on 128-byte lines were timed - wrong sums, same 8.45 ms: the line
+    // traffic of the unaligned strips is not what bounds the accumulation)
     bt.dw = (lo_u >> 1) + 64u * static_cast<uint32_t>(sidx);
     const uint32_t o0p1 = static_cast<uint32_t>(128 * sidx + 1) - (lo_u & 1u);
     // (shuffles stay outside conditionals: ds_bpermute returns 0 from an inactive source lane)
@@ -417,14 +419,20 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     int64_t q0 = q00;
     for (;;) {
       const bool adv = j + 1 >= A.nb;  // wave-uniform
-      uint32_t loN;
-      int lenN;
-      int64_t uD;
-      double yD;
-      bool vD;
-      load_bounds(uC, vC, loN, lenN);
-      load_uy(q0 + 3 * stride, uD, yD, vD);
-      asm volatile("" : "+v"(loN), "+v"(lenN), "+v"(uD), "+v"(yD));  // keep them out of `if (adv)`
+      // The block-level loads (slice bounds of block k + 2, (u, y) of block k + 3) are issued HERE,
+      // every iteration, and consumed in `if (adv)` after the batch has been added.  (Earlier
+      // versions pinned them with an `asm("" : "+v")` use, which made the wave wait for them
+      // on the spot - s_waitcnt vmcnt(0) at the top of the loop.  Without it the compiler keeps
+      // them here and waits at the use; the measured time is the same, 8.45 ms: the loop is not
+      // bound by that round trip either.)
+      const uint32_t *tpN = p.xt_tptr + uC * tp_stride + tile;
+      const uint32_t loN = tpN[0], hiN = tpN[1];
+      const int64_t qD = q0 + 3 * stride + lane;
+      const bool vD = lane < 16 && qD < te;
+      const int64_t qDc = min(qD, te - 1);
+      const int64_t uD = p.t_idx[qDc];
+      double yD = 1.0;
+      if (!ACC32) yD = p.t_val[qDc];
       const int jn = adv ? 0 : j + 1;
       const Batch nxt = make_batch(adv ? B.lo : A.lo, adv ? B.len : A.len, adv ? B.y : A.y,
                                    adv ? B.pin : A.pin, adv ? B.total : A.total, jn);
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       if (adv) {
         A = B;
         B.lo = loN;
-        B.len = lenN;
+        B.len = vC ? static_cast<int>(hiN - loN) : 0;
         B.y = yC;
         count_strips(B);
         uC = uD;
