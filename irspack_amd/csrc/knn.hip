@@ -413,11 +413,14 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     count_strips(A);
     count_strips(B);
     Batch cur = make_batch(A.lo, A.len, A.y, A.pin, A.total, 0);
-    uint32_t wc[16], wn[16];
-    issue_idx(cur, wc);
+    uint32_t w0[16], w1[16];
+    issue_idx(cur, w0);
     int j = 0;
     int64_t q0 = q00;
-    for (;;) {
+    // one batch: issue the next batch's words into `wn`, add the current one from `wc`; the two
+    // buffers swap roles by calling it twice per trip (no 16-register copy per batch).  Returns
+    // true when the row is finished.
+    auto one_batch = [&](uint32_t (&wc)[16], uint32_t (&wn)[16]) -> bool {
       const bool adv = j + 1 >= A.nb;  // wave-uniform
       // The block-level loads (slice bounds of block k + 2, (u, y) of block k + 3) are issued HERE,
       // every iteration, and consumed in `if (adv)` after the batch has been added.  (Earlier
@@ -448,12 +451,15 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
         yC = yD;
         vC = vD;
         q0 += stride;
-        if (q0 >= te) break;
+        if (q0 >= te) return true;
       }
       j = jn;
       cur = nxt;
-#pragma unroll
-      for (int t = 0; t < 16; t++) wc[t] = wn[t];
+      return false;
+    };
+    for (;;) {
+      if (one_batch(w0, w1)) break;
+      if (one_batch(w1, w0)) break;
     }
   }
   // (the column norms of this thread's first eight columns are fetched while the slower
