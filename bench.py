@@ -408,7 +408,7 @@ def knn_leg(X, ceilings):
                      "note": "kernel time covers accumulate + epilogue + select + merge; "
                              "HBM side prices the reference's 4 B column id per multiply-add; "
                              "traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE of the tile kernel "
-                             "(profiles/r02_knn_pmc_hbm.json): the 2-byte column stream is "
+                             "(profiles/r03_knn_pmc_hbm.json): the 2-byte column stream is "
                              "re-read per target row from Infinity Cache / HBM"},
         "out_nnz": int(S.nnz),
     }
