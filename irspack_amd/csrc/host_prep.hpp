@@ -169,19 +169,90 @@ static HostCsr transpose(const HostCsr &x) {
   return t;
 }
 
+// std::mt19937's output stream in bulk: the same recurrence and tempering (Matsumoto & Nishimura's
+// MT19937, [rand.eng.mers]: w = 32, n = 624, m = 397, r = 31, a = 0x9908b0df, u = 11, s = 7,
+// b = 0x9d2c5680, t = 15, c = 0xefc60000, l = 18, seeding multiplier 1812433253), but a whole
+// state block is regenerated and tempered by three branch-free loops the compiler vectorises
+// (the lag of the recurrence, n - m = 227, is far wider than a vector) instead of one call per
+// word with its "block exhausted?" branch: ~0.5 ns a word against 2.5.
+// (AVX2 clones of the two loops, chosen at load time: 0.67 ns a word against 1.28 with SSE2 and
+// 2.5 for std::mt19937 on this toolchain; the device pass of hipcc parses this header too and
+// knows no function multiversioning)
+// (... and the ifunc resolver of a clone runs before a sanitizer's runtime is up: plain loops there)
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer) || __has_feature(address_sanitizer)
+#define IRS_MT_NO_CLONES 1
+#endif
+#endif
+#if defined(__SANITIZE_THREAD__) || defined(__SANITIZE_ADDRESS__)
+#define IRS_MT_NO_CLONES 1
+#endif
+#if defined(__x86_64__) && defined(__linux__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(IRS_MT_NO_CLONES)
+#define IRS_MT_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define IRS_MT_CLONES
+#endif
+class Mt19937Bulk {
+ public:
+  explicit Mt19937Bulk(uint32_t seed) {
+    mt_[0] = seed;
+    for (uint32_t i = 1; i < N; i++) mt_[i] = 1812433253u * (mt_[i - 1] ^ (mt_[i - 1] >> 30)) + i;
+  }
+  // the next `count` outputs of the engine
+  IRS_MT_CLONES void fill(uint32_t *out, size_t count) {
+    size_t done = 0;
+    while (done < count) {
+      if (pos_ == N) {
+        twist();
+        pos_ = 0;
+      }
+      const size_t take = std::min<size_t>(count - done, N - pos_);
+      const uint32_t *src = mt_ + pos_;
+      uint32_t *dst = out + done;
+      for (size_t i = 0; i < take; i++) {
+        uint32_t y = src[i];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        dst[i] = y;
+      }
+      pos_ += take;
+      done += take;
+    }
+  }
+
+ private:
+  static constexpr uint32_t N = 624, M = 397;
+  static uint32_t mix(uint32_t hi, uint32_t lo, uint32_t far) {
+    const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+    return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  IRS_MT_CLONES void twist() {
+    // x[k + n] = x[k + m] ^ twist(x[k], x[k + 1]); in place, in the order of [rand.eng.mers]
+    for (uint32_t k = 0; k < N - M; k++) mt_[k] = mix(mt_[k], mt_[k + 1], mt_[k + M]);
+    for (uint32_t k = N - M; k < N - 1; k++) mt_[k] = mix(mt_[k], mt_[k + 1], mt_[k + M - N]);
+    mt_[N - 1] = mix(mt_[N - 1], mt_[0], mt_[M - 1]);
+  }
+  uint32_t mt_[N];
+  uint32_t pos_ = N;
+};
+
 // Solver::initialize, hpp:64-76: libstdc++ mt19937 + normal_distribution<float>
 // on the host, so a libstdc++ build of the reference draws the same stream.
 // Both matrices are drawn from generators with the SAME seed (hpp:718-719), so the shorter one
 // is a prefix of the longer one's stream: `n` rows are drawn once.
-static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int64_t K, int64_t n) {
+// `block_attempts`: attempts per block of the parallel path (tests shrink it).
+static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int64_t K, int64_t n,
+                                      size_t block_attempts = size_t(1) << 24) {
   std::vector<float> h(static_cast<size_t>(n) * K, 0.0f);
   if (!(init_stdev > 0)) return h;  // the reference leaves the matrix uninitialised; we zero it
   // std::sqrt(factor.cols()) takes the integral overload (hpp:68-69): the quotient is formed
   // in double and rounded to float once
   const float sd = static_cast<float>(static_cast<double>(init_stdev) / std::sqrt(static_cast<double>(K)));
-  std::mt19937 gen(random_seed);
   const size_t total = h.size();
   if (total < (size_t(1) << 18)) {
+    std::mt19937 gen(random_seed);
     std::normal_distribution<float> dist(0.0, sd);
     for (size_t i = 0; i < total; i++) h[i] = dist(gen);
     return h;
@@ -193,8 +264,8 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
   // engine, accepted or not, and an accepted attempt yields two variates (y * m first, the
   // saved x * m next).  So attempt j owns the words 2 j, 2 j + 1 whatever happened before it,
   // and the output position of an accepted attempt is twice the number of accepted attempts
-  // before it: the engine's words are generated sequentially (the only serial part, ~2.5 ns a
-  // word) and the attempts are evaluated by all host threads with a prefix count.
+  // before it.  The engine's words are the only serial part: one thread generates block b + 1
+  // (Mt19937Bulk) while all the others evaluate the attempts of block b with a prefix count.
   auto canonical = [](uint32_t w) {
     const float r = static_cast<float>(w) / 4294967296.0f;
     return r >= 1.0f ? std::nextafter(1.0f, 0.0f) : r;
@@ -211,19 +282,37 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
     a.ok = !(a.r2 > 1.0f || a.r2 == 0.0f);
     return a;
   };
-  const size_t BLK = size_t(1) << 24;  // attempts per block (128 MB of words)
+  const size_t BLK = std::max<size_t>(block_attempts, 1024);
   const int n_thr = static_cast<int>(std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
   // (sized to what the call needs, no zero fill: a 2^18-value factor used to allocate and clear
   // 128 MB per trainer)
-  RawVector<uint32_t> words;
-  words.resize(2 * std::min(BLK, static_cast<size_t>(((total + 1) / 2) * 1.3) + 4096));
-  std::vector<size_t> cnt(n_thr + 1);
-  size_t produced = 0;
-  while (produced < total) {
+  auto block_size = [&](size_t produced) {  // attempts of the block that starts at `produced`
     const size_t want_pairs = (total - produced + 1) / 2;
     // ~78.5 % of the attempts are accepted; a short block at the end
-    const size_t na = std::min(BLK, static_cast<size_t>(want_pairs * 1.3) + 4096);
-    for (size_t i = 0; i < 2 * na; i++) words[i] = static_cast<uint32_t>(gen());
+    return std::min(BLK, static_cast<size_t>(want_pairs * 1.3) + 4096);
+  };
+  Mt19937Bulk engine(static_cast<uint32_t>(random_seed));
+  RawVector<uint32_t> buf[2];
+  const size_t first = block_size(0);
+  buf[0].resize(2 * first);
+  engine.fill(buf[0].data(), 2 * first);
+  std::vector<size_t> cnt(n_thr + 1);
+  size_t produced = 0;
+  int cur = 0;
+  while (produced < total) {
+    const size_t na = block_size(produced);  // (the words of this block are already in buf[cur])
+    const uint32_t *words = buf[cur].data();
+    // The next block is generated beside this one's evaluation when this one cannot finish the
+    // matrix (at most its 2 na values).  Its size is known only afterwards: a full block is
+    // generated and the unused tail of the stream is dropped - nothing else draws from it.
+    const bool ahead = produced + 2 * na < total;
+    size_t ahead_attempts = 0;
+    std::thread producer;
+    if (ahead) {
+      ahead_attempts = block_size(produced + 2 * (na * 7 / 10));  // (no smaller than the next block will ask for)
+      buf[1 - cur].resize(2 * ahead_attempts);
+      producer = std::thread([&, ahead_attempts] { engine.fill(buf[1 - cur].data(), 2 * ahead_attempts); });
+    }
     auto range = [&](int th, size_t &b, size_t &e) {
       b = na * th / n_thr;
       e = na * (th + 1) / n_thr;
@@ -258,6 +347,21 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
     for (int k = 0; k < n_thr; k++) cnt[k + 1] += cnt[k];
     run(emit);
     produced = std::min(total, produced + 2 * cnt[n_thr]);
+    if (ahead) {
+      producer.join();
+      cur = 1 - cur;
+      if (produced < total && buf[cur].size() < 2 * block_size(produced)) {
+        // (an acceptance rate below 0.7 over a whole block - never seen: the stream goes on
+        // where the producer stopped)
+        const size_t have = buf[cur].size(), need = 2 * block_size(produced);
+        buf[cur].resize(need);
+        engine.fill(buf[cur].data() + have, need - have);
+      }
+    } else if (produced < total) {  // (the estimate fell short: the next block, synchronously)
+      const size_t nb = block_size(produced);
+      buf[cur].resize(2 * nb);
+      engine.fill(buf[cur].data(), 2 * nb);
+    }
   }
   return h;
 }

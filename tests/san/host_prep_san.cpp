@@ -82,11 +82,23 @@ int main() {
     }
     CHECK(T.indptr[cb] == 0 && T.indptr[cols] == T.indptr[ce]);
   }
+  // ---- the bulk engine is std::mt19937, word for word (odd chunk sizes cross the state blocks)
+  for (const uint32_t seed : {42u, 0u, 5489u, 0xffffffffu}) {
+    ials::Mt19937Bulk bulk(seed);
+    std::mt19937 ref(seed);
+    std::vector<uint32_t> got(100003);
+    for (const size_t chunk : {size_t(1), size_t(623), size_t(624), size_t(625), size_t(100003), size_t(7)}) {
+      bulk.fill(got.data(), chunk);
+      for (size_t i = 0; i < chunk; i++) CHECK(got[i] == static_cast<uint32_t>(ref()));
+    }
+  }
   // ---- the parallel random stream is the sequential libstdc++ one, bit for bit (> 2^18 values)
   for (const int64_t K : {int64_t(64), int64_t(10)}) {
     const int64_t n = K == 64 ? 6000 : 40000;
     const float stdev = 0.1f;
-    const std::vector<float> par = ials::draw_factor(stdev, 42, K, n);
+    // (K = 10: blocks of 30,000 attempts, i.e. eight blocks with the producer thread one ahead)
+    const std::vector<float> par = K == 64 ? ials::draw_factor(stdev, 42, K, n)
+                                           : ials::draw_factor(stdev, 42, K, n, 30000);
     CHECK(par.size() == static_cast<size_t>(n * K) && par.size() >= (size_t(1) << 18));
     std::mt19937 gen(42);
     const float sd = static_cast<float>(static_cast<double>(stdev) / std::sqrt(static_cast<double>(K)));

@@ -44,6 +44,17 @@ def test_host_preparation_under_address_and_ub_sanitizers(tmp_path):
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_preparation_plain_optimised_build(tmp_path):
+    """The same harness without a sanitizer at -O3: this is the build in which the bulk Mersenne
+    Twister runs its AVX2 clones (the sanitizer builds take the plain loops - an ifunc resolver
+    runs before a sanitizer's runtime is up), compared word for word with std::mt19937 and
+    variate for variate with std::normal_distribution."""
+    r = _build_and_run(tmp_path, ["-O3"], {})
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "host_prep_san ok" in r.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
 @pytest.mark.parametrize("san", ["thread", "address"])
 def test_cpu_oracle_under_sanitizers(san):
     """`make -C oracle SAN=thread|address san`: the multi-threaded CPU oracle (atomic-cursor row
