@@ -1769,7 +1769,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       // (asymmetric cosine: norms are s^(1 - alpha) and s^alpha - inside [1, s] only for alpha in
       // [0, 1]; outside, a float32 norm may underflow where the float64 one does not)
       const bool as_ok = c->sim_type != IRS_SIM_ASYMMETRIC || (p.alpha >= 0.0 && p.alpha <= 1.0);
-      const bool fast = acc32 && !big && divides && tv_ok && as_ok && p.shrinkage >= 0.0 && p.shrinkage < 1e30 &&
+      // (the candidate list holds FAST_CAP columns: a request for more than half of that would send
+      // most pairs to the redo list, i.e. accumulate them twice)
+      const bool fast = acc32 && !big && p.top_k <= FAST_CAP / 2 && divides && tv_ok && as_ok && p.shrinkage >= 0.0 &&
+                        p.shrinkage < 1e30 &&
                         !(fast_env && fast_env[0] == '0');
       if (fast) {
         sc.redo_list.alloc(slots);

@@ -69,6 +69,17 @@ def test_matches_oracle(kind, kw, Xname, top_k):
     assert_same_csr(got, exp, rtol=1e-12)
 
 
+@pytest.mark.parametrize("top_k", [700, 1024, 1025, 1500, 2048, 2500])
+def test_top_k_around_the_candidate_list_size(top_k):
+    """Binary data, 3,000 items that all co-occur: requests up to 1,024 take the approximate
+    selection (its candidate list holds 2,048 columns), larger ones the exact kernel, above 2,048
+    the threshold merge - the same rows as the oracle on every side of the two boundaries."""
+    r = np.random.RandomState(11)
+    Xt = sps.csr_matrix((r.rand(3000, 400) < 0.2).astype(float))
+    g, o = make("cosine", Xt, shrinkage=0.0, normalize=True)
+    assert_same_csr(g.compute_similarity(Xt, top_k), o.compute_similarity(Xt, top_k))
+
+
 @pytest.mark.parametrize("X,normalize", [(X_many, True), (X_small, False), (X_many_dense, True)])
 def test_cosine_dense_formula(X, normalize):
     # tests/recommenders/test_knn.py:33-51
