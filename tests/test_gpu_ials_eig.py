@@ -58,7 +58,7 @@ def check_decomposition(P, Q, lam, st, K):
 def short_row_matrix(n_users, n_items, seed, weights):
     rng = np.random.default_rng(seed)
     deg = rng.integers(0, 33, size=n_users)
-    deg[:6] = [0, 1, 16, 17, 32, 2]
+    deg[:10] = [0, 1, 16, 17, 32, 2, 8, 9, 7, 31]  # (the class boundaries of the short-row kernels: 8 | 9, 16 | 17, 32)
     rows = np.repeat(np.arange(n_users), deg)
     cols = np.concatenate([rng.choice(n_items, size=d, replace=False) for d in deg])
     vals = (rng.uniform(0.25, 3.0, size=rows.shape[0]) if weights else np.ones(rows.shape[0])).astype(np.float32)
