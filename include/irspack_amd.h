@@ -185,6 +185,9 @@ irs_status irs_ials_synchronize(irs_ials_trainer *t);
 /* Per-kernel HIP-event timing (profiling aid for bench.py).  enable != 0 turns
  * recording on and clears the counters; `names`/`ms`/`launches` receive up to
  * `cap` entries. */
+/* Which rows of the last half-step were solved in the eigenbasis of the Gramian (measurement /
+ * tests only, no reference counterpart): bit 0 = the rows of <= 32 stored entries. */
+int32_t irs_ials_last_eigenbasis(irs_ials_trainer *t);
 irs_status irs_ials_profile(irs_ials_trainer *t, int32_t enable);
 irs_status irs_ials_profile_read(irs_ials_trainer *t, int32_t cap,
                                  char (*names)[48], double *ms,
@@ -270,6 +273,19 @@ irs_status irs_eval_get_metrics(irs_evaluator *e, int32_t is_f64,
                                 int64_t offset, int64_t n_threads,
                                 int32_t recall_with_cutoff, irs_metrics *out,
                                 int64_t *item_cnt);
+/* The caller loop of evaluation/evaluator.py:371-393 (score chunks) and :417-438 (model blocks)
+ * for one block, on the device: the host block is uploaded ONCE (the upload is the copy the
+ * reference makes at :387, so the caller's array is never written), the stored entries of the
+ * mask rows are set to -inf there (:389 / :432; the caller passes the NONZERO entries only:
+ * mask_indptr has rows + 1 entries, mask_indices[mask_indptr[r] - mask_indptr[0] ..) are the
+ * columns of row r; NULL = no mask) and the block is ranked once per cutoff (:390-391 /
+ * :433-439).  out[c] / item_cnt[c * n_items ..] receive the metrics of cutoffs[c]. */
+irs_status irs_eval_get_metrics_masked(irs_evaluator *e, int32_t is_f64, const void *scores,
+                                       int64_t rows, const int64_t *mask_indptr,
+                                       const int32_t *mask_indices, int32_t n_cutoffs,
+                                       const int64_t *cutoffs, int64_t offset,
+                                       int64_t n_threads, int32_t recall_with_cutoff,
+                                       irs_metrics *out, int64_t *item_cnt);
 /* Fused device path used by the Evaluator counterpart when the model is an
  * iALS trainer of this library: scores = user[begin:end] @ item^T (hpp:942-984)
  * are produced, masked (evaluator.py:417-432, mask = CSR rows given here, set

@@ -113,6 +113,7 @@ EXPORTED_SYMBOLS = [
     "irs_ials_finish_gramian_async",
     "irs_ials_half_step_async",
     "irs_ials_synchronize",
+    "irs_ials_last_eigenbasis",
     "irs_ials_profile",
     "irs_ials_profile_read",
     "irs_knn_create",
@@ -125,6 +126,7 @@ EXPORTED_SYMBOLS = [
     "irs_eval_create",
     "irs_eval_destroy",
     "irs_eval_get_metrics",
+    "irs_eval_get_metrics_masked",
     "irs_eval_get_metrics_ials",
     "irs_eval_cache_mask",
     "irs_eval_last_stats",

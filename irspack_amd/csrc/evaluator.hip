@@ -1133,6 +1133,19 @@ __global__ void mask_rows_kernel(float *scores, int64_t rows, int64_t n_items,
   }
 }
 
+// the same for a block of either score type whose mask rows arrive with the call
+// (irs_eval_get_metrics_masked): mask_ptr is relative to the first row of the block
+template <class T>
+__global__ void mask_block_kernel(T *scores, int64_t rows, int64_t n_items,
+                                  const int64_t *mask_ptr, const int32_t *mask_idx) {
+  const int64_t row = blockIdx.x;
+  if (row >= rows) return;
+  for (int64_t q = mask_ptr[row] + threadIdx.x; q < mask_ptr[row + 1]; q += blockDim.x) {
+    const int32_t j = mask_idx[q];
+    if (j >= 0 && j < n_items) scores[row * n_items + j] = -std::numeric_limits<T>::infinity();
+  }
+}
+
 }  // namespace eval
 }  // namespace irs
 
@@ -1923,6 +1936,59 @@ irs_status irs_eval_get_metrics(irs_evaluator *e, int32_t is_f64, const void *sc
         rank_block<float>(e, e->score_buf.ptr, rows, cutoff, offset, recall_with_cutoff != 0, s);
     }
     finish_accumulate(e, out, item_cnt, s);
+  });
+}
+
+irs_status irs_eval_get_metrics_masked(irs_evaluator *e, int32_t is_f64, const void *scores,
+                                       int64_t rows, const int64_t *mask_indptr,
+                                       const int32_t *mask_indices, int32_t n_cutoffs,
+                                       const int64_t *cutoffs, int64_t offset,
+                                       int64_t n_threads, int32_t recall_with_cutoff,
+                                       irs_metrics *out, int64_t *item_cnt) {
+  return guard([&] {
+    check_arg(e && out && item_cnt && cutoffs, "null argument.");
+    check_arg(rows >= 0 && n_cutoffs >= 0, "negative count.");
+    check_arg(rows == 0 || scores != nullptr, "null score block.");
+    for (int32_t c = 0; c < n_cutoffs; c++) validate_call(e, rows, cutoffs[c], offset, n_threads);
+    IRS_HIP(hipSetDevice(e->device));
+    hipStream_t s = nullptr;
+    DeviceBuffer<int64_t> mptr;
+    DeviceBuffer<int32_t> midx;
+    if (rows > 0) {
+      const size_t bytes = static_cast<size_t>(rows) * e->n_items * (is_f64 ? 8 : 4);
+      e->score_buf.alloc(bytes);
+      IRS_HIP(hipMemcpyAsync(e->score_buf.ptr, scores, bytes, hipMemcpyHostToDevice, s));
+      const int64_t mnnz = mask_indptr ? mask_indptr[rows] - mask_indptr[0] : 0;
+      if (mnnz > 0) {
+        check_arg(mask_indices != nullptr, "mask_indices is null.");
+        std::vector<int64_t> mp(rows + 1);
+        for (int64_t r = 0; r <= rows; r++) {
+          mp[r] = mask_indptr[r] - mask_indptr[0];
+          check_arg(mp[r] >= (r ? mp[r - 1] : 0), "mask_indptr must not decrease.");
+        }
+        mptr.upload(mp, s);
+        midx.upload(mask_indices, static_cast<size_t>(mnnz), s);
+        if (is_f64)
+          hipLaunchKernelGGL(mask_block_kernel<double>, dim3(static_cast<unsigned>(rows)), dim3(64), 0, s,
+                             reinterpret_cast<double *>(e->score_buf.ptr), rows, e->n_items, mptr.ptr,
+                             midx.ptr);
+        else
+          hipLaunchKernelGGL(mask_block_kernel<float>, dim3(static_cast<unsigned>(rows)), dim3(64), 0, s,
+                             reinterpret_cast<float *>(e->score_buf.ptr), rows, e->n_items, mptr.ptr,
+                             midx.ptr);
+        IRS_HIP(hipGetLastError());
+      }
+    }
+    for (int32_t c = 0; c < n_cutoffs; c++) {
+      begin_accumulate(e, s);
+      if (rows > 0) {
+        if (is_f64)
+          rank_block<double>(e, e->score_buf.ptr, rows, cutoffs[c], offset, recall_with_cutoff != 0, s);
+        else
+          rank_block<float>(e, e->score_buf.ptr, rows, cutoffs[c], offset, recall_with_cutoff != 0, s);
+      }
+      finish_accumulate(e, out + c, item_cnt + static_cast<int64_t>(c) * e->n_items, s);
+    }
   });
 }
 

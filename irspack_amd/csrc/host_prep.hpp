@@ -297,21 +297,32 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
   buf[0].resize(2 * first);
   engine.fill(buf[0].data(), 2 * first);
   std::vector<size_t> cnt(n_thr + 1);
-  size_t produced = 0;
+  size_t produced = 0, avail = first;  // attempts whose words are in buf[cur]
   int cur = 0;
+  // joins on every way out of a scope: an exception (thread creation can fail) must surface as an
+  // irs_status error, not end in std::terminate on a joinable std::thread
+  struct Joiner {
+    std::vector<std::thread> th;
+    ~Joiner() {
+      for (auto &t : th)
+        if (t.joinable()) t.join();
+    }
+  };
   while (produced < total) {
-    const size_t na = block_size(produced);  // (the words of this block are already in buf[cur])
+    // EVERY attempt in the buffer is evaluated (emission stops at `total`): a block that used
+    // fewer than it holds would drop the unread words and leave the libstdc++ stream
+    const size_t na = avail;
     const uint32_t *words = buf[cur].data();
     // The next block is generated beside this one's evaluation when this one cannot finish the
     // matrix (at most its 2 na values).  Its size is known only afterwards: a full block is
     // generated and the unused tail of the stream is dropped - nothing else draws from it.
     const bool ahead = produced + 2 * na < total;
     size_t ahead_attempts = 0;
-    std::thread producer;
+    Joiner producer;
     if (ahead) {
       ahead_attempts = block_size(produced + 2 * (na * 7 / 10));  // (no smaller than the next block will ask for)
       buf[1 - cur].resize(2 * ahead_attempts);
-      producer = std::thread([&, ahead_attempts] { engine.fill(buf[1 - cur].data(), 2 * ahead_attempts); });
+      producer.th.emplace_back([&, ahead_attempts] { engine.fill(buf[1 - cur].data(), 2 * ahead_attempts); });
     }
     auto range = [&](int th, size_t &b, size_t &e) {
       b = na * th / n_thr;
@@ -337,10 +348,9 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
       }
     };
     auto run = [&](auto fn) {
-      std::vector<std::thread> th;
-      for (int k = 1; k < n_thr; k++) th.emplace_back(fn, k);
+      Joiner workers;
+      for (int k = 1; k < n_thr; k++) workers.th.emplace_back(fn, k);
       fn(0);
-      for (auto &t : th) t.join();
     };
     cnt[0] = 0;
     run(count);
@@ -348,19 +358,22 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
     run(emit);
     produced = std::min(total, produced + 2 * cnt[n_thr]);
     if (ahead) {
-      producer.join();
+      producer.th[0].join();
       cur = 1 - cur;
-      if (produced < total && buf[cur].size() < 2 * block_size(produced)) {
+      avail = ahead_attempts;
+      if (produced < total && avail < block_size(produced)) {
         // (an acceptance rate below 0.7 over a whole block - never seen: the stream goes on
         // where the producer stopped)
-        const size_t have = buf[cur].size(), need = 2 * block_size(produced);
-        buf[cur].resize(need);
-        engine.fill(buf[cur].data() + have, need - have);
+        const size_t need = block_size(produced);
+        buf[cur].resize(2 * need);  // (RawVector keeps its contents)
+        engine.fill(buf[cur].data() + 2 * avail, 2 * (need - avail));
+        avail = need;
       }
-    } else if (produced < total) {  // (the estimate fell short: the next block, synchronously)
-      const size_t nb = block_size(produced);
+    } else if (produced < total) {  // (the estimate fell short: the next block, synchronously; every
+      const size_t nb = block_size(produced);  // word of this one was read, so the engine is in step)
       buf[cur].resize(2 * nb);
       engine.fill(buf[cur].data(), 2 * nb);
+      avail = nb;
     }
   }
   return h;

@@ -580,6 +580,13 @@ void launch_gk_solve(irs_ials_trainer *t, Side &sd, const float *other, float *t
                                             : static_cast<int>(std::min<uint64_t>(sc->max_cg_steps, 1u << 20));
     const size_t lds = (4 * static_cast<size_t>(t->KP) + 8) * sizeof(float) +
                        4 * static_cast<size_t>(t->KP) * sizeof(double);  // vectors + float64 partial sums
+    // a row's CG vectors live in the workgroup's LDS (160 KB per compute unit on gfx950): say so
+    // instead of letting the launch fail (Cholesky and iALS++ work from global scratch at any K)
+    if (lds > 160u * 1024u)
+      throw std::invalid_argument(
+          "solver_type = CG keeps 48 bytes of a row's vectors per (padded) factor dimension in LDS: "
+          "n_components = " + std::to_string(t->K) + " needs " + std::to_string(lds) +
+          " bytes, the device has 163840 (n_components <= 3392 works); use CHOLESKY or IALSPP above.");
     IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gk_cg_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
     t->prof.begin(pidx == 0 ? "ials_solve_cg_user" : "ials_solve_cg_item", t->stream);
@@ -1998,9 +2005,9 @@ irs_status irs_ials_eigen_debug_(const float *P, int64_t K, int32_t device, floa
   });
 }
 
-// Internal hook (diagnostics / tests): 1 when the last half-step solved its short rows in the
-// eigenbasis of the Gramian (ials_eig_kernels.hpp).
-int32_t irs_ials_eig_last_(irs_ials_trainer *t) { return t ? t->eig_last : 0; }
+// Diagnostics / tests: which rows of the last half-step were solved in the eigenbasis of the
+// Gramian (ials_eig_kernels.hpp); bit 0 = the short rows (<= 32 stored entries).
+int32_t irs_ials_last_eigenbasis(irs_ials_trainer *t) { return t ? t->eig_last : 0; }
 
 irs_status irs_ials_profile(irs_ials_trainer *t, int32_t enable) {
   return guard([&] {

@@ -84,7 +84,12 @@ __global__ __launch_bounds__(1024) void eig_jacobi_kernel(const float *__restric
   static_assert(G <= 64 && (G & (G - 1)) == 0 && TPR * PPT == NP, "thread mapping");
   __shared__ double sh_cs[2][NP], sh_sn[2][NP];
   __shared__ unsigned int sh_off;   // the sweep's largest remaining coupling (float bits), see phase 1
-  __shared__ unsigned int sh_amax;  // largest squared column norm of W seen so far (float bits)
+  // largest squared column norm of W seen so far (float bits), in three slots used in rotation:
+  // round n reads slot (n - 1) % 3 - complete since the barrier of round n - 1 - and folds it, with
+  // its own norms, into slot n % 3; slot (n + 1) % 3 is the one round n - 2 wrote and nobody touches.
+  // (One word read while other pairs' leaders atomicMax it made the convergence measure, and with it
+  // the sweep count and the factors, depend on wave timing.)
+  __shared__ unsigned int sh_amax[3];
   __shared__ float sh_lam[KP];
   const int tid = threadIdx.x, pr = tid / G, l = tid % G;
   const int qr = tid / TPR, qt = tid % TPR;  // phase 2: row, part
@@ -126,13 +131,23 @@ __global__ __launch_bounds__(1024) void eig_jacobi_kernel(const float *__restric
   }
   if (tid == 0) {
     sh_off = 0u;
-    sh_amax = 0u;
+    sh_amax[0] = sh_amax[1] = sh_amax[2] = 0u;
   }
   __syncthreads();
-  int sweeps = 0;
+  {  // the first round's "previous" slot: the largest squared column norm of the starting W
+    constexpr int TPC = 1024 / KP;  // threads per column
+    const int col = tid / TPC, part = tid % TPC;
+    double s = 0;
+    for (int r = part; r < KP; r += TPC) s = fma(W[col * KP + r], W[col * KP + r], s);
+#pragma unroll
+    for (int off = 1; off < TPC; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (part == 0) atomicMax(&sh_amax[2], __float_as_uint(static_cast<float>(s)));
+  }
+  __syncthreads();
+  int sweeps = 0, slot = 0;  // slot = (rounds so far) % 3
   for (int sweep = 0; sweep < 16; sweep++) {
     sweeps = sweep + 1;
-    for (int rd = 0; rd < KP - 1; rd++) {
+    for (int rd = 0; rd < KP - 1; rd++, slot = slot == 2 ? 0 : slot + 1) {
       // ---- phase 1: rotation of pair `pr`, applied to its two columns of W
       {
         const int i = top_col(pr, rd), j = bot_col(pr, rd);
@@ -157,6 +172,11 @@ __global__ __launch_bounds__(1024) void eig_jacobi_kernel(const float *__restric
         }
         double cs = 1.0, sn = 0.0;
         const double ab = a * b;
+        // (running maximum of the squared column norms over the earlier rounds: never above
+        // lambda_max^2; every pair folds the previous slot into this round's, so the slots only grow)
+        const float mab = fmaxf(static_cast<float>(a), static_cast<float>(b));
+        const float amax = fmaxf(__uint_as_float(sh_amax[slot == 0 ? 2 : slot - 1]), mab);
+        if (l == 0) atomicMax(&sh_amax[slot], __float_as_uint(amax));
         if (ab > 0.0 && c != 0.0) {
           // |c| / sqrt(a b): only its size matters (convergence test), float arithmetic.  The
           // ANGLE may be approximate too - any (cs, sn) with cs^2 + sn^2 = 1 to float64 accuracy
@@ -171,14 +191,9 @@ __global__ __launch_bounds__(1024) void eig_jacobi_kernel(const float *__restric
           // rank-deficient factors has eigenvalues at 1e-7 of the largest, whose columns of W are
           // rounding noise - and every call then ran all 16 sweeps.)
           const float cf = static_cast<float>(c);
-          const float mab = fmaxf(static_cast<float>(a), static_cast<float>(b));
-          const float amax = fmaxf(__uint_as_float(sh_amax), mab);  // (running maximum: never above lambda_max^2)
           const float rel = fabsf(cf) * __builtin_amdgcn_rsqf(fmaxf(mab, 1e-37f)) *
                             __builtin_amdgcn_rsqf(fmaxf(amax, 1e-37f));
-          if (l == 0) {
-            atomicMax(&sh_off, __float_as_uint(rel));
-            atomicMax(&sh_amax, __float_as_uint(mab));
-          }
+          if (l == 0) atomicMax(&sh_off, __float_as_uint(rel));
           if (c * c > 1e-30 * ab) {
             const float zeta = static_cast<float>(b - a) / (2.0f * cf);
             const float tf = (zeta >= 0.f ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));

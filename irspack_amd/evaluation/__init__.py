@@ -2,7 +2,7 @@
 surface and the ``Evaluator`` host class that drives it (irspack/evaluation/__init__.py)."""
 
 from ._core_evaluator import EvaluatorCore, Metrics, evaluate_list_vs_list
-from .evaluator import METRIC_NAMES, Evaluator, TargetMetric
+from .evaluator import METRIC_NAMES, Evaluator, EvaluatorWithColdUser, TargetMetric
 
-__all__ = ["Evaluator", "EvaluatorCore", "Metrics", "METRIC_NAMES", "TargetMetric",
+__all__ = ["Evaluator", "EvaluatorWithColdUser", "EvaluatorCore", "Metrics", "METRIC_NAMES", "TargetMetric",
            "evaluate_list_vs_list"]

@@ -131,6 +131,38 @@ def _ragged(lists: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
     return ptr_, flat
 
 
+class MaskRows:
+    """The NONZERO pattern of a mask matrix (``scores[mask.nonzero()] = -inf``,
+    evaluator.py:389 / :432: stored zeros do not mask) prepared once for row-range slicing:
+    ``rows(b, e)`` hands ``irs_eval_get_metrics_masked`` views of the row pointers and the
+    column indices of rows ``[b, e)`` without copying either."""
+
+    def __init__(self, mask: Any, n_cols: int) -> None:
+        m = mask if sps.isspmatrix_csr(mask) else sps.csr_matrix(mask)
+        if m.shape[1] != n_cols:
+            raise ValueError(f"mask must have {n_cols} columns, got {m.shape[1]}.")
+        indptr, indices = m.indptr, m.indices
+        if m.nnz and not np.all(m.data != 0):
+            keep = m.data != 0
+            row_of = np.repeat(np.arange(m.shape[0]), np.diff(indptr))[keep]
+            indices = indices[keep]
+            indptr = np.zeros(m.shape[0] + 1, dtype=np.int64)
+            np.cumsum(np.bincount(row_of, minlength=m.shape[0]), out=indptr[1:])
+        self.n_rows = int(m.shape[0])
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        if self.indices.size and (self.indices.min() < 0 or self.indices.max() >= n_cols):
+            raise ValueError("mask column index out of range.")
+
+    def rows(self, begin: int, end: int) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+        if begin < 0 or end > self.n_rows or end < begin:
+            raise ValueError("mask rows out of range.")
+        p = self.indptr[begin:end + 1]
+        if p[-1] == p[0]:
+            return None, None
+        return p, self.indices[p[0]:p[-1]]
+
+
 class EvaluatorCore:
     """``EvaluatorCore(ground_truth, recommendable)`` — evaluator.cpp:181-374, :449-480."""
 
@@ -191,6 +223,40 @@ class EvaluatorCore:
     def get_metrics_f32(self, score_array, cutoff, offset, n_threads, recall_with_cutoff=False):
         return self._get(score_array, False, cutoff, offset, n_threads, recall_with_cutoff)
 
+    def get_metrics_masked(self, score_array: np.ndarray, mask: Optional["MaskRows"],
+                           mask_begin: int, cutoffs: Sequence[int], offset: int, n_threads: int,
+                           recall_with_cutoff: bool = False) -> List[Metrics]:
+        """One block of the caller loops of evaluation/evaluator.py:371-393 / :417-438 in one
+        device call (``irs_eval_get_metrics_masked``, not in the reference): the block is
+        uploaded once, rows ``mask_begin ..`` of ``mask`` are set to ``-inf`` on the device
+        (``score_array`` itself is never written) and the block is ranked once per cutoff.
+        Returns one ``Metrics`` per cutoff, equal to masking on the host and calling
+        ``get_metrics_f32/_f64`` per cutoff."""
+        if not isinstance(score_array, np.ndarray) or score_array.ndim != 2 or \
+                score_array.dtype not in (np.dtype("float32"), np.dtype("float64")):
+            raise TypeError("score_array must be a 2-D float32 or float64 ndarray.")
+        if score_array.shape[1] != self.n_items:
+            raise ValueError("score_array.shape[1] must equal n_items.")
+        if offset < 0 or n_threads < 0 or any(int(c) < 0 for c in cutoffs):
+            raise TypeError("cutoff / offset / n_threads must be non-negative (size_t).")
+        scores = np.ascontiguousarray(score_array)
+        rows, nc = scores.shape[0], len(cutoffs)
+        cut = np.asarray([int(c) for c in cutoffs], dtype=np.int64)
+        sts = (MetricsStruct * max(nc, 1))()
+        cnt = np.zeros((max(nc, 1), self.n_items), dtype=np.int64)
+        mp, mi = (None, None) if mask is None else mask.rows(mask_begin, mask_begin + rows)
+        check(
+            lib().irs_eval_get_metrics_masked(
+                self._h, C.c_int32(1 if scores.dtype == np.float64 else 0),
+                scores.ctypes.data_as(C.c_void_p), C.c_int64(rows),
+                None if mp is None else ptr(mp, C.c_int64),
+                None if mi is None else ptr(mi, C.c_int32), C.c_int32(nc), ptr(cut, C.c_int64),
+                C.c_int64(offset), C.c_int64(n_threads), C.c_int32(1 if recall_with_cutoff else 0),
+                sts, ptr(cnt, C.c_int64),
+            )
+        )
+        return [Metrics._from_struct(self.n_items, sts[i], cnt[i]) for i in range(nc)]
+
     def get_metrics_ials(self, trainer, begin: int, end: int, mask: Optional[sps.csr_matrix],
                          cutoff: int, offset: int, recall_with_cutoff: bool = False) -> Metrics:
         """Fused device path (not in the reference): score, mask and rank users
@@ -246,11 +312,13 @@ class EvaluatorCore:
                 "tiles_total": int(st.tiles_total), "tiles_scored": int(st.tiles_scored),
                 "sample_items": int(st.sample_items)}
 
-    #: ``True``: hash EVERY byte of the mask on every ``get_metrics_ials`` call (xxhash when
-    #: installed, else CRC-32: ~15 ms for 20 M entries, next to a 2 ms device pass) instead of the
-    #: sampled fingerprint below.  Masks are otherwise to be treated as immutable while an
-    #: evaluator holds them; ``invalidate_mask()`` forces a re-upload after an in-place edit.
-    strict_mask_fingerprint = False
+    #: ``True`` (the default): EVERY byte of the mask is hashed on every ``get_metrics_ials``
+    #: call (xxhash when installed, else CRC-32: ~15 ms for 20 M entries, next to a 2 ms device
+    #: pass), so a mask edited in place is noticed and uploaded again.  ``False`` trades that for a
+    #: sampled fingerprint (row-pointer sum + CRC of 1024 strided samples: microseconds) for callers
+    #: that treat their masks as immutable, e.g. a tuning loop; ``invalidate_mask()`` then forces a
+    #: re-upload after an in-place edit.
+    strict_mask_fingerprint = True
 
     def invalidate_mask(self) -> None:
         """Drop the device-resident mask: the next ``get_metrics_ials`` call converts and uploads
@@ -260,11 +328,10 @@ class EvaluatorCore:
 
     @classmethod
     def _mask_fingerprint(cls, mask: sps.spmatrix) -> int:
-        """Content check for the device-resident mask (it runs on every call, next to a device
-        pass of two milliseconds).  Default: the sum of the row pointers and a CRC of 1024
-        strided samples each of the pointers, column indices and values - an in-place edit that
-        keeps nnz, the pointer sum and every sampled entry goes unnoticed (``invalidate_mask()``
-        or a new object for that).  ``strict_mask_fingerprint = True`` hashes all of it."""
+        """Content check for the device-resident mask, run on every call.  Default: a hash of all
+        of its row pointers, column indices and values.  With ``strict_mask_fingerprint = False``:
+        the sum of the row pointers and a CRC of 1024 strided samples of each array - an in-place
+        edit that keeps nnz, the pointer sum and every sampled entry then goes unnoticed."""
         import zlib
 
         m = mask if sps.isspmatrix_csr(mask) else sps.csr_matrix(mask)

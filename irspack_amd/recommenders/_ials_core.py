@@ -231,12 +231,12 @@ class IALSSolverConfigBuilder:  # IALSLearningConfig.hpp:114-147, wrapper.cpp:11
         self.max_cg_steps = max_cg_steps
         return self
 
-    def set_ialspp_subspace_dimension(self, v: int) -> "IALSSolverConfigBuilder":
-        self.ialspp_subspace_dimension = v
+    def set_ialspp_subspace_dimension(self, ialspp_subspace_dimension: int) -> "IALSSolverConfigBuilder":
+        self.ialspp_subspace_dimension = ialspp_subspace_dimension
         return self
 
-    def set_ialspp_iteration(self, v: int) -> "IALSSolverConfigBuilder":
-        self.ialspp_iteration = v
+    def set_ialspp_iteration(self, ialspp_iteration: int) -> "IALSSolverConfigBuilder":
+        self.ialspp_iteration = ialspp_iteration
         return self
 
 
@@ -688,9 +688,9 @@ class IALSTrainer:
     def last_half_step_used_eigenbasis(self) -> bool:
         """diagnostics: the last half-step solved its short rows (<= 32 stored entries) in the
         eigenbasis of the Gramian (csrc/ials_eig_kernels.hpp)"""
-        f = lib().irs_ials_eig_last_
+        f = lib().irs_ials_last_eigenbasis
         f.restype = C.c_int32
-        return bool(f(self._h))
+        return bool(f(self._h) & 1)
 
     def profile(self, enable: bool) -> None:
         check(lib().irs_ials_profile(self._h, C.c_int32(1 if enable else 0)))

@@ -4,7 +4,7 @@
 the registry metaclass and config classes are orchestration and out of scope.
 """
 
-from typing import Any, Optional, Union
+from typing import Any, Callable, Optional, Union
 
 import numpy as np
 import scipy.sparse as sps
@@ -52,7 +52,18 @@ class BaseRecommender:
         return scores
 
     def get_score_cold_user(self, X: Any) -> np.ndarray:
-        raise NotImplementedError("get_score_cold_user is not implemented.")
+        raise NotImplementedError(
+            f"get_score_cold_user is not implemented for {self.__class__.__name__}!")
+
+    def _create_cold_user_with_item_features_scorer(self, item_features: Any) -> Callable[[Any], np.ndarray]:
+        """base.py:353-362: lets an evaluator prepare feature-derived item state once and score
+        many user blocks against it."""
+        return lambda X: self.get_score_cold_user_with_item_features(X, item_features)
+
+    def get_score_cold_user_with_item_features(self, X: Any, item_features: Any) -> np.ndarray:
+        # base.py:364-389
+        raise NotImplementedError("Scoring additional items from features is not implemented for "
+                                  f"{self.__class__.__name__}.")
 
     def get_score_cold_user_remove_seen(self, X: Any) -> np.ndarray:
         score = self.get_score_cold_user(X)

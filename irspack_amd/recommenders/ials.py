@@ -11,7 +11,7 @@ follows ``base_earlystop.py:106-149`` without the Optuna / progress-bar parts.
 import enum
 import pickle
 from io import BytesIO
-from typing import IO, Any, Optional
+from typing import IO, Any, Callable, Optional
 
 import numpy as np
 import scipy.sparse as sps
@@ -38,6 +38,13 @@ def str_to_solver_type(t: str) -> SolverType:
 
 def str_to_loss_type(t: str) -> LossType:
     return _enum_by_name(LossType, t)
+
+
+def _feature_matrix_as_float32(X: Any) -> Any:
+    # ials.py:58-61
+    if sps.issparse(X):
+        return sps.csr_matrix(X, dtype=np.float32)
+    return np.asarray(X, dtype=np.float32, order="C")
 
 
 class IALSTrainer:
@@ -100,19 +107,33 @@ class IALSTrainer:
     def user_scores(self, begin: int, end: int) -> np.ndarray:
         return self.core_trainer.user_scores(begin, end, self.solver_config)
 
-    def transform_user(self, X: Any) -> np.ndarray:
-        return self.core_trainer.transform_user(X, self.prediction_time_solver_config)
+    def transform_user(self, X: Any, user_features: Any = None) -> np.ndarray:
+        # ials.py:167-179
+        if user_features is None:
+            return self.core_trainer.transform_user(X, self.prediction_time_solver_config)
+        return self.core_trainer.transform_user_with_feature(
+            X, _feature_matrix_as_float32(user_features), self.prediction_time_solver_config)
 
-    def transform_item(self, X: Any) -> np.ndarray:
-        return self.core_trainer.transform_item(X, self.prediction_time_solver_config)
+    def transform_item(self, X: Any, item_features: Any = None) -> np.ndarray:
+        # ials.py:181-193
+        if item_features is None:
+            return self.core_trainer.transform_item(X, self.prediction_time_solver_config)
+        return self.core_trainer.transform_item_with_feature(
+            X, _feature_matrix_as_float32(item_features), self.prediction_time_solver_config)
 
     def transform_user_with_feature(self, X: Any, features: Any) -> np.ndarray:
-        return self.core_trainer.transform_user_with_feature(X, features,
-                                                             self.prediction_time_solver_config)
+        return self.transform_user(X, user_features=features)
 
     def transform_item_with_feature(self, X: Any, features: Any) -> np.ndarray:
-        return self.core_trainer.transform_item_with_feature(X, features,
-                                                             self.prediction_time_solver_config)
+        return self.transform_item(X, item_features=features)
+
+    def transform_user_feature(self, user_features: Any) -> np.ndarray:
+        # ials.py:195-198
+        return self.core_trainer.transform_user_feature(_feature_matrix_as_float32(user_features))
+
+    def transform_item_feature(self, item_features: Any) -> np.ndarray:
+        # ials.py:200-203
+        return self.core_trainer.transform_item_feature(_feature_matrix_as_float32(item_features))
 
 
 # confidence scaling modes accepted by IALSRecommender (ials.py:113-115): "none" | "log"
@@ -145,8 +166,11 @@ class IALSRecommender(BaseRecommender):
                  lambda_user_feature: float = 0.0, lambda_item_feature: float = 0.0,
                  feature_warmup_epochs: int = 0) -> None:
         super().__init__(X_train_all)
-        self.user_features = user_features
-        self.item_features = item_features
+        # ials.py:421-432
+        self.user_features = None if user_features is None else _feature_matrix_as_float32(user_features)
+        self.item_features = None if item_features is None else _feature_matrix_as_float32(item_features)
+        if (self.user_features is not None or self.item_features is not None) and solver_type == "IALSPP":
+            raise ValueError("Feature-aware iALS does not support IALSPP.")
         self.lambda_user_feature = lambda_user_feature
         self.lambda_item_feature = lambda_item_feature
         self.feature_warmup_epochs = feature_warmup_epochs
@@ -256,8 +280,33 @@ class IALSRecommender(BaseRecommender):
     def get_score_block(self, begin: int, end: int) -> np.ndarray:
         return self.trainer_as_ials.user_scores(begin, end)
 
-    def get_score_cold_user(self, X: Any) -> np.ndarray:
-        return self.get_score_from_user_embedding(self.compute_user_embedding(X))
+    def get_score_cold_user(self, X: Any, user_features: Any = None) -> np.ndarray:
+        # ials.py:487-491
+        return self.get_score_from_user_embedding(
+            self.compute_user_embedding(X, user_features=user_features))
+
+    def _create_cold_user_with_item_features_scorer(self, item_features: Any) -> Callable[[Any], np.ndarray]:
+        # ials.py:493-517: the feature-only items' embeddings are computed once, every user block
+        # is then one fold-in and two products
+        if self.item_features is None:
+            raise NotImplementedError("IALSRecommender must be trained with item_features before it "
+                                      "can score additional items from features.")
+        if item_features.shape[0]:
+            item_embedding = self.compute_item_embedding_from_features(item_features)
+        else:
+            item_embedding = np.empty((0, self.n_components), dtype=self.get_item_embedding().dtype)
+
+        def scorer(X: Any) -> np.ndarray:
+            user_embedding = self.compute_user_embedding(X)
+            known_scores = self.get_score_from_user_embedding(user_embedding)
+            additional_scores = user_embedding.dot(item_embedding.T)
+            return np.concatenate([known_scores, additional_scores], axis=1)
+
+        return scorer
+
+    def get_score_cold_user_with_item_features(self, X: Any, item_features: Any) -> np.ndarray:
+        # ials.py:519-525
+        return self._create_cold_user_with_item_features_scorer(item_features)(X)
 
     def get_user_embedding(self) -> np.ndarray:
         return self.trainer_as_ials.core_trainer.user
@@ -272,16 +321,35 @@ class IALSRecommender(BaseRecommender):
                                       item_embedding: np.ndarray) -> np.ndarray:
         return self.get_user_embedding()[user_indices].dot(item_embedding.T)
 
+    def _scaled_f32(self, X: Any) -> sps.csr_matrix:
+        return self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling,
+                             self.epsilon)
+
     def compute_user_embedding(self, X: Any, user_features: Any = None) -> np.ndarray:
-        Xs = self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling,
-                           self.epsilon)
-        if user_features is not None:
-            return self.trainer_as_ials.transform_user_with_feature(Xs, user_features)
-        return self.trainer_as_ials.transform_user(Xs)
+        # ials.py:538-563
+        return self.trainer_as_ials.transform_user(self._scaled_f32(X), user_features=user_features)
+
+    def compute_user_embedding_from_features(self, user_features: Any) -> np.ndarray:
+        """ials.py:565-576: the feature-aware system with an EMPTY interaction history (it keeps
+        the loss on the unobserved items, so it is not ``user_features @ user_feature_weight``)."""
+        X = sps.csr_matrix((user_features.shape[0], self.n_items), dtype=np.float32)
+        return self.compute_user_embedding(X, user_features=user_features)
+
+    def get_score_cold_user_from_features(self, user_features: Any) -> np.ndarray:
+        # ials.py:578-582
+        return self.get_score_from_user_embedding(
+            self.compute_user_embedding_from_features(user_features))
 
     def compute_item_embedding(self, X: Any, item_features: Any = None) -> np.ndarray:
-        Xs = self._scale_X(sps.csr_matrix(X).astype(np.float32), self.confidence_scaling,
-                           self.epsilon)
-        if item_features is not None:
-            return self.trainer_as_ials.transform_item_with_feature(Xs, item_features)
-        return self.trainer_as_ials.transform_item(Xs)
+        # ials.py:584-609
+        return self.trainer_as_ials.transform_item(self._scaled_f32(X), item_features=item_features)
+
+    def compute_item_embedding_from_features(self, item_features: Any) -> np.ndarray:
+        # ials.py:611-622
+        X = sps.csr_matrix((self.n_users, item_features.shape[0]), dtype=np.float32)
+        return self.compute_item_embedding(X, item_features=item_features)
+
+    def get_score_from_item_features(self, user_indices: np.ndarray, item_features: Any) -> np.ndarray:
+        # ials.py:624-628
+        return self.get_score_from_item_embedding(
+            user_indices, self.compute_item_embedding_from_features(item_features))

@@ -97,17 +97,17 @@ def _retrieve(score: np.ndarray, allowed_item_indices: Sequence[Sequence[int]], 
     return result
 
 
-def retrieve_recommend_from_score_f32(score, allowed_item_indices, cutoff: int, n_threads: int = 1,
+def retrieve_recommend_from_score_f32(score, allowed_indices, cutoff: int, n_threads: int = 1,
                                       *, device: Optional[int] = None):
     """util.hpp:426-504 for float32 scores (bound as ``retrieve_recommend_from_score_f32``)."""
-    return _retrieve(np.asarray(score, dtype=np.float32), allowed_item_indices, cutoff, n_threads,
+    return _retrieve(np.asarray(score, dtype=np.float32), allowed_indices, cutoff, n_threads,
                      device)
 
 
-def retrieve_recommend_from_score_f64(score, allowed_item_indices, cutoff: int, n_threads: int = 1,
+def retrieve_recommend_from_score_f64(score, allowed_indices, cutoff: int, n_threads: int = 1,
                                       *, device: Optional[int] = None):
     """util.hpp:426-504 for float64 scores (bound as ``retrieve_recommend_from_score_f64``)."""
-    return _retrieve(np.asarray(score, dtype=np.float64), allowed_item_indices, cutoff, n_threads,
+    return _retrieve(np.asarray(score, dtype=np.float64), allowed_indices, cutoff, n_threads,
                      device)
 
 

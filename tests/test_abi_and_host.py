@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.irs_abi_version() == 2  # IRS_ABI_VERSION: irs_ceilings grew in round 3
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """The dynamic symbol table is the header, no more (cross-file helpers and C++ template
+    instances stay local: csrc/Makefile cuts the linker's export list from the header)."""
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.check_output([nm, "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == set(_lib.EXPORTED_SYMBOLS), exported ^ set(_lib.EXPORTED_SYMBOLS)
+
+
 def test_struct_layouts_match_header():
     import ctypes as C
 

@@ -218,26 +218,27 @@ def test_fused_ials_path_matches_block_path(single_pass, monkeypatch):
     second = core.get_metrics_ials(t, 0, U, edited, 20, 0, False)
     np.testing.assert_array_equal(first.item_cnt, fused.item_cnt)
     np.testing.assert_array_equal(second.item_cnt, nomask.item_cnt)
-    # an edit that the SAMPLED fingerprint cannot see (one unsampled value, same nnz and
-    # pointers): invalidate_mask() - or the strict, whole-array fingerprint - picks it up
-    sneaky = tr.copy().astype(np.float32)
-    core.get_metrics_ials(t, 0, U, sneaky, 20, 0, False)
-    step = max(1, sneaky.data.size // 1024)
-    sneaky.data[np.arange(sneaky.data.size) % step != 0] = 0.0  # every unsampled entry: no longer masked
-    stale = core.get_metrics_ials(t, 0, U, sneaky, 20, 0, False)
-    np.testing.assert_array_equal(stale.item_cnt, fused.item_cnt)  # (the documented blind spot)
-    core.invalidate_mask()
-    fresh = core.get_metrics_ials(t, 0, U, sneaky, 20, 0, False)
-    assert (fresh.item_cnt != fused.item_cnt).any()
-    type(core).strict_mask_fingerprint = True
+    # an edit of one unsampled value (same nnz and pointers): the default, whole-array fingerprint
+    # notices it; the opt-in SAMPLED fingerprint cannot see it - invalidate_mask() picks it up
+    step = max(1, tr.data.size // 1024)
+    assert type(core).strict_mask_fingerprint is True
+    sneaky2 = tr.copy().astype(np.float32)
+    core.get_metrics_ials(t, 0, U, sneaky2, 20, 0, False)
+    sneaky2.data[np.arange(sneaky2.data.size) % step != 0] = 0.0  # every unsampled entry: no longer masked
+    strict = core.get_metrics_ials(t, 0, U, sneaky2, 20, 0, False)
+    assert (strict.item_cnt != fused.item_cnt).any()
+    type(core).strict_mask_fingerprint = False
     try:
-        sneaky2 = tr.copy().astype(np.float32)
-        core.get_metrics_ials(t, 0, U, sneaky2, 20, 0, False)
-        sneaky2.data[np.arange(sneaky2.data.size) % step != 0] = 0.0
-        strict = core.get_metrics_ials(t, 0, U, sneaky2, 20, 0, False)
-        np.testing.assert_array_equal(strict.item_cnt, fresh.item_cnt)
+        sneaky = tr.copy().astype(np.float32)
+        core.get_metrics_ials(t, 0, U, sneaky, 20, 0, False)
+        sneaky.data[np.arange(sneaky.data.size) % step != 0] = 0.0
+        stale = core.get_metrics_ials(t, 0, U, sneaky, 20, 0, False)
+        np.testing.assert_array_equal(stale.item_cnt, fused.item_cnt)  # (the documented blind spot)
+        core.invalidate_mask()
+        fresh = core.get_metrics_ials(t, 0, U, sneaky, 20, 0, False)
+        np.testing.assert_array_equal(fresh.item_cnt, strict.item_cnt)
     finally:
-        type(core).strict_mask_fingerprint = False
+        type(core).strict_mask_fingerprint = True
     # cutoffs on the wave-per-row kernel with 8 entries per lane, and on the general kernel
     for cutoff in (50, 64, 100):
         f2 = core.get_metrics_ials(t, 0, U, tr, cutoff, 0, True)
