@@ -27,6 +27,7 @@
 #include "ials_short_kernels.hpp"
 #include "ials_gk_kernels.hpp"
 #include "ials_eig_kernels.hpp"
+#include "ials_mf_kernels.hpp"
 
 namespace irs {
 
@@ -88,6 +89,12 @@ struct Side {
   int32_t n_tasks = 0, n_split = 0, n_slots = 0, n_long = 0;
   // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
   int32_t n_short = 0, n_short16 = 0, n_short8 = 0;
+  // matrix-free CG at 128 < K <= 256 (ials_mf_kernels.hpp): rows_by_len is cut into the
+  // level-synchronous rows (more than MF_NCAP entries, chunked) and the resident classes of at most
+  // 320 / 192 / 96 / 32 entries; mf_class[c] = first index of class c in rows_by_len, [5] = end
+  DeviceBuffer<MfLongRow> mf_lrows;
+  DeviceBuffer<MfChunk> mf_chunks;
+  int32_t mf_n_lrows = 0, mf_n_chunks = 0, mf_class[6] = {0, 0, 0, 0, 0, 0};
   bool unit = false;  // every stored confidence is exactly 1 (UNIT kernels)
   bool positive = false;  // every stored confidence is > 0 (eigenbasis short-row kernels)
   float reg_min = 0.f;    // smallest per-row regulariser of the rows [row_begin, row_end)
@@ -199,6 +206,34 @@ struct Side {
           order[start[max_len - (ip32[r + 1] - ip32[r])]++] = static_cast<int32_t>(r);
       }
       rows_by_len.upload(order, s);
+      if (cfg.K > 128 && cfg.K <= 256) {  // the classes of the matrix-free CG kernels
+        const int32_t caps[5] = {INT32_MAX, MF_NCAP, 192, 96, 32};  // class c: length <= caps[c]
+        size_t i = 0;
+        for (int c = 0; c < 5; c++) {
+          mf_class[c] = static_cast<int32_t>(i);
+          const int32_t lower = c < 4 ? caps[c + 1] : -1;  // class c: lower < length <= caps[c]
+          while (i < order.size() && ip32[order[i] + 1] - ip32[order[i]] > lower) i++;
+        }
+        mf_class[5] = static_cast<int32_t>(order.size());
+        std::vector<MfLongRow> lr;
+        std::vector<MfChunk> ch;
+        for (int32_t k = 0; k < mf_class[1]; k++) {
+          const int32_t r = order[k], b = ip32[r], e = ip32[r + 1], nz = e - b;
+          const int32_t nch = (nz + MF_CHUNK - 1) / MF_CHUNK;
+          const int32_t per = (((nz + nch - 1) / nch) + 15) & ~15;  // whole 16-entry groups
+          MfLongRow L{r, static_cast<int32_t>(ch.size()), 0, 0};
+          for (int32_t c = b; c < e; c += per) {
+            ch.push_back(MfChunk{k, c, std::min(c + per, e), 0});
+            L.n_chunks++;
+          }
+          lr.push_back(L);
+        }
+        mf_n_lrows = static_cast<int32_t>(lr.size());
+        mf_n_chunks = static_cast<int32_t>(ch.size());
+        mf_lrows.upload(lr, s);
+        mf_chunks.upload(ch, s);
+        IRS_HIP(hipStreamSynchronize(s));
+      }
       n_long = 0;  // rows long enough for a whole workgroup (ialspp_long_kernel)
       while (n_long < static_cast<int32_t>(order.size()) &&
              ip32[order[n_long] + 1] - ip32[order[n_long]] > 2048)
@@ -311,6 +346,10 @@ struct irs_ials_trainer {
   int eig_token = 0;
   float eig_stats_host[4] = {0, 0, 0, 0};
   bool opt_eig = true;  // IRSPACK_AMD_IALS_EIG
+  // matrix-free CG at 128 < K <= 256 (ials_mf_kernels.hpp): state of the level-synchronous rows
+  DeviceBuffer<float> mf_vec, mf_xs, mf_rs, mf_partial, mf_r2;
+  DeviceBuffer<int32_t> mf_done;
+  bool opt_mf = true;   // IRSPACK_AMD_IALS_MF
   int32_t eig_last = 0; // 1: the last half-step took the eigenbasis path (diagnostics)
   bool gk() const { return KP > 256; }   // K > 256: every size is a run-time value
   Profiler prof;
@@ -802,6 +841,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
   t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
   t->opt_eig = env_flag("IRSPACK_AMD_IALS_EIG", true);
+  t->opt_mf = env_flag("IRSPACK_AMD_IALS_MF", true);
 }
 
 // Eigen-decomposition of P[pidx] (row-major [KP, KP]) into the trainer's eig_* buffers.
@@ -1040,6 +1080,96 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
   return true;
 }
 
+// step_cg (hpp:199-264) at 128 < K <= 256, matrix free (ials_mf_kernels.hpp): the resident classes
+// on the trainer's stream, the level-synchronous rows (one pair of launches per product) on the
+// second stream beside them.
+void launch_mf_cg(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
+                  const irs_ials_solver_config *sc) {
+  MfParams p{};
+  p.rows = sd.rows_by_len.ptr;
+  p.indptr = sd.indptr.ptr;
+  p.indices = sd.indices.ptr;
+  p.data = sd.data.ptr;
+  p.other = other;
+  p.target = target;
+  p.reg = sd.reg.ptr;
+  p.P = t->P[pidx].ptr;
+  p.bias = t->cfg.loss_type == IRS_LOSS_IALSPP ? 0.0f : t->cfg.alpha0;  // hpp:190-191
+  p.K = static_cast<int32_t>(t->K);
+  p.max_cg_steps = sc->max_cg_steps == 0 ? static_cast<int32_t>(t->K)  // hpp:232-234
+                                         : static_cast<int32_t>(std::min<uint64_t>(sc->max_cg_steps, 1u << 20));
+  p.err_flag = t->err_flag.ptr;
+  const int32_t n_long = sd.mf_n_lrows;
+  const bool fork = n_long > 0 && sd.mf_class[5] > sd.mf_class[1];
+  hipStream_t ls = t->stream;
+  if (fork) {
+    if (!t->stream2) {
+      IRS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+      IRS_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+      IRS_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    }
+    IRS_HIP(hipEventRecord(t->ev_fork, t->stream));
+    IRS_HIP(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+    ls = t->stream2;
+  }
+  if (n_long > 0) {
+    const size_t KP = static_cast<size_t>(t->KP);
+    t->mf_vec.alloc(n_long * KP);
+    t->mf_xs.alloc(n_long * KP);
+    t->mf_rs.alloc(n_long * KP);
+    t->mf_partial.alloc(static_cast<size_t>(sd.mf_n_chunks) * 2 * KP);
+    t->mf_r2.alloc(n_long);
+    t->mf_done.alloc(n_long);
+    p.lrows = sd.mf_lrows.ptr;
+    p.chunks = sd.mf_chunks.ptr;
+    p.n_lrows = n_long;
+    p.n_chunks = sd.mf_n_chunks;
+    p.vec = t->mf_vec.ptr;
+    p.xs = t->mf_xs.ptr;
+    p.rs = t->mf_rs.ptr;
+    p.partial = t->mf_partial.ptr;
+    p.r2 = t->mf_r2.ptr;
+    p.done = t->mf_done.ptr;
+    t->prof.begin(pidx == 0 ? "ials_long_cg_user" : "ials_long_cg_item", ls);
+    auto chain = [&](auto init, auto chunk, auto rowk) {
+      hipLaunchKernelGGL(init, dim3(n_long), dim3(256), 0, ls, p);
+      for (int step = 0; step <= p.max_cg_steps; step++) {
+        hipLaunchKernelGGL(chunk, dim3(sd.mf_n_chunks), dim3(256), 0, ls, p, step == 0 ? 1 : 0);
+        hipLaunchKernelGGL(rowk, dim3(n_long), dim3(256), 0, ls, p, step);
+      }
+    };
+    if (t->T == 12) chain(mf_long_init_kernel<192>, mf_chunk_kernel<192>, mf_row_kernel<192>);
+    else chain(mf_long_init_kernel<256>, mf_chunk_kernel<256>, mf_row_kernel<256>);
+    t->prof.end(ls);
+  }
+  t->prof.begin(pidx == 0 ? "ials_solve_cg_user" : "ials_solve_cg_item", t->stream);
+  auto resident = [&](auto kernel, int cls) {
+    const int32_t first = sd.mf_class[cls], count = sd.mf_class[cls + 1] - first;
+    if (count <= 0) return;
+    MfParams q = p;
+    q.row_first = first;
+    q.n_rows = count;
+    hipLaunchKernelGGL(kernel, dim3(count), dim3(256), 0, t->stream, q);
+  };
+  if (t->T == 12) {
+    resident(mf_cg_resident_kernel<192, 20>, 1);
+    resident(mf_cg_resident_kernel<192, 12>, 2);
+    resident(mf_cg_resident_kernel<192, 6>, 3);
+    resident(mf_cg_resident_kernel<192, 2>, 4);
+  } else {
+    resident(mf_cg_resident_kernel<256, 20>, 1);
+    resident(mf_cg_resident_kernel<256, 12>, 2);
+    resident(mf_cg_resident_kernel<256, 6>, 3);
+    resident(mf_cg_resident_kernel<256, 2>, 4);
+  }
+  t->prof.end(t->stream);
+  if (fork) {
+    IRS_HIP(hipEventRecord(t->ev_join, ls));
+    IRS_HIP(hipStreamWaitEvent(t->stream, t->ev_join, 0));
+  }
+  IRS_HIP(hipGetLastError());
+}
+
 // Solver::step (hpp:664-679) for side `s` over the rows of `sd`, writing `target`.
 void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *target, int pidx,
                   const irs_ials_solver_config *sc, const float *prior = nullptr) {
@@ -1079,6 +1209,10 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     irs_ials_solver_config eff = *sc;
     if (pp_direct) eff.solver_type = IRS_SOLVER_CHOLESKY;
     launch_gk_solve(t, sd, other, target, pidx, &eff, prior, flag);
+    return;
+  }
+  if (sc->solver_type == IRS_SOLVER_CG && t->T > 8 && prior == nullptr && t->opt_mf) {
+    launch_mf_cg(t, sd, other, target, pidx, sc);
     return;
   }
   SolveParams p;

@@ -170,6 +170,54 @@ def ials_solver_step(target: np.ndarray, X: sps.csr_matrix, other: np.ndarray,
     return tgt
 
 
+# ---- the float64 arbiter (liboracle_f64.so: ials_oracle.cpp compiled with Real = double) ----
+_SO64 = os.path.join(_HERE, "liboracle_f64.so")
+_lib64: Optional[C.CDLL] = None
+
+
+def lib64() -> C.CDLL:
+    global _lib64
+    if _lib64 is None:
+        src = os.path.join(_HERE, "ials_oracle.cpp")
+        if not os.path.exists(_SO64) or os.path.getmtime(src) > os.path.getmtime(_SO64):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "f64"])
+        _lib64 = C.CDLL(_SO64)
+        _lib64.orc_last_error.restype = C.c_char_p
+    return _lib64
+
+
+def ials_gramian_f64(F: np.ndarray, alpha0: float, n_threads: int = 1) -> np.ndarray:
+    """prepare_p (hpp:78-115) of the float32 factors ``F`` in float64."""
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    n, K = F.shape
+    P = np.empty((K, K), dtype=np.float64)
+    _check(lib64().orc_ials_gramian(_p(F, C.c_double), C.c_int64(n), C.c_int64(K),
+                                    C.c_float(alpha0), C.c_uint64(n_threads),
+                                    _p(P, C.c_double)), lib64().orc_last_error)
+    return P
+
+
+def ials_solver_step_f64(target: np.ndarray, X: sps.csr_matrix, other: np.ndarray,
+                         P: Optional[np.ndarray], mc: ModelConfig, sc: SolverConfig,
+                         n_threads: int = 1) -> np.ndarray:
+    """One Solver::step (hpp:664-679) - the SAME restatement as ``ials_solver_step``, same
+    iteration, exits and regulariser - with factors, Gramian and every intermediate in float64:
+    what both float32 implementations (this oracle's and the GPU's) approximate.  ``P`` = None
+    computes the float64 Gramian of ``other``.  Returns float64 rows."""
+    X, indptr, indices, data = _csr_args(X, np.float32)
+    tgt = np.array(target, dtype=np.float64, order="C", copy=True)
+    other = np.ascontiguousarray(other, dtype=np.float64)
+    if P is None:
+        P = ials_gramian_f64(other, mc.alpha0, n_threads)
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    _check(lib64().orc_ials_solver_step(
+        _p(tgt, C.c_double), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]),
+        _p(indptr, C.c_int64), _p(indices, C.c_int32), _p(data, C.c_float),
+        _p(other, C.c_double), _p(P, C.c_double), C.byref(mc), C.byref(sc),
+        C.c_int64(0), C.c_int64(X.shape[0])), lib64().orc_last_error)
+    return tgt
+
+
 class IALSTrainer:
     """Restatement of irspack::ials::IALSTrainer (hpp:709-984)."""
 

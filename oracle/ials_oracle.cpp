@@ -13,7 +13,11 @@
 // own tests hold for this path (tests/recommenders/test_ials.py:185-227,
 // 431-449, 456-513, 551-570, 627-697), re-stated in tests/test_oracle_ials.py.
 //
-// Arithmetic is `float` like the reference (definitions.hpp:6).  The dense
+// Arithmetic is `Real` = `float` like the reference (definitions.hpp:6); `make f64` builds
+// the SAME sources with Real = double (liboracle_f64.so: factors, Gramian and every
+// intermediate in float64; matrix values, config scalars, the regulariser of hpp:117-120 and
+// the 1e-20 exits stay the float values both float32 implementations use) - the arbiter the
+// parity tests measure the GPU and this float32 oracle against, row by row.  The dense
 // pieces Eigen provides (SYRK rank update, LLT, GEMV) are restated as plain
 // loops; summation order inside those differs from Eigen's vectorised kernels,
 // which is why factor parity is tolerance-based.
@@ -27,6 +31,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#ifndef ORACLE_REAL
+#define ORACLE_REAL float
+#endif
+using Real = ORACLE_REAL;
 
 namespace {
 
@@ -90,7 +99,7 @@ Csr transpose(const Csr &x) {
 
 // Solver::initialize, hpp:64-76.  Same libstdc++ engine + distribution
 // classes as a libstdc++ build of the reference => identical stream.
-void initialize(float *factor, int64_t rows, int64_t K, const ModelConfig &c) {
+void initialize(Real *factor, int64_t rows, int64_t K, const ModelConfig &c) {
   if (c.init_stdev > 0) {
     std::mt19937 gen(c.random_seed);
     std::normal_distribution<float> dist(
@@ -109,23 +118,23 @@ void initialize(float *factor, int64_t rows, int64_t K, const ModelConfig &c) {
 // atomic cursor, which makes its own float sums vary from run to run (up to 1e-4 relative
 // on ill-conditioned rows downstream); the checker deals them round-robin instead so that
 // it is reproducible.
-void prepare_p(const float *F, int64_t n, int64_t K, float alpha0,
-               uint64_t n_threads, float *P) {
+void prepare_p(const Real *F, int64_t n, int64_t K, float alpha0,
+               uint64_t n_threads, Real *P) {
   if (n_threads == 0)
     throw std::invalid_argument("n_threads must be strictly positive.");
   const int64_t mb_size = 16;
-  std::vector<std::vector<float>> partial(n_threads,
-                                          std::vector<float>(K * K, 0.0f));
+  std::vector<std::vector<Real>> partial(n_threads,
+                                          std::vector<Real>(K * K, 0.0f));
   auto work = [&](size_t tid) {
-    float *Pl = partial[tid].data();
+    Real *Pl = partial[tid].data();
     for (int64_t b = static_cast<int64_t>(tid) * mb_size; b < n;
          b += static_cast<int64_t>(n_threads) * mb_size) {
       int64_t e = std::min<int64_t>(b + mb_size, n);
       for (int64_t r = b; r < e; r++) {
-        const float *row = F + r * K;
+        const Real *row = F + r * K;
         for (int64_t i = 0; i < K; i++) {
-          float ri = row[i];
-          float *dst = Pl + i * K;
+          Real ri = row[i];
+          Real *dst = Pl + i * K;
           for (int64_t j = 0; j < K; j++) dst[j] += ri * row[j];
         }
       }
@@ -141,7 +150,7 @@ void prepare_p(const float *F, int64_t n, int64_t K, float alpha0,
   for (int64_t i = 0; i < K * K; i++) P[i] *= alpha0;
 }
 
-// Solver::compute_reg, hpp:117-120 (float pow).
+// Solver::compute_reg, hpp:117-120 (float pow, whatever Real is).
 inline float compute_reg(int64_t nnz, int64_t other_size, const ModelConfig &c) {
   return c.reg * std::pow(c.alpha0 * other_size + nnz, c.nu);
 }
@@ -149,29 +158,29 @@ inline float compute_reg(int64_t nnz, int64_t other_size, const ModelConfig &c) 
 // Dense upper Cholesky A = U^T U followed by the two triangular solves;
 // restates Eigen::LLT<Ref<DenseMatrix>, Upper> + solve (hpp:316-323).
 // Returns false when the factorisation meets a non-positive pivot.
-bool llt_upper_solve(float *A, float *b, int64_t K) {
+bool llt_upper_solve(Real *A, Real *b, int64_t K) {
   // A is row-major, only the upper triangle is referenced.
   for (int64_t j = 0; j < K; j++) {
-    float d = A[j * K + j];
+    Real d = A[j * K + j];
     for (int64_t t = 0; t < j; t++) d -= A[t * K + j] * A[t * K + j];
     if (!(d > 0.0f)) return false;
     d = std::sqrt(d);
     A[j * K + j] = d;
     for (int64_t i = j + 1; i < K; i++) {
-      float s = A[j * K + i];
+      Real s = A[j * K + i];
       for (int64_t t = 0; t < j; t++) s -= A[t * K + j] * A[t * K + i];
       A[j * K + i] = s / d;
     }
   }
   // U^T y = b
   for (int64_t i = 0; i < K; i++) {
-    float s = b[i];
+    Real s = b[i];
     for (int64_t t = 0; t < i; t++) s -= A[t * K + i] * b[t];
     b[i] = s / A[i * K + i];
   }
   // U x = y
   for (int64_t i = K - 1; i >= 0; i--) {
-    float s = b[i];
+    Real s = b[i];
     for (int64_t t = i + 1; t < K; t++) s -= A[i * K + t] * b[t];
     b[i] = s / A[i * K + i];
   }
@@ -179,8 +188,8 @@ bool llt_upper_solve(float *A, float *b, int64_t K) {
 }
 
 // Solver::step_cholesky, hpp:273-331 with BatchedRankUpdater<64>, hpp:37-58.
-void step_cholesky(float *target, int64_t n_rows, const Csr &X,
-                   const float *other, int64_t n_other, const float *P,
+void step_cholesky(Real *target, int64_t n_rows, const Csr &X,
+                   const Real *other, int64_t n_other, const Real *P,
                    const ModelConfig &config, const SolverConfig &sc,
                    int64_t row_begin, int64_t row_end) {
   const int64_t K = config.K;
@@ -191,10 +200,10 @@ void step_cholesky(float *target, int64_t n_rows, const Csr &X,
   std::atomic<int> failed(0);
   auto work = [&]() {
     const int64_t NB = 64;
-    std::vector<float> buffer(NB * K), P_local(K * K), B(K);
-    const float observation_bias =
+    std::vector<Real> buffer(NB * K), P_local(K * K), B(K);
+    const Real observation_bias =
         config.loss_type == 1 ? 0.0f : config.alpha0;  // hpp:289-290
-    std::vector<float> acc(K);
+    std::vector<Real> acc(K);
     auto consume = [&](int64_t n_batch) {
       // target.rankUpdate(buffer^T): upper triangle += buffer^T buffer (hpp:48).
       // The batch product is summed first and then added, like Eigen's kernel.
@@ -208,16 +217,16 @@ void step_cholesky(float *target, int64_t n_rows, const Csr &X,
         const int64_t ni = std::min<int64_t>(4, K - i0);
         for (int64_t j0 = i0 & ~int64_t(15); j0 < K; j0 += 16) {
           const int64_t nj = std::min<int64_t>(16, K - j0);
-          float a4[4][16];
+          Real a4[4][16];
           for (int a = 0; a < 4; a++)
             for (int c = 0; c < 16; c++) a4[a][c] = 0.0f;
           if (ni == 4 && nj == 16) {
             for (int64_t r = 0; r < n_batch; r++) {
-              const float *br = buffer.data() + r * K;
-              const float b0 = br[i0], b1 = br[i0 + 1], b2 = br[i0 + 2], b3 = br[i0 + 3];
+              const Real *br = buffer.data() + r * K;
+              const Real b0 = br[i0], b1 = br[i0 + 1], b2 = br[i0 + 2], b3 = br[i0 + 3];
 #pragma GCC unroll 16
               for (int c = 0; c < 16; c++) {
-                const float bj = br[j0 + c];
+                const Real bj = br[j0 + c];
                 a4[0][c] += b0 * bj;
                 a4[1][c] += b1 * bj;
                 a4[2][c] += b2 * bj;
@@ -226,7 +235,7 @@ void step_cholesky(float *target, int64_t n_rows, const Csr &X,
             }
           } else {
             for (int64_t r = 0; r < n_batch; r++) {
-              const float *br = buffer.data() + r * K;
+              const Real *br = buffer.data() + r * K;
               for (int64_t a = 0; a < ni; a++)
                 for (int64_t c = 0; c < nj; c++) a4[a][c] += br[i0 + a] * br[j0 + c];
             }
@@ -239,11 +248,11 @@ void step_cholesky(float *target, int64_t n_rows, const Csr &X,
       return;
 #endif
       for (int64_t i = 0; i < K; i++) {
-        float *a = acc.data();
+        Real *a = acc.data();
         for (int64_t j = i; j < K; j++) a[j] = 0.0f;
         for (int64_t r = 0; r < n_batch; r++) {
-          const float bi = buffer[r * K + i];
-          const float *br = buffer.data() + r * K;
+          const Real bi = buffer[r * K + i];
+          const Real *br = buffer.data() + r * K;
           for (int64_t j = i; j < K; j++) a[j] += bi * br[j];
         }
         for (int64_t j = i; j < K; j++) P_local[i * K + j] += a[j];
@@ -256,21 +265,21 @@ void step_cholesky(float *target, int64_t n_rows, const Csr &X,
       std::fill(B.begin(), B.end(), 0.0f);
       int64_t nnz = 0, n_batch = 0;
       for (int64_t p = X.indptr[row]; p < X.indptr[row + 1]; p++) {
-        const float *v = other + static_cast<int64_t>(X.indices[p]) * K;
-        const float c = X.data[p];
-        const float sc_ = std::sqrt(c);  // hpp:41
+        const Real *v = other + static_cast<int64_t>(X.indices[p]) * K;
+        const Real c = X.data[p];
+        const Real sc_ = std::sqrt(c);  // hpp:41
         for (int64_t k = 0; k < K; k++) buffer[n_batch * K + k] = sc_ * v[k];
         n_batch++;
         if (n_batch >= NB) {
           consume(n_batch);
           n_batch = 0;
         }
-        const float w = observation_bias + c;  // hpp:305
+        const Real w = observation_bias + c;  // hpp:305
         for (int64_t k = 0; k < K; k++) B[k] += w * v[k];
         nnz++;
       }
       if (n_batch > 0) consume(n_batch);
-      const float reg = compute_reg(nnz, n_other, config);  // hpp:309-310
+      const Real reg = compute_reg(nnz, n_other, config);  // hpp:309-310
       for (int64_t i = 0; i < K; i++) P_local[i * K + i] += reg;
       if (!llt_upper_solve(P_local.data(), B.data(), K)) {
         failed.store(1);
@@ -292,8 +301,8 @@ void step_cholesky(float *target, int64_t n_rows, const Csr &X,
 }
 
 // Solver::step_cg, hpp:170-271 (no prior).
-void step_cg(float *target, int64_t n_rows, const Csr &X, const float *other,
-             int64_t n_other, const float *P, const ModelConfig &config,
+void step_cg(Real *target, int64_t n_rows, const Csr &X, const Real *other,
+             int64_t n_other, const Real *P, const ModelConfig &config,
              const SolverConfig &sc, int64_t row_begin, int64_t row_end) {
   const int64_t K = config.K;
   if (sc.n_threads == 0)
@@ -302,73 +311,73 @@ void step_cg(float *target, int64_t n_rows, const Csr &X, const float *other,
   std::atomic<int64_t> cursor(row_begin);
   std::atomic<int> failed(0);
   auto work = [&]() {
-    std::vector<float> b(K), x(K), r(K), p(K), Ap(K);
-    const float observation_bias =
+    std::vector<Real> b(K), x(K), r(K), p(K), Ap(K);
+    const Real observation_bias =
         config.loss_type == 1 ? 0.0f : config.alpha0;  // hpp:190-191
     while (true) {
       int64_t row = cursor.fetch_add(1);
       if (row >= row_end || failed.load()) break;
-      float *trow = target + row * K;
+      Real *trow = target + row * K;
       std::copy(trow, trow + K, x.begin());  // warm start, hpp:199
       const int64_t nnz = X.indptr[row + 1] - X.indptr[row];
-      const float reg = compute_reg(nnz, n_other, config);
+      const Real reg = compute_reg(nnz, n_other, config);
       if (nnz == 0) {  // hpp:207-210
         std::fill(trow, trow + K, 0.0f);
         continue;
       }
       std::fill(b.begin(), b.end(), 0.0f);
       for (int64_t q = X.indptr[row]; q < X.indptr[row + 1]; q++) {
-        const float *v = other + static_cast<int64_t>(X.indices[q]) * K;
-        const float w = observation_bias + X.data[q];
+        const Real *v = other + static_cast<int64_t>(X.indices[q]) * K;
+        const Real w = observation_bias + X.data[q];
         for (int64_t k = 0; k < K; k++) b[k] += w * v[k];
       }
       // r = b - P x - reg x - sum c (v.x) v, hpp:222-228
       for (int64_t i = 0; i < K; i++) {
-        float s = 0.0f;
+        Real s = 0.0f;
         for (int64_t k = 0; k < K; k++) s += P[i * K + k] * x[k];
         r[i] = b[i] - s;
       }
       for (int64_t i = 0; i < K; i++) r[i] -= reg * x[i];
       for (int64_t q = X.indptr[row]; q < X.indptr[row + 1]; q++) {
-        const float *v = other + static_cast<int64_t>(X.indices[q]) * K;
-        float vdotx = 0.0f;
+        const Real *v = other + static_cast<int64_t>(X.indices[q]) * K;
+        Real vdotx = 0.0f;
         for (int64_t k = 0; k < K; k++) vdotx += v[k] * x[k];
-        const float w = X.data[q] * vdotx;
+        const Real w = X.data[q] * vdotx;
         for (int64_t k = 0; k < K; k++) r[k] -= w * v[k];
       }
       p = r;
       const uint64_t cg_max_iter =
           sc.max_cg_steps == 0u ? static_cast<uint64_t>(K) : sc.max_cg_steps;
       for (uint64_t it = 0; it < cg_max_iter; it++) {
-        float r2 = 0.0f;
+        Real r2 = 0.0f;
         for (int64_t k = 0; k < K; k++) r2 += r[k] * r[k];
         if (r2 <= 1e-20f) break;  // hpp:238
         for (int64_t i = 0; i < K; i++) {
-          float s = 0.0f;
+          Real s = 0.0f;
           for (int64_t k = 0; k < K; k++) s += P[i * K + k] * p[k];
           Ap[i] = s;
         }
         for (int64_t i = 0; i < K; i++) Ap[i] += reg * p[i];
         for (int64_t q = X.indptr[row]; q < X.indptr[row + 1]; q++) {
-          const float *v = other + static_cast<int64_t>(X.indices[q]) * K;
-          float vdotp = 0.0f;
+          const Real *v = other + static_cast<int64_t>(X.indices[q]) * K;
+          Real vdotp = 0.0f;
           for (int64_t k = 0; k < K; k++) vdotp += v[k] * p[k];
-          const float w = X.data[q] * vdotp;
+          const Real w = X.data[q] * vdotp;
           for (int64_t k = 0; k < K; k++) Ap[k] += w * v[k];
         }
-        float denom = 0.0f;
+        Real denom = 0.0f;
         for (int64_t k = 0; k < K; k++) denom += p[k] * Ap[k];
         if (!(denom > 0.0f) || !std::isfinite(denom)) {  // hpp:250-254
           failed.store(1);
           break;
         }
-        const float alpha = r2 / denom;
+        const Real alpha = r2 / denom;
         for (int64_t k = 0; k < K; k++) x[k] += alpha * p[k];
         for (int64_t k = 0; k < K; k++) r[k] -= alpha * Ap[k];
-        float r2new = 0.0f;
+        Real r2new = 0.0f;
         for (int64_t k = 0; k < K; k++) r2new += r[k] * r[k];
         if (r2new <= 1e-20f) break;  // hpp:258
-        const float beta = r2new / r2;  // hpp:261
+        const Real beta = r2new / r2;  // hpp:261
         for (int64_t k = 0; k < K; k++) p[k] = r[k] + beta * p[k];
       }
       if (failed.load()) break;
@@ -385,13 +394,13 @@ void step_cg(float *target, int64_t n_rows, const Csr &X, const float *other,
 }
 
 // Solver::_prediction, hpp:387-421.
-std::vector<float> prediction(const Csr &X, const float *target,
-                              const float *other, int64_t K) {
-  std::vector<float> pred(X.indptr[X.rows]);
+std::vector<Real> prediction(const Csr &X, const Real *target,
+                              const Real *other, int64_t K) {
+  std::vector<Real> pred(X.indptr[X.rows]);
   for (int64_t row = 0; row < X.rows; row++)
     for (int64_t q = X.indptr[row]; q < X.indptr[row + 1]; q++) {
-      const float *v = other + static_cast<int64_t>(X.indices[q]) * K;
-      float s = 0.0f;
+      const Real *v = other + static_cast<int64_t>(X.indices[q]) * K;
+      Real s = 0.0f;
       for (int64_t k = 0; k < K; k++) s += target[row * K + k] * v[k];
       pred[q] = s;
     }
@@ -400,26 +409,26 @@ std::vector<float> prediction(const Csr &X, const float *target,
 
 // Solver::_step_dimrange, hpp:423-514 (single-threaded restatement; rows are
 // independent so thread count does not change results).
-void step_dimrange(int64_t d0, int64_t d1, std::vector<float> &pred,
-                   float *target, const Csr &X, const float *other,
-                   int64_t n_other, const float *P, const ModelConfig &config) {
+void step_dimrange(int64_t d0, int64_t d1, std::vector<Real> &pred,
+                   Real *target, const Csr &X, const Real *other,
+                   int64_t n_other, const Real *P, const ModelConfig &config) {
   const int64_t K = config.K, D = d1 - d0;
-  std::vector<float> A(D * D), B(D), vc(D);
-  const float observation_bias = config.loss_type == 1 ? 0.0f : config.alpha0;
+  std::vector<Real> A(D * D), B(D), vc(D);
+  const Real observation_bias = config.loss_type == 1 ? 0.0f : config.alpha0;
   for (int64_t row = 0; row < X.rows; row++) {
     for (int64_t i = 0; i < D; i++)
       for (int64_t j = 0; j < D; j++) A[i * D + j] = P[(d0 + i) * K + d0 + j];
     const int64_t nnz = X.indptr[row + 1] - X.indptr[row];
-    const float reg = compute_reg(nnz, n_other, config);
+    const Real reg = compute_reg(nnz, n_other, config);
     for (int64_t i = 0; i < D; i++) {  // B = P_subspaced * target.row, hpp:473-474
-      float s = 0.0f;
+      Real s = 0.0f;
       for (int64_t k = 0; k < K; k++) s += P[(d0 + i) * K + k] * target[row * K + k];
       B[i] = s + reg * target[row * K + d0 + i];  // hpp:476-477
     }
     for (int64_t q = X.indptr[row]; q < X.indptr[row + 1]; q++) {
-      const float *v = other + static_cast<int64_t>(X.indices[q]) * K + d0;
-      const float c = X.data[q];
-      const float residual = c * (pred[q] - 1) - observation_bias;  // hpp:485-486
+      const Real *v = other + static_cast<int64_t>(X.indices[q]) * K + d0;
+      const Real c = X.data[q];
+      const Real residual = c * (pred[q] - 1) - observation_bias;  // hpp:485-486
       for (int64_t i = 0; i < D; i++)
         for (int64_t j = i; j < D; j++) A[i * D + j] += c * v[i] * v[j];
       for (int64_t i = 0; i < D; i++) B[i] += residual * v[i];
@@ -428,8 +437,8 @@ void step_dimrange(int64_t d0, int64_t d1, std::vector<float> &pred,
     llt_upper_solve(A.data(), B.data(), D);  // no info() check at hpp:495-497
     for (int64_t i = 0; i < D; i++) target[row * K + d0 + i] -= B[i];  // hpp:498
     for (int64_t q = X.indptr[row]; q < X.indptr[row + 1]; q++) {
-      const float *v = other + static_cast<int64_t>(X.indices[q]) * K + d0;
-      float s = 0.0f;
+      const Real *v = other + static_cast<int64_t>(X.indices[q]) * K + d0;
+      Real s = 0.0f;
       for (int64_t i = 0; i < D; i++) s += B[i] * v[i];
       pred[q] -= s;  // hpp:504-505
     }
@@ -439,13 +448,13 @@ void step_dimrange(int64_t d0, int64_t d1, std::vector<float> &pred,
 // Solver::step_ialspp / step_icd, hpp:516-630.  With subspace dimension 1 the
 // reference takes the scalar iCD branch (hpp:673-677); its arithmetic is the
 // D = 1 case of _step_dimrange.
-void step_ialspp(float *target, const Csr &X, const float *other,
-                 int64_t n_other, const float *P, const ModelConfig &config,
+void step_ialspp(Real *target, const Csr &X, const Real *other,
+                 int64_t n_other, const Real *P, const ModelConfig &config,
                  const SolverConfig &sc) {
   const int64_t K = config.K;
   const int64_t sub = std::max<int64_t>(1, sc.ialspp_subspace_dimension);
   for (uint64_t it = 0; it < sc.ialspp_iteration; it++) {
-    std::vector<float> pred = prediction(X, target, other, K);
+    std::vector<Real> pred = prediction(X, target, other, K);
     for (int64_t c = 0; c < K; c += sub)
       step_dimrange(c, std::min(c + sub, K), pred, target, X, other, n_other, P,
                     config);
@@ -453,8 +462,8 @@ void step_ialspp(float *target, const Csr &X, const float *other,
 }
 
 // Solver::step dispatcher, hpp:664-679.
-void solver_step(float *target, int64_t n_rows, const Csr &X,
-                 const float *other, int64_t n_other, const float *P,
+void solver_step(Real *target, int64_t n_rows, const Csr &X,
+                 const Real *other, int64_t n_other, const Real *P,
                  const ModelConfig &config, const SolverConfig &sc,
                  int64_t row_begin, int64_t row_end) {
   if (sc.solver_type == 1)
@@ -469,7 +478,7 @@ void solver_step(float *target, int64_t n_rows, const Csr &X,
 struct Trainer {  // IALSTrainer, hpp:709-720, 986-999
   ModelConfig config;
   int64_t K, n_users, n_items;
-  std::vector<float> user, item, P_user, P_item;
+  std::vector<Real> user, item, P_user, P_item;
   Csr X, X_t;
   bool has_X = false;
 };
@@ -493,7 +502,7 @@ extern "C" {
 
 const char *orc_last_error() { return g_last_error.c_str(); }
 
-int orc_ials_init(float *factor, int64_t rows, int64_t K, float init_stdev,
+int orc_ials_init(Real *factor, int64_t rows, int64_t K, float init_stdev,
                   int32_t seed) {
   return guard([&] {
     ModelConfig c{static_cast<uint64_t>(K), 0, 0, 0, init_stdev, seed, 1};
@@ -501,15 +510,15 @@ int orc_ials_init(float *factor, int64_t rows, int64_t K, float init_stdev,
   });
 }
 
-int orc_ials_gramian(const float *F, int64_t n, int64_t K, float alpha0,
-                     uint64_t n_threads, float *P) {
+int orc_ials_gramian(const Real *F, int64_t n, int64_t K, float alpha0,
+                     uint64_t n_threads, Real *P) {
   return guard([&] { prepare_p(F, n, K, alpha0, n_threads, P); });
 }
 
 // One Solver::step on caller-owned arrays (used for half-epoch parity checks).
-int orc_ials_solver_step(float *target, int64_t n_rows, int64_t n_cols,
+int orc_ials_solver_step(Real *target, int64_t n_rows, int64_t n_cols,
                          const int64_t *indptr, const int32_t *indices,
-                         const float *data, const float *other, const float *P,
+                         const float *data, const Real *other, const Real *P,
                          const ModelConfig *config, const SolverConfig *sc,
                          int64_t row_begin, int64_t row_end) {
   return guard([&] {
@@ -541,8 +550,8 @@ void *orc_ials_create(const ModelConfig *config, int64_t n_users,
 
 void orc_ials_destroy(void *h) { delete static_cast<Trainer *>(h); }
 
-float *orc_ials_user_ptr(void *h) { return static_cast<Trainer *>(h)->user.data(); }
-float *orc_ials_item_ptr(void *h) { return static_cast<Trainer *>(h)->item.data(); }
+Real *orc_ials_user_ptr(void *h) { return static_cast<Trainer *>(h)->user.data(); }
+Real *orc_ials_item_ptr(void *h) { return static_cast<Trainer *>(h)->item.data(); }
 
 // IALSTrainer::step, hpp:758-789 (non-feature branch :784-788).
 int orc_ials_step(void *h, const SolverConfig *sc) {
@@ -564,13 +573,13 @@ int orc_ials_step(void *h, const SolverConfig *sc) {
 // side 1: X is [n_users, m] (transposed internally) -> [m, K] item vectors.
 int orc_ials_transform(void *h, int side, int64_t rows, int64_t cols,
                        const int64_t *indptr, const int32_t *indices,
-                       const float *data, const SolverConfig *sc, float *out) {
+                       const float *data, const SolverConfig *sc, Real *out) {
   Trainer *t = static_cast<Trainer *>(h);
   return guard([&] {
     Csr X = make_csr(rows, cols, indptr, indices, data);
-    const float *other = side == 0 ? t->item.data() : t->user.data();
+    const Real *other = side == 0 ? t->item.data() : t->user.data();
     const int64_t n_other = side == 0 ? t->n_items : t->n_users;
-    float *P = side == 0 ? t->P_user.data() : t->P_item.data();
+    Real *P = side == 0 ? t->P_user.data() : t->P_item.data();
     prepare_p(other, n_other, t->K, t->config.alpha0, sc->n_threads, P);
     if (side == 1) X = transpose(X);
     if (X.cols != n_other)  // hpp:126-131
@@ -583,7 +592,7 @@ int orc_ials_transform(void *h, int side, int64_t rows, int64_t cols,
 }
 
 // IALSTrainer::compute_loss, hpp:836-940 (non-feature terms).
-int orc_ials_compute_loss(void *h, const SolverConfig *sc, float *out) {
+int orc_ials_compute_loss(void *h, const SolverConfig *sc, Real *out) {
   Trainer *t = static_cast<Trainer *>(h);
   return guard([&] {
     const int64_t K = t->K;
@@ -591,26 +600,26 @@ int orc_ials_compute_loss(void *h, const SolverConfig *sc, float *out) {
               t->P_user.data());
     prepare_p(t->user.data(), t->n_users, K, t->config.alpha0, sc->n_threads,
               t->P_item.data());
-    float loss = 0;
+    Real loss = 0;
     if (t->config.alpha0 != 0.0f) {  // hpp:840-844
-      float s = 0;
+      Real s = 0;
       for (int64_t i = 0; i < K * K; i++) s += t->P_user[i] * t->P_item[i];
       loss = s / t->config.alpha0;
     }
-    const float bias = t->config.loss_type == 1 ? 0.0f : t->config.alpha0;
-    float loss_local = 0;
+    const Real bias = t->config.loss_type == 1 ? 0.0f : t->config.alpha0;
+    Real loss_local = 0;
     for (int64_t u = 0; u < t->n_users; u++) {
       int64_t nnz = 0;
       for (int64_t q = t->X.indptr[u]; q < t->X.indptr[u + 1]; q++) {
         nnz++;
-        const float *v = t->item.data() + static_cast<int64_t>(t->X.indices[q]) * K;
-        float pred = 0;
+        const Real *v = t->item.data() + static_cast<int64_t>(t->X.indices[q]) * K;
+        Real pred = 0;
         for (int64_t k = 0; k < K; k++) pred += t->user[u * K + k] * v[k];
-        const float c = t->X.data[q];
+        const Real c = t->X.data[q];
         loss_local += c * pred * pred - 2 * (c + bias) * pred + c + bias;  // hpp:867-869
       }
-      const float reg = compute_reg(nnz, t->n_items, t->config);
-      float n2 = 0;
+      const Real reg = compute_reg(nnz, t->n_items, t->config);
+      Real n2 = 0;
       for (int64_t k = 0; k < K; k++) n2 += t->user[u * K + k] * t->user[u * K + k];
       loss_local += reg * n2;
     }
@@ -618,8 +627,8 @@ int orc_ials_compute_loss(void *h, const SolverConfig *sc, float *out) {
     loss_local = 0;
     for (int64_t i = 0; i < t->n_items; i++) {
       const int64_t nnz = t->X_t.indptr[i + 1] - t->X_t.indptr[i];
-      const float reg = compute_reg(nnz, t->n_users, t->config);
-      float n2 = 0;
+      const Real reg = compute_reg(nnz, t->n_users, t->config);
+      Real n2 = 0;
       for (int64_t k = 0; k < K; k++) n2 += t->item[i * K + k] * t->item[i * K + k];
       loss_local += reg * n2;
     }
@@ -630,7 +639,7 @@ int orc_ials_compute_loss(void *h, const SolverConfig *sc, float *out) {
 
 // IALSTrainer::user_scores, hpp:942-984.
 int orc_ials_user_scores(void *h, int64_t begin, int64_t end,
-                         const SolverConfig *sc, float *out) {
+                         const SolverConfig *sc, Real *out) {
   Trainer *t = static_cast<Trainer *>(h);
   return guard([&] {
     if (sc->n_threads == 0)
@@ -650,7 +659,7 @@ int orc_ials_user_scores(void *h, int64_t begin, int64_t end,
         int64_t e = std::min(r + 16, m);
         for (; r < e; r++)
           for (int64_t i = 0; i < t->n_items; i++) {
-            float s = 0;
+            Real s = 0;
             for (int64_t k = 0; k < K; k++)
               s += t->user[(begin + r) * K + k] * t->item[i * K + k];
             out[r * t->n_items + i] = s;

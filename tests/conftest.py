@@ -131,3 +131,43 @@ def record_parity(test: str, config: str, **fields) -> None:
     except OSError as exc:  # a read-only checkout must not fail the parity test itself
         print(f"record_parity: {exc}", file=sys.stderr)
     print("PARITY", json.dumps(rec))
+
+
+def rows_vs_float64(gpu, oracle32, ref64, floor: float = 1e-6):
+    """Per-row distances of the GPU rows and of the float32 oracle's rows from the float64
+    evaluation of the same algorithm (``oracle.ials_solver_step_f64``): ``||a_r - ref_r|| /
+    max(||ref_r||, floor * max ||ref||)`` for both."""
+    ref = np.asarray(ref64, dtype=np.float64)
+    den = np.linalg.norm(ref, axis=1)
+    den = np.maximum(den, floor * max(float(den.max()) if den.size else 0.0, 1e-300))
+    e_gpu = np.linalg.norm(np.asarray(gpu, dtype=np.float64) - ref, axis=1) / den
+    e_orc = np.linalg.norm(np.asarray(oracle32, dtype=np.float64) - ref, axis=1) / den
+    return e_gpu, e_orc
+
+
+def assert_float64_bar(gpu, oracle32, ref64, what: str, test: str = "", rtol: float = 1e-4,
+                       slack: float = 1.0, **extra) -> None:
+    """The factor-parity bar with float64 as the arbiter of EVERY row: the GPU's worst row is no
+    farther from the float64 rows than the float32 oracle's worst row (or ``rtol``, whichever is
+    larger; ``slack`` > 1 where the two maxima are a handful of rows of a noisy tail), and - given
+    at least 1000 rows - 99.9 % of the GPU's rows are within ``rtol`` of float64.  The achieved distributions go to the parity
+    log."""
+    e_gpu, e_orc = rows_vs_float64(gpu, oracle32, ref64)
+    g32 = np.linalg.norm(np.asarray(gpu, np.float64) - np.asarray(oracle32, np.float64), axis=1)
+    d32 = np.linalg.norm(np.asarray(oracle32, np.float64), axis=1)
+    e32 = g32 / np.maximum(d32, 1e-6 * max(float(d32.max()) if d32.size else 0.0, 1e-300))
+    q = lambda e, p: float(np.quantile(e, p)) if e.size else 0.0  # noqa: E731
+    record_parity(test or "float64_bar", what, n_rows=int(e_gpu.size),
+                  gpu_vs_f64_worst=float(e_gpu.max()) if e_gpu.size else 0.0,
+                  gpu_vs_f64_p999=q(e_gpu, 0.999), gpu_vs_f64_median=q(e_gpu, 0.5),
+                  oracle_f32_vs_f64_worst=float(e_orc.max()) if e_orc.size else 0.0,
+                  oracle_f32_vs_f64_p999=q(e_orc, 0.999), oracle_f32_vs_f64_median=q(e_orc, 0.5),
+                  gpu_vs_oracle_f32_worst=float(e32.max()) if e32.size else 0.0,
+                  n_rows_gpu_over_1e_4_vs_f64=int((e_gpu >= rtol).sum()),
+                  n_rows_oracle_over_1e_4_vs_f64=int((e_orc >= rtol).sum()), **extra)
+    if not e_gpu.size:
+        return
+    assert np.isfinite(e_gpu).all(), what
+    assert e_gpu.max() <= max(rtol, slack * e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))
+    if e_gpu.size >= 1000:  # (of a few dozen rows the 99.9 % quantile IS the worst row)
+        assert q(e_gpu, 0.999) <= rtol, (what, q(e_gpu, 0.999))
