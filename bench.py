@@ -86,20 +86,58 @@ def algorithmic_epoch(X, K, solver):
 
 
 def executed_cg_flops(X, K, cg_steps=3, short_max=32):
-    """What the CG kernels EXECUTE per epoch: rows above `short_max` stored
-    entries (at K <= 256) build the explicit K x K system on the matrix cores (the rank update
-    of the Cholesky path) and iterate on it with dense mat-vecs; rows up to `short_max` entries
-    and every row at K > 256 run the matrix-free form the algorithmic count prices."""
+    """What the CG kernels EXECUTE per epoch: at K <= 128 rows above `short_max`
+    stored entries build the explicit K x K system on the matrix cores (the rank update of the
+    Cholesky path) and iterate on it with dense mat-vecs; rows up to `short_max` entries and
+    every row at K > 128 (round 4: ials_mf_kernels.hpp; K > 256: gk_cg_kernel) run the
+    matrix-free form the algorithmic count prices.  IRSPACK_AMD_IALS_MF=0 puts 128 < K <= 256
+    back on the explicit build."""
     total = 0.0
+    matrix_free_above = 128 if os.environ.get("IRSPACK_AMD_IALS_MF", "1") != "0" else 256
     for Xs in (X, X.T.tocsr()):
         nnz_r = np.diff(Xs.indptr).astype(np.float64)
-        if K > 256:
+        if K > matrix_free_above:
             total += float((nnz_r * (cg_steps + 2) * 4 * K + (cg_steps + 1) * 2.0 * K * K).sum())
             continue
         dense = nnz_r > short_max
         total += float((nnz_r[dense] * (K * (K + 1) + 2 * K) + (cg_steps + 1) * 2.0 * K * K).sum())
         total += float((nnz_r[~dense] * (cg_steps + 2) * 4 * K + (cg_steps + 1) * 2.0 * K * K).sum())
     return total
+
+
+def executed_cholesky_flops(X, K, eig_sides, short_max=32):
+    """What the Cholesky kernels EXECUTE per epoch.  Rows above `short_max` stored entries (and
+    every row of a side that did not take the eigenbasis path) build and factorise the K x K
+    system: the algorithmic count.  On a side in `eig_sides` (K <= 128) the rows of
+    at most `short_max` entries are solved in the low-rank (Woodbury) form in the eigenbasis of the
+    Gramian - per row of n entries: S = V~ D V~^T (n^2 K), its n x n factorisation (n^3 / 3), two
+    n x K products (4 n K) - plus, once per half-step, the table product V~ = V Q (2 n_other K^2)
+    and the rotation of the solved short rows back (2 R_short K^2); the float64 Jacobi
+    decomposition (one workgroup) is not counted."""
+    total = 0.0
+    for side, Xs in enumerate((X, X.T.tocsr())):
+        n = np.diff(Xs.indptr).astype(np.float64)
+        dense = np.ones(n.shape, dtype=bool) if side not in eig_sides else n > short_max
+        total += float((n[dense] * (K * (K + 1) + 2 * K) + K ** 3 / 3.0 + 2.0 * K * K).sum())
+        s = n[~dense]
+        total += float((s * s * K + s ** 3 / 3.0 + 4.0 * s * K).sum())
+        if side in eig_sides:
+            total += 2.0 * Xs.shape[1] * K * K + 2.0 * float((~dense).sum()) * K * K
+    return total
+
+
+def eigenbasis_sides(trainer, sc):
+    """sides (0 user, 1 item) whose half-step takes the eigenbasis short-row path (a diagnostic of
+    the library; one extra half-step per side, untimed)"""
+    sides = []
+    for side in (0, 1):
+        trainer.partial_gramian_async(side)
+        trainer.finish_gramian_async(side)
+        trainer.half_step_async(side, sc)
+        trainer.synchronize()
+        if trainer.last_half_step_used_eigenbasis():
+            sides.append(side)
+    return sides
 
 
 def roof(bound, achieved, ceilings, **more):
@@ -250,6 +288,14 @@ def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
         more = {"executed_gflop_per_epoch": priced / 1e9,
                 "matrix_free_algorithmic_gflop_per_epoch": flops / 1e9,
                 "executed_over_algorithmic_flops": priced / flops}
+    else:
+        # Cholesky: sides whose short rows are solved in the eigenbasis of the Gramian (configs[3])
+        # execute FEWER flops than K^3 / 3 per row: price what runs, so that no fraction exceeds 1
+        sides = eigenbasis_sides(trainer, solver_config(kind))
+        if sides:
+            priced = executed_cholesky_flops(X, K, sides)
+            more = {"executed_gflop_per_epoch": priced / 1e9, "eigenbasis_sides": sides,
+                    "executed_over_algorithmic_flops": priced / flops}
     return {
         "solver": kind + (" max_cg_steps=3" if kind == "CG" else ""),
         "ms_per_epoch": dt * 1e3, "updates_per_s": (U + I) / dt, "steps": steps, "warmup": warmup,
@@ -322,11 +368,49 @@ def holdout(X, seed=7):
     return gt, mask
 
 
+def block_path_leg(ev, trainer, mask, n_users=8192, mb_size=128):
+    """The DROP-IN block path, timed on the first `n_users` users: what runs when a maintainer puts
+    this library's EvaluatorCore / IALSTrainer under the reference's own Python Evaluator
+    (INTEGRATION.md option A; evaluation/evaluator.py:417-438): per 128-user block
+    ``get_score_block`` (scores to the host), ``scores[mask.nonzero()] = -inf`` in numpy,
+    ``get_metrics_f32`` (block back to the device, ranked).  Beside it the same loop with this
+    package's own block call (``get_metrics_masked``: the mask applied on the device copy)."""
+    from irspack_amd.evaluation._core_evaluator import MaskRows, Metrics
+    from irspack_amd.recommenders._ials_core import IALSSolverConfigBuilder
+
+    sc = IALSSolverConfigBuilder().set_n_threads(1).build()
+    n = min(n_users, ev.n_users)
+    out = {}
+    for name in ("reference_loop", "masked_call"):
+        rows = MaskRows(mask, ev.n_items) if name == "masked_call" else None
+        acc = Metrics(ev.n_items)
+        t0 = time.perf_counter()
+        for b in range(0, n, mb_size):
+            e = min(b + mb_size, n)
+            scores = trainer.user_scores(b, e, sc)
+            if rows is None:
+                scores[mask[b:e].nonzero()] = -np.inf
+                acc.merge(ev.get_metrics_f32(scores, 20, b, 1, False))
+            else:
+                acc.merge(ev.get_metrics_masked(scores, rows, b, [20], b, 1, False)[0])
+        dt = time.perf_counter() - t0
+        out[name] = {"users": n, "mb_size": mb_size, "wall_s": dt, "users_per_s": n / dt,
+                     "ndcg@20": acc.as_dict()["ndcg"]}
+    return out
+
+
 def evaluator_leg(X, trainer, K, ceilings):
+    """Fused scoring + nDCG@20 over all users on a 20 % hold-out.  The scored model is fitted on
+    the TRAINING entries only (three CG epochs; `trainer`, fitted on all of X, is not used: its
+    scores would have seen the hold-out), so ndcg@20 is a held-out figure - of a synthetic matrix."""
     from irspack_amd.evaluation._core_evaluator import EvaluatorCore
+    from irspack_amd.recommenders._ials_core import IALSTrainer
 
     U, I = X.shape
     gt, mask = holdout(X)
+    trainer = IALSTrainer(model_config(K), mask)
+    for _ in range(3):
+        trainer.step(solver_config("CG"))
     ev = EvaluatorCore(gt, [])
     ev.get_metrics_ials(trainer, 0, 2048, mask[:2048], 20, 0, False)  # warm-up
     t0 = time.perf_counter()
@@ -354,6 +438,8 @@ def evaluator_leg(X, trainer, K, ceilings):
         "wall_s_incl_pcie": wall, "users_per_s": U / wall,
         "scores_per_s": U * float(I) / wall, "ndcg@20": m.as_dict()["ndcg"],
         "device_path": st,
+        "model": "iALS fitted on the training entries (the mask) only: 3 CG epochs",
+        "drop_in_block_path": block_path_leg(ev, trainer, mask),
         "tiles_scored_frac": st["tiles_scored"] / max(1, st["tiles_total"]),
         "roofline": both_terms(flops, byts, wall, ceilings, bound="mfma",
                                scope="whole call (host wall clock); after pruning the call is "

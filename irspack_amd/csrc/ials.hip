@@ -90,11 +90,11 @@ struct Side {
   // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
   int32_t n_short = 0, n_short16 = 0, n_short8 = 0;
   // matrix-free CG at 128 < K <= 256 (ials_mf_kernels.hpp): rows_by_len is cut into the
-  // level-synchronous rows (more than MF_NCAP entries, chunked) and the resident classes of at most
-  // 320 / 192 / 96 / 32 entries; mf_class[c] = first index of class c in rows_by_len, [5] = end
+  // level-synchronous rows (more than MF_NCAP entries, chunked) and the resident classes of
+  // MF_CAPS; mf_class[c] = first index of class c in rows_by_len, [MF_CLASSES] = end
   DeviceBuffer<MfLongRow> mf_lrows;
   DeviceBuffer<MfChunk> mf_chunks;
-  int32_t mf_n_lrows = 0, mf_n_chunks = 0, mf_class[6] = {0, 0, 0, 0, 0, 0};
+  int32_t mf_n_lrows = 0, mf_n_chunks = 0, mf_class[MF_CLASSES + 1] = {};
   bool unit = false;  // every stored confidence is exactly 1 (UNIT kernels)
   bool positive = false;  // every stored confidence is > 0 (eigenbasis short-row kernels)
   float reg_min = 0.f;    // smallest per-row regulariser of the rows [row_begin, row_end)
@@ -207,14 +207,13 @@ struct Side {
       }
       rows_by_len.upload(order, s);
       if (cfg.K > 128 && cfg.K <= 256) {  // the classes of the matrix-free CG kernels
-        const int32_t caps[5] = {INT32_MAX, MF_NCAP, 192, 96, 32};  // class c: length <= caps[c]
         size_t i = 0;
-        for (int c = 0; c < 5; c++) {
+        for (int c = 0; c < MF_CLASSES; c++) {
           mf_class[c] = static_cast<int32_t>(i);
-          const int32_t lower = c < 4 ? caps[c + 1] : -1;  // class c: lower < length <= caps[c]
+          const int32_t lower = c + 1 < MF_CLASSES ? MF_CAPS[c + 1] : -1;  // class c: lower < length <= MF_CAPS[c]
           while (i < order.size() && ip32[order[i] + 1] - ip32[order[i]] > lower) i++;
         }
-        mf_class[5] = static_cast<int32_t>(order.size());
+        mf_class[MF_CLASSES] = static_cast<int32_t>(order.size());
         std::vector<MfLongRow> lr;
         std::vector<MfChunk> ch;
         for (int32_t k = 0; k < mf_class[1]; k++) {
@@ -1100,7 +1099,8 @@ void launch_mf_cg(irs_ials_trainer *t, Side &sd, const float *other, float *targ
                                          : static_cast<int32_t>(std::min<uint64_t>(sc->max_cg_steps, 1u << 20));
   p.err_flag = t->err_flag.ptr;
   const int32_t n_long = sd.mf_n_lrows;
-  const bool fork = n_long > 0 && sd.mf_class[5] > sd.mf_class[1];
+  static const bool fork_ok = env_flag("IRSPACK_AMD_MF_FORK", true);  // 0: one stream (A/B, profiling)
+  const bool fork = fork_ok && n_long > 0 && sd.mf_class[MF_CLASSES] > sd.mf_class[1];
   hipStream_t ls = t->stream;
   if (fork) {
     if (!t->stream2) {
@@ -1143,24 +1143,26 @@ void launch_mf_cg(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     t->prof.end(ls);
   }
   t->prof.begin(pidx == 0 ? "ials_solve_cg_user" : "ials_solve_cg_item", t->stream);
-  auto resident = [&](auto kernel, int cls) {
+  auto resident = [&](auto kernel, int cls, int rows_per_wg, int waves) {
     const int32_t first = sd.mf_class[cls], count = sd.mf_class[cls + 1] - first;
     if (count <= 0) return;
     MfParams q = p;
     q.row_first = first;
     q.n_rows = count;
-    hipLaunchKernelGGL(kernel, dim3(count), dim3(256), 0, t->stream, q);
+    hipLaunchKernelGGL(kernel, dim3(ceil_div(count, rows_per_wg)), dim3(64 * waves), 0, t->stream, q);
   };
+  // classes 1 .. 4 of MF_CAPS: <= 320 (eight waves on one row), 160 (four), 80 (two rows of two
+  // waves), 40 (four rows of one wave)
   if (t->T == 12) {
-    resident(mf_cg_resident_kernel<192, 20>, 1);
-    resident(mf_cg_resident_kernel<192, 12>, 2);
-    resident(mf_cg_resident_kernel<192, 6>, 3);
-    resident(mf_cg_resident_kernel<192, 2>, 4);
+    resident(mf_cg_rows_kernel<192, 1, 8, 10>, 1, 1, 8);
+    resident(mf_cg_rows_kernel<192, 1, 4, 10>, 2, 1, 4);
+    resident(mf_cg_rows_kernel<192, 2, 2, 10>, 3, 2, 4);
+    resident(mf_cg_rows_kernel<192, 4, 1, 10>, 4, 4, 4);
   } else {
-    resident(mf_cg_resident_kernel<256, 20>, 1);
-    resident(mf_cg_resident_kernel<256, 12>, 2);
-    resident(mf_cg_resident_kernel<256, 6>, 3);
-    resident(mf_cg_resident_kernel<256, 2>, 4);
+    resident(mf_cg_rows_kernel<256, 1, 8, 10>, 1, 1, 8);
+    resident(mf_cg_rows_kernel<256, 1, 4, 10>, 2, 1, 4);
+    resident(mf_cg_rows_kernel<256, 2, 2, 10>, 3, 2, 4);
+    resident(mf_cg_rows_kernel<256, 4, 1, 10>, 4, 4, 4);
   }
   t->prof.end(t->stream);
   if (fork) {

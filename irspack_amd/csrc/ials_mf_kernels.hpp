@@ -7,15 +7,16 @@
 // rank update runs on the matrix cores and the system lives in one wave's registers); at K = 256 it
 // executed 9 x the algorithmic flops (45 ms per epoch on the ML-20M shape).  Here:
 //
-//   * rows of at most MF_NCAP = 320 stored entries (mf_cg_resident_kernel): one 256-thread
-//     workgroup per row GATHERS THE ROW'S FACTOR ROWS ONCE INTO REGISTERS - 16 lanes per gathered
-//     row, four entries per wave instruction, wave w of the four holds the entries
-//     q = 16 j + 4 w + g (g = lane >> 4) - and all s + 1 products (and the right-hand side) run on
-//     those registers: the dot v_q . vec is DPL = KP / 16 fused multiply-adds and one 16-lane DPP
-//     sum, the update DPL more.  P vec: wave w takes rows [KP w / 4, KP (w + 1) / 4) of P, lane l
-//     the columns 4 l .. 4 l + 3 (P is symmetric: one coalesced 16-byte load per lane and row).
-//     The 16 + 4 partial vectors of a product meet in LDS and thread t sums dimension t in a fixed
-//     order.  x, r, p of dimension t live in thread t's registers.
+//   * rows of at most MF_NCAP = 320 stored entries (mf_cg_rows_kernel): a workgroup solves
+//     R = 4, 2 or 1 rows (of at most 40, 80, 160 / 320 entries) with W = 1, 2, 4 / 8 waves per row
+//     and GATHERS THE ROWS' FACTOR ROWS ONCE INTO REGISTERS - 16 lanes per gathered row, four
+//     entries per wave instruction, ten such groups per wave - and all s + 1 products (and the
+//     right-hand side) run on those registers: the dot v_q . vec is KP / 16 fused multiply-adds
+//     and one 16-lane DPP sum, the update KP / 16 more.  P vec: every wave takes its share of the
+//     rows of P, lane l the columns 4 l .. 4 l + 3 (P is symmetric: one coalesced 16-byte load per
+//     lane and row of P), for ALL R rows of the workgroup at once.  The partial vectors of a
+//     product meet in LDS and each thread sums its dimensions in a fixed order.  With one wave per
+//     row a row's dot products are wave reductions: two barriers per product instead of eight.
 //   * longer rows run LEVEL-SYNCHRONOUSLY (mf_chunk_kernel + mf_row_kernel, one pair of launches
 //     per product, on a second stream beside the resident kernels): the row's entries are cut
 //     into chunks of <= MF_CHUNK entries, one workgroup per chunk streams its entries once per
@@ -34,8 +35,12 @@
 namespace irs {
 namespace ials {
 
-constexpr int MF_NCAP = 320;    // longest resident row: 20 groups of 4 entries per wave
+constexpr int MF_NCAP = 320;    // longest resident row: 8 waves x 10 groups of 4 entries
+// row classes by stored entries, longest first: class 0 = level-synchronous, then the resident
+// classes of mf_cg_rows_kernel<KP, R, W, 10> (capacity 40 W): <1, 8>, <1, 4>, <2, 2>, <4, 1>
 constexpr int MF_CHUNK = 1024;  // entries per chunk of a level-synchronous row
+constexpr int MF_CLASSES = 5;
+constexpr int32_t MF_CAPS[MF_CLASSES] = {INT32_MAX, MF_NCAP, 160, 80, 40};
 
 struct MfLongRow {
   int32_t row;          // row of the solved side
@@ -112,20 +117,26 @@ __device__ __forceinline__ float mf_block_sum(float v, float *red, int w, int la
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// one group of four gathered rows held by a wave (16 lanes per row, DPL floats per lane)
+// one group of four gathered rows held by a wave (16 lanes per row; lane m: dims 4 m + 64 i + e)
 template <int NV> struct MfGroup {
   f32x4 v[NV];
   float c;
 };
 
+// (index and confidence are loaded by the caller, for ALL its groups before the first row load: an
+// index load issued between two groups' row loads makes the wait for it - vmcnt counts in order -
+// drain the row loads in front of it, and the groups of a row were fetched one latency after the
+// other: 20 groups of a 320-entry row took 200 us from the 142 MB user table)
 template <int NV>
-__device__ __forceinline__ void mf_load_group(MfGroup<NV> &grp, const MfParams &p, int KP, int q, bool ok,
-                                              int q_safe, int m) {
-  const int idx = p.indices[ok ? q : q_safe];
-  grp.c = ok ? p.data[q] : 0.f;
-  const float *src = p.other + static_cast<size_t>(idx) * KP + 4 * NV * m;
+__device__ __forceinline__ void mf_load_group(MfGroup<NV> &grp, const MfParams &p, int KP, int idx, float c,
+                                              int m) {
+  grp.c = c;
+  // lane m takes the dims 4 m .. 4 m + 3 of every 64-dim block: each of the NV load instructions
+  // reads 256 contiguous bytes per gathered row (16 B per lane at a 64 B stride touched every cache
+  // line of the row from every instruction)
+  const float *src = p.other + static_cast<size_t>(idx) * KP + 4 * m;
 #pragma unroll
-  for (int i = 0; i < NV; i++) grp.v[i] = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+  for (int i = 0; i < NV; i++) grp.v[i] = *reinterpret_cast<const f32x4 *>(src + 64 * i);
 }
 
 // acc += c (v . pl) v for the lane's slice of one gathered row
@@ -155,110 +166,228 @@ __device__ __forceinline__ void mf_rhs_update(const MfGroup<NV> &grp, float bias
     for (int e = 0; e < 4; e++) acc[i][e] = fmaf(s, grp.v[i][e], acc[i][e]);
 }
 
-// ---- rows of at most 16 J stored entries: everything on chip -------------------------------
-template <int KP, int J>
-__global__ __launch_bounds__(256, J <= 2 ? 3 : (J <= 6 ? 2 : 1)) void mf_cg_resident_kernel(MfParams p) {
-  constexpr int DPL = KP / 16, NV = DPL / 4;
-  __shared__ __attribute__((aligned(16))) float ps[KP];
-  __shared__ __attribute__((aligned(16))) float part[20][KP];
-  __shared__ float red[4];
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, m = lane & 15;
-  const int row = p.rows[p.row_first + blockIdx.x];
-  const int b = p.indptr[row], n = p.indptr[row + 1] - b;
-  float *trow = p.target + static_cast<size_t>(row) * KP;
-  if (n == 0) {  // hpp:207-210
-    if (tid < KP) trow[tid] = 0.f;
-    return;
-  }
-  const bool act = tid < p.K;  // thread t owns dimension t of x, r, p
-  const float reg = p.reg[row];
-  MfGroup<NV> grp[J];
+// (P vec)[columns 4 l ..] over this wave's rows of P for the R vectors of a workgroup's rows: every
+// 16-byte load of P serves all R rows
+template <int KP, int R, int NW>
+__device__ __forceinline__ void mf_p_times_vecs(const float *__restrict__ P, const float (*vecs)[KP], int w,
+                                                int lane, f32x4 (&out)[R]) {
+  constexpr int KQ = KP / NW;  // rows of P per wave
 #pragma unroll
-  for (int j = 0; j < J; j++) {
-    if (16 * j + 4 * w < n) {  // (wave uniform)
-      const int q = 16 * j + 4 * w + g;
-      mf_load_group<NV>(grp[j], p, KP, b + q, q < n, b, m);
-    } else {
-      grp[j].c = 0.f;
+  for (int r = 0; r < R; r++) out[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (4 * lane < KP) {
+    const float *Pw = P + static_cast<size_t>(KQ * w) * KP + 4 * lane;
+#pragma unroll 2
+    for (int k = 0; k < KQ; k += 4) {
+      f32x4 rw[4];
 #pragma unroll
-      for (int i = 0; i < NV; i++) grp[j].v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < 4; e++) rw[e] = *reinterpret_cast<const f32x4 *>(Pw + static_cast<size_t>(k + e) * KP);
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const f32x4 pk = *reinterpret_cast<const f32x4 *>(&vecs[r][KQ * w + k]);  // (one address: broadcast)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          out[r][i] = fmaf(rw[0][i], pk.x, out[r][i]);
+          out[r][i] = fmaf(rw[1][i], pk.y, out[r][i]);
+          out[r][i] = fmaf(rw[2][i], pk.z, out[r][i]);
+          out[r][i] = fmaf(rw[3][i], pk.w, out[r][i]);
+        }
+      }
     }
   }
-  // the 16 (+ 4) partial vectors of a pass -> thread t's sum of dimension t, in a fixed order
+}
+
+// ---- rows of at most 4 J W stored entries: everything on chip --------------------------------
+// One workgroup of NW = R W waves solves R rows side by side, W waves per row (W = 1: every
+// reduction of a row is a wave reduction, no barrier; W = 8: a 512-thread workgroup on one row).
+// Wave wr of a row holds the entries q = 4 (j W + wr) + g of the row in registers: J = 10 groups,
+// 160 registers, so that TWO waves fit a SIMD - with one (J = 20: 420 registers) a compute unit sat
+// through every latency of its only workgroup (61 % of the wave cycles waiting, 28 % issuing).  The
+// rows of a workgroup are neighbours in the longest-first list and advance in lockstep: the
+// barriers of a product (vectors complete -> partial vectors complete) are shared, and so is every
+// load of P (mf_p_times_vecs).  Thread tr of a row owns DPT consecutive dimensions of x, r, p.
+template <int KP, int R, int W, int J>
+__global__ __launch_bounds__(64 * R * W, 2) void mf_cg_rows_kernel(MfParams p) {
+  constexpr int NW = R * W, DPL = KP / 16, NV = DPL / 4, DPT = W >= 4 ? 1 : 4 / W, NS = 4 * W + NW;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float ps[R][KP];
+  __shared__ __attribute__((aligned(16))) float part[R][NS][KP];
+  __shared__ float red[R][W];
+  __shared__ int alive[R];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = lane >> 4, m = lane & 15;
+  const int r = w / W, wr = w % W, tr = wr * 64 + lane, d0 = tr * DPT;
+  const int ridx = R * static_cast<int>(blockIdx.x) + r;
+  const bool has_row = ridx < p.n_rows;
+  const int row = has_row ? p.rows[p.row_first + ridx] : 0;
+  const int b = has_row ? p.indptr[row] : 0, n = has_row ? p.indptr[row + 1] - b : 0;
+  float *trow = p.target + static_cast<size_t>(row) * KP;
+  const float reg = has_row ? p.reg[row] : 0.f;
+  const bool dims_in = d0 < KP;  // (KP = 192: the last threads of a row own nothing)
+  bool act[DPT];
+#pragma unroll
+  for (int i = 0; i < DPT; i++) act[i] = dims_in && d0 + i < p.K;
+  MfGroup<NV> grp[J];
+  {
+    int idx[J];
+    float cq[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {  // entries past the row's end: the row's first entry, weight 0
+      const int q = 4 * (j * W + wr) + g;
+      idx[j] = n > 0 ? p.indices[b + (q < n ? q : 0)] : 0;
+      cq[j] = q < n ? p.data[b + q] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+      if (4 * (j * W + wr) < n) {  // (wave uniform)
+        mf_load_group<NV>(grp[j], p, KP, idx[j], cq[j], m);
+      } else {
+        grp[j].c = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; i++) grp[j].v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
   auto store_gathered = [&](const f32x4 (&acc)[NV]) {
 #pragma unroll
-    for (int i = 0; i < NV; i++) *reinterpret_cast<f32x4 *>(&part[4 * w + g][DPL * m + 4 * i]) = acc[i];
+    for (int i = 0; i < NV; i++) *reinterpret_cast<f32x4 *>(&part[r][4 * wr + g][4 * m + 64 * i]) = acc[i];
   };
-  auto sum_slots = [&](int n_slots) {
-    double s = 0.0;
-    if (tid < KP)
-      for (int sl = 0; sl < n_slots; sl++) s += static_cast<double>(part[sl][tid]);
-    return s;
+  // sum of the first n_slots partial vectors of this row over this thread's dimensions (fixed order)
+  auto sum_slots = [&](int n_slots, float (&out)[DPT]) {
+    double s[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; i++) s[i] = 0.0;
+    if (dims_in)
+      for (int sl = 0; sl < n_slots; sl++) {
+        float v[DPT];
+        if constexpr (DPT == 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4 *>(&part[r][sl][d0]);
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else if constexpr (DPT == 2) {
+          const f32x2 t = *reinterpret_cast<const f32x2 *>(&part[r][sl][d0]);
+          v[0] = t.x; v[1] = t.y;
+        } else {
+          v[0] = part[r][sl][d0];
+        }
+#pragma unroll
+        for (int i = 0; i < DPT; i++) s[i] += static_cast<double>(v[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < DPT; i++) out[i] = static_cast<float>(s[i]);
+  };
+  // sum over the threads of this row; with W > 1 every wave of the workgroup must call it
+  auto row_sum = [&](float v) {
+    v = wave_sum(v);
+    if constexpr (W > 1) {
+      __syncthreads();
+      if (lane == 0) red[r][wr] = v;
+      __syncthreads();
+      v = red[r][0];
+#pragma unroll
+      for (int k = 1; k < W; k++) v += red[r][k];
+    }
+    return v;
+  };
+  auto dot = [&](const float (&a)[DPT], const float (&c)[DPT]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPT; i++) s = fmaf(a[i], c[i], s);
+    return row_sum(s);
   };
   // right-hand side b = sum (bias + c) v (hpp:212-221)
-  float rhs;
+  float rr[DPT];
   {
     f32x4 acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < J; j++)
-      if (16 * j + 4 * w < n) mf_rhs_update<NV>(grp[j], p.bias, 16 * j + 4 * w + g < n, acc);
+      if (4 * (j * W + wr) < n) mf_rhs_update<NV>(grp[j], p.bias, 4 * (j * W + wr) + g < n, acc);
     store_gathered(acc);
     __syncthreads();
-    rhs = static_cast<float>(sum_slots(16));
+    sum_slots(4 * W, rr);
   }
-  // A vec for the vector in ps (hpp:222-228, 240-247); every thread returns dimension tid
-  auto matvec = [&]() {
-    __syncthreads();  // ps complete; the slots of the previous pass have been read
-    const f32x4 pp = mf_p_times_vec<KP>(p.P, ps, w, lane);
+  // A vec for the vectors in ps (hpp:222-228, 240-247), AFTER the barrier that completed them; every
+  // thread gets its dimensions of its row's product
+  auto matvec = [&](float (&out)[DPT]) {
+    f32x4 pp[R];
+    mf_p_times_vecs<KP, R, NW>(p.P, ps, w, lane, pp);
     f32x4 pl[NV], acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) {
-      pl[i] = *reinterpret_cast<const f32x4 *>(ps + DPL * m + 4 * i);
+      pl[i] = *reinterpret_cast<const f32x4 *>(&ps[r][4 * m + 64 * i]);
       acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int j = 0; j < J; j++)
-      if (16 * j + 4 * w < n) mf_dot_update<NV>(grp[j], pl, acc);
+      if (4 * (j * W + wr) < n) mf_dot_update<NV>(grp[j], pl, acc);
     store_gathered(acc);
-    if (4 * lane < KP) *reinterpret_cast<f32x4 *>(&part[16 + w][4 * lane]) = pp;
+    if (4 * lane < KP) {
+#pragma unroll
+      for (int k = 0; k < R; k++) *reinterpret_cast<f32x4 *>(&part[k][4 * W + w][4 * lane]) = pp[k];
+    }
     __syncthreads();
-    const float s = static_cast<float>(sum_slots(20));
-    return tid < KP ? fmaf(reg, ps[tid], s) : 0.f;  // + reg vec LAST
+    sum_slots(NS, out);
+#pragma unroll
+    for (int i = 0; i < DPT; i++) out[i] = dims_in ? fmaf(reg, ps[r][d0 + i], out[i]) : 0.f;  // + reg vec LAST
   };
-  float x = act ? trow[tid] : 0.f;  // warm start (hpp:199); fold-in passes a zeroed target
-  float r = act ? rhs : 0.f;
-  if (tid < KP) ps[tid] = x;
-  {
-    const float Ax = matvec();
-    r = act ? r - Ax : 0.f;
+  bool active = has_row && n > 0;
+  float x[DPT], pv[DPT], Ap[DPT];
+#pragma unroll
+  for (int i = 0; i < DPT; i++) {
+    x[i] = (active && act[i]) ? trow[d0 + i] : 0.f;  // warm start (hpp:199); fold-in passes a zeroed target
+    rr[i] = (active && act[i]) ? rr[i] : 0.f;
+    if (dims_in) ps[r][d0 + i] = x[i];
   }
-  float pv = r;
-  float r2 = mf_block_sum(r * r, red, w, lane);
+  __syncthreads();
+  matvec(Ap);
+#pragma unroll
+  for (int i = 0; i < DPT; i++) {
+    rr[i] = act[i] ? rr[i] - Ap[i] : 0.f;
+    pv[i] = rr[i];
+  }
+  float r2 = dot(rr, rr);
   bool singular = false;
   for (int it = 0; it < p.max_cg_steps; it++) {
-    if (r2 <= 1e-20f) break;  // hpp:238
-    __syncthreads();          // (every thread has read the previous ps)
-    if (tid < KP) ps[tid] = pv;
-    float Ap = matvec();
-    Ap = act ? Ap : 0.f;
-    const float denom = mf_block_sum(pv * Ap, red, w, lane);
-    if (!(denom > 0.f) || !__builtin_isfinite(denom)) {  // hpp:250-254
+    if (active && r2 <= 1e-20f) active = false;  // hpp:238
+    if (lane == 0 && wr == 0) alive[r] = active ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < DPT; i++)
+      if (dims_in) ps[r][d0 + i] = pv[i];
+    __syncthreads();  // vectors and flags complete; the previous product's slots have been read
+    int any = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) any |= alive[k];
+    if (!any) break;  // (uniform over the workgroup)
+    matvec(Ap);
+#pragma unroll
+    for (int i = 0; i < DPT; i++) Ap[i] = act[i] ? Ap[i] : 0.f;
+    const float denom = dot(pv, Ap);
+    if (active && (!(denom > 0.f) || !__builtin_isfinite(denom))) {  // hpp:250-254
       singular = true;
-      break;
+      active = false;
     }
-    const float alpha = r2 / denom;
-    x = fmaf(alpha, pv, x);
-    r = fmaf(-alpha, Ap, r);
-    const float r2n = mf_block_sum(r * r, red, w, lane);
-    if (r2n <= 1e-20f) break;  // hpp:258
-    const float beta = r2n / r2;  // hpp:261
-    pv = fmaf(beta, pv, r);
-    r2 = r2n;
+    const float alpha = active ? r2 / denom : 0.f;
+#pragma unroll
+    for (int i = 0; i < DPT; i++) {
+      x[i] = fmaf(alpha, pv[i], x[i]);
+      rr[i] = fmaf(-alpha, Ap[i], rr[i]);
+    }
+    const float r2n = dot(rr, rr);
+    if (active) {
+      if (r2n <= 1e-20f) {  // hpp:258
+        active = false;
+      } else {
+        const float beta = r2n / r2;  // hpp:261
+#pragma unroll
+        for (int i = 0; i < DPT; i++) pv[i] = fmaf(beta, pv[i], rr[i]);
+        r2 = r2n;
+      }
+    }
   }
-  if (singular && tid == 0) atomicOr(p.err_flag, 4);
-  if (tid < KP) trow[tid] = act ? x : 0.f;
+  if (singular && lane == 0 && wr == 0) atomicOr(p.err_flag, 4);
+  if (has_row && dims_in) {
+#pragma unroll
+    for (int i = 0; i < DPT; i++) trow[d0 + i] = (n > 0 && act[i]) ? x[i] : 0.f;  // (n == 0: hpp:207-210)
+  }
 }
 
 // ---- level-synchronous rows ------------------------------------------------------------------
@@ -278,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void mf_chunk_kernel(MfParams p, int first)
   f32x4 pl[NV], acc[NV], accb[NV];
 #pragma unroll
   for (int i = 0; i < NV; i++) {
-    pl[i] = *reinterpret_cast<const f32x4 *>(ps + DPL * m + 4 * i);
+    pl[i] = *reinterpret_cast<const f32x4 *>(ps + 4 * m + 64 * i);
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -286,11 +415,16 @@ __global__ __launch_bounds__(256, 2) void mf_chunk_kernel(MfParams p, int first)
   // entries q = 16 j + 4 w + g of the chunk; DEPTH groups are loaded before the first is used
   for (int j0 = 0; 16 * j0 + 4 * w < n; j0 += DEPTH) {
     MfGroup<NV> grp[DEPTH];
+    int idx[DEPTH];
+    float cq[DEPTH];
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) {
       const int q = 16 * (j0 + d) + 4 * w + g;
-      mf_load_group<NV>(grp[d], p, KP, ch.begin + q, q < n, ch.begin, m);
+      idx[d] = p.indices[ch.begin + (q < n ? q : 0)];
+      cq[d] = q < n ? p.data[ch.begin + q] : 0.f;
     }
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) mf_load_group<NV>(grp[d], p, KP, idx[d], cq[d], m);
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) {
       mf_dot_update<NV>(grp[d], pl, acc);
@@ -302,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void mf_chunk_kernel(MfParams p, int first)
     if (pass) __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; i++)
-      *reinterpret_cast<f32x4 *>(&part[4 * w + g][DPL * m + 4 * i]) = pass ? accb[i] : acc[i];
+      *reinterpret_cast<f32x4 *>(&part[4 * w + g][4 * m + 64 * i]) = pass ? accb[i] : acc[i];
     __syncthreads();
     if (tid < KP) {
       double s = 0.0;

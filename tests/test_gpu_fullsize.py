@@ -317,6 +317,43 @@ def test_fused_evaluator_ml20m_vs_oracle(X20, K, path, monkeypatch):
     assert full.total_user == X20.shape[0] and full.valid_user == X20.shape[0]
 
 
+@pytest.mark.parametrize("K", [64, 256])
+def test_fused_evaluator_all_users_on_the_bench_holdout(X20, K):
+    """THE call bench.py times (evaluator_leg): nDCG@20 over all 138,493 users, ground truth = the
+    20 % per-row hold-out of synthetic.holdout_split (seed 7, ~4.0 M entries), mask = the other
+    80 %, default path (norm-bound pruning keeps a few percent of the score tiles) - against the
+    oracle fed the same scores in 20,000-user blocks, masked on the host, merged like
+    Metrics::merge (evaluator.cpp:76-85).  Counters and histogram bit-exact, sums 1e-12."""
+    from irspack_amd.synthetic import holdout_split
+
+    train, test = holdout_split(X20, 0.2, 7)
+    gt, mask = sps.csr_matrix(test, dtype=np.float64), sps.csr_matrix(train, dtype=np.float32)
+    mc, sc, _, _ = configs(K, "CG")
+    t = IALSTrainer(mc, train)  # fitted on the training entries only (no leakage into the hold-out)
+    for _ in range(2):
+        t.step(sc)
+    U, I = X20.shape
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    got = core.get_metrics_ials(t, 0, U, mask, 20, 0, False)
+    stats = core.last_call_stats()
+    raw, cnt = np.zeros(7), np.zeros(I, dtype=np.int64)
+    for b in range(0, U, 20_000):
+        e = min(b + 20_000, U)
+        om = ocore.get_metrics_f32(masked_scores(t, b, e, mask, sc), 20, b, CORES)
+        raw += om.raw()
+        cnt += om.item_cnt()
+    record_parity("test_fused_evaluator_all_users_on_the_bench_holdout",
+                  f"ml20m K={K} nDCG@20 all {U} users, 20 % hold-out ({gt.nnz} entries)",
+                  path=stats["path"], tiles_scored=stats["tiles_scored"], tiles_total=stats["tiles_total"],
+                  hard_rows=stats["hard_rows"], histogram_equal=bool(np.array_equal(got.item_cnt, cnt)),
+                  valid_user=int(got.valid_user), total_user=int(got.total_user),
+                  ndcg_rel_err=float(abs(got.ndcg - raw[4]) / max(abs(raw[4]), 1e-300)))
+    np.testing.assert_array_equal(got.item_cnt, cnt)
+    assert (got.valid_user, got.total_user) == (int(raw[0]), int(raw[1])) and got.total_user == U
+    np.testing.assert_allclose([got.hit, got.recall, got.ndcg, got.precision, got.map], raw[2:], rtol=1e-12)
+    assert stats["path"] == "emit_bounded"  # the path the bench line reports
+
+
 @pytest.mark.parametrize("kind", ["CG", "CHOLESKY"])
 def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
     """configs[3] shape at 1/50 scale: 200 k x 20 k, geometric degrees (mean 9), Zipf items whose
