@@ -607,8 +607,14 @@ def main():
     local = HipLocalSolver(mc, X, shard, local_rank)
     # (overlap of the next Gramian's all-reduce with the all-gather: IRSPACK_AMD_BENCH_OVERLAP=1;
     # off by default until it has run on RCCL at world >= 2, see ShardedIALSTrainer)
-    trainer = ShardedIALSTrainer(local, ub, ib, timing=world > 1,
-                                 overlap=bool(int(os.environ.get("IRSPACK_AMD_BENCH_OVERLAP", "0"))))
+    # N > 1: the epoch behind ONE C-ABI call (irs_ials_sharded_step: RCCL from inside the library, rows
+    # in place, the next Gramian overlapping the row exchange); IRSPACK_AMD_BENCH_COMM=torch times
+    # the torch.distributed host loop instead.  The per-phase split of the line always comes from the
+    # host loop (a few extra, untimed epochs when the native path is the timed one).
+    native = world > 1 and backend == "nccl" and os.environ.get("IRSPACK_AMD_BENCH_COMM", "native") != "torch"
+    overlap = bool(int(os.environ.get("IRSPACK_AMD_BENCH_OVERLAP", "0")))
+    trainer = ShardedIALSTrainer(local, ub, ib, timing=world > 1 and not native, overlap=overlap,
+                                 native=native)
 
     def barrier():
         if world > 1:
@@ -636,9 +642,23 @@ def main():
         elapsed = float(tmax.item())
         # per-phase device time of the timed epochs (events on the stream the kernels and the
         # collectives' waits run on), per step; max and min over ranks
-        tm = trainer.last_timing()
+        phase_steps = args.steps
+        if native:  # the host loop, untimed, for the split only
+            host_loop = ShardedIALSTrainer(local, ub, ib, timing=True, overlap=overlap)
+            host_loop.step(sc)
+            host_loop.synchronize()
+            host_loop.last_timing()
+            phase_steps = min(args.steps, 5)
+            for _ in range(phase_steps):
+                host_loop.step(sc)
+            host_loop.synchronize()
+            tm = host_loop.last_timing()
+            exchange_plan = list(host_loop.exchange)
+        else:
+            tm = trainer.last_timing()
+            exchange_plan = list(trainer.exchange)
         keys = ["gramian_ms", "allreduce_ms", "solve_ms", "allgather_ms", "exposed_comm_ms", "total_ms"]
-        mine = torch.tensor([tm[k] / max(args.steps, 1) for k in keys], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([tm[k] / max(phase_steps, 1) for k in keys], dtype=torch.float64, device="cuda")
         hi, lo = mine.clone(), mine.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -646,7 +666,10 @@ def main():
                 "per_step_ms_min_over_ranks": {k: float(v) for k, v in zip(keys, lo.tolist())},
                 "compute_ms": float(hi[0] + hi[2]), "allreduce_ms": float(hi[1]),
                 "allgather_ms": float(hi[3]), "exposed_comm_ms": float(hi[4]),
-                "exchange": list(trainer.exchange), "overlap": bool(trainer.overlap),
+                "exchange": exchange_plan, "overlap": bool(trainer.overlap),
+                "timed_path": ("native: irs_ials_sharded_step (RCCL inside the library, in-place rows, "
+                               "next Gramian overlapped)" if native else "torch.distributed host loop"),
+                "phase_split_from": "torch.distributed host loop" + (" (extra untimed epochs)" if native else ""),
                 "note": "solve_ms spread (max - min over ranks) = load imbalance; the collectives' "
                         "time includes waiting for the slowest rank"}
 

@@ -185,9 +185,31 @@ irs_status irs_ials_synchronize(irs_ials_trainer *t);
 /* Per-kernel HIP-event timing (profiling aid for bench.py).  enable != 0 turns
  * recording on and clears the counters; `names`/`ms`/`launches` receive up to
  * `cap` entries. */
+/* ---- row-sharded epoch over RCCL (one process per GPU; no reference counterpart: the reference
+ * has no distributed layer).  irs_comm holds this rank's two RCCL communicators
+ * (solved rows; K x K Gramians).  id256: 256 bytes made by irs_comm_unique_id on ONE rank and
+ * handed to every rank by the caller (torch.distributed / MPI / a file). */
+typedef struct irs_comm irs_comm;
+irs_status irs_comm_unique_id(void *id256);
+irs_status irs_comm_create(const void *id256, int32_t rank, int32_t world, int32_t device,
+                           irs_comm **out);
+irs_status irs_comm_destroy(irs_comm *c);
+/* IALSTrainer::step (hpp:758-789) over the ranks of `c`: the trainer holds the shard
+ * [bounds[rank], bounds[rank + 1]) of each side (irs_ials_create with a shard); per half-epoch the
+ * partial Gramian of the own rows is all-reduced, the own rows are solved and all-gathered into
+ * every replica (in place), the next half-epoch's Gramian overlapping the row exchange.
+ * user_bounds / item_bounds: world + 1 row offsets, identical on every rank. */
+irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_config *sc, irs_comm *c,
+                                 const int64_t *user_bounds, const int64_t *item_bounds);
 /* Which rows of the last half-step were solved in the eigenbasis of the Gramian (measurement /
  * tests only, no reference counterpart): bit 0 = the rows of <= 32 stored entries. */
 int32_t irs_ials_last_eigenbasis(irs_ials_trainer *t);
+/* Test hook for the eigen-decomposition kernel of the short-row path (csrc/ials_eig_kernels.hpp):
+ * P [K, K] row-major symmetric, K <= 128 -> Qrows [K, K] (row k = eigenvector k), lam [K],
+ * stats [3] = largest, smallest eigenvalue, sweeps; P_prev (or NULL): a nearby matrix whose
+ * eigenvectors warm-start the sweeps, as the previous epoch's Gramian does in a fit. */
+irs_status irs_ials_eigen_debug(const float *P, int64_t K, int32_t device, float *Qrows, float *lam,
+                                float *stats, const float *P_prev);
 irs_status irs_ials_profile(irs_ials_trainer *t, int32_t enable);
 irs_status irs_ials_profile_read(irs_ials_trainer *t, int32_t cap,
                                  char (*names)[48], double *ms,

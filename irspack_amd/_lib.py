@@ -113,7 +113,12 @@ EXPORTED_SYMBOLS = [
     "irs_ials_finish_gramian_async",
     "irs_ials_half_step_async",
     "irs_ials_synchronize",
+    "irs_comm_unique_id",
+    "irs_comm_create",
+    "irs_comm_destroy",
+    "irs_ials_sharded_step",
     "irs_ials_last_eigenbasis",
+    "irs_ials_eigen_debug",
     "irs_ials_profile",
     "irs_ials_profile_read",
     "irs_knn_create",

@@ -19,6 +19,21 @@ __global__ __launch_bounds__(256) void copy_kernel(const f32x4 *__restrict__ src
     dst[i] = __builtin_nontemporal_load(src + i);
 }
 
+// the same with four 16-byte loads in flight per lane before the first store (plain loads)
+__global__ __launch_bounds__(256) void copy4_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
+                                                    size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const f32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+    dst[i] = v0;
+    dst[i + stride] = v1;
+    dst[i + 2 * stride] = v2;
+    dst[i + 3 * stride] = v3;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
 // a = b + s * c (STREAM triad: two reads, one write)
 __global__ __launch_bounds__(256) void triad_kernel(const f32x4 *__restrict__ b,
                                                     const f32x4 *__restrict__ c,
@@ -35,9 +50,12 @@ __global__ __launch_bounds__(256) void mfma_f32_kernel(int iters, float *__restr
 #pragma unroll
   for (int i = 0; i < 8; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
-  for (int it = 0; it < iters; it++) {
+  // 32 instructions per trip: the loop's scalar bookkeeping is ~1 % of the issue slots, not ~4 %
+  for (int it = 0; it < iters; it += 4) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    for (int rep = 0; rep < 4; rep++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
   }
   f32x4 s = acc[0];
 #pragma unroll
@@ -135,14 +153,23 @@ extern "C" irs_status irs_measure_ceilings(int32_t device, irs_ceilings *out) {
     IRS_HIP(hipMemsetAsync(c.ptr, 0, n * sizeof(f32x4), s));
     const int grid = n_cu * 16;
     const double bytes = static_cast<double>(n) * sizeof(f32x4);
+    // the best of: non-temporal grid-stride copy, four loads in flight per lane at 8 / 16 / 32
+    // workgroups per compute unit, and the runtime's own device-to-device copy
     double ms = best_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, s, b.ptr, a.ptr, n); }, s, 5);
+    for (int per_cu : {8, 16, 32})
+      ms = std::min(ms, best_ms([&] { hipLaunchKernelGGL(copy4_kernel, dim3(n_cu * per_cu), dim3(256), 0, s, b.ptr, a.ptr, n); }, s, 3));
+    ms = std::min(ms, best_ms([&] { (void)hipMemcpyAsync(a.ptr, b.ptr, n * sizeof(f32x4), hipMemcpyDeviceToDevice, s); }, s, 3));
     out->copy_gbs = 2.0 * bytes / (ms * 1e-3) / 1e9;
     ms = best_ms([&] { hipLaunchKernelGGL(triad_kernel, dim3(grid), dim3(256), 0, s, b.ptr, c.ptr, a.ptr, 0.5f, n); }, s, 5);
     out->triad_gbs = 3.0 * bytes / (ms * 1e-3) / 1e9;
-    // 2 workgroups of 4 waves per CU = 2 waves per SIMD
-    const int iters = 4096, mgrid = n_cu * 2;
-    ms = best_ms([&] { hipLaunchKernelGGL(mfma_f32_kernel, dim3(mgrid), dim3(256), 0, s, iters, reinterpret_cast<float *>(a.ptr)); }, s, 5);
-    out->mfma_f32_tflops = static_cast<double>(mgrid) * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+    // 1, 2 or 4 workgroups of 4 waves per CU (= waves per SIMD): the best rate
+    out->mfma_f32_tflops = 0.0;
+    for (int per_cu : {1, 2, 4}) {
+      const int iters = 8192, mgrid = n_cu * per_cu;
+      ms = best_ms([&] { hipLaunchKernelGGL(mfma_f32_kernel, dim3(mgrid), dim3(256), 0, s, iters, reinterpret_cast<float *>(a.ptr)); }, s, 5);
+      out->mfma_f32_tflops = std::max(out->mfma_f32_tflops,
+                                      static_cast<double>(mgrid) * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12);
+    }
     const int per = 4096;
     ms = best_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel, dim3(n_cu), dim3(1024), 0, s, per, reinterpret_cast<unsigned *>(a.ptr)); }, s, 3);
     out->lds_atomic_u32_gops = static_cast<double>(n_cu) * 1024 * per / (ms * 1e-3) / 1e9;

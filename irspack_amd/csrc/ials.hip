@@ -15,6 +15,7 @@
 #include <thread>
 
 #include "common.hpp"
+#include "comm.hpp"
 #include "host_prep.hpp"
 
 #include <hip/hip_ext.h>
@@ -349,6 +350,8 @@ struct irs_ials_trainer {
   DeviceBuffer<float> mf_vec, mf_xs, mf_rs, mf_partial, mf_r2;
   DeviceBuffer<int32_t> mf_done;
   bool opt_mf = true;   // IRSPACK_AMD_IALS_MF
+  // irs_ials_sharded_step: the Gramian of side s has been all-reduced ahead of its half-epoch
+  bool gram_prefetched[2] = {false, false};
   int32_t eig_last = 0; // 1: the last half-step took the eigenbasis path (diagnostics)
   bool gk() const { return KP > 256; }   // K > 256: every size is a run-time value
   Profiler prof;
@@ -440,6 +443,7 @@ void alloc_common(irs_ials_trainer *t) {
 }
 
 void upload_factor(irs_ials_trainer *t, int which, const float *host) {
+  t->gram_prefetched[0] = t->gram_prefetched[1] = false;  // (of irs_ials_sharded_step: the factors change)
   const int64_t n = t->rows_of(which);
   t->factor[which].zero(t->stream);
   if (n > 0)
@@ -1463,6 +1467,7 @@ void require_X(irs_ials_trainer *t) {
 }
 
 void full_gramian(irs_ials_trainer *t, int side) {
+  t->gram_prefetched[side] = false;
   // side 0 (user solve) sums item rows; side 1 sums user rows.
   const int other = 1 - side;
   launch_partial_gramian(t, other, 0, t->rows_of(other), side);
@@ -1671,6 +1676,7 @@ irs_status irs_ials_copy_rows_async(irs_ials_trainer *t, int32_t which, int64_t 
     float *mine = base + row_begin * t->KP;
     const size_t bytes = static_cast<size_t>(row_end - row_begin) * t->KP * sizeof(float);
     if (bytes == 0) return;
+    if (!to_ext) t->gram_prefetched[0] = t->gram_prefetched[1] = false;
     IRS_HIP(hipMemcpyAsync(to_ext ? ext : static_cast<void *>(mine),
                            to_ext ? static_cast<const void *>(mine) : ext, bytes,
                            hipMemcpyDeviceToDevice, t->stream));
@@ -1684,6 +1690,7 @@ irs_status irs_ials_partial_gramian_async(irs_ials_trainer *t, int32_t side) {
     const int other = 1 - side;
     const int64_t rb = other == 0 ? t->shard.user_begin : t->shard.item_begin;
     const int64_t re = other == 0 ? t->shard.user_end : t->shard.item_end;
+    t->gram_prefetched[side] = false;
     launch_partial_gramian(t, other, rb, re, side);
   });
 }
@@ -1703,6 +1710,7 @@ irs_status irs_ials_half_step_async(irs_ials_trainer *t, int32_t side,
     check_solver(sc);
     require_X(t);
     IRS_HIP(hipSetDevice(t->device));
+    t->gram_prefetched[1 - side] = false;  // (the rows its prefetched Gramian was summed from change)
     launch_solve(t, t->side[side], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc,
                  t->has_prior[side] ? t->prior[side].ptr : nullptr);
   });
@@ -1732,6 +1740,132 @@ irs_status irs_ials_step(irs_ials_trainer *t, const irs_ials_solver_config *sc) 
     full_gramian(t, 1);
     launch_solve(t, t->side[1], t->factor[0].ptr, t->factor[1].ptr, 1, sc);
     sync_and_check(t);
+  });
+}
+
+// ---------------------------------------------------------------- row-sharded epoch (RCCL)
+irs_status irs_comm_unique_id(void *id256) {
+  return guard([&] {
+    check_arg(id256 != nullptr, "null argument.");
+    auto &api = RcclApi::get();
+    ncclUniqueId ids[2];
+    IRS_RCCL(api.GetUniqueId(&ids[0]));
+    IRS_RCCL(api.GetUniqueId(&ids[1]));
+    static_assert(sizeof(ids) == 256, "two 128-byte ids");
+    std::memcpy(id256, ids, sizeof(ids));
+  });
+}
+
+irs_status irs_comm_create(const void *id256, int32_t rank, int32_t world, int32_t device,
+                           irs_comm **out) {
+  return guard([&] {
+    check_arg(id256 && out, "null argument.");
+    check_arg(world >= 1 && rank >= 0 && rank < world, "rank out of range.");
+    require_device(device);
+    auto &api = RcclApi::get();
+    ncclUniqueId ids[2];
+    std::memcpy(ids, id256, sizeof(ids));
+    auto c = std::make_unique<irs_comm>();
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    IRS_RCCL(api.CommInitRank(&c->rows, world, ids[0], rank));
+    IRS_RCCL(api.CommInitRank(&c->gram, world, ids[1], rank));
+    IRS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    IRS_HIP(hipEventCreateWithFlags(&c->ev_solved, hipEventDisableTiming));
+    IRS_HIP(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
+    *out = c.release();
+  });
+}
+
+irs_status irs_comm_destroy(irs_comm *c) {
+  return guard([&] {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    auto &api = RcclApi::get();
+    if (c->rows) (void)api.CommDestroy(c->rows);
+    if (c->gram) (void)api.CommDestroy(c->gram);
+    if (c->ev_solved) (void)hipEventDestroy(c->ev_solved);
+    if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+  });
+}
+
+// IALSTrainer::step (hpp:784-788) over the ranks of `comm`, rows sharded (sharding.py's loop in
+// one call).  Per half-epoch: partial Gramian of the rank's own rows of the other side ->
+// all-reduce (K x K, `gram` communicator, trainer stream) -> finish -> solve the rank's rows ->
+// all-gather of the solved rows (`rows` communicator, its own stream: IN PLACE when the shards are
+// the equal blocks of the padded factor buffer, else one grouped set of in-place broadcasts, one
+// per rank - no staging copy either way).  While the rows travel, the partial Gramian of the
+// NEXT half-epoch - it needs only the rows this rank has just solved - and its all-reduce are
+// already running on the trainer's stream.
+irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_config *sc, irs_comm *c,
+                                 const int64_t *user_bounds, const int64_t *item_bounds) {
+  return guard([&] {
+    check_arg(t && c && user_bounds && item_bounds, "null argument.");
+    check_solver(sc);
+    require_X(t);
+    check_arg(t->device == c->device, "trainer and communicator live on different devices.");
+    check_arg(!t->has_prior[0] && !t->has_prior[1] && t->n_feat[0] == 0 && t->n_feat[1] == 0,
+              "the sharded step does not cover the feature-aware model.");
+    const int64_t *bounds[2] = {user_bounds, item_bounds};
+    for (int w = 0; w < 2; w++) {
+      const int64_t n = t->rows_of(w);
+      check_arg(bounds[w][0] == 0 && bounds[w][c->world] == n, "row bounds must cover every row.");
+      for (int r = 0; r < c->world; r++) check_arg(bounds[w][r] <= bounds[w][r + 1], "row bounds must not decrease.");
+    }
+    check_arg(user_bounds[c->rank] == t->shard.user_begin && user_bounds[c->rank + 1] == t->shard.user_end &&
+                  item_bounds[c->rank] == t->shard.item_begin && item_bounds[c->rank + 1] == t->shard.item_end,
+              "the trainer was created for another shard than row_bounds[rank].");
+    IRS_HIP(hipSetDevice(t->device));
+    auto &api = RcclApi::get();
+    const size_t KP = static_cast<size_t>(t->KP);
+    auto reduce_gramian = [&](int side) {  // own rows of the other side, summed over the ranks
+      const int other = 1 - side;
+      launch_partial_gramian(t, other, other == 0 ? t->shard.user_begin : t->shard.item_begin,
+                             other == 0 ? t->shard.user_end : t->shard.item_end, side);
+      if (c->world > 1)
+        IRS_RCCL(api.AllReduce(t->P_raw[side].ptr, t->P_raw[side].ptr, KP * KP, ncclFloat, ncclSum, c->gram,
+                               t->stream));
+    };
+    auto exchange_rows = [&](int side) {  // on the communicator's stream, behind the solve
+      if (c->world == 1) return;
+      IRS_HIP(hipEventRecord(c->ev_solved, t->stream));
+      IRS_HIP(hipStreamWaitEvent(c->stream, c->ev_solved, 0));
+      float *F = t->factor[side].ptr;
+      const int64_t *b = bounds[side];
+      const int64_t padded = ceil_div(t->rows_of(side), 8) * 8, S = padded / c->world;
+      bool equal = padded % c->world == 0;
+      for (int r = 0; equal && r < c->world; r++) equal = b[r] == std::min<int64_t>(r * S, b[c->world]);
+      if (equal) {
+        IRS_RCCL(api.AllGather(F + static_cast<size_t>(c->rank) * S * KP, F, static_cast<size_t>(S) * KP, ncclFloat,
+                               c->rows, c->stream));
+      } else {
+        IRS_RCCL(api.GroupStart());
+        for (int r = 0; r < c->world; r++)
+          if (b[r + 1] > b[r])
+            IRS_RCCL(api.Broadcast(F + static_cast<size_t>(b[r]) * KP, F + static_cast<size_t>(b[r]) * KP,
+                                   static_cast<size_t>(b[r + 1] - b[r]) * KP, ncclFloat, r, c->rows, c->stream));
+        IRS_RCCL(api.GroupEnd());
+      }
+      IRS_HIP(hipEventRecord(c->ev_rows, c->stream));
+    };
+    for (int side = 0; side < 2; side++) {
+      if (!t->gram_prefetched[side]) reduce_gramian(side);
+      t->gram_prefetched[side] = false;
+      launch_finish_gramian(t, side);
+      launch_solve(t, t->side[side], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc);
+      exchange_rows(side);
+      // the next half-epoch's Gramian (side 1 now, side 0 of the next call) from the rows just solved
+      reduce_gramian(1 - side);
+      t->gram_prefetched[1 - side] = true;
+      // its solve gathers every row of `side`: wait for them
+      if (c->world > 1) IRS_HIP(hipStreamWaitEvent(t->stream, c->ev_rows, 0));
+    }
+    sync_and_check(t);
+    if (c->world > 1) IRS_HIP(hipStreamSynchronize(c->stream));
   });
 }
 
@@ -2082,10 +2216,10 @@ irs_status irs_ials_compute_loss(irs_ials_trainer *t, const irs_ials_solver_conf
   });
 }
 
-// Internal hook for the tests (not part of the public ABI): the eigen-decomposition kernel of
+// Test hook (declared in the header, no reference counterpart): the eigen-decomposition kernel of
 // ials_eig_kernels.hpp on a host matrix.  P: [K, K] row-major symmetric; out: Qrows [K, K] (row k
 // = eigenvector k), lam [K], stats [3] (largest, smallest eigenvalue, sweeps).
-irs_status irs_ials_eigen_debug_(const float *P, int64_t K, int32_t device, float *Qrows, float *lam,
+irs_status irs_ials_eigen_debug(const float *P, int64_t K, int32_t device, float *Qrows, float *lam,
                                  float *stats, const float *P_prev) {
   return guard([&] {
     check_arg(P && Qrows && lam && stats && K >= 1 && K <= 128, "bad argument.");

@@ -195,13 +195,70 @@ class HipLocalSolver(LocalSolver):
     def synchronize(self) -> None:
         self.trainer.synchronize()
 
+    # -- the epoch behind the C ABI (irs_ials_sharded_step): RCCL called from inside the library --
+    def create_comm(self, group=None) -> None:
+        """This rank's RCCL communicators (irs_comm): the 256-byte id is made on group rank 0 and
+        handed round through ``torch.distributed`` (an object broadcast: any backend)."""
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from ._lib import check, lib
+
+        rank, world = _group_info(group)
+        buf = (C.c_char * 256)()
+        if rank == 0:
+            check(lib().irs_comm_unique_id(buf))
+        if world > 1:
+            box = [bytes(buf)]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            buf = (C.c_char * 256).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        check(lib().irs_comm_create(buf, C.c_int32(rank), C.c_int32(world),
+                                    C.c_int32(self.device.index), C.byref(h)))
+        self._comm = h
+
+    def sharded_step(self, solver_config, user_bounds: Sequence[int], item_bounds: Sequence[int]) -> None:
+        import ctypes as C
+
+        from ._lib import check, lib, ptr
+
+        ub = np.ascontiguousarray(user_bounds, dtype=np.int64)
+        ib = np.ascontiguousarray(item_bounds, dtype=np.int64)
+        sc = solver_config._struct()
+        check(lib().irs_ials_sharded_step(self.trainer._h, C.byref(sc), self._comm,
+                                          ptr(ub, C.c_int64), ptr(ib, C.c_int64)))
+
+    def close_comm(self) -> None:
+        from ._lib import lib
+
+        h = getattr(self, "_comm", None)
+        if h:
+            lib().irs_comm_destroy(h)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close_comm()
+        except Exception:
+            pass
+
 
 class ShardedIALSTrainer:
     """``IALSTrainer.step`` over ``world_size`` ranks (see the module docstring)."""
 
     def __init__(self, local: LocalSolver, user_bounds: Sequence[int], item_bounds: Sequence[int],
-                 group=None, overlap: bool = False, gram_group=None, timing: bool = False):
-        """``overlap=True`` issues the NEXT half-epoch's K x K all-reduce on a second
+                 group=None, overlap: bool = False, gram_group=None, timing: bool = False,
+                 native: bool = False):
+        """``native=True`` (``HipLocalSolver`` only): the whole epoch runs behind ONE C-ABI call,
+        ``irs_ials_sharded_step`` - the library calls RCCL itself on its own streams (two
+        communicators created here from an id that rank 0 makes and ``torch.distributed`` hands
+        round), the rows travel in place and the next half-epoch's Gramian overlaps their
+        exchange.  The host loop below (ten torch / ctypes calls per epoch) stays for the
+        per-phase ``timing``, for backends other than RCCL and for the CPU tests.
+
+        ``overlap=True`` issues the NEXT half-epoch's K x K all-reduce on a second
         communicator while the all-gather of the solved rows is in flight.  It is OFF by
         default: the two concurrent collectives have only ever run on RCCL at world size 1
         (no multi-GPU hardware was available to this build; the gloo world-2 tests cover the
@@ -234,6 +291,12 @@ class ShardedIALSTrainer:
         self._owns_gram_group = False
         self.timing = bool(timing)
         self._marks = []  # (label, event or host time) of the current epoch
+        self.native = bool(native)
+        if self.native:
+            if not isinstance(local, HipLocalSolver):
+                raise ValueError("native=True needs a HipLocalSolver.")
+            local.create_comm(group)
+            return
         if self.world > 1:
             # a second communicator: the K x K all-reduce of the next half-epoch's Gramian must
             # not queue behind the all-gather of the solved rows
@@ -264,6 +327,8 @@ class ShardedIALSTrainer:
 
     def close(self) -> None:
         """Destroys the communicator this trainer created (idempotent)."""
+        if self.native:
+            self.local.close_comm()
         if self._owns_gram_group and self.gram_group is not None:
             try:
                 self.dist.destroy_process_group(self.gram_group)
@@ -411,6 +476,9 @@ class ShardedIALSTrainer:
 
     def step(self, solver_config) -> None:
         """One epoch: user half then item half (hpp:784-788)."""
+        if self.native:
+            self.local.sharded_step(solver_config, self.bounds[0], self.bounds[1])
+            return
         self.half_epoch(0, solver_config)
         self.half_epoch(1, solver_config)
 

@@ -170,4 +170,7 @@ def assert_float64_bar(gpu, oracle32, ref64, what: str, test: str = "", rtol: fl
     assert np.isfinite(e_gpu).all(), what
     assert e_gpu.max() <= max(rtol, slack * e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))
     if e_gpu.size >= 1000:  # (of a few dozen rows the 99.9 % quantile IS the worst row)
-        assert q(e_gpu, 0.999) <= rtol, (what, q(e_gpu, 0.999))
+        # (... and never asked to be closer to float64 than the float32 oracle itself manages: the
+        # configs[3] users whose solution has norm 1e-7 next to a warm start of norm 1e-3 lose 3-4
+        # digits to cancellation in ANY float32 evaluation - oracle p99.9 1.6e-4, GPU 1.2e-4)
+        assert q(e_gpu, 0.999) <= max(rtol, q(e_orc, 0.999)), (what, q(e_gpu, 0.999), q(e_orc, 0.999))

@@ -7,9 +7,11 @@ full configs[3] matrix (10 M x 1 M, 95 M stored entries, K = 128).  On the ML-20
 row is compared with the CPU oracle (K = 64 and K = 256 factors, all 26,744 kNN rows); on the
 10 M-user matrix every row the kernels treat specially (all split rows, the longest unsplit
 rows) plus 20,000 random ones.  Every comparison appends its ACHIEVED errors to
-gpurun_out/parity_gpu.jsonl (conftest.record_parity; tracked copy profiles/parity_r03.json).
+gpurun_out/parity_gpu.jsonl (conftest.record_parity; tracked copy profiles/parity_r04.json).
 
-Bars: factors per row ``||gpu_r - oracle_r|| / ||oracle_r|| < 1e-4`` (north_star); kNN indices
+Bars: factors per row, with float64 as the arbiter of EVERY row (round 4: the oracle's sources
+compiled with Real = double): the GPU's worst row no farther from float64 than the float32
+oracle's worst row (or 1e-4), 99.9 % of its rows within 1e-4 (assert_rows_match); kNN indices
 bit-exact, values 1e-12; evaluator counters and histogram bit-exact, fp64 sums 1e-12.
 Reference semantics: IALSTrainer.hpp:273-331 (Cholesky), :170-271 (CG), knn.hpp:111-136,
 evaluator.cpp:292-367.
@@ -21,7 +23,7 @@ import pytest
 import scipy.sparse as sps
 
 import oracle as O
-from conftest import record_parity, row_rel_err
+from conftest import assert_float64_bar, record_parity, row_rel_err, rows_vs_float64
 from irspack_amd.evaluation._core_evaluator import EvaluatorCore
 from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder, IALSSolverConfigBuilder,
                                                   IALSTrainer, SolverType)
@@ -75,96 +77,36 @@ def row_sample(Xs, n_random, seed, chunk=1024, n_longest_unsplit=64):
     return np.unique(np.concatenate([split, longest, rnd])), split
 
 
-def cg_float64(A, b, x0, steps):
-    """step_cg (hpp:199-264) in float64: the exact-arithmetic value of what GPU and oracle compute"""
-    x = x0.copy()
-    r = b - A @ x
-    p = r.copy()
-    for _ in range(steps):
-        r2 = r @ r
-        if r2 <= 1e-20:
-            break
-        Ap = A @ p
-        alpha = r2 / (p @ Ap)
-        x += alpha * p
-        r -= alpha * Ap
-        r2n = r @ r
-        if r2n <= 1e-20:
-            break
-        p = r + (r2n / r2) * p
-    return x
-
-
-def rows_float64(kind, Xs, rows, tgt0, oth0, alpha0=ALPHA0, reg=REG):
-    """float64 evaluation of the half-step for a few rows (unit confidences, loss IALSPP)"""
+def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alpha0=ALPHA0, reg=REG,
+                      slack=1.0):
+    """EVERY row against the float64 arbiter (round 4).  `want` are the float32 oracle's rows; the
+    SAME restatement compiled with Real = double (oracle/liboracle_f64.so, `make -C oracle f64`:
+    same iteration, exits and float regulariser, factors / Gramian / every intermediate in float64)
+    evaluates all of `rows`, and both float32 implementations are measured against it:
+      * the GPU's worst row is no farther from float64 than the oracle's worst row (or RTOL,
+        whichever is larger; `slack` > 1 only where the two maxima are a handful of rows of a
+        noisy tail: the configs[3] rows of norm 1e-7 next to a warm start of norm 1e-3);
+      * 99.9 % of the GPU's rows are within RTOL of float64.
+    Two correct float32 implementations cannot agree to 1e-4 on every row - under truncated CG
+    the oracle's sequential sums over rows of 10^4 entries are up to 2e-3 from exact arithmetic -
+    which is why float64, not the float32 oracle, is the yardstick.  The achieved distributions
+    (gpu_vs_f64, oracle_f32_vs_f64, gpu_vs_oracle_f32) go to the parity log."""
     K = oth0.shape[1]
-    O64 = oth0.astype(np.float64)
-    P = alpha0 * O64.T @ O64
-    out = np.empty((len(rows), K))
-    for j, r in enumerate(rows):
-        sl = slice(Xs.indptr[r], Xs.indptr[r + 1])
-        V = O64[Xs.indices[sl]]
-        reg_r = np.float32(reg) * (np.float32(alpha0) * np.float32(Xs.shape[1]) + np.float32(sl.stop - sl.start))
-        A = P + V.T @ V + float(reg_r) * np.eye(K)
-        b = V.sum(axis=0)
-        out[j] = np.linalg.solve(A, b) if kind == "CHOLESKY" else cg_float64(A, b, tgt0[r].astype(np.float64), 3)
-    return out
-
-
-FAR_FRACTION = 1e-3  # at most 0.1 % of the compared rows may be farther than RTOL from float64
-
-
-def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alpha0=ALPHA0, reg=REG):
-    """Per row: within RTOL of the oracle.  Where it is not, the float64 evaluation of the same
-    algorithm arbitrates: under truncated CG (and for rows with thousands of stored entries) a
-    float32 implementation's own rounding - the CPU restatement's sequential accumulation of the
-    matrix-free product like the reference's loop hpp:222-247, the GPU's MFMA partial sums - is
-    up to ~3e-4 (the oracle on rows of 10^4 entries: 2e-3) away from exact arithmetic on the
-    worst rows, so two correct float32 implementations cannot agree to 1e-4 on every row.
-    Rules, with EVERY row compared:
-      * the rows that differ from the oracle by more than RTOL (at most 5 %: the arbiter must
-        stay affordable) are evaluated in float64;
-      * on those rows the GPU must be within 5 RTOL of the float64 result, at most
-        FAR_FRACTION of all rows - or as many as the oracle itself has - may be farther than
-        RTOL from it, and its worst row must be no farther from float64 than three times the
-        oracle's worst row (the two tails are different rows: the comparison is between the
-        distributions, not row by row).
-    The achieved figures go to the parity log whatever the outcome."""
-    num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
-    den = np.linalg.norm(want.astype(np.float64), axis=1)
-    err = num / np.maximum(den, 1e-6 * den.max())
-    far = np.flatnonzero(~(err < RTOL))
-    rec = dict(n_rows=int(len(rows)), worst_row_err=float(err.max()), median_row_err=float(np.median(err)),
-               p999_row_err=float(np.quantile(err, 0.999)), worst_row=int(rows[int(np.argmax(err))]),
-               worst_row_nnz=int(np.diff(Xs.indptr)[rows[int(np.argmax(err))]]),
-               n_rows_over_1e_4=int(far.size), worst_vs_float64=None, oracle_vs_float64=None)
-    e_gpu = e_orc = None
-    if 0 < far.size <= max(50, 0.05 * len(rows)):
-        ref = rows_float64(kind, Xs, rows[far], tgt0, oth0, alpha0, reg)
-        nref = np.linalg.norm(ref, axis=1)
-        e_gpu = np.linalg.norm(got[far] - ref, axis=1) / nref
-        e_orc = np.linalg.norm(want[far] - ref, axis=1) / nref
-        rec.update(worst_vs_float64=float(e_gpu.max()), oracle_vs_float64=float(e_orc.max()),
-                   n_rows_gpu_over_1e_4_vs_float64=int((e_gpu >= RTOL).sum()),
-                   n_rows_oracle_over_1e_4_vs_float64=int((e_orc >= RTOL).sum()))
-    record_parity(test or "fullsize", str(what), **rec)
-    assert far.size <= max(50, 0.05 * len(rows)), (what, far.size, float(err.max()))
-    if far.size:
-        # (5 RTOL: the worst rows are those where three CG steps have NOT converged - ML-20M user
-        # 38077: ||r||^2 = 32, 67, 1.7, 19 over the steps, 8 % from the solution - and the
-        # iteration amplifies any float32 rounding by the conditioning, for GPU and oracle
-        # alike: 1.6e-4 .. 3.7e-4 from float64 for either, run to run; scripts/debug/cg_row_probe.py)
-        # (... and never asked to be closer to float64 than the oracle itself manages: its
-        # sequential float32 sums over rows of 10^4 entries reach 1e-3 .. 2e-3)
-        assert e_gpu.max() < max(5 * RTOL, e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))
-        # (rows of norm ~1e-7 next to a warm start of norm ~1e-3 lose 3-4 digits to cancellation
-        # in ANY float32 evaluation: the oracle's own count is the yardstick there)
-        assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows), (e_orc >= RTOL).sum()), (
-            what, int((e_gpu >= RTOL).sum()), int((e_orc >= RTOL).sum()))
-        # (three times: the tails are a handful of rows - 3 or 4 of 200,000 on the configs[3]-like
-        # matrix - and the ratio of two such maxima moves between 0.7 and 2.1 from run to run)
-        assert e_gpu.max() <= max(3 * e_orc.max(), RTOL), (what, float(e_gpu.max()), float(e_orc.max()))
-    return float(err.max()), int(far.size)
+    _, _, omc, osc = configs(K, kind, alpha0, reg)
+    if kind == "CG":
+        # Truncated CG: a handful of rows per 10^5 have NOT converged after three steps (ML-20M
+        # user 38077, 142 entries: ||r||^2 = 32, 67, 1.7, 19) and amplify any float32 rounding by
+        # their conditioning - 2e-4 .. 4e-4 from float64 for the oracle and for the GPU alike, on
+        # different rows, run to run.  The two maxima are single rows of those tails: the GPU's may
+        # be up to twice the oracle's; the 99.9 % bar and the counts in the log are the
+        # distribution-level statement (GPU p99.9 1.2e-5 against the oracle's 3.1e-5 at K = 64).
+        slack = max(slack, 2.0)
+    ref64 = O.ials_solver_step_f64(tgt0[rows], Xs[rows], oth0, None, omc, osc, CORES)
+    nnz = np.diff(Xs.indptr)[rows]
+    e_gpu, _ = rows_vs_float64(got, want, ref64)
+    assert_float64_bar(got, want, ref64, str(what), test=test or "fullsize", rtol=RTOL, slack=slack,
+                       worst_row=int(rows[int(np.argmax(e_gpu))]), worst_row_nnz=int(nnz[int(np.argmax(e_gpu))]))
+    return float(e_gpu.max()), int((e_gpu >= RTOL).sum())
 
 
 def oracle_rows(target0, Xs, rows, other0, omc, osc):
@@ -377,7 +319,7 @@ def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
         want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
         assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
                           f"c4_small (200k x 20k) K=128 {kind} {'user' if side == 0 else 'item'} half, all rows",
-                          test="test_ials_k128_c4_like_short_rows_vs_oracle")
+                          test="test_ials_k128_c4_like_short_rows_vs_oracle", slack=3.0)
         assert np.isfinite(got).all()
 
 
@@ -472,7 +414,7 @@ def test_ials_k128_c4_full_matrix_vs_oracle(XC4, kind):
         assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
                           f"c4 FULL (10M x 1M, nnz={X.nnz}) K=128 {kind} {'user' if side == 0 else 'item'} half, "
                           f"{split.size} split rows + 64 longest + 20k random",
-                          test="test_ials_k128_c4_full_matrix_vs_oracle")
+                          test="test_ials_k128_c4_full_matrix_vs_oracle", slack=3.0)
         del got, want
 
 
@@ -500,11 +442,10 @@ def test_ials_k64_bf16x3_rank_update_is_fp32_accurate(X20, X20t, monkeypatch):
         assert_rows_match(kind, got16[rows], want, Xs, rows, tgt0, oth0,
                           f"ml20m K=64 bf16x3 rank update {'user' if side == 0 else 'item'} half, sample",
                           test="test_ials_k64_bf16x3_rank_update_is_fp32_accurate")
-        sub = rows[:: max(1, len(rows) // 300)]  # ~300 rows against float64
-        ref = rows_float64(kind, Xs, sub, tgt0, oth0)
-        nref = np.linalg.norm(ref, axis=1)
-        e32 = np.linalg.norm(got32[sub] - ref, axis=1) / nref
-        e16 = np.linalg.norm(got16[sub] - ref, axis=1) / nref
+        # and against the float64 arbiter: the bf16x3 path next to the fp32 path, all sampled rows
+        ref = O.ials_solver_step_f64(tgt0[rows], Xs[rows], oth0, None, omc, osc, CORES)
+        e32, _ = rows_vs_float64(got32[rows], want, ref)
+        e16, _ = rows_vs_float64(got16[rows], want, ref)
         assert e16.max() < 2 * e32.max() + 1e-6, (side, float(e16.max()), float(e32.max()))
         assert np.median(e16) < 2 * np.median(e32) + 1e-7, (side, float(np.median(e16)), float(np.median(e32)))
 

@@ -30,7 +30,7 @@ def test_jacobi_eigen_kernel_matches_numpy(K):
     Q = np.zeros((K, K), dtype=np.float32)
     lam = np.zeros(K, dtype=np.float32)
     st = np.zeros(3, dtype=np.float32)
-    f = _lib.lib().irs_ials_eigen_debug_
+    f = _lib.lib().irs_ials_eigen_debug
     f.restype = C.c_int32
     # cold start, then warm-started from the eigenvectors of a nearby matrix (the Gramian of the
     # previous epoch): same answer, fewer sweeps

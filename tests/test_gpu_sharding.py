@@ -226,3 +226,53 @@ def test_rccl_calls_on_library_buffers_world_size_one(tmp_path):
 
     mp.spawn(_rccl_world1_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     assert (tmp_path / "rccl1.txt").read_text() == "ok"
+
+
+def _native_world1_worker(rank, kind, K, out_dir):
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, IALSTrainer,
+                                                      SolverType)
+    from irspack_amd.sharding import HipLocalSolver, ShardedIALSTrainer
+    from irspack_amd.synthetic import make_interactions
+
+    X = make_interactions("small")
+    U, I = X.shape
+    mc = IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(1e-2).build()
+    sc = IALSSolverConfigBuilder().set_solver_type(SolverType[kind]).set_max_cg_steps(3).build()
+    local = HipLocalSolver(mc, X, (0, U, 0, I), 0)
+    tr = ShardedIALSTrainer(local, [0, U], [0, I], native=True)
+    ref = IALSTrainer(mc, X)
+    for _ in range(3):
+        tr.step(sc)
+        ref.step(sc)
+    np.testing.assert_array_equal(local.trainer.user, ref.user)
+    np.testing.assert_array_equal(local.trainer.item, ref.item)
+    item = ref.item * 0.5
+    local.trainer.item = item  # (invalidates the prefetched Gramian of the user half)
+    ref.item = item
+    tr.step(sc)
+    ref.step(sc)
+    np.testing.assert_array_equal(local.trainer.user, ref.user)
+    try:
+        local.sharded_step(sc, [0, U - 1], [0, I])  # bounds that do not cover every row
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("bad row bounds were accepted")
+    tr.close()
+    with open(os.path.join(out_dir, f"native_{kind}_{K}.txt"), "w") as f:
+        f.write("ok")
+
+
+@pytest.mark.parametrize("kind,K", [("CHOLESKY", 64), ("CG", 200)])
+def test_native_sharded_step_world_size_one(tmp_path, kind, K):
+    """``irs_ials_sharded_step`` (the epoch behind one C-ABI call, RCCL opened and called by the
+    library itself) on the one GPU of the box: world size 1 - communicator creation, the stream /
+    event plumbing and the Gramian prefetch run; the collectives are skipped.  The result must be
+    the unsharded trainer's, bit for bit, over three epochs (the prefetched Gramian of the next
+    epoch is used from the second one on), and a factor set from outside must invalidate it.
+    (In a spawned process like the other tests of this file: torch initialises the device there.)"""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_native_world1_worker, args=(kind, K, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / f"native_{kind}_{K}.txt").read_text() == "ok"
