@@ -422,6 +422,19 @@ def evaluator_leg(X, trainer, K, ceilings):
         m = ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
         walls.append(time.perf_counter() - t0)  # the mask is resident, as in a tuning loop
     wall = min(walls)
+    # (the default re-hashes every byte of the resident mask on every call - an in-place edit must
+    # not go unnoticed; a tuning loop that treats its mask as immutable opts out)
+    type(ev).strict_mask_fingerprint = False
+    try:
+        ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
+        sampled = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ev.get_metrics_ials(trainer, 0, U, mask, 20, 0, False)
+            sampled.append(time.perf_counter() - t0)
+    finally:
+        type(ev).strict_mask_fingerprint = True
+    wall_sampled = min(sampled)
     # The call no longer computes the dense contraction: the norm bound leaves a few percent of
     # the 64 x 64 score tiles (same lists, tests/test_gpu_fullsize.py).  `scores_per_s` stays
     # the dense-equivalent rate (what a caller gets); the roofline is priced on the flops the
@@ -436,6 +449,9 @@ def evaluator_leg(X, trainer, K, ceilings):
                      f"ground truth = 20 % per-row hold-out ({gt.nnz} entries), mask = the other 80 %"),
         "wall_s_first_call_incl_mask_upload": wall_first,
         "wall_s_incl_pcie": wall, "users_per_s": U / wall,
+        "wall_s_sampled_mask_fingerprint": wall_sampled, "users_per_s_sampled_mask_fingerprint": U / wall_sampled,
+        "mask_check": ("default: every byte of the resident mask hashed per call (xxh3 / CRC-32); "
+                       "EvaluatorCore.strict_mask_fingerprint = False: 1024-sample fingerprint"),
         "scores_per_s": U * float(I) / wall, "ndcg@20": m.as_dict()["ndcg"],
         "device_path": st,
         "model": "iALS fitted on the training entries (the mask) only: 3 CG epochs",

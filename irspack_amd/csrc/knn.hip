@@ -54,7 +54,10 @@ struct Params {
   const double *t_val;
   const double *t_stat;       // per target row (norm / pow / count), see epilogue
   const double *t_scale;      // per target row: power of two that maps its products to the
-                              // 64-bit fixed-point accumulators (weighted paths)
+                              // 64-bit fixed-point accumulators (weighted paths); NEGATIVE: the
+                              // row's products span a wide range - two limbs, see `hi_stash`
+  uint64_t *hi_stash;         // [workgroups x TILE]: the first limbs of a wide-range pair while the
+                              // second ones are accumulated
   const int32_t *row_order;   // work-sorted list of target rows of this call
   int32_t n_rows;             // rows in this call
   int32_t n_tiles;
@@ -253,7 +256,16 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   //      spends ~16 instructions: positions are 32-bit (nnz < 2^31), bounds travel by
   //      v_readlane, the column fields are stored as LDS byte offsets (column * 4) and the
   //      atomic is issued by every lane (lanes outside the slice add to their sink).
-  const double fx_scale = ACC32 ? 1.0 : p.t_scale[r];
+  // Wide-range rows (weights spanning many decades: tf-idf / BM25 / RP3beta powers on large
+  // matrices): one scale per row leaves a column whose sum is tiny next to the row's bound with
+  // few significant bits.  Their sums are kept in TWO 64-bit limbs - q_hi = round(v 2^s) as always,
+  // q_lo = round((v 2^s - q_hi) 2^40) - accumulated in two passes over the same slices into the
+  // same LDS block (the first limbs wait in global scratch meanwhile): integer adds, so still
+  // independent of the order of arrival, and 2^-40 of the one-limb rounding step.
+  const double ts_ = ACC32 ? 1.0 : p.t_scale[r];
+  const bool wide = !ACC32 && ts_ < 0.0;
+  const double fx_scale = ACC32 ? 1.0 : fabs(ts_);
+  int pass = 0;
   auto add = [&](uint32_t off4, bool ok, double v) {
     if (ACC32) {
       // (lanes outside their slice are masked off - v_cmp + exec save / restore on the scalar unit,
@@ -268,10 +280,13 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       // * 2^-(s+1).  With the sentinel (positive data) a product never rounds to 0: the
       // column must leave the "untouched" pattern.
       const uint32_t a = ok ? 2 * off4 : SINK_BYTES + 8 * lane;
-      long long q = __double2ll_rn(v * fx_scale);
+      const double scaled = v * fx_scale;  // (a power of two: exact)
+      long long q = __double2ll_rn(scaled);
       if (SENTINEL) q = q == 0 ? 1 : q;
+      // second limb: what the first one left out (|scaled - q| <= 1; above 2^53 both are the same integer)
+      if (pass == 1) q = __double2ll_rn((scaled - static_cast<double>(q)) * 0x1p40);
       atomicAdd(reinterpret_cast<unsigned long long *>(smem + a), static_cast<unsigned long long>(q));
-      if (!SENTINEL && ok) {
+      if (!SENTINEL && ok && pass == 0) {
         const uint32_t j = off4 >> 2, bit = 1u << (j & 31);
         if (!(bits[j >> 5] & bit)) atomicOr(&bits[j >> 5], bit);
       }
@@ -401,6 +416,16 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   // loads are issued with every batch (their results are used when the block advances): a
   // load under a branch would make hipcc drain the queue.
   const int64_t q00 = tb + 16 * wv;
+  uint64_t *const stash = ACC32 ? nullptr : p.hi_stash + static_cast<size_t>(blockIdx.x) * TILE;
+  for (pass = 0; pass < (wide ? 2 : 1); pass++) {
+  if (!ACC32 && pass == 1) {  // first limbs out, accumulators back to zero
+    __syncthreads();
+    for (int i = tid; i < width; i += THREADS) {
+      stash[i] = static_cast<uint64_t>(__double_as_longlong(acc[i]));
+      acc[i] = 0.0;
+    }
+    __syncthreads();
+  }
   if (q00 < te) {
     Block A, B;
     int64_t uA, uB, uC;
@@ -463,6 +488,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       if (one_batch(w1, w0)) break;
     }
   }
+  }  // pass
   // (the column norms of this thread's first eight columns are fetched while the slower
   // waves finish accumulating)
   constexpr int PER = TILE / THREADS;  // 16
@@ -772,8 +798,13 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       } else {
         // fixed-point sum -> double (one rounding).  Sentinel: the accumulator started at the
         // bit pattern of -0.0 = INT64_MIN, the sum is the difference.
-        const uint64_t fx = static_cast<uint64_t>(__double_as_longlong(acc[min(i, TILE - 1)]));
-        raw[k] = static_cast<double>(static_cast<long long>(fx ^ (SENTINEL ? NEG_ZERO_BITS : 0ull))) *
+        uint64_t fx = static_cast<uint64_t>(__double_as_longlong(acc[min(i, TILE - 1)]));
+        double low = 0.0;
+        if (wide) {  // (block-uniform) the accumulator holds the second limb, the stash the first
+          low = static_cast<double>(static_cast<long long>(fx)) * 0x1p-40;
+          fx = stash[min(i, TILE - 1)];
+        }
+        raw[k] = (static_cast<double>(static_cast<long long>(fx ^ (SENTINEL ? NEG_ZERO_BITS : 0ull))) + low) *
                  fx_inv;
         const bool st = SENTINEL ? fx != NEG_ZERO_BITS
                                  : ((bits[min(i, TILE - 1) >> 5] >> (i & 31)) & 1u) != 0u;
@@ -1213,6 +1244,7 @@ struct irs_knn_computer {
   bool xt_nonzero = false;  // |x| in (1e-150, 1e150) for every stored x
   bool xt_positive = false; // every stored x > 0
   std::vector<double> xt_rowmax;  // host: max |x| per feature row (bound of a target row's sums)
+  std::vector<double> xt_rowmin;  // host: min |x| per feature row (smallest product of a target row)
   // last result (host)
   std::vector<int64_t> res_ptr;
   DeviceBuffer<int32_t> res_idx;  // the last result stays on the device until irs_knn_fetch
@@ -1226,6 +1258,7 @@ struct irs_knn_computer {
     DeviceBuffer<int64_t> t_ptr, res_ptr;
     DeviceBuffer<int32_t> t_idx, order, cand_idx, cand_cnt, out_idx, out_cnt, cursor, slot_of, redo_list;
     DeviceBuffer<double> t_val, t_stat, t_scale, cand_val, out_val;
+    DeviceBuffer<uint64_t> hi_stash;
   } scratch;
 };
 
@@ -1347,6 +1380,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     };
     c->xt_row_len.resize(Xt.rows);
     c->xt_rowmax.assign(Xt.rows, 0.0);
+    c->xt_rowmin.assign(Xt.rows, 0.0);
     hipStream_t s = nullptr;
     const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
     check_arg(xt_nnz < (int64_t(1) << 31) - 1024, "nnz must be below 2^31.");
@@ -1363,16 +1397,18 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       bool ones = true, safe = true, pos = true;
       for (int64_t u = blk[k]; u < blk[k + 1]; u++) {
         c->xt_row_len[u] = Xt.indptr[u + 1] - Xt.indptr[u];
-        double mx = 0.0;
+        double mx = 0.0, mn = std::numeric_limits<double>::infinity();
         for (int64_t q = Xt.indptr[u]; q < Xt.indptr[u + 1]; q++) {
           const double v = Xt.data[q], a = std::fabs(v);
           mx = std::max(mx, a);
+          if (a > 0.0) mn = std::min(mn, a);
           ones &= v == 1.0;
           safe &= a > 1e-150 && a < 1e150;
           pos &= v > 0.0;
           idx16[q] = static_cast<uint16_t>((Xt.indices[q] % TILE) * 4);
         }
         c->xt_rowmax[u] = mx;
+        c->xt_rowmin[u] = std::isfinite(mn) ? mn : 0.0;
         const int32_t *b = Xt.indices.data() + Xt.indptr[u], *e = Xt.indices.data() + Xt.indptr[u + 1];
         uint32_t *dst = tptr.data() + u * (n_tiles + 1);
         for (int64_t t = 0; t < n_tiles; t++)
@@ -1492,7 +1528,11 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     // threads below cut [e_begin, e_end) by lower_bound, which on a non-monotone array yields
     // rows whose entries lie outside that range (an out-of-bounds host read instead of this error)
     for (int64_t i = row_begin; i < row_end; i++) check_arg(ip[i + 1] >= ip[i], "malformed indptr.");
-    std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0);
+    std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0), any_wide(0);
+    // IRSPACK_AMD_KNN_WIDE: 0 = never two limbs (A/B), 1 = every weighted row (tests); else by range
+    const char *wide_env = std::getenv("IRSPACK_AMD_KNN_WIDE");
+    const bool wide_ok = !(wide_env && wide_env[0] == '0');
+    const double wide_ratio = (wide_env && wide_env[0] == '1') ? 0.0 : 2.3e5;
     // The row pointers and column indices of the call's rows travel to the device on a second
     // host thread while this one walks them (the values follow later, and only if the kernel
     // reads them).  An index out of range is found by the walk below before any kernel runs.
@@ -1544,7 +1584,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         const bool unit = binarise || chunk_ones;
         for (int64_t i = r0; i < r1; i++) {
           if (ip[i + 1] < ip[i]) { bad = true; break; }
-          double ss = 0, bound = 0;
+          double ss = 0, bound = 0, minprod = std::numeric_limits<double>::infinity();
           int64_t w = 0;
           if (unit) {
             if (cols <= 0 && ip[i + 1] > ip[i]) { bad = true; break; }
@@ -1556,6 +1596,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
               const int32_t jc = std::min(std::max(j, 0), static_cast<int32_t>(cols - 1));
               w += c->xt_row_len[jc];
               bound += c->xt_rowmax[jc];
+              if (c->xt_rowmin[jc] > 0.0) minprod = std::min(minprod, c->xt_rowmin[jc]);
             }
             if (lo_j < 0 || hi_j >= cols) { bad = true; break; }
             ss = static_cast<double>(ip[i + 1] - ip[i]);
@@ -1571,6 +1612,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
               const double ax = std::fabs(x);
               safe &= ax > 1e-150 && ax < 1e150;  // no stored zero, no underflow of x * y
               bound += ax * c->xt_rowmax[j];      // >= |any sum of this product row|
+              if (ax > 0.0 && c->xt_rowmin[j] > 0.0) minprod = std::min(minprod, ax * c->xt_rowmin[j]);
             }
           }
           if (bad) break;
@@ -1589,6 +1631,14 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
             int ex = 0;
             (void)std::frexp(bound, &ex);  // bound < 2^ex
             tscale[i - row_begin] = std::ldexp(1.0, 61 - ex);
+            // One limb rounds every product to a multiple of 2^-s ~ bound 2^-61: 1e-13 of the row's
+            // smallest possible product as long as bound / minprod < 2.3e5.  Beyond that (weights
+            // over many decades, very long rows) the row is summed in two limbs (negative scale):
+            // twice the accumulation time, 2^-40 of the rounding step.
+            if (wide_ok && std::isfinite(minprod) && bound > wide_ratio * minprod) {
+              tscale[i - row_begin] = -tscale[i - row_begin];
+              any_wide.store(1, std::memory_order_relaxed);
+            }
           }
         }
         if (!positive) not_positive.store(1);
@@ -1682,6 +1732,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     p.t_val = t_val.ptr;
     p.t_stat = t_stat.ptr;
     p.t_scale = t_scale.ptr;
+    p.hi_stash = nullptr;
     p.row_order = d_order.ptr;
     p.n_rows = static_cast<int32_t>(n);
     p.n_tiles = n_tiles;
@@ -1722,6 +1773,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     }
     p.n_slots = static_cast<int32_t>(slots);
     const unsigned grid = static_cast<unsigned>(std::min<size_t>(slots, static_cast<size_t>(std::max(n_cu, 1))));
+    if (!acc32 && any_wide.load()) {  // first limbs of the wide-range pairs, one tile per resident workgroup
+      sc.hi_stash.alloc(static_cast<size_t>(grid) * TILE);
+      p.hi_stash = sc.hi_stash.ptr;
+    }
     auto launch = [&](auto kernel) {
       IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,

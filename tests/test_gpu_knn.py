@@ -421,3 +421,45 @@ def test_adversarial_exact_ties_with_weights():
             np.testing.assert_array_equal(got.data, want.data)
         else:
             np.testing.assert_allclose(got.data, want.data, rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("mode", ["by_range", "forced", "off"])
+def test_weights_over_twelve_decades_keep_their_small_sums(mode, monkeypatch):
+    """Weights from 1e-6 to 1e6 in one matrix: a column whose sum is 1e-12 of its row's largest
+    possible sum has few significant bits left in a one-limb fixed-point accumulator (one scale per
+    row).  Such rows are summed in TWO 64-bit limbs (two passes over the slices, the second one
+    accumulating what the first rounding left out): values within 1e-12 of the oracle's float64
+    sums for every stored column, bit-identical from run to run, top-k sets equal.  "off"
+    (IRSPACK_AMD_KNN_WIDE=0, the one-limb sums) shows that the case is real: its small sums are
+    NOT within 1e-12."""
+    if mode != "by_range":
+        monkeypatch.setenv("IRSPACK_AMD_KNN_WIDE", "1" if mode == "forced" else "0")
+    rng2 = np.random.default_rng(9)
+    U, I = 1500, 900
+    mask = rng2.random((U, I)) < 0.03
+    decades = rng2.integers(-6, 7, size=I)  # one magnitude per item: products span 1e-12 .. 1e12
+    W = np.where(mask, rng2.uniform(1.0, 9.0, size=(U, I)) * 10.0 ** decades[None, :], 0.0)
+    arg = sps.csr_matrix(W.T)            # items x users, weighted
+    tgt = sps.csr_matrix(W.T)            # weighted targets too (user-kNN style: both operands)
+    top_k = I                            # every stored column: small and large sums alike
+    comp = K.CosineSimilarityComputer(arg, 0.0, False)  # normalize=False: the raw sums
+    a = comp.compute_similarity(tgt, top_k)
+    b = comp.compute_similarity(tgt, top_k)
+    want = O.KNNComputer("cosine", arg, 0.0, normalize=False, n_threads=8).compute_similarity(tgt, top_k)
+    for m in (a, b, want):
+        m.sort_indices()
+    assert np.array_equal(a.indptr, want.indptr) and np.array_equal(a.indices, want.indices)
+    assert np.array_equal(a.data.view(np.uint64), b.data.view(np.uint64))  # order-independent sums
+    rel = np.abs(a.data - want.data) / np.abs(want.data)
+    if mode == "off":
+        assert rel.max() > 1e-9  # (the one-limb sums lose the small columns: the reason for two limbs)
+    else:
+        assert rel.max() <= 1e-12, float(rel.max())
+    # and the usual top-k request on the same data: same sets as the oracle
+    if mode != "off":
+        a5 = comp.compute_similarity(tgt, 20)
+        w5 = O.KNNComputer("cosine", arg, 0.0, normalize=False, n_threads=8).compute_similarity(tgt, 20)
+        a5.sort_indices()
+        w5.sort_indices()
+        assert np.array_equal(a5.indices, w5.indices)
+        np.testing.assert_allclose(a5.data, w5.data, rtol=1e-12, atol=0)
