@@ -249,6 +249,9 @@ irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
                          double *data);
 /* Seconds spent in device kernels of the last irs_knn_compute (HIP events) and
  * the number of multiply-adds it performed. */
+/* Measurement only: multiply-adds of the last call that were added one by one (the rest came out of
+ * the dense block of the popular items, csrc/knn.hip), and the rows of that block (0: none). */
+irs_status irs_knn_last_walked(irs_knn_computer *c, int64_t *walked_macs, int32_t *dense_rows);
 irs_status irs_knn_last_stats(irs_knn_computer *c, double *kernel_ms,
                               int64_t *macs);
 /* remove_diagonal, cpp_source/util.hpp:211-226 (in place on `data`). */

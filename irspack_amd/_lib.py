@@ -126,6 +126,7 @@ EXPORTED_SYMBOLS = [
     "irs_knn_compute",
     "irs_knn_fetch",
     "irs_knn_last_stats",
+    "irs_knn_last_walked",
     "irs_remove_diagonal",
     "irs_retrieve_recommend",
     "irs_eval_create",

@@ -918,10 +918,23 @@ bool eig_begin(irs_ials_trainer *t, Side &sd, int pidx, bool cg) {
   // launches next, must not reach the device before it is resident.  It reports that through a
   // host-pinned word; the wait is the time the stream's earlier work (the Gramian) still needs,
   // bounded so that a lost report costs speed, not progress.
+  // NOTE (blocking): on a side that takes this path half_step_async / irs_ials_step are therefore NOT
+  // asynchronous - the host waits here for the Gramian to finish (then yields its core instead of
+  // spinning hot) and again in eig_finish for the decomposition's statistics (the conditioning
+  // decision is taken on the host).  A report that never arrives is logged: it costs 200 ms per
+  // half-step, silently it would look like a slow kernel.
   const auto t0 = std::chrono::steady_clock::now();
-  while (__atomic_load_n(t->eig_resident, __ATOMIC_ACQUIRE) != t->eig_token &&
+  bool seen = false;
+  int spins = 0;
+  while (!(seen = __atomic_load_n(t->eig_resident, __ATOMIC_ACQUIRE) == t->eig_token) &&
          std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
-    ;
+    if (++spins > 2000) std::this_thread::yield();
+  if (!seen) {
+    static std::atomic<int> warned{0};
+    if (warned.fetch_add(1) < 3)
+      fprintf(stderr, "irspack_amd: the eigen-decomposition kernel did not report residency within 200 ms "
+                      "(side %d); the long rows' kernels are launched without waiting for it\n", pidx);
+  }
   return true;
 }
 

@@ -40,6 +40,8 @@ class _Computer:
         self._h: Optional[C.c_void_p] = h
         self.last_kernel_ms = 0.0
         self.last_macs = 0
+        self.last_walked_macs = 0
+        self.dense_block_rows = 0
 
     def __del__(self) -> None:
         h = getattr(self, "_h", None)
@@ -90,6 +92,10 @@ class _Computer:
         macs = C.c_int64(0)
         check(lib().irs_knn_last_stats(self._h, C.byref(ms), C.byref(macs)))
         self.last_kernel_ms, self.last_macs = float(ms.value), int(macs.value)
+        walked, dense_rows = C.c_int64(0), C.c_int32(0)
+        check(lib().irs_knn_last_walked(self._h, C.byref(walked), C.byref(dense_rows)))
+        #: (measurement) multiply-adds added one by one / rows of the dense popular block
+        self.last_walked_macs, self.dense_block_rows = int(walked.value), int(dense_rows.value)
         res = sps.csr_matrix((o_val[: nnz.value], o_idx[: nnz.value], o_ptr),
                              shape=(re - rb, self._N))
         res.has_sorted_indices = True

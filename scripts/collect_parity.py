@@ -2,7 +2,7 @@
 `pytest -m gpu` run on the GPU box) into the tracked profiles/parity_rNN.json: the last
 record per (test, config), sorted, plus a per-test summary.
 
-    python scripts/collect_parity.py [gpurun_out/parity_gpu.jsonl] [profiles/parity_r03.json]
+    python scripts/collect_parity.py [gpurun_out/parity_gpu.jsonl] [profiles/parity_r04.json]
 """
 import json
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main() -> None:
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_gpu.jsonl")
-    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "parity_r03.json")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "parity_r04.json")
     last = {}
     with open(src) as f:
         for line in f:
@@ -32,7 +32,14 @@ def main() -> None:
         s["n_comparisons"] += 1
         for key, name in (("worst_row_err", "worst_row_err_vs_oracle"), ("worst_vs_float64", "worst_gpu_vs_float64"),
                           ("oracle_vs_float64", "worst_oracle_vs_float64"), ("n_rows_over_1e_4", "max_rows_over_1e-4_vs_oracle"),
-                          ("worst_value_rel_err", "worst_value_rel_err")):
+                          ("worst_value_rel_err", "worst_value_rel_err"),
+                          # round 4: float64 is the arbiter of every row (conftest.assert_float64_bar)
+                          ("gpu_vs_f64_worst", "worst_gpu_vs_float64"), ("gpu_vs_f64_p999", "worst_gpu_p999_vs_float64"),
+                          ("oracle_f32_vs_f64_worst", "worst_oracle_vs_float64"),
+                          ("oracle_f32_vs_f64_p999", "worst_oracle_p999_vs_float64"),
+                          ("gpu_vs_oracle_f32_worst", "worst_row_err_vs_oracle"),
+                          ("n_rows_gpu_over_1e_4_vs_f64", "max_rows_gpu_over_1e-4_vs_float64"),
+                          ("n_rows_oracle_over_1e_4_vs_f64", "max_rows_oracle_over_1e-4_vs_float64")):
             v = r.get(key)
             if v is not None:
                 s[name] = max(s.get(name, 0), v)
