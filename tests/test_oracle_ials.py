@@ -347,3 +347,49 @@ def test_cg_fold_in_starts_from_zero(X_small):
     err = np.linalg.norm(got[live] - want[live], axis=1) / np.linalg.norm(want[live], axis=1)
     assert err.max() < 2e-5, err.max()
     assert np.all(got[3] == 0)
+
+
+@pytest.mark.parametrize("kind,steps", [("CG", 1), ("CG", 3), ("CHOLESKY", 0)])
+@pytest.mark.parametrize("loss", ["IALSPP", "ORIGINAL"])
+def test_float64_arbiter_build_is_pinned(kind, steps, loss):
+    """``liboracle_f64.so`` (the oracle's sources with Real = double: the arbiter of the GPU
+    parity tests) against the independent numpy float64 restatements above, at 1e-10 (CG) / 1e-7
+    (Cholesky) per row - orders below the distances it arbitrates - and the float32 oracle against it at the
+    2e-5 / 2e-4 of its own pins: one algorithm, three arithmetic widths."""
+    rng = np.random.default_rng(5 + steps)
+    X = sps.random(70, 50, density=0.15, format="csr", random_state=8, dtype=np.float64)
+    X.data = rng.uniform(0.5, 3.0, X.nnz)
+    X = X.tolil()
+    X.rows[5], X.data[5] = [], []
+    X = X.tocsr()
+    K, alpha0, reg, nu = 12, 0.25, 0.05, 0.5
+    mc = O.model_config(K, alpha0=alpha0, reg=reg, nu=nu, loss_type=loss)
+    sc = O.solver_config(2, kind, max(steps, 1))
+    user0 = (rng.standard_normal((70, K)) * 0.3).astype(np.float32)
+    item0 = (rng.standard_normal((50, K)) * 0.3).astype(np.float32)
+    bias = 0.0 if loss == "IALSPP" else alpha0
+    Xf = X.astype(np.float32)
+    live = np.flatnonzero(np.diff(X.indptr) > 0)
+    got64 = O.ials_solver_step_f64(user0, Xf, item0, None, mc, sc, 2)
+    assert got64.dtype == np.float64
+    if kind == "CG":
+        want, _ = cg_half_step_float64(Xf, user0, item0, alpha0, reg, nu, bias, steps)
+    else:  # the normal equations of test_half_step_vs_normal_equations, float regulariser
+        i64 = item0.astype(np.float64)
+        P = np.float64(np.float32(alpha0)) * i64.T @ i64
+        want = np.zeros((70, K))
+        for r in live:
+            sl = slice(X.indptr[r], X.indptr[r + 1])
+            V, c = i64[X.indices[sl]], Xf.data[sl].astype(np.float64)
+            regr = np.float32(reg) * np.power(np.float32(alpha0) * np.float32(50) + np.float32(sl.stop - sl.start), np.float32(nu))
+            A = P + (V * c[:, None]).T @ V + float(regr) * np.eye(K)
+            want[r] = np.linalg.solve(A, ((c + np.float64(np.float32(bias)))[:, None] * V).sum(axis=0))
+    err = np.linalg.norm(got64[live] - want[live], axis=1) / np.linalg.norm(want[live], axis=1)
+    # (Cholesky: numpy's float32 power and libm's powf may differ in the last bit of the
+    # regulariser of hpp:117-120, 6e-8 of it: 1e-7 there, 1e-10 where the restatement takes the float)
+    assert err.max() < (1e-10 if kind == "CG" else 1e-7), err.max()
+    if kind == "CG":
+        assert np.all(got64[5] == 0)
+    got32 = O.ials_solver_step(user0, Xf, item0, O.ials_gramian(item0, alpha0, 1), mc, sc)
+    e32 = np.linalg.norm(got32[live] - got64[live], axis=1) / np.linalg.norm(got64[live], axis=1)
+    assert e32.max() < (2e-5 if kind == "CG" else 2e-4), e32.max()
