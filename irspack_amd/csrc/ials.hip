@@ -1839,18 +1839,23 @@ irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_conf
       const int other = 1 - side;
       launch_partial_gramian(t, other, other == 0 ? t->shard.user_begin : t->shard.item_begin,
                              other == 0 ? t->shard.user_end : t->shard.item_end, side);
-      if (c->world > 1)
-        IRS_RCCL(api.AllReduce(t->P_raw[side].ptr, t->P_raw[side].ptr, KP * KP, ncclFloat, ncclSum, c->gram,
-                               t->stream));
+      // (also at world size 1, where it is the identity: the one-GPU tests then run the very calls,
+      // buffers and counts of a multi-GPU epoch)
+      IRS_RCCL(api.AllReduce(t->P_raw[side].ptr, t->P_raw[side].ptr, KP * KP, ncclFloat, ncclSum, c->gram,
+                             t->stream));
     };
+    // IRSPACK_AMD_SHARD_EXCHANGE=broadcast: the grouped in-place broadcasts even for equal blocks (tests)
+    static const bool force_bcast = [] {
+      const char *e = std::getenv("IRSPACK_AMD_SHARD_EXCHANGE");
+      return e && e[0] == 'b';
+    }();
     auto exchange_rows = [&](int side) {  // on the communicator's stream, behind the solve
-      if (c->world == 1) return;
       IRS_HIP(hipEventRecord(c->ev_solved, t->stream));
       IRS_HIP(hipStreamWaitEvent(c->stream, c->ev_solved, 0));
       float *F = t->factor[side].ptr;
       const int64_t *b = bounds[side];
       const int64_t padded = ceil_div(t->rows_of(side), 8) * 8, S = padded / c->world;
-      bool equal = padded % c->world == 0;
+      bool equal = padded % c->world == 0 && !force_bcast;
       for (int r = 0; equal && r < c->world; r++) equal = b[r] == std::min<int64_t>(r * S, b[c->world]);
       if (equal) {
         IRS_RCCL(api.AllGather(F + static_cast<size_t>(c->rank) * S * KP, F, static_cast<size_t>(S) * KP, ncclFloat,
@@ -1875,10 +1880,10 @@ irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_conf
       reduce_gramian(1 - side);
       t->gram_prefetched[1 - side] = true;
       // its solve gathers every row of `side`: wait for them
-      if (c->world > 1) IRS_HIP(hipStreamWaitEvent(t->stream, c->ev_rows, 0));
+      IRS_HIP(hipStreamWaitEvent(t->stream, c->ev_rows, 0));
     }
     sync_and_check(t);
-    if (c->world > 1) IRS_HIP(hipStreamSynchronize(c->stream));
+    IRS_HIP(hipStreamSynchronize(c->stream));
   });
 }
 

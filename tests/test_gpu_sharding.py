@@ -264,15 +264,21 @@ def _native_world1_worker(rank, kind, K, out_dir):
         f.write("ok")
 
 
-@pytest.mark.parametrize("kind,K", [("CHOLESKY", 64), ("CG", 200)])
-def test_native_sharded_step_world_size_one(tmp_path, kind, K):
+@pytest.mark.parametrize("kind,K,exchange", [("CHOLESKY", 64, "allgather"), ("CG", 200, "allgather"),
+                                            ("CHOLESKY", 64, "broadcast")])
+def test_native_sharded_step_world_size_one(tmp_path, kind, K, exchange, monkeypatch):
     """``irs_ials_sharded_step`` (the epoch behind one C-ABI call, RCCL opened and called by the
     library itself) on the one GPU of the box: world size 1 - communicator creation, the stream /
     event plumbing and the Gramian prefetch run; the collectives are skipped.  The result must be
     the unsharded trainer's, bit for bit, over three epochs (the prefetched Gramian of the next
     epoch is used from the second one on), and a factor set from outside must invalidate it.
+    The collectives themselves ARE issued (an all-reduce / all-gather / broadcast over one rank is
+    the identity): the calls, buffers, counts, streams and events are those of a multi-GPU epoch.
+    "broadcast": the grouped in-place broadcasts of uneven shards, forced for the equal ones.
     (In a spawned process like the other tests of this file: torch initialises the device there.)"""
     import torch.multiprocessing as mp
+
+    monkeypatch.setenv("IRSPACK_AMD_SHARD_EXCHANGE", exchange)
 
     mp.spawn(_native_world1_worker, args=(kind, K, str(tmp_path)), nprocs=1, join=True)
     assert (tmp_path / f"native_{kind}_{K}.txt").read_text() == "ok"
