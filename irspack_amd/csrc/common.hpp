@@ -48,17 +48,26 @@ void require_device(int device);
 template <class T> struct DeviceBuffer {
   T *ptr = nullptr;
   size_t count = 0;
+  bool owned = true;  // false: `ptr` is another buffer's memory (borrow)
   DeviceBuffer() = default;
   DeviceBuffer(const DeviceBuffer &) = delete;
   DeviceBuffer &operator=(const DeviceBuffer &) = delete;
   ~DeviceBuffer() { release(); }
   void release() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr && owned) (void)hipFree(ptr);
     ptr = nullptr;
     count = 0;
+    owned = true;
+  }
+  // read-only alias of another buffer (which must outlive this one)
+  void borrow(const DeviceBuffer &other) {
+    release();
+    ptr = other.ptr;
+    count = other.count;
+    owned = false;
   }
   void alloc(size_t n) {
-    if (n <= count && ptr) return;
+    if (n <= count && ptr && owned) return;
     release();
     if (n == 0) n = 1;
     IRS_HIP(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));

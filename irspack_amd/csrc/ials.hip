@@ -100,15 +100,22 @@ struct Side {
   bool positive = false;  // every stored confidence is > 0 (eigenbasis short-row kernels)
   float reg_min = 0.f;    // smallest per-row regulariser of the rows [row_begin, row_end)
 
+  // `share`: a Side already built from the same matrix - its device copies of the CSR arrays and
+  // of the regulariser are borrowed (row chunks of a shard, irs_ials_sharded_step)
   void build(const HostCsr &m, int64_t rb, int64_t re, const irs_ials_model_config &cfg,
-             hipStream_t s) {
+             hipStream_t s, const Side *share = nullptr) {
     n_rows = m.rows;
     n_other = m.cols;
     row_begin = rb;
     row_end = re;
     nnz = m.indptr[m.rows];
-    unit = std::all_of(m.data.begin(), m.data.end(), [](float v) { return v == 1.0f; });
-    positive = unit || std::all_of(m.data.begin(), m.data.end(), [](float v) { return v > 0.0f; });
+    if (share) {
+      unit = share->unit;
+      positive = share->positive;
+    } else {
+      unit = std::all_of(m.data.begin(), m.data.end(), [](float v) { return v == 1.0f; });
+      positive = unit || std::all_of(m.data.begin(), m.data.end(), [](float v) { return v > 0.0f; });
+    }
     std::vector<int32_t> ip32(m.rows + 1);
     for (int64_t r = 0; r <= m.rows; r++) ip32[r] = static_cast<int32_t>(m.indptr[r]);
     std::vector<float> regs(m.rows);
@@ -180,8 +187,14 @@ struct Side {
       n_short++;
     }
     n_slots = slots;
-    indptr.upload(ip32, s);
-    {
+    if (share) {
+      indptr.borrow(share->indptr);
+      indices.borrow(share->indices);
+      data.borrow(share->data);
+    } else {
+      indptr.upload(ip32, s);
+    }
+    if (!share) {
       // the gather pipeline loads whole 64-entry blocks up to two blocks past a row's end:
       // 320 zero entries behind the arrays (set on the device; no padded host copies)
       const size_t ne = m.indices.size();
@@ -239,7 +252,8 @@ struct Side {
              ip32[order[n_long] + 1] - ip32[order[n_long]] > 2048)
         n_long++;
     }
-    reg.upload(regs, s);
+    if (share) reg.borrow(share->reg);
+    else reg.upload(regs, s);
     tasks.upload(tk, s);
     split.upload(sp, s);
     n_fold = static_cast<int32_t>(fg.size());
@@ -352,6 +366,9 @@ struct irs_ials_trainer {
   bool opt_mf = true;   // IRSPACK_AMD_IALS_MF
   // irs_ials_sharded_step: the Gramian of side s has been all-reduced ahead of its half-epoch
   bool gram_prefetched[2] = {false, false};
+  // ... and the rows of the shard cut into chunks that are solved and exchanged one after the
+  // other (IRSPACK_AMD_SHARD_CHUNKS at creation; empty: one solve, one exchange)
+  std::vector<std::unique_ptr<Side>> chunk_side[2];
   int32_t eig_last = 0; // 1: the last half-step took the eigenbasis path (diagnostics)
   bool gk() const { return KP > 256; }   // K > 256: every size is a run-time value
   Profiler prof;
@@ -1587,6 +1604,22 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     item_thread.join();
     if (item_error) std::rethrow_exception(item_error);
     mark("both sides");
+    if (const char *ce = std::getenv("IRSPACK_AMD_SHARD_CHUNKS")) {
+      // row chunks of the shard for irs_ials_sharded_step: chunk c of a side is solved while chunk
+      // c - 1 is on the wire.  Same kernels on shorter task lists; the CSR arrays are shared.
+      const int C = std::max(1, std::min(16, std::atoi(ce)));
+      for (int w = 0; w < 2 && C > 1; w++) {
+        const int64_t rb = w == 0 ? t->shard.user_begin : t->shard.item_begin;
+        const int64_t re = w == 0 ? t->shard.user_end : t->shard.item_end;
+        for (int c = 0; c < C; c++) {
+          auto sd = std::make_unique<Side>();
+          sd->build(w == 0 ? X : Xt, rb + (re - rb) * c / C, rb + (re - rb) * (c + 1) / C, t->cfg, t->stream,
+                    &t->side[w]);
+          t->chunk_side[w].push_back(std::move(sd));
+        }
+      }
+      mark("row chunks");
+    }
     t->has_X = true;
     draw_thread.join();
     mark("draw (rest)");
@@ -1849,15 +1882,27 @@ irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_conf
       const char *e = std::getenv("IRSPACK_AMD_SHARD_EXCHANGE");
       return e && e[0] == 'b';
     }();
-    auto exchange_rows = [&](int side) {  // on the communicator's stream, behind the solve
+    // chunk k of n_chunks of every rank's rows (n_chunks == 1: the whole shards)
+    auto exchange_rows = [&](int side, int k, int n_chunks) {  // on the communicator's stream, behind the solve
       IRS_HIP(hipEventRecord(c->ev_solved, t->stream));
       IRS_HIP(hipStreamWaitEvent(c->stream, c->ev_solved, 0));
       float *F = t->factor[side].ptr;
       const int64_t *b = bounds[side];
       const int64_t padded = ceil_div(t->rows_of(side), 8) * 8, S = padded / c->world;
-      bool equal = padded % c->world == 0 && !force_bcast;
+      bool equal = padded % c->world == 0 && !force_bcast && n_chunks == 1;
       for (int r = 0; equal && r < c->world; r++) equal = b[r] == std::min<int64_t>(r * S, b[c->world]);
-      if (equal) {
+      if (n_chunks > 1) {
+        // rank r's chunk k = rows [b_r + len_r k / C, b_r + len_r (k + 1) / C): the same formula the
+        // chunk task lists were cut with at creation
+        IRS_RCCL(api.GroupStart());
+        for (int r = 0; r < c->world; r++) {
+          const int64_t len = b[r + 1] - b[r], lo = b[r] + len * k / n_chunks, hi = b[r] + len * (k + 1) / n_chunks;
+          if (hi > lo)
+            IRS_RCCL(api.Broadcast(F + static_cast<size_t>(lo) * KP, F + static_cast<size_t>(lo) * KP,
+                                   static_cast<size_t>(hi - lo) * KP, ncclFloat, r, c->rows, c->stream));
+        }
+        IRS_RCCL(api.GroupEnd());
+      } else if (equal) {
         IRS_RCCL(api.AllGather(F + static_cast<size_t>(c->rank) * S * KP, F, static_cast<size_t>(S) * KP, ncclFloat,
                                c->rows, c->stream));
       } else {
@@ -1874,8 +1919,16 @@ irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_conf
       if (!t->gram_prefetched[side]) reduce_gramian(side);
       t->gram_prefetched[side] = false;
       launch_finish_gramian(t, side);
-      launch_solve(t, t->side[side], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc);
-      exchange_rows(side);
+      const int n_chunks = static_cast<int>(t->chunk_side[side].size());
+      if (n_chunks > 1) {
+        for (int k = 0; k < n_chunks; k++) {  // chunk k travels while chunk k + 1 is solved
+          launch_solve(t, *t->chunk_side[side][k], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc);
+          exchange_rows(side, k, n_chunks);
+        }
+      } else {
+        launch_solve(t, t->side[side], t->factor[1 - side].ptr, t->factor[side].ptr, side, sc);
+        exchange_rows(side, 0, 1);
+      }
       // the next half-epoch's Gramian (side 1 now, side 0 of the next call) from the rows just solved
       reduce_gramian(1 - side);
       t->gram_prefetched[1 - side] = true;

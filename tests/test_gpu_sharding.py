@@ -264,9 +264,10 @@ def _native_world1_worker(rank, kind, K, out_dir):
         f.write("ok")
 
 
-@pytest.mark.parametrize("kind,K,exchange", [("CHOLESKY", 64, "allgather"), ("CG", 200, "allgather"),
-                                            ("CHOLESKY", 64, "broadcast")])
-def test_native_sharded_step_world_size_one(tmp_path, kind, K, exchange, monkeypatch):
+@pytest.mark.parametrize("kind,K,exchange,chunks", [("CHOLESKY", 64, "allgather", 1), ("CG", 200, "allgather", 1),
+                                                   ("CHOLESKY", 64, "broadcast", 1), ("CHOLESKY", 64, "allgather", 3),
+                                                   ("CG", 200, "allgather", 2), ("CG", 128, "allgather", 4)])
+def test_native_sharded_step_world_size_one(tmp_path, kind, K, exchange, chunks, monkeypatch):
     """``irs_ials_sharded_step`` (the epoch behind one C-ABI call, RCCL opened and called by the
     library itself) on the one GPU of the box: world size 1 - communicator creation, the stream /
     event plumbing and the Gramian prefetch run; the collectives are skipped.  The result must be
@@ -275,10 +276,14 @@ def test_native_sharded_step_world_size_one(tmp_path, kind, K, exchange, monkeyp
     The collectives themselves ARE issued (an all-reduce / all-gather / broadcast over one rank is
     the identity): the calls, buffers, counts, streams and events are those of a multi-GPU epoch.
     "broadcast": the grouped in-place broadcasts of uneven shards, forced for the equal ones.
+    chunks > 1 (IRSPACK_AMD_SHARD_CHUNKS): the rows of the shard cut into chunks with task lists of
+    their own, each exchanged behind its own solve: same bits (rows are independent).
     (In a spawned process like the other tests of this file: torch initialises the device there.)"""
     import torch.multiprocessing as mp
 
     monkeypatch.setenv("IRSPACK_AMD_SHARD_EXCHANGE", exchange)
+    if chunks > 1:  # the shard's rows solved and exchanged in chunks (chunk k + 1 solved while chunk k travels)
+        monkeypatch.setenv("IRSPACK_AMD_SHARD_CHUNKS", str(chunks))
 
     mp.spawn(_native_world1_worker, args=(kind, K, str(tmp_path)), nprocs=1, join=True)
     assert (tmp_path / f"native_{kind}_{K}.txt").read_text() == "ok"
