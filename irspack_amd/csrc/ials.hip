@@ -1188,15 +1188,15 @@ void launch_mf_cg(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   // classes 1 .. 4 of MF_CAPS: <= 320 (eight waves on one row), 160 (four), 80 (two rows of two
   // waves), 40 (four rows of one wave)
   if (t->T == 12) {
-    resident(mf_cg_rows_kernel<192, 1, 8, 10>, 1, 1, 8);
-    resident(mf_cg_rows_kernel<192, 1, 4, 10>, 2, 1, 4);
-    resident(mf_cg_rows_kernel<192, 2, 2, 10>, 3, 2, 4);
-    resident(mf_cg_rows_kernel<192, 4, 1, 10>, 4, 4, 4);
+    resident(mf_cg_rows_kernel<192, 1, 8, MF_J>, 1, 1, 8);
+    resident(mf_cg_rows_kernel<192, 1, 4, MF_J>, 2, 1, 4);
+    resident(mf_cg_rows_kernel<192, 2, 2, MF_J>, 3, 2, 4);
+    resident(mf_cg_rows_kernel<192, 4, 1, MF_J>, 4, 4, 4);
   } else {
-    resident(mf_cg_rows_kernel<256, 1, 8, 10>, 1, 1, 8);
-    resident(mf_cg_rows_kernel<256, 1, 4, 10>, 2, 1, 4);
-    resident(mf_cg_rows_kernel<256, 2, 2, 10>, 3, 2, 4);
-    resident(mf_cg_rows_kernel<256, 4, 1, 10>, 4, 4, 4);
+    resident(mf_cg_rows_kernel<256, 1, 8, MF_J>, 1, 1, 8);
+    resident(mf_cg_rows_kernel<256, 1, 4, MF_J>, 2, 1, 4);
+    resident(mf_cg_rows_kernel<256, 2, 2, MF_J>, 3, 2, 4);
+    resident(mf_cg_rows_kernel<256, 4, 1, MF_J>, 4, 4, 4);
   }
   t->prof.end(t->stream);
   if (fork) {

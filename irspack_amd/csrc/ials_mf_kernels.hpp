@@ -35,12 +35,19 @@
 namespace irs {
 namespace ials {
 
-constexpr int MF_NCAP = 320;    // longest resident row: 8 waves x 10 groups of 4 entries
+#ifndef IRS_MF_J
+#define IRS_MF_J 10
+#endif
+#ifndef IRS_MF_PUNROLL
+#define IRS_MF_PUNROLL 2
+#endif
+constexpr int MF_J = IRS_MF_J;           // groups of four gathered rows a wave keeps in registers
+constexpr int MF_NCAP = 32 * MF_J;       // longest resident row: 8 waves x MF_J groups of 4 entries
 // row classes by stored entries, longest first: class 0 = level-synchronous, then the resident
 // classes of mf_cg_rows_kernel<KP, R, W, 10> (capacity 40 W): <1, 8>, <1, 4>, <2, 2>, <4, 1>
 constexpr int MF_CHUNK = 1024;  // entries per chunk of a level-synchronous row
 constexpr int MF_CLASSES = 5;
-constexpr int32_t MF_CAPS[MF_CLASSES] = {INT32_MAX, MF_NCAP, 160, 80, 40};
+constexpr int32_t MF_CAPS[MF_CLASSES] = {INT32_MAX, MF_NCAP, 16 * MF_J, 8 * MF_J, 4 * MF_J};
 
 struct MfLongRow {
   int32_t row;          // row of the solved side
@@ -176,7 +183,7 @@ __device__ __forceinline__ void mf_p_times_vecs(const float *__restrict__ P, con
   for (int r = 0; r < R; r++) out[r] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (4 * lane < KP) {
     const float *Pw = P + static_cast<size_t>(KQ * w) * KP + 4 * lane;
-#pragma unroll 2
+#pragma unroll IRS_MF_PUNROLL
     for (int k = 0; k < KQ; k += 4) {
       f32x4 rw[4];
 #pragma unroll

@@ -160,6 +160,39 @@ inline float compute_reg(int64_t nnz, int64_t other_size, const ModelConfig &c) 
 // Returns false when the factorisation meets a non-positive pivot.
 bool llt_upper_solve(Real *A, Real *b, int64_t K) {
   // A is row-major, only the upper triangle is referenced.
+#ifdef ORACLE_FAST
+  // cpu_baseline build only (make fast): the same factorisation in its row-oriented (axpy) form -
+  // the inner loops run over contiguous row tails and vectorise, where the column-oriented dot
+  // products below walk A with stride K - what an optimised LLT (Eigen's) does.  Another summation
+  // order than the parity build's, which is why parity never uses it.
+  for (int64_t j = 0; j < K; j++) {
+    Real *rj = A + j * K;
+    for (int64_t t = 0; t < j; t++) {
+      const Real *rt = A + t * K;
+      const Real a = rt[j];
+      for (int64_t i = j; i < K; i++) rj[i] -= a * rt[i];
+    }
+    Real d = rj[j];
+    if (!(d > 0.0f)) return false;
+    d = std::sqrt(d);
+    const Real inv = 1 / d;
+    rj[j] = d;
+    for (int64_t i = j + 1; i < K; i++) rj[i] *= inv;
+  }
+  for (int64_t i = 0; i < K; i++) {  // U^T y = b, by rows of U (axpy)
+    b[i] /= A[i * K + i];
+    const Real yi = b[i];
+    const Real *ri = A + i * K;
+    for (int64_t t = i + 1; t < K; t++) b[t] -= ri[t] * yi;
+  }
+  for (int64_t i = K - 1; i >= 0; i--) {  // U x = y (dot over the contiguous row tail)
+    const Real *ri = A + i * K;
+    Real s = b[i];
+    for (int64_t t = i + 1; t < K; t++) s -= ri[t] * b[t];
+    b[i] = s / ri[i];
+  }
+  return true;
+#endif
   for (int64_t j = 0; j < K; j++) {
     Real d = A[j * K + j];
     for (int64_t t = 0; t < j; t++) d -= A[t * K + j] * A[t * K + j];
