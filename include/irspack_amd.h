@@ -330,6 +330,11 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t,
 irs_status irs_eval_cache_mask(irs_evaluator *e, int64_t rows, const int64_t *mask_indptr,
                                const int32_t *mask_indices);
 
+/* 64-bit content fingerprint of a host buffer, computed on several host threads: the check that the
+ * device-resident mask of irs_eval_cache_mask is still the caller's matrix (every byte, every call;
+ * no reference counterpart).  Not cryptographic. */
+irs_status irs_fingerprint(const void *data, int64_t n_bytes, uint64_t seed, uint64_t *out);
+
 /* What the last irs_eval_get_metrics_ials call did (measurement only, no reference
  * counterpart).  path: 0 = score block + ranking (two passes), 1 = threshold-filtered
  * candidates, 2 = threshold-filtered with norm-bound pruning, 3 = single-pass streaming top-k. */

@@ -136,6 +136,7 @@ EXPORTED_SYMBOLS = [
     "irs_eval_get_metrics_ials",
     "irs_eval_cache_mask",
     "irs_eval_last_stats",
+    "irs_fingerprint",
     "irs_measure_ceilings",
 ]
 

@@ -19,6 +19,9 @@
 #include <limits>
 #include <memory>
 
+#include <thread>
+#include <cstring>
+
 #include "common.hpp"
 
 namespace irs {
@@ -2078,6 +2081,62 @@ irs_status irs_eval_cache_mask(irs_evaluator *e, int64_t rows, const int64_t *ma
     e->mask_idx.upload(mask_indices, static_cast<size_t>(std::max<int64_t>(mask_indptr[rows], 1)), s);
     IRS_HIP(hipStreamSynchronize(s));
     e->mask_rows = rows;
+  });
+}
+
+// 64-bit content fingerprint of a host buffer on several threads (the strict check of the
+// evaluator's device-resident mask: every byte of ~140 MB per call, 4.5 ms with one thread of
+// xxh3).  Not cryptographic: per 1 MiB piece a multiply-rotate mix of its 8-byte words (any changed
+// word changes the piece's value), the pieces combined with their position.
+irs_status irs_fingerprint(const void *data, int64_t n_bytes, uint64_t seed, uint64_t *out) {
+  return guard([&] {
+    check_arg(out != nullptr && n_bytes >= 0 && (data != nullptr || n_bytes == 0), "bad argument.");
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    constexpr int64_t PIECE = int64_t(1) << 20;
+    const int64_t n_pieces = ceil_div(n_bytes, PIECE);
+    const int n_thr = static_cast<int>(std::max<int64_t>(
+        1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()), n_pieces / 4 + 1})));
+    auto mix = [](uint64_t h, uint64_t w) {
+      h ^= w * 0x9E3779B97F4A7C15ull;
+      h = (h << 29) | (h >> 35);
+      return h * 0xD6E8FEB86659FD93ull;
+    };
+    auto piece_hash = [&](int64_t k) {
+      const int64_t b = k * PIECE, e = std::min(n_bytes, b + PIECE);
+      uint64_t h[4] = {seed ^ 0x243F6A8885A308D3ull, seed ^ 0x13198A2E03707344ull, seed ^ 0xA4093822299F31D0ull,
+                       seed ^ 0x082EFA98EC4E6C89ull};  // four independent lanes: the loop pipelines
+      int64_t i = b;
+      for (; i + 32 <= e; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        h[0] = mix(h[0], w[0]);
+        h[1] = mix(h[1], w[1]);
+        h[2] = mix(h[2], w[2]);
+        h[3] = mix(h[3], w[3]);
+      }
+      uint64_t tail[4] = {0, 0, 0, 0};
+      std::memcpy(tail, p + i, static_cast<size_t>(e - i));
+      for (int q = 0; q < 4; q++) h[q] = mix(h[q], tail[q] + static_cast<uint64_t>(e - i));
+      return mix(mix(h[0], h[1]), mix(h[2], h[3]) + static_cast<uint64_t>(k));
+    };
+    std::vector<uint64_t> part(static_cast<size_t>(n_thr), 0);
+    auto work = [&](int t) {
+      uint64_t acc = 0;
+      for (int64_t k = t; k < n_pieces; k += n_thr) acc += mix(piece_hash(k), static_cast<uint64_t>(k) + 1);
+      part[t] = acc;
+    };
+    {
+      std::vector<std::thread> th;
+      struct Join {
+        std::vector<std::thread> &v;
+        ~Join() { for (auto &t : v) if (t.joinable()) t.join(); }
+      } join{th};
+      for (int t = 1; t < n_thr; t++) th.emplace_back(work, t);
+      work(0);
+    }
+    uint64_t h = mix(seed, static_cast<uint64_t>(n_bytes));
+    for (int t = 0; t < n_thr; t++) h += part[t];  // (a sum: independent of the thread count's dealing)
+    *out = h;
   });
 }
 

@@ -336,18 +336,17 @@ class EvaluatorCore:
 
         m = mask if sps.isspmatrix_csr(mask) else sps.csr_matrix(mask)
         if cls.strict_mask_fingerprint:
-            try:
-                import xxhash
-
-                hx = xxhash.xxh3_64()
-                for a in (m.indptr, m.indices, m.data):
-                    hx.update(np.ascontiguousarray(a).view(np.uint8))
-                return hx.intdigest()
-            except ImportError:
-                h = 0
-                for a in (m.indptr, m.indices, m.data):
-                    h = zlib.crc32(np.ascontiguousarray(a).view(np.uint8), h)
-                return h
+            # every byte of the three arrays, hashed by the library on several host threads
+            # (irs_fingerprint: ~1 ms for the 16 M-entry mask of the ML-20M shape; one thread of
+            # xxh3 took 4.5 ms of a 6.1 ms call)
+            h = 0
+            for a in (m.indptr, m.indices, m.data):
+                a = np.ascontiguousarray(a)
+                out = C.c_uint64(0)
+                check(lib().irs_fingerprint(a.ctypes.data_as(C.c_void_p), C.c_int64(a.nbytes),
+                                            C.c_uint64(h), C.byref(out)))
+                h = int(out.value)
+            return h
         h = int(m.indptr.sum(dtype=np.int64)) & 0xFFFFFFFF
         for a in (m.indptr, m.indices, m.data):
             h = zlib.crc32(np.ascontiguousarray(a[:: max(1, a.size // 1024)]).tobytes(), h)
