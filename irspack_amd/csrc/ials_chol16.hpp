@@ -24,6 +24,9 @@
 namespace irs {
 namespace ials {
 
+#ifndef IRS_CHOL16_TRSM_CHUNK
+#define IRS_CHOL16_TRSM_CHUNK(T) ((T) <= 4 ? 2 : 4)
+#endif
 template <int T> struct Chol16Geo {
   static constexpr int KP = 16 * T;
   static constexpr int WS = 16 * 17;                 // a 16 x 16 tile, row stride 17
@@ -37,108 +40,7 @@ template <int T> struct Chol16Geo {
   static constexpr int tix(int i, int j) { return i * T - i * (i - 1) / 2 + (j - i); }
 };
 
-template <int Q>
-__device__ __forceinline__ void diag_subpanel_dpp_q(f32x4 &Cd, f32x4 &E, bool &bad);
-__device__ __forceinline__ void diag_subpanel_dpp(f32x4 &Cd, f32x4 &E, bool &bad, int q) {
-  // q is a constant after unrolling; the switch folds
-  switch (q) {
-    case 0: diag_subpanel_dpp_q<0>(Cd, E, bad); break;
-    case 1: diag_subpanel_dpp_q<1>(Cd, E, bad); break;
-    case 2: diag_subpanel_dpp_q<2>(Cd, E, bad); break;
-    default: diag_subpanel_dpp_q<3>(Cd, E, bad); break;
-  }
-}
-
-// S = R^T R of one 16 x 16 tile in accumulator layout, E = R^-T alongside.  `Cd` is
-// consumed; its strictly lower triangle only ever holds rounding noise and is never read as
-// a result.  scrR / scrE: 16 x 17 floats each, private to the wave.
-__device__ __forceinline__ void diag_factor16(f32x4 &Cd, f32x4 &E, float *scrR, float *scrE,
-                                              bool &bad) {
-  const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, m = lane & 15;
-#pragma unroll
-  for (int r = 0; r < 4; r++) E[r] = (4 * g + r == m) ? 1.0f : 0.0f;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-#ifdef IRS_CHOL16_SELECT
-    const bool mine = g == q;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float piv = readlane_f(Cd[r], 20 * q + r);
-      bad |= !(piv > 0.f);
-      const float rinv = __builtin_amdgcn_rsqf(piv);
-      const float mult = mine ? rinv : 1.0f;
-      Cd[r] *= mult;
-      E[r] *= mult;
-#pragma unroll
-      for (int r2 = r + 1; r2 < 4; r2++) {
-        const float sv = readlane_f(Cd[r], 20 * q + r2);  // R[k][k2]
-        const float sm_ = mine ? sv : 0.f;
-        Cd[r2] = fmaf(-sm_, Cd[r], Cd[r2]);
-        E[r2] = fmaf(-sm_, E[r], E[r2]);
-      }
-    }
-#else
-    // The 4 x 4 elimination of the sub-panel touches the lanes of group q only: run it under that
-    // execution mask (one s_and_saveexec per sub-panel) instead of selecting a neutral operand per
-    // operation - the scalars come from v_readlane, which ignores the mask: 3 instead of 5 vector
-    // instructions per eliminated pair, 4 instead of 5 per pivot (round 4: ~250 of the ~1100 vector
-    // instructions of a 64 x 64 factorisation).
-#ifdef IRS_CHOL16_READLANE
-    if (g == q) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float piv = readlane_f(Cd[r], 20 * q + r);
-        bad |= !(piv > 0.f);
-        const float rinv = __builtin_amdgcn_rsqf(piv);
-        Cd[r] *= rinv;
-        E[r] *= rinv;
-#pragma unroll
-        for (int r2 = r + 1; r2 < 4; r2++) {
-          const float sv = readlane_f(Cd[r], 20 * q + r2);  // R[k][k2]
-          Cd[r2] = fmaf(-sv, Cd[r], Cd[r2]);
-          E[r2] = fmaf(-sv, E[r], E[r2]);
-        }
-      }
-    }
-#else
-    // The multiplier R[k][k2] is lane 4 q + r2 of the 16-lane row that holds the sub-panel: the DPP
-    // row broadcast of v_fmac_f32 itself delivers it (row_elim below), so an eliminated pair costs two
-    // vector instructions instead of v_readlane + two (96 fewer per 64 x 64 system).
-    if (g == q) diag_subpanel_dpp(Cd, E, bad, q);
-#endif
-#endif
-    if (q == 3) break;
-    // rows 4q .. 4q+3 are final: rank-4 update of the rows below them (and of E).  Every group
-    // stores its four rows (no divergent branch: the block stays one scheduling region), the
-    // read picks the sub-panel's.
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      scrR[(4 * g + r) * 17 + m] = Cd[r];
-      scrE[(4 * g + r) * 17 + m] = E[r];
-    }
-    __threadfence_block();
-    const float a = scrR[(4 * q + g) * 17 + m];
-    const float e = scrE[(4 * q + g) * 17 + m];
-    __threadfence_block();
-    const float na = (m > 4 * q + 3) ? -a : 0.f;  // rows up to the sub-panel are final
-    Cd = __builtin_amdgcn_mfma_f32_16x16x4f32(na, a, Cd, 0, 0, 0);
-    E = __builtin_amdgcn_mfma_f32_16x16x4f32(na, e, E, 0, 0, 0);
-  }
-}
-
-// ---- Four systems' diagonal tiles factorised by ONE wave (round 4) ------------------------------
-// In the accumulator layout the rows of a 4-row sub-panel live in one 16-lane group, so a wave that
-// factorises its own tile runs the ~42 vector instructions of a sub-panel for 16 useful lanes, and
-// pays them 16 times per 64 x 64 system: ~670 of the ~1060 vector instructions of a solve.  When the
-// four waves of a workgroup solve four rows in step, each hands its tile over through LDS and ONE
-// wave factorises the four of them together: lane (s, m) holds column m of system s, register i is
-// row i.  A row operation then is one instruction for four systems, and the broadcast of a row's
-// element to the lanes of its group is the DPP `row_newbcast` of the instruction itself
-// (v_fmac_f32_dpp: no v_readlane, no select, no MFMA for the rows below the sub-panel):
-// 240 + ~100 vector instructions for four tiles against ~4 x 265 (matrix-core work included).
-// The factorising wave changes with the block column, so the four SIMDs share the work.
-//
+// DPP forms of a row operation (used by diag_factor16 and by the batched factorisations below).
 // v_fmac_f32_dpp has no builtin form that the compiler folds (the DPP combiner runs before
 // v_fma_f32 becomes the two-address v_fmac_f32), hence inline assembly; the wait states between a
 // vector write and a DPP read of the same register (2) are carried by the `s_nop 1` of the first
@@ -165,8 +67,39 @@ __device__ __forceinline__ void row_elim(float &xi, float &yi, const float xk, c
                : "+v"(yi)
                : "v"(xk), "v"(yk), "n"(N));
 }
-template <int Q>
-__device__ __forceinline__ void diag_subpanel_dpp_q(f32x4 &Cd, f32x4 &E, bool &bad) {
+
+// The 4 x 4 elimination of sub-panel Q (rows 4 Q .. 4 Q + 3, all in lane group Q) of [Cd | E].
+// Round 4, first: under the execution mask of group Q (one s_and_saveexec) instead of selecting a
+// neutral operand per operation (-250 of ~1100 vector instructions per 64 x 64 system).  Then: the
+// multiplier R[k][k2] is lane 4 Q + r2 of the 16-lane row that holds the sub-panel, so the DPP row
+// broadcast of v_fmac_f32 itself delivers it - two vector instructions per eliminated pair instead
+// of v_readlane + two (-96 per system; same-box A/B: user half -2.3 %).
+// -DIRS_CHOL16_READLANE restores the v_readlane form.
+#ifdef IRS_CHOL16_READLANE
+constexpr bool CHOL16_DPP = false;
+#else
+constexpr bool CHOL16_DPP = true;
+#endif
+// DPP = false: the v_readlane form (the 256-register workgroup kernels of K > 128 spill 0.5 KB per
+// lane around the pinned assembly of the DPP form)
+template <int Q, bool DPP>
+__device__ __forceinline__ void diag_subpanel(f32x4 &Cd, f32x4 &E, bool &bad) {
+  if constexpr (!DPP) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const float piv = readlane_f(Cd[r], 20 * Q + r);
+    bad |= !(piv > 0.f);
+    const float rinv = __builtin_amdgcn_rsqf(piv);
+    Cd[r] *= rinv;
+    E[r] *= rinv;
+#pragma unroll
+    for (int r2 = r + 1; r2 < 4; r2++) {
+      const float sv = readlane_f(Cd[r], 20 * Q + r2);  // R[k][k2]
+      Cd[r2] = fmaf(-sv, Cd[r], Cd[r2]);
+      E[r2] = fmaf(-sv, E[r], E[r2]);
+    }
+  }
+  } else {
   float c[4] = {Cd[0], Cd[1], Cd[2], Cd[3]}, e[4] = {E[0], E[1], E[2], E[3]};
   auto pivot = [&](auto rc) {
     constexpr int r = decltype(rc)::value;
@@ -185,8 +118,64 @@ __device__ __forceinline__ void diag_subpanel_dpp_q(f32x4 &Cd, f32x4 &E, bool &b
   pivot(std::integral_constant<int, 3>{});
   Cd = f32x4{c[0], c[1], c[2], c[3]};
   E = f32x4{e[0], e[1], e[2], e[3]};
+  }
 }
 
+// S = R^T R of one 16 x 16 tile in accumulator layout, E = R^-T alongside.  `Cd` is
+// consumed; its strictly lower triangle only ever holds rounding noise and is never read as
+// a result.  scrR / scrE: 16 x 17 floats each, private to the wave.
+template <int Q, bool DPP>
+__device__ __forceinline__ void diag_factor16_step(f32x4 &Cd, f32x4 &E, float *scrR, float *scrE, bool &bad) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+  if (g == Q) diag_subpanel<Q, DPP>(Cd, E, bad);
+  if constexpr (Q < 3) {
+    // rows 4Q .. 4Q+3 are final: rank-4 update of the rows below them (and of E).  Every group
+    // stores its four rows (no divergent branch: the block stays one scheduling region), the
+    // read picks the sub-panel's.
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      scrR[(4 * g + r) * 17 + m] = Cd[r];
+      scrE[(4 * g + r) * 17 + m] = E[r];
+    }
+    __threadfence_block();
+    const float a = scrR[(4 * Q + g) * 17 + m];
+    const float e = scrE[(4 * Q + g) * 17 + m];
+    __threadfence_block();
+    const float na = (m > 4 * Q + 3) ? -a : 0.f;  // rows up to the sub-panel are final
+    Cd = __builtin_amdgcn_mfma_f32_16x16x4f32(na, a, Cd, 0, 0, 0);
+    E = __builtin_amdgcn_mfma_f32_16x16x4f32(na, e, E, 0, 0, 0);
+  }
+}
+template <bool DPP = CHOL16_DPP>
+__device__ __forceinline__ void diag_factor16(f32x4 &Cd, f32x4 &E, float *scrR, float *scrE,
+                                              bool &bad) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, m = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; r++) E[r] = (4 * g + r == m) ? 1.0f : 0.0f;
+  diag_factor16_step<0, DPP>(Cd, E, scrR, scrE, bad);
+  diag_factor16_step<1, DPP>(Cd, E, scrR, scrE, bad);
+  diag_factor16_step<2, DPP>(Cd, E, scrR, scrE, bad);
+  diag_factor16_step<3, DPP>(Cd, E, scrR, scrE, bad);
+}
+
+// ---- Four systems' diagonal tiles factorised by ONE wave (round 4) ------------------------------
+// In the accumulator layout the rows of a 4-row sub-panel live in one 16-lane group, so a wave that
+// factorises its own tile runs the ~42 vector instructions of a sub-panel for 16 useful lanes, and
+// pays them 16 times per 64 x 64 system: ~670 of the ~1060 vector instructions of a solve.  When the
+// four waves of a workgroup solve four rows in step, each hands its tile over through LDS and ONE
+// wave factorises the four of them together: lane (s, m) holds column m of system s, register i is
+// row i.  A row operation then is one instruction for four systems, and the broadcast of a row's
+// element to the lanes of its group is the DPP `row_newbcast` of the instruction itself
+// (v_fmac_f32_dpp: no v_readlane, no select, no MFMA for the rows below the sub-panel):
+// 240 + ~100 vector instructions for four tiles against ~4 x 265 (matrix-core work included).
+// The factorising wave changes with the block column, so the four SIMDs share the work.
+//
+// v_fmac_f32_dpp has no builtin form that the compiler folds (the DPP combiner runs before
+// v_fma_f32 becomes the two-address v_fmac_f32), hence inline assembly; the wait states between a
+// vector write and a DPP read of the same register (2) are carried by the `s_nop 1` of the first
+// instruction of each group.
 template <int K, int... I>
 __device__ __forceinline__ void factor16x4_step(float (&X)[16], float (&Y)[16], bool &bad,
                                                 std::integer_sequence<int, I...>) {
@@ -242,10 +231,11 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     for (int r = 0; r < 4; r++)
       if (4 * g + r == m) acc[C::tix(i, i)][r] += (T * m + i < K) ? reg : 1.0f;
 
-  // right-hand side as tile row T: every row of tile (T, I) is b_I^T
-  f32x4 bacc[T];
+  // right-hand side as tile row T: every row of tile (T, I) is b_I^T, so one register per tile
+  // carries it between the matrix-core phases (16 identical rows: 4 x fewer registers held)
+  float by[T];
 #pragma unroll
-  for (int i = 0; i < T; i++) bacc[i] = f32x4{b4[i], b4[i], b4[i], b4[i]};
+  for (int i = 0; i < T; i++) by[i] = b4[i];
 
   bool bad = false;
   IPHASE_BEGIN;
@@ -283,32 +273,34 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     for (int J = I + 1; J < T; J++)
 #pragma unroll
       for (int r = 0; r < 4; r++) pan[(16 * J + 4 * g + r) * 17 + m] = acc[C::tix(I, J)][r];
-#pragma unroll
-    for (int r = 0; r < 4; r++) pan[(KP + 4 * g + r) * 17 + m] = bacc[I][r];
+    pan[KP * 17 + m] = by[I];  // (one row; every group writes the same 16 values)
     __threadfence_block();
-    // (chunks of four tiles bound the operand registers; within a chunk the tiles' MFMA
-    // chains are interleaved)
+    // (chunks of CH tiles bound the operand registers; within a chunk the tiles' MFMA chains are
+    // interleaved.  K <= 64: two tiles, 16 registers less at the kernel's pressure peak - what
+    // four waves per SIMD need)
+    constexpr int CH = IRS_CHOL16_TRSM_CHUNK(T);
 #pragma unroll
-    for (int J0 = I + 1; J0 <= T; J0 += 4) {
-      float aS[4][4];  // A[i][k] = S[i][k]: lane (g, i) reads row i, column 4 s + g
-      f32x4 D[4];
+    for (int J0 = I + 1; J0 <= T; J0 += CH) {
+      float aS[CH][4];  // A[i][k] = S[i][k]: lane (g, i) reads row i, column 4 s + g
+      f32x4 D[CH];
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
+      for (int c = 0; c < CH; c++) {
         D[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (J0 + c <= T) {
 #pragma unroll
-          for (int s = 0; s < 4; s++) aS[c][s] = pan[(16 * (J0 + c) + m) * 17 + 4 * s + g];
+          for (int s = 0; s < 4; s++)
+            aS[c][s] = J0 + c < T ? pan[(16 * (J0 + c) + m) * 17 + 4 * s + g] : pan[KP * 17 + 4 * s + g];
         }
       }
 #pragma unroll
       for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < CH; c++)
           if (J0 + c <= T) D[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[c][s], bE[s], D[c], 0, 0, 0);
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
+      for (int c = 0; c < CH; c++) {
         if (J0 + c < T) acc[C::tix(I, J0 + c < T ? J0 + c : I)] = D[c];
-        if (J0 + c == T) bacc[I] = D[c];
+        if (J0 + c == T) by[I] = D[c][0];
       }
     }
     __threadfence_block();  // (all operand reads done before the results overwrite the panel)
@@ -318,9 +310,12 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     for (int J = I + 1; J < T; J++)
 #pragma unroll
       for (int r = 0; r < 4; r++) pan[(16 * J + 4 * g + r) * 17 + m] = acc[C::tix(I, J)][r];
-    if (g == 0) pan[KP * 17 + m] = bacc[I][0];
+    if (g == 0) pan[KP * 17 + m] = by[I];
     __threadfence_block();
     // ---- (3) trailing update of the tiles right of block column I
+    f32x4 bacc[T];
+#pragma unroll
+    for (int j = I + 1; j < T; j++) bacc[j] = f32x4{by[j], by[j], by[j], by[j]};
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       float op[T], nop[T];
@@ -339,6 +334,8 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
         bacc[J2] = __builtin_amdgcn_mfma_f32_16x16x4f32(nopy, op[J2], bacc[J2], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int j = I + 1; j < T; j++) by[j] = bacc[j][0];
     __threadfence_block();  // the next step overwrites the panel and the scratch
     IPHASE(3);
   }
@@ -348,7 +345,7 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
   // ---- back substitution L^T x = y: z in registers (lane (g, n): z_I[n])
   float z[T], x[T];
 #pragma unroll
-  for (int i = 0; i < T; i++) z[i] = bacc[i][0];
+  for (int i = 0; i < T; i++) z[i] = by[i];
 #pragma unroll
   for (int J = T - 1; J >= 0; J--) {
     if (lane < 16) zx[lane] = z[J];

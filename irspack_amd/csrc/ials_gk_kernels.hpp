@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void gk_chol_kernel(GkParams p) {
     };
     if (wv == 0) {
       f32x4 Cd = accumulate(I), E;
-      diag_factor16(Cd, E, scr, scr + 16 * 17, bad);
+      diag_factor16<false>(Cd, E, scr, scr + 16 * 17, bad);
       float *dst = sys + gk_tile_off(I, I);  // the slot of L_II keeps E = L_II^-1 (L_II is not needed again)
 #pragma unroll
       for (int r = 0; r < 4; r++) dst[(4 * g + r) * 16 + m] = E[r];

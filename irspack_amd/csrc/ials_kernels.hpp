@@ -38,6 +38,9 @@ constexpr int SOLVE_WAVES = 1;  // waves per solve workgroup: waves never cooper
 #ifndef SOLVE_MIN_WAVES_PER_SIMD
 #define SOLVE_MIN_WAVES_PER_SIMD 2  // register budget hint (waves per SIMD)
 #endif
+#ifndef SOLVE_MIN_WAVES_PER_SIMD_K64
+#define SOLVE_MIN_WAVES_PER_SIMD_K64 SOLVE_MIN_WAVES_PER_SIMD  // the same for the K <= 64 kernels (A/B builds)
+#endif
 
 struct Task {
   int32_t row;    // row of the solved side
@@ -106,6 +109,14 @@ struct SolveParams {
   const float *prior;   // feature prior [n_rows, KP] or null: rhs += reg_r * prior_r
                         // (step_cholesky_with_prior hpp:363, step_cg hpp:212-215)
 };
+
+// The wave's index inside its workgroup as a SCALAR: `threadIdx.x >> 6` alone is a per-lane value to
+// the compiler, and everything derived from it - the wave's task, its row, begin / end, the loop
+// bounds, the factor-row addresses - then lives in vector registers and is computed by vector
+// instructions (the Task of ials_solve_kernel cost 4 registers and was spilled at 128 registers).
+__device__ __forceinline__ int wave_in_block() {
+  return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+}
 
 __device__ __forceinline__ float readlane_f(float x, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
@@ -254,6 +265,35 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
     }
     load_dims<T>(col_base + static_cast<size_t>(idx) * KP, v[k]);
   };
+  // The same fetch in two stages for the loop body.  ds_bpermute_b32 adds an immediate offset to its
+  // address register, but hipcc materialises `perm_base + 16 j` in a register of its own for each of
+  // the 16 sub-steps and keeps all of them live through the loop: 15 registers that decide between
+  // three and four waves per SIMD.  Issued from inline assembly with `offset:16 j` the permute needs
+  // the one base register; its s_waitcnt is ours to place (the compiler does not see the LDS
+  // operation): after the sub-step's matrix instructions, where the compiler put its own.
+  auto perm_issue = [&](unsigned &pidx, float &pc, int blk_idx, float blk_c, int j) {
+    asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(pidx) : "v"(perm_base), "v"(blk_idx), "i"(16 * j));
+    if constexpr (!UNIT)
+      asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(pc) : "v"(perm_base), "v"(blk_c), "i"(16 * j));
+  };
+  auto fetch_finish = [&](int k, unsigned pidx, float pc, int j, int entry0, auto all_valid) {
+    if constexpr (UNIT)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pidx));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pidx), "+v"(pc));
+    unsigned idx = pidx;
+    const bool valid = decltype(all_valid)::value || entry0 + 4 * j + g < n;
+    if constexpr (UNIT) {
+      idx = valid ? idx : zero_row;
+      const uint32_t off = idx * static_cast<uint32_t>(KP * sizeof(float)) + lane_off;
+      load_dims<T>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(other) + off), v[k]);
+      return;
+    } else {
+      vc[k] = valid ? pc : 0.f;
+      vw[k] = valid ? bias + pc : 0.f;
+    }
+    load_dims<T>(col_base + static_cast<size_t>(idx) * KP, v[k]);
+  };
   auto consume = [&](int k) {
     float cv[T];
 #pragma unroll
@@ -304,11 +344,18 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   auto block = [&](int &cur_i, float &cur_c, const int nxt_i, const float nxt_c, auto all_valid) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {  // sub-step j of this block; its gather was issued D earlier
-      consume(j % D);
+      unsigned pidx;
+      float pc = 0.f;
       if (j + D < 16)
-        fetch(j % D, cur_i, cur_c, j + D, 4 * s0, all_valid);
+        perm_issue(pidx, pc, cur_i, cur_c, j + D);
       else
-        fetch(j % D, nxt_i, nxt_c, j + D - 16, 4 * s0 + 64, all_valid);
+        perm_issue(pidx, pc, nxt_i, nxt_c, j + D - 16);
+      consume(j % D);
+      __builtin_amdgcn_sched_barrier(0);  // (the wait below stays behind the matrix instructions)
+      if (j + D < 16)
+        fetch_finish(j % D, pidx, pc, j + D, 4 * s0, all_valid);
+      else
+        fetch_finish(j % D, pidx, pc, j + D - 16, 4 * s0 + 64, all_valid);
       if (j == 15 - D) {  // last use of this set: reload it with block + 2
         cur_i = ip[4 * s0 + 128];
         if constexpr (!UNIT) cur_c = dp[4 * s0 + 128];
@@ -945,7 +992,7 @@ __device__ unsigned long long ials_phase_clk[8 * 4096];
 // diag_factor16x4).  A workgroup with a chunk of a split row or past the end of the list runs its
 // waves independently, as WAVES == 1 does.
 template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false, int WAVES = SOLVE_WAVES>
-__global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : SOLVE_MIN_WAVES_PER_SIMD) void ials_solve_kernel(SolveParams p) {
+__global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? SOLVE_MIN_WAVES_PER_SIMD_K64 : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
   static_assert(!BF16X3 || (UNIT && SOLVER == 0 && T == 4 && MODE == 0), "bf16x3: unit-confidence Cholesky at K <= 64");
   static_assert(WAVES == 1 || (WAVES == 4 && SOLVER == 0), "cooperating waves: the Cholesky kernels only");
   using G = Geo<T>;
@@ -955,7 +1002,9 @@ __global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : SOLVE_MIN_
   constexpr int LDS_PER_WAVE = SOLVER == 0 ? Chol16Geo<T>::LDS_FLOATS
                                            : (T == 8 ? CholGeo<T>::SPILL_CG_FLOATS : G::LDS_FLOATS);
   __shared__ __attribute__((aligned(16))) float lds[WAVES * LDS_PER_WAVE];
-  const int wid = threadIdx.x >> 6;
+  // (K = 128: with the scalar task the register allocator spills 800 bytes per lane where the
+  // per-lane form spills 12 - the two starts of the accumulators become real branches)
+  const int wid = T <= 4 ? wave_in_block() : static_cast<int>(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int w = blockIdx.x * WAVES + wid;
   float *sm = lds + wid * LDS_PER_WAVE;

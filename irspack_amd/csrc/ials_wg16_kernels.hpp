@@ -246,7 +246,7 @@ __device__ __forceinline__ void wg_cholesky16(f32x4 (&acc)[WgGeo<T>::TPW],
           }
         }
       }
-      diag_factor16(Cd, E, scr0, scr1, bad);
+      diag_factor16<false>(Cd, E, scr0, scr1, bad);
       float *dst = wt + I * WS;
 #pragma unroll
       for (int r = 0; r < 4; r++) dst[(4 * g + r) * 17 + m] = E[r];

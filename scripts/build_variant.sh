@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../irspack_amd/csrc"
 mkdir -p ../variants /tmp/irs_var_$1
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -Xarch_host -ffp-contract=off $2"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -mllvm -pragma-unroll-threshold=65536 -Xarch_host -ffp-contract=off $2"
 for f in ials knn evaluator ceilings device_sort; do
   if [ "$f" = "${VARIANT_FILE:-ials}" ] || [ ! -f /tmp/irs_var_base/$f.o ]; then
     /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o /tmp/irs_var_$1/$f.o &
