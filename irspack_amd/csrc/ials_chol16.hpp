@@ -75,6 +75,19 @@ __device__ __forceinline__ void row_elim(float &xi, float &yi, const float xk, c
 // broadcast of v_fmac_f32 itself delivers it - two vector instructions per eliminated pair instead
 // of v_readlane + two (-96 per system; same-box A/B: user half -2.3 %).
 // -DIRS_CHOL16_READLANE restores the v_readlane form.
+// Sum over the 16 lanes of a row (DPP row shifts, zero fill): lane 15 of the row holds the total.
+__device__ __forceinline__ float row_sum16(float v) {
+  auto shr = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                 0xf, 0xf, true));
+  };
+  v += shr(v, std::integral_constant<int, 0x111>{});  // row_shr:1
+  v += shr(v, std::integral_constant<int, 0x112>{});  // row_shr:2
+  v += shr(v, std::integral_constant<int, 0x114>{});  // row_shr:4
+  v += shr(v, std::integral_constant<int, 0x118>{});  // row_shr:8
+  return v;
+}
+
 #ifdef IRS_CHOL16_READLANE
 constexpr bool CHOL16_DPP = false;
 #else
@@ -231,11 +244,10 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     for (int r = 0; r < 4; r++)
       if (4 * g + r == m) acc[C::tix(i, i)][r] += (T * m + i < K) ? reg : 1.0f;
 
-  // right-hand side as tile row T: every row of tile (T, I) is b_I^T, so one register per tile
-  // carries it between the matrix-core phases (16 identical rows: 4 x fewer registers held)
-  float by[T];
-#pragma unroll
-  for (int i = 0; i < T; i++) by[i] = b4[i];
+  // The right-hand side used to ride through the factorisation as one more tile ROW (16 identical
+  // rows: y = L^-1 b for 40 of the 128 matrix instructions of a 64 x 64 system, 1,280 issue cycles for
+  // 2 K multiply-adds).  Round 4: the forward substitution runs on the vector unit after the
+  // factorisation (forward_substitute16 below: ~170 vector instructions).
 
   bool bad = false;
   IPHASE_BEGIN;
@@ -261,46 +273,42 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
       __threadfence_block();
     }
     IPHASE(1);
-    // ---- (2) TRSM: L_JI = S_JI E^T, y_I = b_I E^T.  B[k][n] = E[n][k]
+    // ---- (2) TRSM: L_JI = S_JI E^T.  B[k][n] = E[n][k]
     float bE[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) bE[s] = wtI[m * 17 + 4 * s + g];
-    // All tiles of the block column (and the rhs row, kept as 16 identical rows at panel rows
-    // KP ..) are staged in the panel buffer at once - it has exactly the layout the transposed
-    // operand read needs - so the step pays ONE LDS round trip and the tiles' MFMA chains
-    // interleave.
+    // All tiles of the block column are staged in the panel buffer at once - it has exactly the
+    // layout the transposed operand read needs - so the step pays ONE LDS round trip and the tiles'
+    // MFMA chains interleave.
 #pragma unroll
     for (int J = I + 1; J < T; J++)
 #pragma unroll
       for (int r = 0; r < 4; r++) pan[(16 * J + 4 * g + r) * 17 + m] = acc[C::tix(I, J)][r];
-    pan[KP * 17 + m] = by[I];  // (one row; every group writes the same 16 values)
     __threadfence_block();
     // (chunks of CH tiles bound the operand registers; within a chunk the tiles' MFMA chains are
     // interleaved.  K <= 64: two tiles, 16 registers less at the kernel's pressure peak - what
     // four waves per SIMD need)
     constexpr int CH = IRS_CHOL16_TRSM_CHUNK(T);
 #pragma unroll
-    for (int J0 = I + 1; J0 <= T; J0 += CH) {
+    for (int J0 = I + 1; J0 < T; J0 += CH) {
       float aS[CH][4];  // A[i][k] = S[i][k]: lane (g, i) reads row i, column 4 s + g
       f32x4 D[CH];
 #pragma unroll
       for (int c = 0; c < CH; c++) {
         D[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (J0 + c <= T) {
+        if (J0 + c < T) {
 #pragma unroll
-          for (int s = 0; s < 4; s++)
-            aS[c][s] = J0 + c < T ? pan[(16 * (J0 + c) + m) * 17 + 4 * s + g] : pan[KP * 17 + 4 * s + g];
+          for (int s = 0; s < 4; s++) aS[c][s] = pan[(16 * (J0 + c) + m) * 17 + 4 * s + g];
         }
       }
 #pragma unroll
       for (int s = 0; s < 4; s++)
 #pragma unroll
         for (int c = 0; c < CH; c++)
-          if (J0 + c <= T) D[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[c][s], bE[s], D[c], 0, 0, 0);
+          if (J0 + c < T) D[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[c][s], bE[s], D[c], 0, 0, 0);
 #pragma unroll
       for (int c = 0; c < CH; c++) {
         if (J0 + c < T) acc[C::tix(I, J0 + c < T ? J0 + c : I)] = D[c];
-        if (J0 + c == T) by[I] = D[c][0];
       }
     }
     __threadfence_block();  // (all operand reads done before the results overwrite the panel)
@@ -310,12 +318,8 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     for (int J = I + 1; J < T; J++)
 #pragma unroll
       for (int r = 0; r < 4; r++) pan[(16 * J + 4 * g + r) * 17 + m] = acc[C::tix(I, J)][r];
-    if (g == 0) pan[KP * 17 + m] = by[I];
     __threadfence_block();
     // ---- (3) trailing update of the tiles right of block column I
-    f32x4 bacc[T];
-#pragma unroll
-    for (int j = I + 1; j < T; j++) bacc[j] = f32x4{by[j], by[j], by[j], by[j]};
 #pragma unroll
     for (int s = 0; s < 4; s++) {
       float op[T], nop[T];
@@ -324,28 +328,61 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
         op[j] = pan[(16 * j + m) * 17 + 4 * s + g];  // L_jI[m][4 s + g]
         nop[j] = -op[j];
       }
-      const float nopy = -pan[KP * 17 + 4 * s + g];
 #pragma unroll
       for (int J2 = I + 1; J2 < T; J2++) {
 #pragma unroll
         for (int J = J2; J < T; J++)
           acc[C::tix(J2, J)] =
               __builtin_amdgcn_mfma_f32_16x16x4f32(nop[J], op[J2], acc[C::tix(J2, J)], 0, 0, 0);
-        bacc[J2] = __builtin_amdgcn_mfma_f32_16x16x4f32(nopy, op[J2], bacc[J2], 0, 0, 0);
       }
     }
-#pragma unroll
-    for (int j = I + 1; j < T; j++) by[j] = bacc[j][0];
     __threadfence_block();  // the next step overwrites the panel and the scratch
     IPHASE(3);
   }
   if (__any(bad)) {
     if (lane == 0) atomicOr(err_flag, 1);
   }
-  // ---- back substitution L^T x = y: z in registers (lane (g, n): z_I[n])
+  // ---- forward substitution L y = b on the vector unit: y_I = E_I (b_I - sum_{J < I} L_IJ y_J).
+  // b_I[m] and y_J[m] live in lane (g, m) (every group a copy); tile L_IJ's register r of lane (g, m)
+  // is L[16 I + 4 g + r][16 J + m], so the products are summed over the 16 lanes of a group (DPP row
+  // shifts), the group's four sums cross to the other layout through 16 floats of LDS, and E_I
+  // (natural coordinates in LDS) is applied like E_J^T in the back substitution below.
   float z[T], x[T];
 #pragma unroll
-  for (int i = 0; i < T; i++) z[i] = by[i];
+  for (int I = 0; I < T; I++) {
+    if (I == 0) {
+      if (lane < 16) zx[lane] = -b4[0];
+    } else {
+      float pr[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) pr[r] = (4 * g + r == m) ? -b4[I] : 0.f;
+#pragma unroll
+      for (int J = 0; J < I; J++) {
+        const f32x4 t = acc[C::tix(J, I)];  // L_IJ
+#pragma unroll
+        for (int r = 0; r < 4; r++) pr[r] = fmaf(t[r], z[J], pr[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) pr[r] = row_sum16(pr[r]);  // lane (g, 15): -w_I[4 g + r]
+      if (m == 15) *reinterpret_cast<f32x4 *>(zx + 4 * g) = f32x4{pr[0], pr[1], pr[2], pr[3]};
+    }
+    __threadfence_block();
+    {
+      const float *e = wt + I * WS + m * 17;  // row n = m of E_I
+      float yq[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const f32x4 wq = *reinterpret_cast<const f32x4 *>(zx + 4 * q);
+        yq[q] = e[4 * q] * wq.x;
+        yq[q] = fmaf(e[4 * q + 1], wq.y, yq[q]);
+        yq[q] = fmaf(e[4 * q + 2], wq.z, yq[q]);
+        yq[q] = fmaf(e[4 * q + 3], wq.w, yq[q]);
+      }
+      z[I] = -((yq[0] + yq[1]) + (yq[2] + yq[3]));  // y_I[n = m]
+    }
+    __threadfence_block();
+  }
+  // ---- back substitution L^T x = y: z in registers (lane (g, n): z_I[n])
 #pragma unroll
   for (int J = T - 1; J >= 0; J--) {
     if (lane < 16) zx[lane] = z[J];
