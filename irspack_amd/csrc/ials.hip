@@ -378,8 +378,6 @@ struct irs_ials_trainer {
   bool opt_pp_chain = true;   // iALS++ prediction passes merged into the rank updates (IRSPACK_AMD_IALSPP_CHAIN)
   bool opt_pp_fork = true;    // iALS++ short-row launch on a second stream (IRSPACK_AMD_IALSPP_FORK)
   bool opt_bf16x3 = false;
-  bool opt_rows2 = false;  // K <= 64 Cholesky: two rows per wave, their diagonal tiles factorised as one batch
-  bool opt_coop = false;  // K <= 64 Cholesky: four rows per workgroup, diagonal tiles factorised together (measured slower: DESIGN 3.1)
 
   int64_t rows_of(int which) const { return which == 0 ? n_users : n_items; }
 };
@@ -862,8 +860,6 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_pp_fork = env_flag("IRSPACK_AMD_IALSPP_FORK", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
   t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
-  t->opt_coop = env_flag("IRSPACK_AMD_IALS_COOP", false);
-  t->opt_rows2 = env_flag("IRSPACK_AMD_IALS_ROWS2", false);
   t->opt_eig = env_flag("IRSPACK_AMD_IALS_EIG", true);
   t->opt_mf = env_flag("IRSPACK_AMD_IALS_MF", true);
 }
@@ -1418,23 +1414,7 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
           t->prof.launch(name, ials_solve_kernel<TT, 1, 0, true>, grid, block, 0, t->stream, p);
         else if (cg)
           t->prof.launch(name, ials_solve_kernel<TT, 1, 0>, grid, block, 0, t->stream, p);
-        else if (t->opt_rows2) {
-          const dim3 grid2(ceil_div(n_regular, 2)), block2(64);
-          if (unit && t->opt_bf16x3 && TT == 4)
-            t->prof.launch(name, ials_solve2_kernel<4, true, true>, grid2, block2, 0, t->stream, p);
-          else if (unit)
-            t->prof.launch(name, ials_solve2_kernel<TT, true, false>, grid2, block2, 0, t->stream, p);
-          else
-            t->prof.launch(name, ials_solve2_kernel<TT, false, false>, grid2, block2, 0, t->stream, p);
-        } else if (t->opt_coop) {
-          const dim3 grid4(ceil_div(n_regular, 4)), block4(256);
-          if (unit && t->opt_bf16x3 && TT == 4)
-            t->prof.launch(name, ials_solve_kernel<4, 0, 0, true, true, 4>, grid4, block4, 0, t->stream, p);
-          else if (unit)
-            t->prof.launch(name, ials_solve_kernel<TT, 0, 0, true, false, 4>, grid4, block4, 0, t->stream, p);
-          else
-            t->prof.launch(name, ials_solve_kernel<TT, 0, 0, false, false, 4>, grid4, block4, 0, t->stream, p);
-        } else if (unit && t->opt_bf16x3 && TT == 4)
+        else if (unit && t->opt_bf16x3 && TT == 4)
           t->prof.launch(name, ials_solve_kernel<4, 0, 0, true, true>, grid, block, 0, t->stream, p);
         else if (unit)
           t->prof.launch(name, ials_solve_kernel<TT, 0, 0, true>, grid, block, 0, t->stream, p);
@@ -1446,9 +1426,6 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         const dim3 grid(ceil_div(sd.n_split, SOLVE_WAVES)), block(64 * SOLVE_WAVES);
         if (cg)
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 1, 1>, grid, block, 0, t->stream, p);
-        else if (t->opt_coop)
-          t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 0, 1, false, false, 4>,
-                         dim3(ceil_div(sd.n_split, 4)), dim3(256), 0, t->stream, p);
         else
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 0, 1>, grid, block, 0, t->stream, p);
       }

@@ -173,64 +173,12 @@ __device__ __forceinline__ void diag_factor16(f32x4 &Cd, f32x4 &E, float *scrR, 
   diag_factor16_step<3, DPP>(Cd, E, scrR, scrE, bad);
 }
 
-// ---- Four systems' diagonal tiles factorised by ONE wave (round 4) ------------------------------
-// In the accumulator layout the rows of a 4-row sub-panel live in one 16-lane group, so a wave that
-// factorises its own tile runs the ~42 vector instructions of a sub-panel for 16 useful lanes, and
-// pays them 16 times per 64 x 64 system: ~670 of the ~1060 vector instructions of a solve.  When the
-// four waves of a workgroup solve four rows in step, each hands its tile over through LDS and ONE
-// wave factorises the four of them together: lane (s, m) holds column m of system s, register i is
-// row i.  A row operation then is one instruction for four systems, and the broadcast of a row's
-// element to the lanes of its group is the DPP `row_newbcast` of the instruction itself
-// (v_fmac_f32_dpp: no v_readlane, no select, no MFMA for the rows below the sub-panel):
-// 240 + ~100 vector instructions for four tiles against ~4 x 265 (matrix-core work included).
-// The factorising wave changes with the block column, so the four SIMDs share the work.
-//
-// v_fmac_f32_dpp has no builtin form that the compiler folds (the DPP combiner runs before
-// v_fma_f32 becomes the two-address v_fmac_f32), hence inline assembly; the wait states between a
-// vector write and a DPP read of the same register (2) are carried by the `s_nop 1` of the first
-// instruction of each group.
-template <int K, int... I>
-__device__ __forceinline__ void factor16x4_step(float (&X)[16], float (&Y)[16], bool &bad,
-                                                std::integer_sequence<int, I...>) {
-  const float piv = row_bcast<K>(X[K]);
-  bad |= !(piv > 0.f);
-  const float rinv = __builtin_amdgcn_rsqf(piv);
-  X[K] *= rinv;
-  Y[K] *= rinv;
-  (row_elim<K + 1 + I, I == 0>(X[K + 1 + I], Y[K + 1 + I], X[K], Y[K]), ...);
-}
-template <int... K>
-__device__ __forceinline__ void factor16x4_steps(float (&X)[16], float (&Y)[16], bool &bad,
-                                                 std::integer_sequence<int, K...>) {
-  (factor16x4_step<K>(X, Y, bad, std::make_integer_sequence<int, 15 - K>{}), ...);
-}
-// tiles: system s's 16 x 17 tile at tiles + s * stride (written by wave s in natural coordinates);
-// E_s = L_s^-1 goes to out + s * stride in the same form.
-__device__ __forceinline__ void diag_factor16x4(const float *tiles, float *out, int stride, bool &bad) {
-  const int lane = threadIdx.x & 63;
-  const int s = lane >> 4, m = lane & 15;
-  const float *src = tiles + s * stride + m;
-  float X[16], Y[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    X[i] = src[i * 17];
-    Y[i] = (i == m) ? 1.0f : 0.0f;
-  }
-  factor16x4_steps(X, Y, bad, std::make_integer_sequence<int, 16>{});
-  float *dst = out + s * stride + m;
-#pragma unroll
-  for (int i = 0; i < 16; i++) dst[i * 17] = Y[i];
-}
-
 // acc: lower-form tiles of A = P + sum c v v^T (no regulariser yet); b4[i] in lane (g, m) =
 // right-hand side at virtual index 16 i + m.
-// WAVES == 4 and `coop` (uniform over the workgroup: all four waves are here with a row each): the
-// diagonal tiles go through diag_factor16x4; `sm` is this wave's slice of the workgroup's LDS,
-// slices LDS_FLOATS apart, wave `wid`'s first.
-template <int T, int WAVES>
+template <int T>
 __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
                                                      float reg, float *sm, float *xrow, int K,
-                                                     int32_t *err_flag, bool coop, int wid) {
+                                                     int32_t *err_flag) {
   using C = Chol16Geo<T>;
   constexpr int KP = C::KP, WS = C::WS;
   const int lane = threadIdx.x & 63;
@@ -255,23 +203,13 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
   for (int I = 0; I < T; I++) {
     float *wtI = wt + I * WS;
     // ---- (1) diagonal tile
-    if (WAVES == 4 && coop) {
-      const f32x4 Cd = acc[C::tix(I, I)];
-#pragma unroll
-      for (int r = 0; r < 4; r++) scr[(4 * g + r) * 17 + m] = Cd[r];
-      __syncthreads();
-      if (wid == (I & 3)) {
-        float *base = sm - wid * C::LDS_FLOATS;  // wave 0's slice
-        diag_factor16x4(base + C::SCR, base + C::WT + I * WS, C::LDS_FLOATS, bad);
-      }
-      __syncthreads();
-    } else {
+    {
       f32x4 Cd = acc[C::tix(I, I)], E;
       diag_factor16(Cd, E, scr, scr + WS, bad);
 #pragma unroll
       for (int r = 0; r < 4; r++) wtI[(4 * g + r) * 17 + m] = E[r];
-      __threadfence_block();
     }
+    __threadfence_block();
     IPHASE(1);
     // ---- (2) TRSM: L_JI = S_JI E^T.  B[k][n] = E[n][k]
     float bE[4];
@@ -439,282 +377,6 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     } else {
 #pragma unroll
       for (int J = 0; J < T; J++) dst[J] = x[J];
-    }
-  }
-  IPHASE(4);
-}
-
-// ---- Two rows per wave (round 4) ------------------------------------------------------------------
-// One wave carries TWO rows' systems through the block Cholesky above, step by step, so that the two
-// diagonal tiles of a step are factorised together without any synchronisation between waves (the
-// four-waves-per-workgroup form above saves more vector instructions and loses more at its barriers).
-// diag_factor16x2: lanes 0..31 hold the tiles (lane (s, m): column m of system s, register i = row
-// i), lanes 32..63 the identity that becomes E = L^-1; a row operation on [S | I] is ONE
-// v_fmac_f32_dpp for both halves and both systems.  The multipliers (the pivot row's elements) are
-// needed by both halves: M = the pivot row's tile half copied into the upper lanes
-// (v_permlane32_swap).  Per step 10 + (15 - k) vector instructions: 280 for two tiles against
-// 2 x ~265 (matrix-core work included) for diag_factor16.
-__device__ __forceinline__ float dup_lower_half(float v) {  // lanes 32..63 <- lanes 0..31
-  // v_permlane32_swap exchanges the upper half of its first operand with the lower half of the second
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v),
-                                                  false, false);
-  return __builtin_bit_cast(float, r[0]);
-}
-template <int N, bool FIRST>
-__device__ __forceinline__ void row_elim1(float &zi, const float mk, const float zk) {
-  if constexpr (FIRST)
-    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(zi)
-                 : "v"(mk), "v"(zk), "n"(N));
-  else
-    asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(zi)
-                 : "v"(mk), "v"(zk), "n"(N));
-}
-template <int K, int... I>
-__device__ __forceinline__ void factor16x2_step(float (&Z)[16], bool &bad, std::integer_sequence<int, I...>) {
-  float M = dup_lower_half(Z[K]);  // every row of 16 lanes now holds its system's pivot row
-  const float piv = row_bcast<K>(M);
-  bad |= !(piv > 0.f);
-  const float rinv = __builtin_amdgcn_rsqf(piv);
-  Z[K] *= rinv;
-  if constexpr (K < 15) {
-    M *= rinv;
-    (row_elim1<K + 1 + I, I == 0>(Z[K + 1 + I], M, Z[K]), ...);
-  }
-}
-template <int... K>
-__device__ __forceinline__ void factor16x2_steps(float (&Z)[16], bool &bad, std::integer_sequence<int, K...>) {
-  (factor16x2_step<K>(Z, bad, std::make_integer_sequence<int, 15 - K>{}), ...);
-}
-
-// Two systems: acc[s], b4[s], reg[s], xrow[s].  `sm`: 2 * Chol16Geo<T>::LDS_FLOATS floats, system s's
-// regions at sm + s * LDS_FLOATS.  Same arithmetic per system as solve_row_cholesky16 except the
-// diagonal tiles (sequential row operations instead of 4-row sub-panels with rank-4 updates).
-template <int T>
-__device__ __forceinline__ void solve_rows2_cholesky16(f32x4 (&acc)[2][Geo<T>::NT], const float (&b4)[2][T],
-                                                       const float (&reg)[2], float *sm,
-                                                       float *const (&xrow)[2], int K, int32_t *err_flag) {
-  using C = Chol16Geo<T>;
-  constexpr int KP = C::KP, WS = C::WS, LS = C::LDS_FLOATS;
-  const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, m = lane & 15;
-
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-#pragma unroll
-    for (int i = 0; i < T; i++)
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (4 * g + r == m) acc[s][C::tix(i, i)][r] += (T * m + i < K) ? reg[s] : 1.0f;
-
-  f32x4 bacc[2][T];
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-#pragma unroll
-    for (int i = 0; i < T; i++) bacc[s][i] = f32x4{b4[s][i], b4[s][i], b4[s][i], b4[s][i]};
-  float idv[4];  // the identity tile in accumulator layout
-#pragma unroll
-  for (int r = 0; r < 4; r++) idv[r] = (4 * g + r == m) ? 1.0f : 0.0f;
-
-  bool bad = false;
-  IPHASE_BEGIN;
-#pragma unroll
-  for (int I = 0; I < T; I++) {
-    // ---- (1) the two diagonal tiles, together.  Tiles of the systems at the start of their panels
-    // (dead here), the identity behind system 0's.
-    {
-#pragma unroll
-      for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) sm[s * LS + C::SCR + (4 * g + r) * 17 + m] = acc[s][C::tix(I, I)][r];
-#pragma unroll
-      for (int r = 0; r < 4; r++) sm[C::SCR + WS + (4 * g + r) * 17 + m] = idv[r];
-      __threadfence_block();
-      const float *src = sm + (g < 2 ? g * LS + C::SCR : C::SCR + WS) + m;
-      float Z[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) Z[i] = src[i * 17];
-      __threadfence_block();
-      factor16x2_steps(Z, bad, std::make_integer_sequence<int, 16>{});
-      if (g >= 2) {
-        float *dst = sm + (g - 2) * LS + C::WT + I * WS + m;
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[i * 17] = Z[i];
-      }
-      __threadfence_block();
-    }
-    IPHASE(1);
-    // ---- (2) TRSM, both systems
-    float bE[2][4];
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) bE[s][q] = sm[s * LS + C::WT + I * WS + m * 17 + 4 * q + g];
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      float *pan = sm + s * LS + C::PAN;
-#pragma unroll
-      for (int J = I + 1; J < T; J++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) pan[(16 * J + 4 * g + r) * 17 + m] = acc[s][C::tix(I, J)][r];
-#pragma unroll
-      for (int r = 0; r < 4; r++) pan[(KP + 4 * g + r) * 17 + m] = bacc[s][I][r];
-    }
-    __threadfence_block();
-#pragma unroll
-    for (int J0 = I + 1; J0 <= T; J0 += 4) {
-      float aS[2][4][4];
-      f32x4 D[2][4];
-#pragma unroll
-      for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          D[s][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (J0 + c <= T) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-              aS[s][c][q] = sm[s * LS + C::PAN + (16 * (J0 + c) + m) * 17 + 4 * q + g];
-          }
-        }
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-          for (int s = 0; s < 2; s++)
-            if (J0 + c <= T)
-              D[s][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[s][c][q], bE[s][q], D[s][c], 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          if (J0 + c < T) acc[s][C::tix(I, J0 + c < T ? J0 + c : I)] = D[s][c];
-          if (J0 + c == T) bacc[s][I] = D[s][c];
-        }
-    }
-    __threadfence_block();
-    IPHASE(2);
-    if (I == T - 1) break;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      float *pan = sm + s * LS + C::PAN;
-#pragma unroll
-      for (int J = I + 1; J < T; J++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) pan[(16 * J + 4 * g + r) * 17 + m] = acc[s][C::tix(I, J)][r];
-      if (g == 0) pan[KP * 17 + m] = bacc[s][I][0];
-    }
-    __threadfence_block();
-    // ---- (3) trailing update
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      float op[2][T], nop[2][T], nopy[2];
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        const float *pan = sm + s * LS + C::PAN;
-#pragma unroll
-        for (int j = I + 1; j < T; j++) {
-          op[s][j] = pan[(16 * j + m) * 17 + 4 * q + g];
-          nop[s][j] = -op[s][j];
-        }
-        nopy[s] = -pan[KP * 17 + 4 * q + g];
-      }
-#pragma unroll
-      for (int J2 = I + 1; J2 < T; J2++) {
-#pragma unroll
-        for (int J = J2; J < T; J++)
-#pragma unroll
-          for (int s = 0; s < 2; s++)
-            acc[s][C::tix(J2, J)] = __builtin_amdgcn_mfma_f32_16x16x4f32(nop[s][J], op[s][J2],
-                                                                         acc[s][C::tix(J2, J)], 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-          bacc[s][J2] = __builtin_amdgcn_mfma_f32_16x16x4f32(nopy[s], op[s][J2], bacc[s][J2], 0, 0, 0);
-      }
-    }
-    __threadfence_block();
-    IPHASE(3);
-  }
-  if (__any(bad)) {
-    if (lane == 0) atomicOr(err_flag, 1);
-  }
-  // ---- back substitution, the two systems side by side (independent chains)
-  float z[2][T], x[2][T];
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-#pragma unroll
-    for (int i = 0; i < T; i++) z[s][i] = bacc[s][i][0];
-#pragma unroll
-  for (int J = T - 1; J >= 0; J--) {
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-      if (lane < 16) sm[s * LS + C::ZX + lane] = z[s][J];
-    __threadfence_block();
-    float xj[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      const float *e = sm + s * LS + C::WT + J * WS + m;
-      const float *zx = sm + s * LS + C::ZX;
-      float xq[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const f32x4 zq = *reinterpret_cast<const f32x4 *>(zx + 4 * q);
-        xq[q] = e[(4 * q) * 17] * zq.x;
-        xq[q] = fmaf(e[(4 * q + 1) * 17], zq.y, xq[q]);
-        xq[q] = fmaf(e[(4 * q + 2) * 17], zq.z, xq[q]);
-        xq[q] = fmaf(e[(4 * q + 3) * 17], zq.w, xq[q]);
-      }
-      xj[s] = (xq[0] + xq[1]) + (xq[2] + xq[3]);
-      x[s][J] = xj[s];
-    }
-    if (J == 0) break;
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-      if (lane < 16) sm[s * LS + C::ZX + 16 + lane] = xj[s];
-    __threadfence_block();
-    f32x4 x4[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) x4[s] = *reinterpret_cast<const f32x4 *>(sm + s * LS + C::ZX + 16 + 4 * g);
-    __threadfence_block();
-#pragma unroll
-    for (int I = 0; I < J; I++)
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        const f32x4 t = acc[s][C::tix(I, J)];
-        float c = t[0] * x4[s].x;
-        c = fmaf(t[1], x4[s].y, c);
-        c = fmaf(t[2], x4[s].z, c);
-        c = fmaf(t[3], x4[s].w, c);
-        c += __shfl_xor(c, 16, 64);
-        c += __shfl_xor(c, 32, 64);
-        z[s][I] -= c;
-      }
-  }
-  bool fin = true;
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-#pragma unroll
-    for (int J = 0; J < T; J++) {
-      const int dim = T * m + J;
-      fin = fin && (__builtin_isfinite(x[s][J]) || dim >= K);
-      x[s][J] = dim < K ? x[s][J] : 0.f;
-    }
-  if (!__all(fin)) {
-    if (lane == 0) atomicOr(err_flag, 2);
-  }
-  if (g == 0) {
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      float *dst = xrow[s] + T * m;
-      if constexpr (T % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < T / 4; q++)
-          *reinterpret_cast<f32x4 *>(dst + 4 * q) = f32x4{x[s][4 * q], x[s][4 * q + 1], x[s][4 * q + 2], x[s][4 * q + 3]};
-      } else {
-#pragma unroll
-        for (int J = 0; J < T; J++) dst[J] = x[s][J];
-      }
     }
   }
   IPHASE(4);

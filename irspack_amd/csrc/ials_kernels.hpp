@@ -967,10 +967,10 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
 
 // The Cholesky solve of these kernels lives in ials_chol16.hpp (which includes this header).
 template <int T> struct Chol16Geo;
-template <int T, int WAVES = 1>
+template <int T>
 __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
                                                      float reg, float *sm, float *xrow, int K,
-                                                     int32_t *err_flag, bool coop = false, int wid = 0);
+                                                     int32_t *err_flag);
 
 // MODE 0: one wave per task.  Whole rows are solved inline; chunks of split
 //         rows store their partial Gramian / rhs.
@@ -987,14 +987,10 @@ __device__ unsigned long long ials_phase_clk[8 * 4096];
 #endif
 
 // BF16X3: the rank update of syrk_gather_bf16x3 (opt-in; UNIT, Cholesky, T == 4 only).
-// WAVES == 4 (Cholesky only): four tasks per workgroup; when all four are whole rows the waves meet
-// at every diagonal tile and one of them factorises the four tiles together (ials_chol16.hpp,
-// diag_factor16x4).  A workgroup with a chunk of a split row or past the end of the list runs its
-// waves independently, as WAVES == 1 does.
-template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false, int WAVES = SOLVE_WAVES>
-__global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? SOLVE_MIN_WAVES_PER_SIMD_K64 : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
+template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false>
+__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? SOLVE_MIN_WAVES_PER_SIMD_K64 : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
   static_assert(!BF16X3 || (UNIT && SOLVER == 0 && T == 4 && MODE == 0), "bf16x3: unit-confidence Cholesky at K <= 64");
-  static_assert(WAVES == 1 || (WAVES == 4 && SOLVER == 0), "cooperating waves: the Cholesky kernels only");
+  constexpr int WAVES = SOLVE_WAVES;
   using G = Geo<T>;
   // Cholesky: lower-form tiles + the 16-row block solve of ials_chol16.hpp
   constexpr bool LOWER = SOLVER == 0;
@@ -1016,13 +1012,7 @@ __global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? 
   const f32x4 *Pacc = reinterpret_cast<const f32x4 *>(LOWER ? p.P_accL : p.P_acc);
 
   IPHASE_BEGIN;
-  bool coop = false;  // uniform over the workgroup
   if constexpr (MODE == 0) {
-    if constexpr (WAVES == 4) {
-      const int w0 = blockIdx.x * WAVES;
-      coop = w0 + WAVES <= p.n_tasks && (p.tasks[w0].slot & p.tasks[w0 + 1].slot & p.tasks[w0 + 2].slot &
-                                         p.tasks[w0 + 3].slot) < 0;
-    }
     if (w >= p.n_tasks) return;
     const Task task = p.tasks[w];
     if (task.slot < 0) {
@@ -1054,8 +1044,8 @@ __global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? 
     // with a prior an empty row is solved like any other (hpp:207): hide nnz == 0 from CG
     const int nnz_cg = p.prior ? max(task.end - task.begin, 1) : task.end - task.begin;
     if constexpr (SOLVER == 0)
-      solve_row_cholesky16<T, WAVES>(acc, bsum, p.reg[task.row], sm,
-                                     p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag, coop, wid);
+      solve_row_cholesky16<T>(acc, bsum, p.reg[task.row], sm,
+                              p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag);
     else if constexpr (T == 8)
       solve_row_cg128<T>(acc, bsum, p.reg[task.row], sm,
                          p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
@@ -1065,7 +1055,6 @@ __global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? 
                            p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
                            p.max_cg_steps, p.warm_start, p.err_flag);
   } else {
-    if constexpr (WAVES == 4) coop = blockIdx.x * WAVES + WAVES <= p.n_split;
     if (w >= p.n_split) return;
     const SplitRow sr = p.split_rows[w];
 #pragma unroll
@@ -1098,8 +1087,8 @@ __global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? 
     }
     add_prior<T>(p, sr.row, bsum);
     if constexpr (SOLVER == 0)
-      solve_row_cholesky16<T, WAVES>(acc, bsum, p.reg[sr.row], sm,
-                                     p.target + static_cast<size_t>(sr.row) * G::KP, p.K, p.err_flag, coop, wid);
+      solve_row_cholesky16<T>(acc, bsum, p.reg[sr.row], sm,
+                              p.target + static_cast<size_t>(sr.row) * G::KP, p.K, p.err_flag);
     else if constexpr (T == 8)
       solve_row_cg128<T>(acc, bsum, p.reg[sr.row], sm,
                          p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
@@ -1108,97 +1097,6 @@ __global__ __launch_bounds__(64 * WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? 
       solve_row<T, SOLVER>(acc, bsum, p.reg[sr.row], sm,
                            p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
                            p.max_cg_steps, p.warm_start, p.err_flag);
-  }
-}
-
-// Two tasks per wave, Cholesky, K <= 64 (round 4): tasks 2 w and 2 w + 1 of the (length-sorted) list.
-// When both are whole rows their systems go through the block Cholesky together
-// (solve_rows2_cholesky16: the diagonal tiles of a step are factorised as one batch); a chunk of a
-// split row, or a last odd task, is handled as ials_solve_kernel<T, 0, 0> handles it.
-template <int T> struct Chol16Geo;
-template <int T>
-__device__ __forceinline__ void solve_rows2_cholesky16(f32x4 (&acc)[2][Geo<T>::NT], const float (&b4)[2][T],
-                                                       const float (&reg)[2], float *sm,
-                                                       float *const (&xrow)[2], int K, int32_t *err_flag);
-
-template <int T, bool UNIT, bool BF16X3>
-__device__ __forceinline__ void gather_task(const SolveParams &p, const Task &task,
-                                            f32x4 (&acc)[Geo<T>::NT], float (&bsum)[T]) {
-  if constexpr (BF16X3)
-    syrk_gather_bf16x3<T>(p.other, p.indices, task.begin, task.end, p.bias, acc, bsum,
-                          static_cast<unsigned>(p.zero_row));
-  else
-    syrk_gather<T, 1, 0, 8, UNIT, true>(p.other, p.indices, p.data, task.begin, task.end, p.bias, acc, bsum,
-                                        static_cast<unsigned>(p.zero_row));
-}
-
-template <int T, bool UNIT = false, bool BF16X3 = false>
-__global__ __launch_bounds__(64, 2) void ials_solve2_kernel(SolveParams p) {
-  static_assert(T <= 4, "two rows per wave: K <= 64");
-  static_assert(!BF16X3 || (UNIT && T == 4), "bf16x3: unit-confidence Cholesky at K <= 64");
-  using G = Geo<T>;
-  constexpr int LS = Chol16Geo<T>::LDS_FLOATS;
-  __shared__ __attribute__((aligned(16))) float sm[2 * LS];
-  const int lane = threadIdx.x & 63;
-  const int t0 = 2 * blockIdx.x;
-  if (t0 >= p.n_tasks) return;
-  const bool has1 = t0 + 1 < p.n_tasks;
-  const Task task0 = p.tasks[t0];
-  const Task task1 = p.tasks[has1 ? t0 + 1 : t0];
-  const f32x4 *Pacc = reinterpret_cast<const f32x4 *>(p.P_accL);
-
-  if (has1 && (task0.slot & task1.slot) < 0) {
-    f32x4 acc[2][G::NT];
-    float bsum[2][T];
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-#pragma unroll
-      for (int i = 0; i < T; i++) bsum[s][i] = 0.f;
-#pragma unroll
-      for (int t = 0; t < G::NT; t++) acc[s][t] = Pacc[t * 64 + lane];
-    }
-    IPHASE_BEGIN;
-    gather_task<T, UNIT, BF16X3>(p, task0, acc[0], bsum[0]);
-    gather_task<T, UNIT, BF16X3>(p, task1, acc[1], bsum[1]);
-    IPHASE(0);
-    add_prior<T>(p, task0.row, bsum[0]);
-    add_prior<T>(p, task1.row, bsum[1]);
-    const float reg[2] = {p.reg[task0.row], p.reg[task1.row]};
-    float *const xrow[2] = {p.target + static_cast<size_t>(task0.row) * G::KP,
-                            p.target + static_cast<size_t>(task1.row) * G::KP};
-    solve_rows2_cholesky16<T>(acc, bsum, reg, sm, xrow, p.K, p.err_flag);
-    return;
-  }
-  // one task at a time
-  for (int k = 0; k < (has1 ? 2 : 1); k++) {
-    const Task task = k == 0 ? task0 : task1;
-    f32x4 acc[G::NT];
-    float bsum[T];
-#pragma unroll
-    for (int i = 0; i < T; i++) bsum[i] = 0.f;
-    if (task.slot < 0) {
-#pragma unroll
-      for (int t = 0; t < G::NT; t++) acc[t] = Pacc[t * 64 + lane];
-    } else {
-#pragma unroll
-      for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    gather_task<T, UNIT, BF16X3>(p, task, acc, bsum);
-    if (task.slot >= 0) {
-      float *dst = p.partials + static_cast<size_t>(task.slot) * G::PARTIAL_FLOATS;
-      f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
-#pragma unroll
-      for (int t = 0; t < G::NT; t++) d4[t * 64 + lane] = acc[t];
-      if (lane < 16) {
-#pragma unroll
-        for (int i = 0; i < T; i++) dst[G::NT * 256 + T * lane + i] = bsum[i];
-      }
-      continue;
-    }
-    add_prior<T>(p, task.row, bsum);
-    solve_row_cholesky16<T>(acc, bsum, p.reg[task.row], sm,
-                            p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag);
-    __threadfence_block();
   }
 }
 
