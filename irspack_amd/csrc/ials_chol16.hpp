@@ -95,7 +95,10 @@ constexpr bool CHOL16_DPP = true;
 #endif
 // DPP = false: the v_readlane form (the 256-register workgroup kernels of K > 128 spill 0.5 KB per
 // lane around the pinned assembly of the DPP form)
-template <int Q, bool DPP>
+// CHECK = false: the pivots are not tested here - a pivot that is not positive leaves NaN or
+// infinity on the diagonal of E (1 / sqrt), which the caller looks at only when the solution came out
+// non-finite (solve_row_cholesky16: 64 vector compares per 64 x 64 system off the common path).
+template <int Q, bool DPP, bool CHECK>
 __device__ __forceinline__ void diag_subpanel(f32x4 &Cd, f32x4 &E, bool &bad) {
   if constexpr (!DPP) {
 #pragma unroll
@@ -117,7 +120,7 @@ __device__ __forceinline__ void diag_subpanel(f32x4 &Cd, f32x4 &E, bool &bad) {
   auto pivot = [&](auto rc) {
     constexpr int r = decltype(rc)::value;
     const float piv = row_bcast<4 * Q + r>(c[r]);
-    bad |= !(piv > 0.f);
+    if constexpr (CHECK) bad |= !(piv > 0.f);
     const float rinv = __builtin_amdgcn_rsqf(piv);
     c[r] *= rinv;
     e[r] *= rinv;
@@ -137,11 +140,11 @@ __device__ __forceinline__ void diag_subpanel(f32x4 &Cd, f32x4 &E, bool &bad) {
 // S = R^T R of one 16 x 16 tile in accumulator layout, E = R^-T alongside.  `Cd` is
 // consumed; its strictly lower triangle only ever holds rounding noise and is never read as
 // a result.  scrR / scrE: 16 x 17 floats each, private to the wave.
-template <int Q, bool DPP>
+template <int Q, bool DPP, bool CHECK>
 __device__ __forceinline__ void diag_factor16_step(f32x4 &Cd, f32x4 &E, float *scrR, float *scrE, bool &bad) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
-  if (g == Q) diag_subpanel<Q, DPP>(Cd, E, bad);
+  if (g == Q) diag_subpanel<Q, DPP, CHECK>(Cd, E, bad);
   if constexpr (Q < 3) {
     // rows 4Q .. 4Q+3 are final: rank-4 update of the rows below them (and of E).  Every group
     // stores its four rows (no divergent branch: the block stays one scheduling region), the
@@ -160,17 +163,23 @@ __device__ __forceinline__ void diag_factor16_step(f32x4 &Cd, f32x4 &E, float *s
     E = __builtin_amdgcn_mfma_f32_16x16x4f32(na, e, E, 0, 0, 0);
   }
 }
-template <bool DPP = CHOL16_DPP>
+template <bool DPP = CHOL16_DPP, bool CHECK = true>
 __device__ __forceinline__ void diag_factor16(f32x4 &Cd, f32x4 &E, float *scrR, float *scrE,
                                               bool &bad) {
+  // (E arrives as the identity tile: the caller keeps it in four registers across its tiles)
+  diag_factor16_step<0, DPP, CHECK>(Cd, E, scrR, scrE, bad);
+  diag_factor16_step<1, DPP, CHECK>(Cd, E, scrR, scrE, bad);
+  diag_factor16_step<2, DPP, CHECK>(Cd, E, scrR, scrE, bad);
+  diag_factor16_step<3, DPP, CHECK>(Cd, E, scrR, scrE, bad);
+}
+// the identity tile in accumulator layout
+__device__ __forceinline__ f32x4 identity_tile16() {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
+  f32x4 E;
 #pragma unroll
   for (int r = 0; r < 4; r++) E[r] = (4 * g + r == m) ? 1.0f : 0.0f;
-  diag_factor16_step<0, DPP>(Cd, E, scrR, scrE, bad);
-  diag_factor16_step<1, DPP>(Cd, E, scrR, scrE, bad);
-  diag_factor16_step<2, DPP>(Cd, E, scrR, scrE, bad);
-  diag_factor16_step<3, DPP>(Cd, E, scrR, scrE, bad);
+  return E;
 }
 
 // acc: lower-form tiles of A = P + sum c v v^T (no regulariser yet); b4[i] in lane (g, m) =
@@ -198,14 +207,15 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
   // factorisation (forward_substitute16 below: ~170 vector instructions).
 
   bool bad = false;
+  const f32x4 ident = identity_tile16();
   IPHASE_BEGIN;
 #pragma unroll
   for (int I = 0; I < T; I++) {
     float *wtI = wt + I * WS;
     // ---- (1) diagonal tile
     {
-      f32x4 Cd = acc[C::tix(I, I)], E;
-      diag_factor16(Cd, E, scr, scr + WS, bad);
+      f32x4 Cd = acc[C::tix(I, I)], E = ident;
+      diag_factor16<CHOL16_DPP, !CHOL16_DPP>(Cd, E, scr, scr + WS, bad);
 #pragma unroll
       for (int r = 0; r < 4; r++) wtI[(4 * g + r) * 17 + m] = E[r];
     }
@@ -277,7 +287,7 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     __threadfence_block();  // the next step overwrites the panel and the scratch
     IPHASE(3);
   }
-  if (__any(bad)) {
+  if (!CHOL16_DPP && __any(bad)) {
     if (lane == 0) atomicOr(err_flag, 1);
   }
   // ---- forward substitution L y = b on the vector unit: y_I = E_I (b_I - sum_{J < I} L_IJ y_J).
@@ -366,7 +376,14 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
     x[J] = dim < K ? x[J] : 0.f;
   }
   if (!__all(fin)) {
-    if (lane == 0) atomicOr(err_flag, 2);
+    // The rare path.  Was it the factorisation (hpp:317-319) or the solve (hpp:321-323)?  A pivot that
+    // was not positive left NaN or infinity as its 1 / sqrt on the diagonal of an E tile.
+    bool badp = false;
+    if (CHOL16_DPP) {
+#pragma unroll
+      for (int J = 0; J < T; J++) badp |= !(wt[J * WS + m * 17 + m] < __builtin_inff());
+    }
+    if (lane == 0) atomicOr(err_flag, __any(badp) ? 3 : 2);
   }
   if (g == 0) {
     float *dst = xrow + T * m;

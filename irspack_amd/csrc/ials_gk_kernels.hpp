@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gk_chol_kernel(GkParams p) {
       return acc;
     };
     if (wv == 0) {
-      f32x4 Cd = accumulate(I), E;
+      f32x4 Cd = accumulate(I), E = identity_tile16();
       diag_factor16<false>(Cd, E, scr, scr + 16 * 17, bad);
       float *dst = sys + gk_tile_off(I, I);  // the slot of L_II keeps E = L_II^-1 (L_II is not needed again)
 #pragma unroll

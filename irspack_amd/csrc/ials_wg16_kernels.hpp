@@ -236,7 +236,7 @@ __device__ __forceinline__ void wg_cholesky16(f32x4 (&acc)[WgGeo<T>::TPW],
     // ---- (1) diagonal tile (I, I): owner wave only
     const int t_diag = I * T - I * (I - 1) / 2;
     if ((t_diag & 3) == W) {
-      f32x4 Cd = {0.f, 0.f, 0.f, 0.f}, E;
+      f32x4 Cd = {0.f, 0.f, 0.f, 0.f}, E = identity_tile16();
 #pragma unroll
       for (int s = 0; s < G::TPW; s++) {
         const int t = G::NW * s + W;
