@@ -104,3 +104,65 @@ def test_headline_kernel_fits_four_waves_per_simd(kernels):
     assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 128, k[".vgpr_count"]
     assert k[".private_segment_fixed_size"] == 0
     assert 16 * k[".group_segment_fixed_size"] <= 160 * 1024
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _vregs(token):
+    import re
+    out = []
+    for m in re.finditer(r"v\[(\d+):(\d+)\]|\bv(\d+)\b", token):
+        if m.group(1):
+            out += list(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.append(int(m.group(3)))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain is not installed")
+def test_no_dpp_read_within_two_wait_states_of_a_vector_write(tmp_path):
+    """gfx9: a vector instruction that writes a register and a DPP instruction that reads it through its
+    lane-permuting operand need two wait states between them, and the hardware does not interlock.  The
+    compiler keeps that for its own DPP instructions; the row operations of the Cholesky diagonal tile
+    (ials_chol16.hpp) are inline assembly, which the hazard recogniser does not look into - their
+    `s_nop 1` covers what the source order puts in front of them, this test covers what the register
+    allocator might (a copy placed right before the assembly).  Fall-through order, every kernel."""
+    import re
+    import subprocess
+
+    if not os.path.exists(LIB):
+        pytest.skip("libirspack_amd.so is not built")
+    data = open(LIB, "rb").read()
+    n_dpp, bad = 0, []
+    for i, (_triple, image) in enumerate(_device_images(data)):
+        elf = tmp_path / f"image{i}.elf"
+        elf.write_bytes(image)
+        text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(elf)], capture_output=True,
+                              text=True, check=True).stdout
+        hist = []  # (registers written by a vector instruction, wait states the instruction is worth)
+        for line in text.split("\n"):
+            m = re.match(r"\s+([a-z_0-9]+)\s*(.*?)\s*(//.*)?$", line)
+            if not m or line.rstrip().endswith(":"):
+                continue
+            op, parts = m.group(1), [p.strip() for p in m.group(2).split(",")]
+            if "_dpp" in op and len(parts) >= 2:
+                n_dpp += 1
+                src = _vregs(parts[1].split(" ")[0])
+                ws = 0
+                for written, cost, txt in reversed(hist):
+                    if ws >= 2:
+                        break
+                    if any(r in written for r in src):
+                        bad.append((txt, line.strip()))
+                        break
+                    ws += cost
+            if op == "s_nop":
+                hist.append((frozenset(), int(parts[0], 0) + 1, line.strip()))
+            elif op.startswith("v_") and not op.startswith("v_cmp"):
+                hist.append((frozenset(_vregs(parts[0])), 1, line.strip()))
+            else:
+                hist.append((frozenset(), 1, line.strip()))
+            del hist[:-4]
+    assert n_dpp > 1000  # (the scan found the instructions it is about)
+    assert not bad, bad[:5]
