@@ -22,6 +22,13 @@ struct HostCsr {
   RawVector<float> data;
 };
 
+// Stored values as the device kernels take them: -0.0 becomes +0.0 (x + 0.0f; every other value,
+// NaN included, is unchanged).  The general-confidence rank update marks an entry past a row's end
+// with c = -0.0 (ials_kernels.hpp: syrk_gather), so the data must not contain that bit pattern.
+static inline void canonical_copy(float *dst, const float *src, int64_t n) {
+  for (int64_t i = 0; i < n; i++) dst[i] = src[i] + 0.0f;
+}
+
 static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
                         const int32_t *indices, const float *data) {
   check_arg(rows >= 0 && cols >= 0, "negative matrix shape.");
@@ -44,7 +51,7 @@ static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
     const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
     if (e <= b) return;
     std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
-    std::memcpy(m.data.data() + b, data + b, (e - b) * sizeof(float));
+    canonical_copy(m.data.data() + b, data + b, e - b);
     int32_t lo = 0, hi = 0;
     for (int64_t q = b; q < e; q++) {
       lo = std::min(lo, indices[q]);
@@ -79,7 +86,8 @@ static HostCsr host_csr_rows(int64_t rows, int64_t cols, const int64_t *indptr,
   const int64_t b = indptr[rb], e = indptr[re];
   for (int64_t r = rb; r <= rows; r++) m.indptr[r] = std::min(indptr[r], e) - b;
   m.indices.assign(indices + b, indices + e);
-  m.data.assign(data + b, data + e);
+  m.data.resize(e - b);
+  canonical_copy(m.data.data(), data + b, e - b);
   for (int64_t p = 0; p < e - b; p++)
     check_arg(m.indices[p] >= 0 && m.indices[p] < cols, "column index out of range.");
   return m;
@@ -109,7 +117,7 @@ static HostCsr transpose_cols(int64_t rows, int64_t cols, const int64_t *indptr,
       if (c < cb || c >= ce) continue;
       const int64_t d = cur[c - cb]++;
       t.indices[d] = static_cast<int32_t>(r);
-      t.data[d] = data[p];
+      t.data[d] = data[p] + 0.0f;  // (canonical_copy's rule)
     }
   return t;
 }

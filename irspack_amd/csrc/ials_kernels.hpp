@@ -243,7 +243,11 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   const float *dp = data + begin + lane;
   const int perm_base = 4 * g;  // ds_bpermute byte address of lane (4j + g) is 16 j + 4 g
   const uint32_t lane_off = static_cast<uint32_t>(T * m * sizeof(float));
-  float v[D][T], vc[D], vw[D];
+  // (general confidences: an entry past the row's end carries c = -0.0 - its c v v^T adds zeros - and
+  // the weight of its right-hand-side term, bias + c, is derived from c when the entry is consumed:
+  // eight registers less than a second ring of weights, which is the difference between three and four
+  // waves per SIMD.  Stored values are canonicalised on the host: -0.0 never comes from the data.)
+  float v[D][T], vc[D];
   // `all_valid` (a compile-time tag): the caller guarantees that the sub-step lies before the
   // row's last one, so no entry has to be neutralised (3 vector instructions less)
   auto fetch = [&](int k, int blk_idx, float blk_c, int j, int entry0, auto all_valid) {
@@ -260,8 +264,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
       return;
     } else {
       const float c = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, blk_c)));
-      vc[k] = valid ? c : 0.f;
-      vw[k] = valid ? bias + c : 0.f;
+      vc[k] = valid ? c : -0.f;
     }
     load_dims<T>(col_base + static_cast<size_t>(idx) * KP, v[k]);
   };
@@ -289,13 +292,19 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
       load_dims<T>(reinterpret_cast<const float *>(reinterpret_cast<const char *>(other) + off), v[k]);
       return;
     } else {
-      vc[k] = valid ? pc : 0.f;
-      vw[k] = valid ? bias + pc : 0.f;
+      vc[k] = valid ? pc : -0.f;
     }
     load_dims<T>(col_base + static_cast<size_t>(idx) * KP, v[k]);
   };
-  auto consume = [&](int k) {
+  // `all_valid`: every entry in the ring was fetched from inside the row (no -0.0 marker to test)
+  auto consume = [&](int k, auto all_valid) {
     float cv[T];
+    float w = 0.f;
+    if constexpr (!UNIT) {
+      w = bias + vc[k];
+      if constexpr (!decltype(all_valid)::value)
+        w = __builtin_bit_cast(unsigned, vc[k]) == 0x80000000u ? 0.f : w;
+    }
 #pragma unroll
     for (int i = 0; i < T; i++) {
       if constexpr (UNIT) {
@@ -303,7 +312,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
         bsum[i] += v[k][i];
       } else {
         cv[i] = vc[k] * v[k][i];
-        bsum[i] = fmaf(vw[k], v[k][i], bsum[i]);
+        bsum[i] = fmaf(w, v[k][i], bsum[i]);
       }
     }
     if constexpr (NW == 1) {
@@ -350,7 +359,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
         perm_issue(pidx, pc, cur_i, cur_c, j + D);
       else
         perm_issue(pidx, pc, nxt_i, nxt_c, j + D - 16);
-      consume(j % D);
+      consume(j % D, all_valid);
       __builtin_amdgcn_sched_barrier(0);  // (the wait below stays behind the matrix instructions)
       if (j + D < 16)
         fetch_finish(j % D, pidx, pc, j + D, 4 * s0, all_valid);
@@ -391,7 +400,7 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   for (int base = 0; base < 15; base += D) {
 #pragma unroll
     for (int k = 0; k < D; k++)
-      if (base + k < rest) consume(k);
+      if (base + k < rest) consume(k, std::false_type{});
     if (base + D < 15 && rest > base + D) {
 #pragma unroll
       for (int k = 0; k < D; k++)

@@ -158,6 +158,37 @@ def test_split_rows_and_long_rows():
         assert rel_err(t.item, o.item) < RTOL
 
 
+@pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
+def test_stored_zeros_of_either_sign_keep_their_bias_term(kind):
+    # A stored entry with value 0.0 - or -0.0 - has confidence 0 but still adds (bias + 0) v to the
+    # right-hand side under the original loss (hpp:289-308).  The general rank update marks the
+    # entries past a row's end with c = -0.0 (ials_kernels.hpp), so the library stores +0.0 for a
+    # -0.0 of the caller (host_prep.hpp: canonical_copy): rows of every length class, lengths that
+    # end inside a four-entry sub-step.
+    rng = np.random.default_rng(11)
+    n_u, n_i = 60, 3000
+    rows = []
+    for u in range(n_u):
+        d = [2050, 1023, 130, 67, 66, 65, 33, 9, 2, 1][u % 10]
+        rows.append(np.sort(rng.choice(n_i, size=d, replace=False)))
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+    indices = np.concatenate(rows).astype(np.int32)
+    data = rng.uniform(0.5, 2.0, size=indices.size).astype(np.float32)
+    z = rng.random(indices.size)
+    data[z < 0.15] = 0.0
+    data[z < 0.07] = -0.0
+    assert np.signbit(data).any()
+    X = sps.csr_matrix((data, indices, indptr), shape=(n_u, n_i))
+    mc, omc = build(64, alpha0=0.5, reg=1e-2, loss="ORIGINAL")
+    sc, osc = solver(kind)
+    t = IALSTrainer(mc, X)
+    o = O.IALSTrainer(omc, X)
+    t.step(sc)
+    o.step(osc)
+    assert rel_err(t.user, o.user) < RTOL
+    assert rel_err(t.item, o.item) < RTOL
+
+
 def test_cg_max_steps_zero_means_K_and_converges_to_cholesky():
     # tests/recommenders/test_ials.py:627-661: converged CG == Cholesky
     X = random_csr(90, 70, 0.15, 4)
