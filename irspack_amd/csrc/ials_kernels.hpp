@@ -177,6 +177,8 @@ template <int T> struct Geo {
   static constexpr int LD = KP + 4;           // LDS row stride (floats); keeps 16 B alignment,
                                               // conflict-free for row-per-lane ds_read_b128
   static constexpr int LDS_FLOATS = KP * LD + KP;
+  static constexpr int CG_ROWS = T == 4 ? KP / 2 : KP;        // solve_row<T, 1>: rows staged per pass
+  static constexpr int CG_LDS_FLOATS = CG_ROWS * LD + KP;
   static constexpr int PARTIAL_FLOATS = NT * 256 + (KP > 64 ? KP : 64);  // tiles + rhs
 };
 
@@ -560,7 +562,24 @@ __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float 
   // rounded at the magnitude of reg vec - visible when reg_r dominates (10^6 items: reg_r = 100)
   // and the solution is orders of magnitude smaller than the warm start.  Padded dims never
   // enter (act is false for them).
-  {
+  // K = 64: the matrix crosses from the accumulator layout to one row per lane in TWO passes of 32
+  // rows (round 4): 9 KB of LDS per wave instead of 17.7, so that the registers (three waves per SIMD)
+  // and not the LDS (nine waves per CU) set the occupancy.  Rows < 32 are the tile rows of lane groups
+  // 0 and 1 (row = 4 (4 g + r) + i), their mirrored elements come from the lanes with m < 8.
+  constexpr int ROWS = Geo<T>::CG_ROWS;
+  constexpr int PASSES = KP / ROWS;
+  float *sb = sm + ROWS * LD;
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < T; i++) sb[T * m + i] = b4[i];
+  }
+  const int li = lane < KP ? lane : KP - 1;
+  float a[KP];
+#pragma unroll
+  for (int pass = 0; pass < PASSES; pass++) {
+    if (pass > 0) __threadfence_block();  // (the first half's rows are in registers)
+    const bool rows_here = PASSES == 1 || (g >> 1) == pass;   // this lane's tile rows are staged now
+    const bool cols_here = PASSES == 1 || (m >> 3) == pass;   // ... its tile columns (mirrored part)
     int t = 0;
 #pragma unroll
     for (int i = 0; i < T; i++)
@@ -569,26 +588,22 @@ __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float 
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = T * (4 * g + r) + i, col = T * m + j;
-          sm[row * LD + col] = acc[t][r];
-          if (i != j) sm[col * LD + row] = acc[t][r];
+          if (rows_here) sm[(row - pass * ROWS) * LD + col] = acc[t][r];
+          if (i != j && cols_here) sm[(col - pass * ROWS) * LD + row] = acc[t][r];
         }
         t++;
       }
-  }
-  float *sb = sm + KP * LD;
-  if (g == 0) {
+    __threadfence_block();
+    if (PASSES == 1 || (li / ROWS) == pass) {
 #pragma unroll
-    for (int i = 0; i < T; i++) sb[T * m + i] = b4[i];
-  }
-  __threadfence_block();
-  const int li = lane < KP ? lane : KP - 1;
-  float a[KP];
-#pragma unroll
-  for (int q = 0; q < KP / 4; q++) {
-    f32x4 t = *reinterpret_cast<const f32x4 *>(sm + li * LD + 4 * q);
-    a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w;
+      for (int q = 0; q < KP / 4; q++) {
+        f32x4 t4 = *reinterpret_cast<const f32x4 *>(sm + (li - pass * ROWS) * LD + 4 * q);
+        a[4 * q] = t4.x; a[4 * q + 1] = t4.y; a[4 * q + 2] = t4.z; a[4 * q + 3] = t4.w;
+      }
+    }
   }
   float bv = sb[li];
+  __threadfence_block();  // (the staging area becomes the vector buffer of the products)
 
   static_assert(SOLVER == 1, "Cholesky is solve_row_cholesky (accumulator layout)");
   {
@@ -1005,7 +1020,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
   constexpr bool LOWER = SOLVER == 0;
   constexpr int RING = (T > 4 && SOLVER == 0) ? 4 : 8;  // gathered sub-steps in flight
   constexpr int LDS_PER_WAVE = SOLVER == 0 ? Chol16Geo<T>::LDS_FLOATS
-                                           : (T == 8 ? CholGeo<T>::SPILL_CG_FLOATS : G::LDS_FLOATS);
+                                           : (T == 8 ? CholGeo<T>::SPILL_CG_FLOATS : G::CG_LDS_FLOATS);
   __shared__ __attribute__((aligned(16))) float lds[WAVES * LDS_PER_WAVE];
   // (K = 128: with the scalar task the register allocator spills 800 bytes per lane where the
   // per-lane form spills 12 - the two starts of the accumulators become real branches)
