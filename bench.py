@@ -246,13 +246,18 @@ def time_epochs(trainer, sc, steps, warmup):
     for _ in range(warmup):
         trainer.step(sc)
     trainer.synchronize()
-    trainer.profile(True)
+    trainer.profile(2)  # (events on the dominant kernel only during the timed epochs: see main())
     t0 = time.perf_counter()
     for _ in range(steps):
         trainer.step(sc)
     trainer.synchronize()
     dt = (time.perf_counter() - t0) / steps
     prof = trainer.profile_read()
+    trainer.profile(True)
+    trainer.step(sc)
+    trainer.synchronize()
+    for name, rec in trainer.profile_read().items():
+        prof.setdefault(name, rec)
     trainer.profile(False)
     return dt, {k: round(v["ms"] / v["launches"], 4) for k, v in prof.items()}
 
@@ -641,7 +646,11 @@ def main():
         trainer.step(sc)
     trainer.synchronize()
     trainer.last_timing()  # drop the warm-up marks
-    local.trainer.profile(True)
+    # The timed steps carry HIP events on the dominant kernel only (the solve of the side with more
+    # rows) - the roofline below is priced on its duration, measured live in this region; event pairs
+    # on all ten launches of an epoch cost 0.05 ms of 2.1.  The other kernels' durations come from two
+    # extra, untimed epochs afterwards.
+    local.trainer.profile(2)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -650,6 +659,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = local.trainer.profile_read()
+    local.trainer.profile(True)
+    for _ in range(2):
+        trainer.step(sc)
+    trainer.synchronize()
+    for name, rec in local.trainer.profile_read().items():
+        prof.setdefault(name, rec)  # (the dominant kernel keeps its timed-region figure)
     local.trainer.profile(False)
     comm = None
     if world > 1:

@@ -210,6 +210,10 @@ int32_t irs_ials_last_eigenbasis(irs_ials_trainer *t);
  * eigenvectors warm-start the sweeps, as the previous epoch's Gramian does in a fit. */
 irs_status irs_ials_eigen_debug(const float *P, int64_t K, int32_t device, float *Qrows, float *lam,
                                 float *stats, const float *P_prev);
+/* Per-kernel device times of the launches that follow (HIP events riding on the dispatches).
+ * enable: 0 off, 1 every launch, 2 the dominant kernel only (the "ials_solve_*" launch of the side
+ * with more rows: event pairs on all ten launches of an epoch cost 0.05 ms of 2.1, which a timed run
+ * should not pay for durations it does not need). */
 irs_status irs_ials_profile(irs_ials_trainer *t, int32_t enable);
 irs_status irs_ials_profile_read(irs_ials_trainer *t, int32_t cap,
                                  char (*names)[48], double *ms,
