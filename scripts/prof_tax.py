@@ -10,7 +10,7 @@ tr = IALSTrainer(mc, X)
 for _ in range(3): tr.step(sc)
 tr.synchronize()
 for rep in range(3):
-    for mode in (False, True):
+    for mode in (False, True, 2):
         tr.profile(mode)
         tr.synchronize()
         t0 = time.perf_counter()
