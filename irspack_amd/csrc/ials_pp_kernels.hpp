@@ -556,7 +556,7 @@ template <int TS, bool ALIGNED, int MODE>
 __global__ __launch_bounds__(256, 2) void ialspp_kernel(PpParams p) {
   using G = PpGeo<TS>;
   extern __shared__ __attribute__((aligned(16))) float pp_lds[];
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wid = wave_in_block(), lane = threadIdx.x & 63;
   const int m = lane & 15;
   const int w = blockIdx.x * 4 + wid;
   if (w >= p.n_rows) return;  // the kernel uses no workgroup barrier
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(64 * PP_LONG_WAVES) void ialspp_long_kernel(PpParam
   using G = PpGeo<TS>;
   using L = PpLongGeo<TS>;
   extern __shared__ __attribute__((aligned(16))) float pp_lds[];
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wid = wave_in_block(), lane = threadIdx.x & 63;
   const int m = lane & 15;
   float *sm = pp_lds;
   float *xs = sm + G::CHOL_FLOATS;
