@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void rows_times_matT_kernel(const float *__
                                                                  const float *__restrict__ Mat, int n_rows) {
   constexpr int NTL = KP / 16, RT = 4;
   const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int w = blockIdx.x * 4 + wave_in_block();
   const int r0 = w * 16 * RT;
   if (r0 >= n_rows) return;
   const float *srow[RT];
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void ials_wb_short_kernel(EigShortParams p)
   using C = Chol16Geo<TT>;
   constexpr int NJ = KP / 16;  // 16-dim segments: lane (g, m) holds dims 16 j + 4 g .. + 3
   extern __shared__ __attribute__((aligned(16))) float wb_lds[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
+  const int wv = wave_in_block(), lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
   const int ti = blockIdx.x * 4 + wv;
   if (ti >= p.n_tasks) return;
   float *sm = wb_lds + wv * (C::LDS_FLOATS + 32 * TT);
@@ -459,7 +459,7 @@ template <int KP>
 __global__ __launch_bounds__(256, 2) void ials_cg_eig_short_kernel(EigShortParams p) {
   constexpr int DPL = KP / 64;
   static_assert(KP % 64 == 0, "lanes over the dims");
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = wave_in_block(), lane = threadIdx.x & 63;
   const int ti = blockIdx.x * 4 + wv;
   if (ti >= p.n_tasks) return;
   const Task task = p.tasks[ti];
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, NEV == 8 ? 4 : 2) void ials_cg_eig16_kernel(Ei
   using E = Eig16<KP, LPR, NEV>;
   constexpr int DPL = E::DPL, NE = E::NE;
   const int lane = threadIdx.x & 63, g = lane / LPR, m = lane % LPR;
-  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPR) + g;
+  const int ti = (blockIdx.x * 4 + wave_in_block()) * (64 / LPR) + g;
   const bool exists = ti < p.n_tasks;
   const Task task = p.tasks[min(ti, p.n_tasks - 1)];
   const int n = exists ? task.end - task.begin : 0;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256, NEV == 8 ? 4 : 2) void ials_wb_eig16_kernel(Ei
   using E = Eig16<KP, LPR, NEV>;
   constexpr int DPL = E::DPL, NE = E::NE;
   const int lane = threadIdx.x & 63, g = lane / LPR, m = lane % LPR;
-  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / LPR) + g;
+  const int ti = (blockIdx.x * 4 + wave_in_block()) * (64 / LPR) + g;
   const bool exists = ti < p.n_tasks;
   const Task task = p.tasks[min(ti, p.n_tasks - 1)];
   const int n = exists ? task.end - task.begin : 0;

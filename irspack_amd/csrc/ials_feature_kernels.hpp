@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void feature_prior_kernel(const int32_t *__res
                                                             int64_t n_rows, int KP,
                                                             float *__restrict__ prior) {  // [rows, KP]
   const int lane = threadIdx.x & 63;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   if (row >= n_rows) return;
   const int k0 = 256 * blockIdx.y + lane;  // blockIdx.y: block of 256 latent dims (K > 256)
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void feature_rhs_kernel(const int32_t *__restr
                                                           int KP, int chunk, int n_feat,
                                                           float *__restrict__ part) {  // [chunks, F, KP]
   __shared__ float sh[4][256];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = wave_in_block();
   const int f = blockIdx.x, c = blockIdx.y;
   const int kb = 256 * blockIdx.z;  // block of 256 latent dims (K > 256)
   const int qb = t_indptr[f] + c * chunk;

@@ -177,7 +177,7 @@ __device__ __forceinline__ void gk_syrk_body(const GkParams &p, int row, int BI,
 
 __global__ __launch_bounds__(256, 2) void gk_syrk_kernel(GkParams p) {
   const int nb = p.Np / 64, nbp = nb * (nb + 1) / 2;
-  const int64_t u = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   if (u >= static_cast<int64_t>(p.n_rows) * nbp) return;
   const int ri = static_cast<int>(u / nbp);
   int bp = static_cast<int>(u % nbp);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void gk_chol_kernel(GkParams p) {
 __global__ __launch_bounds__(256) void gk_pred_kernel(GkParams p, const float *__restrict__ delta,
                                                       float *__restrict__ pred, int mode) {
   const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
-  const int64_t ri = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t ri = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   if (ri >= p.n_rows) return;
   const int row = p.rows[p.row_first + ri];
   const int b = p.indptr[row], e = p.indptr[row + 1];
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void gk_gramian_partial_kernel(const float *__
                                                                  float *__restrict__ partial) {
   const int lane = threadIdx.x & 63, g = lane >> 4, m = lane & 15;
   const int nb = KP / 64, nbp = nb * (nb + 1) / 2;
-  const int64_t u = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   if (u >= static_cast<int64_t>(n_slabs) * nbp) return;
   const int slab = static_cast<int>(u / nbp);
   int bp = static_cast<int>(u % nbp), BI = 0;
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void gk_user_scores_kernel(const float *__rest
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
   const int64_t item_tiles = (n_items + 63) / 64;
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   const int64_t ut = w / item_tiles, it = w % item_tiles;
   if (ut * 64 >= m_rows) return;
   const float *up[4], *ip[4];
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void gk_loss_rows_kernel(const float *__restri
                                                            float *__restrict__ row_loss) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   if (row >= n_rows) return;
   const float *u = target + row * KP;
   float loss = 0.f;

@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
   using G = Geo<T>;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   f32x4 acc[G::NT];
 #pragma unroll
   for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(256) void user_scores_kernel(const float *__restric
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
   const int64_t item_tiles = (n_items + 63) / 64;
-  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   const int64_t ut = w / item_tiles, it = w % item_tiles;
   if (ut * 64 >= m_rows) return;
   const float *up[4], *ip[4];
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(const float *__restrict_
   constexpr int KP = Geo<T>::KP;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_in_block();
   if (row >= n_rows) return;
   float u[T];
   load_dims<T>(target + row * KP + T * m, u);

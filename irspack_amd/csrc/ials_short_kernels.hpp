@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * SHORT_WAVES, CAP == 16 ? 4 : (NR == 1 ? 3 : 2)
                 "unsupported shape");
   extern __shared__ __attribute__((aligned(16))) float short_smem[];
   float *Psh = short_smem;                       // KP * KP
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = wave_in_block();
   float *vsh = short_smem + KP * KP + wv * (NR * KP);   // this wave's parked vectors
   for (int i = threadIdx.x; i < KP * KP; i += 64 * SHORT_WAVES) {
     const int k = i / KP, d = i % KP;
