@@ -15,6 +15,15 @@
 
 namespace irs {
 
+#ifdef __HIPCC__
+// The wave's index inside its workgroup as a scalar (`threadIdx.x >> 6` alone is a per-lane value to
+// the compiler: the wave's row, its bounds and pointers then live in vector registers and are
+// computed by vector instructions).  ials_kernels.hpp has the same helper for the iALS kernels.
+__device__ __forceinline__ int wave_index_in_block() {
+  return __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+}
+#endif
+
 std::string &last_error();
 
 // The reference signals errors with std::invalid_argument (-> ValueError) and

@@ -114,7 +114,7 @@ __device__ unsigned long long fz_phase_clk[8];  // development: device-clock pha
 template <int KP, bool RESIDENT>
 __global__ __launch_bounds__(256, 1) void fused_topk_kernel(FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
-  const int wid = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int wid = wave_index_in_block(), ln = threadIdx.x & 63;
   const int g = ln >> 4, m = ln & 15;
   unsigned char *slab = fz_smem + wid * FZ_LDS_PER_WAVE;
   float *S = reinterpret_cast<float *>(slab);
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void mask_bitmap_kernel(const int64_t *__restr
                                                           const int32_t *__restrict__ mask_idx,
                                                           int64_t rows, int64_t words,
                                                           uint64_t *__restrict__ bits) {
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (row >= rows) return;
   const int ln = threadIdx.x & 63;
   unsigned long long *dst = reinterpret_cast<unsigned long long *>(bits + row * words);
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void mask_bitmap_kernel(const int64_t *__restr
 __global__ __launch_bounds__(256) void mask_count_kernel(const uint64_t *__restrict__ bits,
                                                          int64_t rows, int64_t words,
                                                          int32_t *__restrict__ n_masked) {
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (row >= rows) return;
   const int ln = threadIdx.x & 63;
   int c = 0;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
                                                          const int32_t *__restrict__ row_list,
                                                          const int32_t *__restrict__ n_list) {
   const int ln = threadIdx.x & 63;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (row >= rows) return;
   // second chance of the hard rows: score row j belongs to row row_list[j] of the call
   if (row_list && row >= *n_list) return;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
 template <int KP, bool BOUNDED>
 __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
-  const int wid = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int wid = wave_index_in_block(), ln = threadIdx.x & 63;
   const int g = ln >> 4, m = ln & 15;
   float *S = reinterpret_cast<float *>(em_smem) + wid * (64 * FZ_SROW);
   int32_t *IDS = reinterpret_cast<int32_t *>(em_smem + 4 * 64 * FZ_SROW * sizeof(float)) + wid * 64;
@@ -719,7 +719,7 @@ __global__ void mask_rows_perm_kernel(float *scores, int64_t rows, int64_t n_sam
 // ENTRY - a flat, coalesced stream - instead of one small workgroup per row
 __global__ __launch_bounds__(256) void mask_row_ids_kernel(const int64_t *__restrict__ mask_ptr,
                                                            int64_t rows, int32_t *__restrict__ mask_row) {
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (row >= rows) return;
   for (int64_t q = mask_ptr[row] + (threadIdx.x & 63); q < mask_ptr[row + 1]; q += 64)
     mask_row[q] = static_cast<int32_t>(row);
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(1024) void wg_scan_kernel(const int32_t *__restrict
 __global__ __launch_bounds__(256) void wg_fill_kernel(const int32_t *__restrict__ wg_prefix,
                                                       const int32_t *__restrict__ limit_tiles,
                                                       int64_t n_ut, int4 *__restrict__ wg_desc) {
-  const int64_t ut = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t ut = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (ut >= n_ut) return;
   const int32_t b = wg_prefix[ut], e = wg_prefix[ut + 1], lim = limit_tiles[ut];
   for (int32_t i = b + (threadIdx.x & 63); i < e; i += 64) {

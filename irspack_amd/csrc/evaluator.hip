@@ -630,7 +630,7 @@ template <int M>
 __global__ __launch_bounds__(256) void rank_cand_kernel(EvalParams p, EmitParams f,
                                                         const int32_t *__restrict__ n_masked) {
   const int ln = threadIdx.x & 63;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (row >= p.rows) return;
   const int64_t u = row + p.offset;
   RowOut res{0, 0, 0, 0, 0, 0, 0};
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void rank_cand_slow_kernel(EvalParams p, EmitP
   __shared__ float cs[4][EM_CAP];
   __shared__ int32_t ci[4][EM_CAP];
   __shared__ int32_t sel[4][64];
-  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ln = threadIdx.x & 63, wv = wave_index_in_block();
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wv;
   if (row >= p.rows || p.todo[row] == 0) return;
   const int64_t u = row + p.offset;
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void fused_finish_kernel(EvalParams p, FusedPa
   __shared__ float cs[4][FZ_MAX_CHUNKS * FZ_MAX_CUTOFF];
   __shared__ int32_t ci[4][FZ_MAX_CHUNKS * FZ_MAX_CUTOFF];
   __shared__ int32_t sel[4][64];
-  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ln = threadIdx.x & 63, wv = wave_index_in_block();
   const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wv;
   if (row >= p.rows) return;
   const int64_t u = row + p.offset;
@@ -856,7 +856,7 @@ template <class T, int M>
 __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
   constexpr int U = 16;
   const int ln = threadIdx.x & 63;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (row >= p.rows) return;
   const int64_t orow = p.row_map ? p.row_map[row] : row;
   const int64_t u = orow + p.offset;

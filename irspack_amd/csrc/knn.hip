@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(256) void knn_compact_kernel(const int32_t *__restr
                                                           int64_t n_rows, int32_t top_k,
                                                           int32_t *__restrict__ dst_idx,
                                                           double *__restrict__ dst_val) {
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (row >= n_rows) return;
   const int lane = threadIdx.x & 63;
   const int64_t b = res_ptr[row], e = res_ptr[row + 1];
@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(256) void pop_syrk_kernel(const int8_t *__restrict_
   while (pair > I) { pair -= I + 1; I++; }
   const int J = pair;
   const int64_t k0 = static_cast<int64_t>(blockIdx.y) * slab, k1 = min(k0 + slab, ld);
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int w = wave_index_in_block(), lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int row_i = 128 * I + 64 * (w >> 1), row_j = 128 * J + 64 * (w & 1);
   (void)nb;
   i32x16 acc[2][2];
