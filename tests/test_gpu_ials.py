@@ -158,6 +158,33 @@ def test_split_rows_and_long_rows():
         assert rel_err(t.item, o.item) < RTOL
 
 
+def test_profile_modes(X_small):
+    # irs_ials_profile: 1 = events on every launch, 2 = on the dominant kernel only (the solve of the
+    # side with more rows; what bench.py's timed steps use).  The factors do not depend on the mode.
+    X = X_small.astype(np.float32)
+    mc, _ = build(16)
+    sc, _ = solver("CHOLESKY")
+    outs = []
+    for mode in (False, True, 2):
+        t = IALSTrainer(mc, X)
+        t.profile(mode)
+        t.step(sc)
+        t.step(sc)
+        prof = t.profile_read()
+        t.profile(False)
+        outs.append((t.user.copy(), t.item.copy()))
+        if mode is False:
+            assert prof == {}
+        elif mode is True:
+            assert {"gramian_partial", "gramian_reduce", "gramian_finish"} <= set(prof)
+            assert prof["ials_solve_cholesky_user"]["launches"] == 2 == prof["ials_solve_cholesky_item"]["launches"]
+        else:
+            dominant = "ials_solve_cholesky_user" if X.shape[0] >= X.shape[1] else "ials_solve_cholesky_item"
+            assert set(prof) == {dominant} and prof[dominant]["launches"] == 2 and prof[dominant]["ms"] > 0
+    for u, i in outs[1:]:
+        assert np.array_equal(u, outs[0][0]) and np.array_equal(i, outs[0][1])
+
+
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
 def test_stored_zeros_of_either_sign_keep_their_bias_term(kind):
     # A stored entry with value 0.0 - or -0.0 - has confidence 0 but still adds (bias + 0) v to the
