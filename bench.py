@@ -578,6 +578,51 @@ def c4_leg(full, ceilings):
     return out
 
 
+def _try_attach_peers(local) -> bool:
+    """Maps the peers' factor buffers / mailboxes on an RCCL communicator that was created without
+    them (collective: every rank calls it); False when any rank cannot."""
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    from irspack_amd._lib import COMM_HANDLE_BYTES, check, lib
+
+    world = dist.get_world_size()
+    blob = None
+    try:
+        mine = (C.c_char * COMM_HANDLE_BYTES)()
+        check(lib().irs_comm_export(local._comm, local.trainer._h, mine))
+        blob = bytes(mine)
+    except (RuntimeError, ValueError):
+        pass
+    blobs = [None] * world
+    dist.all_gather_object(blobs, blob)
+    ok = all(b is not None for b in blobs)
+    if ok:
+        try:
+            allb = (C.c_char * (COMM_HANDLE_BYTES * world)).from_buffer_copy(b"".join(blobs))
+            check(lib().irs_comm_attach(local._comm, local.trainer._h, allb))
+        except (RuntimeError, ValueError) as exc:
+            local.peers_error = repr(exc)
+            ok = False
+    votes = [None] * world
+    dist.all_gather_object(votes, ok)
+    local.peers_attached = all(votes)
+    return local.peers_attached
+
+
+def _factor_digest(tr) -> float:
+    """A number that changes with any bit of the two factor matrices (float64 sums of the float32
+    values weighted by position) - compared for EQUALITY between runs of the same arithmetic."""
+    import numpy as np
+
+    out = 0.0
+    for F in (tr.user, tr.item):
+        w = (np.arange(F.size, dtype=np.float64) % 8191.0 + 1.0).reshape(F.shape)
+        out += float((F.astype(np.float64) * w).sum())
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -628,19 +673,82 @@ def main():
     local = HipLocalSolver(mc, X, shard, local_rank)
     # (overlap of the next Gramian's all-reduce with the all-gather: IRSPACK_AMD_BENCH_OVERLAP=1;
     # off by default until it has run on RCCL at world >= 2, see ShardedIALSTrainer)
-    # N > 1: the epoch behind ONE C-ABI call (irs_ials_sharded_step: RCCL from inside the library, rows
-    # in place, the next Gramian overlapping the row exchange); IRSPACK_AMD_BENCH_COMM=torch times
-    # the torch.distributed host loop instead.  The per-phase split of the line always comes from the
-    # host loop (a few extra, untimed epochs when the native path is the timed one).
-    native = world > 1 and backend == "nccl" and os.environ.get("IRSPACK_AMD_BENCH_COMM", "native") != "torch"
+    # N > 1: the epoch behind ONE C-ABI call (irs_ials_sharded_step: the transport driven from inside
+    # the library, rows in place, the next Gramian overlapping the row exchange);
+    # IRSPACK_AMD_BENCH_COMM=torch times the torch.distributed host loop instead, =local the RCCL-free
+    # peer-store transport.  The native path is set up and tried COLLECTIVELY before anything is timed
+    # (ShardedIALSTrainer: every rank votes; one failure = every rank on the host loop; a hang = exit
+    # code 3 from the watchdog) and the line says which path was timed.  The per-phase split of the
+    # line always comes from the host loop (a few extra, untimed epochs when the native path is timed).
+    comm_choice = os.environ.get("IRSPACK_AMD_BENCH_COMM", "native")
+    want_native = world > 1 and comm_choice != "torch" and (backend == "nccl" or comm_choice == "local")
     overlap = bool(int(os.environ.get("IRSPACK_AMD_BENCH_OVERLAP", "0")))
-    trainer = ShardedIALSTrainer(local, ub, ib, timing=world > 1 and not native, overlap=overlap,
-                                 native=native)
+    watchdog_s = float(os.environ.get("IRSPACK_AMD_BENCH_WATCHDOG_S", "600"))
+    trainer = ShardedIALSTrainer(local, ub, ib, timing=False, overlap=overlap,
+                                 native=("local" if comm_choice == "local" else "rccl") if want_native else False,
+                                 exchange="peer" if comm_choice == "local" else "auto", watchdog_s=watchdog_s)
+    preflight = None
+    if want_native:
+        preflight = {"requested": "local (peer stores)" if comm_choice == "local" else "rccl",
+                     "created": bool(trainer.native), "first_epoch": False}
+        if trainer.native:
+            preflight["first_epoch"] = bool(trainer.preflight_step(sc))
+        if trainer.native_error:
+            preflight["error"] = trainer.native_error
+        preflight["peers_mapped"] = bool(getattr(local, "peers_attached", False))
+    native = bool(trainer.native)
+    if world > 1 and not native:  # the host loop is the timed path: it carries the phase marks itself
+        trainer.timing = True
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # The row exchanges of the native path, A/B: a few untimed epochs of each from the same factors
+    # (max over ranks of the host clock around barrier + synchronize), a checksum of the factors they
+    # end on (the exchange moves rows, it does not compute: every mode must end on the same bits), and
+    # the fastest mode whose bits agree becomes the timed one (IRSPACK_AMD_BENCH_EXCHANGE pins it).
+    exchange_ab = None
+    if native and trainer.native_transport == "rccl":
+        pinned = os.environ.get("IRSPACK_AMD_BENCH_EXCHANGE")
+        modes = ["auto", "mesh"] + (["peer"] if local.peers_attached or _try_attach_peers(local) else [])
+        ab_epochs = int(os.environ.get("IRSPACK_AMD_BENCH_AB_EPOCHS", "4"))
+        user0, item0 = local.trainer.user, local.trainer.item
+        exchange_ab = {"epochs_each": ab_epochs, "modes": {}}
+        for mode in modes:
+            rec = {}
+            try:
+                trainer.set_exchange(mode)
+                local.trainer.user, local.trainer.item = user0, item0
+                trainer.step(sc)  # (first use of a mode: connection set-up inside RCCL)
+                local.trainer.user, local.trainer.item = user0, item0
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(ab_epochs):
+                    trainer.step(sc)
+                trainer.synchronize()
+                barrier()
+                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                rec["ms_per_epoch"] = float(dt.item()) / ab_epochs * 1e3
+                digest = _factor_digest(local.trainer)
+                lohi = torch.tensor([digest, -digest], dtype=torch.float64, device="cuda")
+                dist.all_reduce(lohi, op=dist.ReduceOp.MIN)  # min(d), -max(d): equal on every rank?
+                rec["digest"] = digest
+                rec["replicas_identical"] = bool(lohi[0].item() == -lohi[1].item())
+            except (RuntimeError, ValueError) as exc:  # (argument errors only: raised before any collective)
+                rec["error"] = repr(exc)
+            exchange_ab["modes"][mode] = rec
+        base = exchange_ab["modes"]["auto"]
+        ok = [m for m, r in exchange_ab["modes"].items()
+              if "error" not in r and r["replicas_identical"] and r["digest"] == base.get("digest")]
+        best = min(ok, key=lambda m: exchange_ab["modes"][m]["ms_per_epoch"]) if ok else "auto"
+        choice = pinned if pinned in exchange_ab["modes"] and pinned in ok else best
+        exchange_ab["timed"] = choice
+        exchange_ab["agree_with_auto"] = ok
+        trainer.set_exchange(choice)
+        local.trainer.user, local.trainer.item = user0, item0
 
     for _ in range(args.warmup):
         trainer.step(sc)
@@ -698,8 +806,10 @@ def main():
                 "compute_ms": float(hi[0] + hi[2]), "allreduce_ms": float(hi[1]),
                 "allgather_ms": float(hi[3]), "exposed_comm_ms": float(hi[4]),
                 "exchange": exchange_plan, "overlap": bool(trainer.overlap),
-                "timed_path": ("native: irs_ials_sharded_step (RCCL inside the library, in-place rows, "
-                               "next Gramian overlapped)" if native else "torch.distributed host loop"),
+                "timed_path": ((f"native: irs_ials_sharded_step (transport {trainer.native_transport} inside the "
+                                f"library, row exchange '{trainer.native_exchange}', in-place rows, next Gramian "
+                                "overlapped)") if native else "torch.distributed host loop"),
+                "native_preflight": preflight, "exchange_ab": exchange_ab,
                 "phase_split_from": "torch.distributed host loop" + (" (extra untimed epochs)" if native else ""),
                 "note": "solve_ms spread (max - min over ranks) = load imbalance; the collectives' "
                         "time includes waiting for the slowest rank"}

@@ -182,22 +182,42 @@ irs_status irs_ials_half_step_async(irs_ials_trainer *t, int32_t side,
 /* Waits for the stream and raises what the reference would have thrown from
  * inside the solve (hpp:317-323, 250-254). */
 irs_status irs_ials_synchronize(irs_ials_trainer *t);
-/* Per-kernel HIP-event timing (profiling aid for bench.py).  enable != 0 turns
- * recording on and clears the counters; `names`/`ms`/`launches` receive up to
- * `cap` entries. */
-/* ---- row-sharded epoch over RCCL (one process per GPU; no reference counterpart: the reference
- * has no distributed layer).  irs_comm holds this rank's two RCCL communicators
- * (solved rows; K x K Gramians).  id256: 256 bytes made by irs_comm_unique_id on ONE rank and
- * handed to every rank by the caller (torch.distributed / MPI / a file). */
+/* ---- row-sharded epoch (one process per GPU; no reference counterpart: the reference has no
+ * distributed layer; the sharded unit is IALSTrainer::step, hpp:758-789).
+ * irs_comm is this rank's transport of the two exchanges a sharded epoch needs: the K x K
+ * all-reduce of the Gramian and the exchange of the freshly solved rows.
+ *   irs_comm_create: two RCCL communicators (solved rows; Gramians).  id256: 256 bytes made by
+ *     irs_comm_unique_id on ONE rank and handed to every rank by the caller (torch.distributed /
+ *     MPI / a file).
+ *   irs_comm_create_local: no RCCL at all - both exchanges are stores into the peers' mapped
+ *     memory (below); needs irs_comm_export + irs_comm_attach before the first step.
+ * How the solved rows reach the other replicas: */
+#define IRS_EXCHANGE_AUTO 0      /* ncclAllGather in place (equal row blocks) or grouped broadcasts */
+#define IRS_EXCHANGE_BROADCAST 1 /* one group of in-place ncclBroadcast, one per rank */
+#define IRS_EXCHANGE_MESH 2      /* one group of ncclSend / ncclRecv: own block to every peer, every
+                                  * peer's block into place - all links of the xGMI mesh at once */
+#define IRS_EXCHANGE_PEER 3      /* a copy kernel stores the own block into every peer's mapped factor
+                                  * buffer; arrival = sequence numbers in mapped flag words */
 typedef struct irs_comm irs_comm;
 irs_status irs_comm_unique_id(void *id256);
 irs_status irs_comm_create(const void *id256, int32_t rank, int32_t world, int32_t device,
                            irs_comm **out);
+irs_status irs_comm_create_local(int32_t rank, int32_t world, int32_t device, irs_comm **out);
 irs_status irs_comm_destroy(irs_comm *c);
+/* Peer stores: irs_comm_export fills handle256 (256 bytes: hipIpc handles of the trainer's two
+ * factor buffers and of the communicator's flag + mailbox block); the caller gathers the blobs of
+ * all ranks in rank order (world x 256 bytes) and gives them to irs_comm_attach on every rank,
+ * which maps the peers' memory.  The trainer must outlive the communicator's use. */
+irs_status irs_comm_export(irs_comm *c, irs_ials_trainer *t, void *handle256);
+irs_status irs_comm_attach(irs_comm *c, irs_ials_trainer *t, const void *handles);
+/* Selects IRS_EXCHANGE_* for the steps that follow (the same value on every rank). */
+irs_status irs_comm_set_exchange(irs_comm *c, int32_t mode);
+int32_t irs_comm_get_exchange(irs_comm *c);
 /* IALSTrainer::step (hpp:758-789) over the ranks of `c`: the trainer holds the shard
  * [bounds[rank], bounds[rank + 1]) of each side (irs_ials_create with a shard); per half-epoch the
- * partial Gramian of the own rows is all-reduced, the own rows are solved and all-gathered into
- * every replica (in place), the next half-epoch's Gramian overlapping the row exchange.
+ * partial Gramian of the own rows is all-reduced, the own rows are solved and exchanged into
+ * every replica (in place), the next half-epoch's Gramian overlapping the row exchange.  What the
+ * reference would throw from inside a solve (hpp:317-323, 250-254) is raised on EVERY rank.
  * user_bounds / item_bounds: world + 1 row offsets, identical on every rank. */
 irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_config *sc, irs_comm *c,
                                  const int64_t *user_bounds, const int64_t *item_bounds);

@@ -86,6 +86,9 @@ class CeilingsStruct(C.Structure):  # irs_ceilings
 
 
 ABI_VERSION = 2  # IRS_ABI_VERSION of include/irspack_amd.h
+# IRS_EXCHANGE_* of include/irspack_amd.h: how irs_ials_sharded_step moves the solved rows
+EXCHANGE_MODES = {"auto": 0, "broadcast": 1, "mesh": 2, "peer": 3}
+COMM_HANDLE_BYTES = 256
 
 # every symbol include/irspack_amd.h declares
 EXPORTED_SYMBOLS = [
@@ -115,7 +118,12 @@ EXPORTED_SYMBOLS = [
     "irs_ials_synchronize",
     "irs_comm_unique_id",
     "irs_comm_create",
+    "irs_comm_create_local",
     "irs_comm_destroy",
+    "irs_comm_export",
+    "irs_comm_attach",
+    "irs_comm_set_exchange",
+    "irs_comm_get_exchange",
     "irs_ials_sharded_step",
     "irs_ials_last_eigenbasis",
     "irs_ials_eigen_debug",

@@ -1509,6 +1509,8 @@ void sync_and_check(irs_ials_trainer *t) {
     IRS_HIP(hipStreamSynchronize(t->stream));
     if (flag & 1) throw std::runtime_error("Cholesky decomposition failed.");  // hpp:318
     if (flag & 2) throw std::runtime_error("Cholesky solve failed.");          // hpp:322
+    if (flag & 8)  // comm.hip: a peer's rows or Gramian did not arrive (IRSPACK_AMD_PEER_TIMEOUT_S)
+      throw std::runtime_error("The sharded step timed out waiting for a peer's stores.");
     throw std::runtime_error(
         "Conjugate-gradient solver encountered a singular system.");  // hpp:252-253
   }
@@ -1813,64 +1815,35 @@ irs_status irs_ials_step(irs_ials_trainer *t, const irs_ials_solver_config *sc) 
   });
 }
 
-// ---------------------------------------------------------------- row-sharded epoch (RCCL)
-irs_status irs_comm_unique_id(void *id256) {
+// ---------------------------------------------------------------- row-sharded epoch (comm.hip)
+irs_status irs_comm_export(irs_comm *c, irs_ials_trainer *t, void *handle256) {
   return guard([&] {
-    check_arg(id256 != nullptr, "null argument.");
-    auto &api = RcclApi::get();
-    ncclUniqueId ids[2];
-    IRS_RCCL(api.GetUniqueId(&ids[0]));
-    IRS_RCCL(api.GetUniqueId(&ids[1]));
-    static_assert(sizeof(ids) == 256, "two 128-byte ids");
-    std::memcpy(id256, ids, sizeof(ids));
+    check_arg(c && t && handle256, "null argument.");
+    check_arg(t->device == c->device, "trainer and communicator live on different devices.");
+    comm_export(c, t->factor[0].ptr, t->factor[1].ptr, t->KP, handle256);
   });
 }
 
-irs_status irs_comm_create(const void *id256, int32_t rank, int32_t world, int32_t device,
-                           irs_comm **out) {
+irs_status irs_comm_attach(irs_comm *c, irs_ials_trainer *t, const void *handles) {
   return guard([&] {
-    check_arg(id256 && out, "null argument.");
-    check_arg(world >= 1 && rank >= 0 && rank < world, "rank out of range.");
-    require_device(device);
-    auto &api = RcclApi::get();
-    ncclUniqueId ids[2];
-    std::memcpy(ids, id256, sizeof(ids));
-    auto c = std::make_unique<irs_comm>();
-    c->rank = rank;
-    c->world = world;
-    c->device = device;
-    IRS_RCCL(api.CommInitRank(&c->rows, world, ids[0], rank));
-    IRS_RCCL(api.CommInitRank(&c->gram, world, ids[1], rank));
-    IRS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    IRS_HIP(hipEventCreateWithFlags(&c->ev_solved, hipEventDisableTiming));
-    IRS_HIP(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
-    *out = c.release();
-  });
-}
-
-irs_status irs_comm_destroy(irs_comm *c) {
-  return guard([&] {
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    auto &api = RcclApi::get();
-    if (c->rows) (void)api.CommDestroy(c->rows);
-    if (c->gram) (void)api.CommDestroy(c->gram);
-    if (c->ev_solved) (void)hipEventDestroy(c->ev_solved);
-    if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    check_arg(c && t && handles, "null argument.");
+    check_arg(t->device == c->device, "trainer and communicator live on different devices.");
+    comm_attach(c, t->factor[0].ptr, t->factor[1].ptr, t->KP, handles);
   });
 }
 
 // IALSTrainer::step (hpp:784-788) over the ranks of `comm`, rows sharded (sharding.py's loop in
 // one call).  Per half-epoch: partial Gramian of the rank's own rows of the other side ->
-// all-reduce (K x K, `gram` communicator, trainer stream) -> finish -> solve the rank's rows ->
-// all-gather of the solved rows (`rows` communicator, its own stream: IN PLACE when the shards are
-// the equal blocks of the padded factor buffer, else one grouped set of in-place broadcasts, one
-// per rank - no staging copy either way).  While the rows travel, the partial Gramian of the
-// NEXT half-epoch - it needs only the rows this rank has just solved - and its all-reduce are
-// already running on the trainer's stream.
+// all-reduce (K x K, trainer stream) -> finish -> solve the rank's rows -> exchange of the solved
+// rows (the communicator's own stream; comm.hip: in-place all-gather / grouped broadcasts / one
+// send-receive group over the mesh / peer stores - no staging copy in any of them).  While the rows
+// travel, the partial Gramian of the NEXT half-epoch - it needs only the rows this rank has just
+// solved - and its all-reduce are already running on the trainer's stream.
+//
+// Errors: everything that can be checked is checked BEFORE the first collective (a rank that
+// throws while the others wait inside a collective would hang the job); what the solves report on
+// the device (hpp:317-323, 250-254: one rank's rows) is all-reduced at the end, so every rank
+// raises the same exception.
 irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_config *sc, irs_comm *c,
                                  const int64_t *user_bounds, const int64_t *item_bounds) {
   return guard([&] {
@@ -1889,55 +1862,34 @@ irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_conf
     check_arg(user_bounds[c->rank] == t->shard.user_begin && user_bounds[c->rank + 1] == t->shard.user_end &&
                   item_bounds[c->rank] == t->shard.item_begin && item_bounds[c->rank + 1] == t->shard.item_end,
               "the trainer was created for another shard than row_bounds[rank].");
+    check_arg(!(c->peer_rows() || c->peer_gram()) || (c->attached && c->KP == t->KP),
+              "peer stores need irs_comm_export + irs_comm_attach on this trainer before the first step.");
     IRS_HIP(hipSetDevice(t->device));
-    auto &api = RcclApi::get();
     const size_t KP = static_cast<size_t>(t->KP);
+    struct Unwind {  // a throw from here on leaves no half-made prefetch behind
+      irs_ials_trainer *t;
+      bool armed = true;
+      ~Unwind() {
+        if (armed) t->gram_prefetched[0] = t->gram_prefetched[1] = false;
+      }
+    } unwind{t};
     auto reduce_gramian = [&](int side) {  // own rows of the other side, summed over the ranks
       const int other = 1 - side;
       launch_partial_gramian(t, other, other == 0 ? t->shard.user_begin : t->shard.item_begin,
                              other == 0 ? t->shard.user_end : t->shard.item_end, side);
-      // (also at world size 1, where it is the identity: the one-GPU tests then run the very calls,
-      // buffers and counts of a multi-GPU epoch)
-      IRS_RCCL(api.AllReduce(t->P_raw[side].ptr, t->P_raw[side].ptr, KP * KP, ncclFloat, ncclSum, c->gram,
-                             t->stream));
+      comm_allreduce(c, t->P_raw[side].ptr, KP * KP, t->stream);
     };
-    // IRSPACK_AMD_SHARD_EXCHANGE=broadcast: the grouped in-place broadcasts even for equal blocks (tests)
-    static const bool force_bcast = [] {
-      const char *e = std::getenv("IRSPACK_AMD_SHARD_EXCHANGE");
-      return e && e[0] == 'b';
-    }();
-    // chunk k of n_chunks of every rank's rows (n_chunks == 1: the whole shards)
-    auto exchange_rows = [&](int side, int k, int n_chunks) {  // on the communicator's stream, behind the solve
-      IRS_HIP(hipEventRecord(c->ev_solved, t->stream));
-      IRS_HIP(hipStreamWaitEvent(c->stream, c->ev_solved, 0));
-      float *F = t->factor[side].ptr;
+    // chunk k of n_chunks of every rank's rows (n_chunks == 1: the whole shards): rank r's chunk k =
+    // rows [b_r + len_r k / C, b_r + len_r (k + 1) / C), the formula the chunk task lists were cut with
+    auto exchange_rows = [&](int side, int k, int n_chunks) {
       const int64_t *b = bounds[side];
-      const int64_t padded = ceil_div(t->rows_of(side), 8) * 8, S = padded / c->world;
-      bool equal = padded % c->world == 0 && !force_bcast && n_chunks == 1;
-      for (int r = 0; equal && r < c->world; r++) equal = b[r] == std::min<int64_t>(r * S, b[c->world]);
-      if (n_chunks > 1) {
-        // rank r's chunk k = rows [b_r + len_r k / C, b_r + len_r (k + 1) / C): the same formula the
-        // chunk task lists were cut with at creation
-        IRS_RCCL(api.GroupStart());
-        for (int r = 0; r < c->world; r++) {
-          const int64_t len = b[r + 1] - b[r], lo = b[r] + len * k / n_chunks, hi = b[r] + len * (k + 1) / n_chunks;
-          if (hi > lo)
-            IRS_RCCL(api.Broadcast(F + static_cast<size_t>(lo) * KP, F + static_cast<size_t>(lo) * KP,
-                                   static_cast<size_t>(hi - lo) * KP, ncclFloat, r, c->rows, c->stream));
-        }
-        IRS_RCCL(api.GroupEnd());
-      } else if (equal) {
-        IRS_RCCL(api.AllGather(F + static_cast<size_t>(c->rank) * S * KP, F, static_cast<size_t>(S) * KP, ncclFloat,
-                               c->rows, c->stream));
-      } else {
-        IRS_RCCL(api.GroupStart());
-        for (int r = 0; r < c->world; r++)
-          if (b[r + 1] > b[r])
-            IRS_RCCL(api.Broadcast(F + static_cast<size_t>(b[r]) * KP, F + static_cast<size_t>(b[r]) * KP,
-                                   static_cast<size_t>(b[r + 1] - b[r]) * KP, ncclFloat, r, c->rows, c->stream));
-        IRS_RCCL(api.GroupEnd());
+      int64_t lo[COMM_MAX_WORLD], hi[COMM_MAX_WORLD];
+      for (int r = 0; r < c->world; r++) {
+        const int64_t len = b[r + 1] - b[r];
+        lo[r] = b[r] + len * k / n_chunks;
+        hi[r] = b[r] + len * (k + 1) / n_chunks;
       }
-      IRS_HIP(hipEventRecord(c->ev_rows, c->stream));
+      comm_exchange_rows(c, side, t->factor[side].ptr, KP, lo, hi, t->rows_of(side), t->stream, n_chunks == 1);
     };
     for (int side = 0; side < 2; side++) {
       if (!t->gram_prefetched[side]) reduce_gramian(side);
@@ -1959,8 +1911,10 @@ irs_status irs_ials_sharded_step(irs_ials_trainer *t, const irs_ials_solver_conf
       // its solve gathers every row of `side`: wait for them
       IRS_HIP(hipStreamWaitEvent(t->stream, c->ev_rows, 0));
     }
-    sync_and_check(t);
+    comm_allreduce_flag(c, t->err_flag.ptr, t->stream);
     IRS_HIP(hipStreamSynchronize(c->stream));
+    sync_and_check(t);
+    unwind.armed = false;
   });
 }
 

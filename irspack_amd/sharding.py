@@ -40,6 +40,7 @@ product implementation (``HipLocalSolver``) drives the HIP library.  Results equ
 the single-GPU ones up to the summation order of the Gramian.
 """
 
+import os
 from typing import List, Sequence, Tuple
 
 import numpy as np
@@ -195,35 +196,95 @@ class HipLocalSolver(LocalSolver):
     def synchronize(self) -> None:
         self.trainer.synchronize()
 
-    # -- the epoch behind the C ABI (irs_ials_sharded_step): RCCL called from inside the library --
-    def create_comm(self, group=None) -> None:
-        """This rank's RCCL communicators (irs_comm): the 256-byte id is made on group rank 0 and
-        handed round through ``torch.distributed`` (an object broadcast: any backend)."""
+    # -- the epoch behind the C ABI (irs_ials_sharded_step): the transport lives inside the library --
+    def create_comm(self, group=None, transport: str = "rccl", peers: bool = True) -> None:
+        """This rank's transport (irs_comm).
+
+        ``transport="rccl"``: two RCCL communicators; the 256-byte id is made on group rank 0 and
+        handed round through ``torch.distributed`` (an object broadcast: any backend).
+        ``transport="local"``: no RCCL - rows and Gramians travel as stores into the peers' mapped
+        memory (``irs_comm_create_local``).  ``peers``: map every rank's factor buffers, mailbox
+        and flags (``irs_comm_export`` / ``irs_comm_attach``, blobs gathered through
+        ``torch.distributed``) - a must for "local", and what ``set_exchange("peer")`` needs on
+        an RCCL communicator; a mapping failure there only leaves ``peers_attached`` False."""
         import ctypes as C
 
         import torch.distributed as dist
 
-        from ._lib import check, lib
+        from ._lib import COMM_HANDLE_BYTES, check, lib
 
         rank, world = _group_info(group)
-        buf = (C.c_char * 256)()
-        if rank == 0:
-            check(lib().irs_comm_unique_id(buf))
-        if world > 1:
-            box = [bytes(buf)]
-            src = dist.get_global_rank(group, 0) if group is not None else 0
-            dist.broadcast_object_list(box, src=src, group=group)
-            buf = (C.c_char * 256).from_buffer_copy(box[0])
+        if os.environ.get("IRSPACK_AMD_TEST_FAIL_COMM_RANK") == str(rank):  # fault injection (tests)
+            raise RuntimeError("injected failure of the communicator set-up on this rank")
         h = C.c_void_p()
-        check(lib().irs_comm_create(buf, C.c_int32(rank), C.c_int32(world),
-                                    C.c_int32(self.device.index), C.byref(h)))
+        if transport == "local":
+            check(lib().irs_comm_create_local(C.c_int32(rank), C.c_int32(world),
+                                              C.c_int32(self.device.index), C.byref(h)))
+        elif transport == "rccl":
+            buf = (C.c_char * 256)()
+            if rank == 0:
+                check(lib().irs_comm_unique_id(buf))
+            if world > 1:
+                box = [bytes(buf)]
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=group)
+                buf = (C.c_char * 256).from_buffer_copy(box[0])
+            check(lib().irs_comm_create(buf, C.c_int32(rank), C.c_int32(world),
+                                        C.c_int32(self.device.index), C.byref(h)))
+        else:
+            raise ValueError("transport must be 'rccl' or 'local'.")
         self._comm = h
+        self.peers_attached = False
+        self.peers_error = None
+        if not peers and transport != "local":
+            return
+        # every rank takes part in the gather whatever happened to its own export: a rank that
+        # cannot export sends None and NOBODY attaches
+        blob, err = None, None
+        try:
+            mine = (C.c_char * COMM_HANDLE_BYTES)()
+            check(lib().irs_comm_export(h, self.trainer._h, mine))
+            blob = bytes(mine)
+        except (RuntimeError, ValueError) as exc:
+            err = repr(exc)
+        blobs = [blob]
+        if world > 1:
+            blobs = [None] * world
+            dist.all_gather_object(blobs, blob, group=group)
+        ok = all(b is not None for b in blobs)
+        if ok:
+            try:
+                allb = (C.c_char * (COMM_HANDLE_BYTES * world)).from_buffer_copy(b"".join(blobs))
+                check(lib().irs_comm_attach(h, self.trainer._h, allb))
+            except (RuntimeError, ValueError) as exc:
+                ok, err = False, repr(exc)
+        if world > 1:  # attached on every rank or on none
+            votes = [None] * world
+            dist.all_gather_object(votes, bool(ok), group=group)
+            if ok and not all(votes):
+                ok, err = False, "another rank could not map the peers' memory"
+        self.peers_attached, self.peers_error = bool(ok), (None if ok else err)
+        if transport == "local" and not ok:
+            self.close_comm()
+            raise RuntimeError(f"peer stores are not available: {err}")
+
+    def set_exchange(self, mode: str) -> None:
+        """How ``sharded_step`` moves the solved rows: "auto" (in-place all-gather / grouped
+        broadcasts), "broadcast", "mesh" (one send / receive group) or "peer" (stores into the
+        peers' mapped buffers; needs ``peers_attached``).  The same value on every rank."""
+        import ctypes as C
+
+        from ._lib import EXCHANGE_MODES, check, lib
+
+        check(lib().irs_comm_set_exchange(self._comm, C.c_int32(EXCHANGE_MODES[mode])))
 
     def sharded_step(self, solver_config, user_bounds: Sequence[int], item_bounds: Sequence[int]) -> None:
         import ctypes as C
 
         from ._lib import check, lib, ptr
 
+        if os.environ.get("IRSPACK_AMD_TEST_FAIL_STEP_RANK") == str(_group_info(None)[0]):  # fault injection (tests)
+            raise RuntimeError("injected failure of the sharded step on this rank")
         ub = np.ascontiguousarray(user_bounds, dtype=np.int64)
         ib = np.ascontiguousarray(item_bounds, dtype=np.int64)
         sc = solver_config._struct()
@@ -245,18 +306,69 @@ class HipLocalSolver(LocalSolver):
             pass
 
 
+def run_with_watchdog(fn, timeout_s: float, what: str):
+    """``fn()`` on a worker thread; a call that has not returned after ``timeout_s`` seconds ends
+    the PROCESS with exit code 3 (a collective that one rank never entered blocks the others
+    inside the driver or on the device, where no exception can reach them: the launcher then
+    takes the other ranks down, which is the only way such a job ever ends).  Exceptions of
+    ``fn`` are re-raised here."""
+    import os
+    import sys
+    import threading
+
+    box = {}
+
+    def target():
+        try:
+            box["value"] = fn()
+        except BaseException as exc:  # noqa: BLE001 - handed to the caller
+            box["error"] = exc
+
+    th = threading.Thread(target=target, daemon=True, name="irspack-amd-watchdog")
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        print(f"irspack_amd: {what} did not finish within {timeout_s:.0f} s; this rank gives up "
+              "(exit code 3).", file=sys.stderr, flush=True)
+        os._exit(3)
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
+def all_ranks_ok(ok: bool, group=None) -> bool:
+    """True when ``ok`` is true on every rank (an object all-gather: any backend, no device)."""
+    import torch.distributed as dist
+
+    rank, world = _group_info(group)
+    if world == 1:
+        return bool(ok)
+    votes = [None] * world
+    dist.all_gather_object(votes, bool(ok), group=group)
+    return all(votes)
+
+
 class ShardedIALSTrainer:
     """``IALSTrainer.step`` over ``world_size`` ranks (see the module docstring)."""
 
     def __init__(self, local: LocalSolver, user_bounds: Sequence[int], item_bounds: Sequence[int],
                  group=None, overlap: bool = False, gram_group=None, timing: bool = False,
-                 native: bool = False):
-        """``native=True`` (``HipLocalSolver`` only): the whole epoch runs behind ONE C-ABI call,
-        ``irs_ials_sharded_step`` - the library calls RCCL itself on its own streams (two
-        communicators created here from an id that rank 0 makes and ``torch.distributed`` hands
-        round), the rows travel in place and the next half-epoch's Gramian overlaps their
-        exchange.  The host loop below (ten torch / ctypes calls per epoch) stays for the
-        per-phase ``timing``, for backends other than RCCL and for the CPU tests.
+                 native=False, exchange: str = "auto", watchdog_s: float = 600.0):
+        """``native`` (``HipLocalSolver`` only): the whole epoch runs behind ONE C-ABI call,
+        ``irs_ials_sharded_step`` - the library moves the Gramians and the solved rows itself on
+        its own streams, the rows travel in place and the next half-epoch's Gramian overlaps
+        their exchange.  ``True`` / ``"rccl"``: two RCCL communicators opened by the library
+        (from an id that rank 0 makes and ``torch.distributed`` hands round); ``"local"``: no
+        RCCL, every exchange is a store into the peers' mapped memory.  ``exchange``: how the
+        rows travel ("auto" | "broadcast" | "mesh" | "peer", ``HipLocalSolver.set_exchange``).
+
+        The native transport is set up COLLECTIVELY: every rank tries (under a watchdog of
+        ``watchdog_s`` seconds: a rank stuck in communicator creation leaves with exit code 3
+        instead of hanging the job), the ranks vote through the torch group, and unless all of
+        them succeeded all of them fall back to the host loop below together
+        (``self.native`` False, the reason in ``self.native_error``).  ``preflight_step`` does
+        the same for the first epoch.  The host loop (ten torch / ctypes calls per epoch) also
+        serves the per-phase ``timing``, backends other than RCCL and the CPU tests.
 
         ``overlap=True`` issues the NEXT half-epoch's K x K all-reduce on a second
         communicator while the all-gather of the solved rows is in flight.  It is OFF by
@@ -292,12 +404,29 @@ class ShardedIALSTrainer:
         self.timing = bool(timing)
         self._marks = []  # (label, event or host time) of the current epoch
         self.native = bool(native)
+        self.native_transport = None
+        self.native_exchange = None
+        self.native_error = None
+        self.watchdog_s = float(watchdog_s)
         if self.native:
             if not isinstance(local, HipLocalSolver):
-                raise ValueError("native=True needs a HipLocalSolver.")
-            local.create_comm(group)
-            return
-        if self.world > 1:
+                raise ValueError("native needs a HipLocalSolver.")
+            transport = native if isinstance(native, str) else "rccl"
+            err = None
+            try:
+                run_with_watchdog(lambda: local.create_comm(group, transport=transport,
+                                                            peers=(transport == "local" or exchange == "peer")),
+                                  self.watchdog_s, "creating the native communicators")
+                local.set_exchange(exchange)
+            except (RuntimeError, ValueError) as exc:
+                err = repr(exc)
+            if all_ranks_ok(err is None, group):
+                self.native_transport, self.native_exchange = transport, exchange
+            else:  # every rank falls back together
+                self.native = False
+                self.native_error = err or "another rank could not set up the native transport"
+                local.close_comm()
+        if not self.native and self.world > 1:
             # a second communicator: the K x K all-reduce of the next half-epoch's Gramian must
             # not queue behind the all-gather of the solved rows
             if self.overlap:
@@ -308,27 +437,66 @@ class ShardedIALSTrainer:
                              else [dist.get_global_rank(group, r) for r in range(self.world)])
                     self.gram_group = dist.new_group(ranks=ranks)
                     self._owns_gram_group = True
-            gather_ok = self._probe_gather(local.factor_view(0))
-            for side in (0, 1):
-                view, b = local.factor_view(side), self.bounds[side]
-                if not gather_ok:
-                    self.exchange[side] = "broadcast"
-                    continue
-                S = view.shape[0] // self.world
-                equal = (view.shape[0] % self.world == 0 and
-                         all(b[r] == min(r * S, b[-1]) for r in range(self.world)))
-                if equal:
-                    self.exchange[side] = "inplace"
-                else:
-                    self.exchange[side] = "padded"
-                    smax = max(b[r + 1] - b[r] for r in range(self.world))
-                    self._stage[side] = torch.zeros((self.world * max(smax, 1), view.shape[1]),
-                                                    dtype=view.dtype, device=view.device)
+            self._plan_host_exchange()
+
+    def _plan_host_exchange(self) -> None:
+        torch, local = self.torch, self.local
+        gather_ok = self._probe_gather(local.factor_view(0))
+        for side in (0, 1):
+            view, b = local.factor_view(side), self.bounds[side]
+            if not gather_ok:
+                self.exchange[side] = "broadcast"
+                continue
+            S = view.shape[0] // self.world
+            equal = (view.shape[0] % self.world == 0 and
+                     all(b[r] == min(r * S, b[-1]) for r in range(self.world)))
+            if equal:
+                self.exchange[side] = "inplace"
+            else:
+                self.exchange[side] = "padded"
+                smax = max(b[r + 1] - b[r] for r in range(self.world))
+                self._stage[side] = torch.zeros((self.world * max(smax, 1), view.shape[1]),
+                                                dtype=view.dtype, device=view.device)
+
+    def set_exchange(self, mode: str) -> None:
+        """Switches the native row exchange (every rank, the same mode; between steps)."""
+        if not self.native:
+            raise RuntimeError("set_exchange needs the native transport.")
+        self.local.set_exchange(mode)
+        self.native_exchange = mode
+
+    def preflight_step(self, solver_config) -> bool:
+        """One native epoch, collectively checked: a rank whose step raises votes no, and unless
+        every rank's step succeeded every rank restores the factors it started from and falls
+        back to the host loop (``self.native`` False; returns False).  A step that does not
+        return within ``watchdog_s`` seconds ends the process with exit code 3 - a collective
+        stuck on the device cannot be recovered from inside the process."""
+        if not self.native:
+            return False
+        tr = self.local.trainer
+        user0, item0 = tr.user, tr.item
+        err = None
+        try:
+            run_with_watchdog(lambda: self.local.sharded_step(solver_config, self.bounds[0], self.bounds[1]),
+                              self.watchdog_s, "the first native sharded epoch")
+        except (RuntimeError, ValueError) as exc:
+            err = repr(exc)
+        if all_ranks_ok(err is None, self.group):
+            return True
+        self.native = False
+        self.native_error = err or "the first native epoch failed on another rank"
+        self.local.close_comm()
+        tr.user, tr.item = user0, item0
+        self._gram_ready = [False, False]
+        if self.world > 1:
+            self._plan_host_exchange()
+        return False
 
     def close(self) -> None:
         """Destroys the communicator this trainer created (idempotent)."""
-        if self.native:
+        if self.native:  # (a host-loop trainer on the same solver must not close another trainer's transport)
             self.local.close_comm()
+            self.native = False
         if self._owns_gram_group and self.gram_group is not None:
             try:
                 self.dist.destroy_process_group(self.gram_group)

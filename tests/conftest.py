@@ -146,31 +146,44 @@ def rows_vs_float64(gpu, oracle32, ref64, floor: float = 1e-6):
 
 
 def assert_float64_bar(gpu, oracle32, ref64, what: str, test: str = "", rtol: float = 1e-4,
-                       slack: float = 1.0, **extra) -> None:
-    """The factor-parity bar with float64 as the arbiter of EVERY row: the GPU's worst row is no
-    farther from the float64 rows than the float32 oracle's worst row (or ``rtol``, whichever is
-    larger; ``slack`` > 1 where the two maxima are a handful of rows of a noisy tail), and - given
-    at least 1000 rows - 99.9 % of the GPU's rows are within ``rtol`` of float64.  The achieved distributions go to the parity
-    log."""
+                       truncated: bool = False, **extra) -> None:
+    """The factor-parity bar with float64 as the arbiter of EVERY row.  The achieved distributions
+    go to the parity log.
+
+    ``truncated=False`` (Cholesky; anything whose exact answer is the solution of the row's system):
+    the GPU's worst row is no farther from float64 than ``rtol`` - or, where the float32 oracle itself
+    is farther (ill-conditioned rows), than the oracle's worst row.  No slack factor.
+
+    ``truncated=True`` (CG after a fixed number of steps, one iALS++ sweep: the iteration has NOT
+    converged on every row, and such a row amplifies any float32 rounding by its conditioning - the
+    oracle's sequential sums as much as the GPU's tree sums, on different rows, run to run): a
+    comparison of two maxima is a comparison of two extreme-value samples, so the bar is stated on the
+    distribution: the GPU's 99.99 % quantile <= max(rtol, the oracle's 99.99 % quantile); the number of
+    GPU rows beyond rtol <= max(the oracle's count, 0.01 % of the rows); and no single row beyond
+    10 x max(rtol, the oracle's worst row) (an outright wrong row is O(1) away)."""
     e_gpu, e_orc = rows_vs_float64(gpu, oracle32, ref64)
     g32 = np.linalg.norm(np.asarray(gpu, np.float64) - np.asarray(oracle32, np.float64), axis=1)
     d32 = np.linalg.norm(np.asarray(oracle32, np.float64), axis=1)
     e32 = g32 / np.maximum(d32, 1e-6 * max(float(d32.max()) if d32.size else 0.0, 1e-300))
     q = lambda e, p: float(np.quantile(e, p)) if e.size else 0.0  # noqa: E731
-    record_parity(test or "float64_bar", what, n_rows=int(e_gpu.size),
+    record_parity(test or "float64_bar", what, n_rows=int(e_gpu.size), truncated=bool(truncated),
                   gpu_vs_f64_worst=float(e_gpu.max()) if e_gpu.size else 0.0,
-                  gpu_vs_f64_p999=q(e_gpu, 0.999), gpu_vs_f64_median=q(e_gpu, 0.5),
+                  gpu_vs_f64_p9999=q(e_gpu, 0.9999), gpu_vs_f64_p999=q(e_gpu, 0.999), gpu_vs_f64_median=q(e_gpu, 0.5),
                   oracle_f32_vs_f64_worst=float(e_orc.max()) if e_orc.size else 0.0,
-                  oracle_f32_vs_f64_p999=q(e_orc, 0.999), oracle_f32_vs_f64_median=q(e_orc, 0.5),
+                  oracle_f32_vs_f64_p9999=q(e_orc, 0.9999), oracle_f32_vs_f64_p999=q(e_orc, 0.999),
+                  oracle_f32_vs_f64_median=q(e_orc, 0.5),
                   gpu_vs_oracle_f32_worst=float(e32.max()) if e32.size else 0.0,
                   n_rows_gpu_over_1e_4_vs_f64=int((e_gpu >= rtol).sum()),
                   n_rows_oracle_over_1e_4_vs_f64=int((e_orc >= rtol).sum()), **extra)
     if not e_gpu.size:
         return
     assert np.isfinite(e_gpu).all(), what
-    assert e_gpu.max() <= max(rtol, slack * e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))
-    if e_gpu.size >= 1000:  # (of a few dozen rows the 99.9 % quantile IS the worst row)
-        # (... and never asked to be closer to float64 than the float32 oracle itself manages: the
-        # configs[3] users whose solution has norm 1e-7 next to a warm start of norm 1e-3 lose 3-4
-        # digits to cancellation in ANY float32 evaluation - oracle p99.9 1.6e-4, GPU 1.2e-4)
-        assert q(e_gpu, 0.999) <= max(rtol, q(e_orc, 0.999)), (what, q(e_gpu, 0.999), q(e_orc, 0.999))
+    if not truncated:
+        assert e_gpu.max() <= max(rtol, e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))
+        return
+    import math
+
+    assert q(e_gpu, 0.9999) <= max(rtol, q(e_orc, 0.9999)), (what, q(e_gpu, 0.9999), q(e_orc, 0.9999))
+    assert int((e_gpu >= rtol).sum()) <= max(int((e_orc >= rtol).sum()), math.ceil(1e-4 * e_gpu.size)), \
+        (what, int((e_gpu >= rtol).sum()), int((e_orc >= rtol).sum()))
+    assert e_gpu.max() <= 10.0 * max(rtol, e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))

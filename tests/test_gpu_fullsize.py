@@ -77,34 +77,29 @@ def row_sample(Xs, n_random, seed, chunk=1024, n_longest_unsplit=64):
     return np.unique(np.concatenate([split, longest, rnd])), split
 
 
-def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alpha0=ALPHA0, reg=REG,
-                      slack=1.0):
+def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alpha0=ALPHA0, reg=REG):
     """EVERY row against the float64 arbiter (round 4).  `want` are the float32 oracle's rows; the
     SAME restatement compiled with Real = double (oracle/liboracle_f64.so, `make -C oracle f64`:
     same iteration, exits and float regulariser, factors / Gramian / every intermediate in float64)
-    evaluates all of `rows`, and both float32 implementations are measured against it:
-      * the GPU's worst row is no farther from float64 than the oracle's worst row (or RTOL,
-        whichever is larger; `slack` > 1 only where the two maxima are a handful of rows of a
-        noisy tail: the configs[3] rows of norm 1e-7 next to a warm start of norm 1e-3);
-      * 99.9 % of the GPU's rows are within RTOL of float64.
+    evaluates all of `rows`, and both float32 implementations are measured against it
+    (conftest.assert_float64_bar):
+      * CHOLESKY: the GPU's worst row within RTOL of float64 (or within the oracle's own worst row
+        where that is larger); no slack factor;
+      * CG x 3 (truncated: a handful of rows per 10^5 have NOT converged after three steps - ML-20M
+        user 38077, 142 entries: ||r||^2 = 32, 67, 1.7, 19 - and amplify any float32 rounding by
+        their conditioning, the oracle's and the GPU's alike, on different rows, run to run): the
+        distribution bar - 99.99 % quantile, count of rows beyond RTOL, no row beyond 10 x the
+        oracle's worst.
     Two correct float32 implementations cannot agree to 1e-4 on every row - under truncated CG
     the oracle's sequential sums over rows of 10^4 entries are up to 2e-3 from exact arithmetic -
     which is why float64, not the float32 oracle, is the yardstick.  The achieved distributions
     (gpu_vs_f64, oracle_f32_vs_f64, gpu_vs_oracle_f32) go to the parity log."""
     K = oth0.shape[1]
     _, _, omc, osc = configs(K, kind, alpha0, reg)
-    if kind == "CG":
-        # Truncated CG: a handful of rows per 10^5 have NOT converged after three steps (ML-20M
-        # user 38077, 142 entries: ||r||^2 = 32, 67, 1.7, 19) and amplify any float32 rounding by
-        # their conditioning - 2e-4 .. 4e-4 from float64 for the oracle and for the GPU alike, on
-        # different rows, run to run.  The two maxima are single rows of those tails: the GPU's may
-        # be up to twice the oracle's; the 99.9 % bar and the counts in the log are the
-        # distribution-level statement (GPU p99.9 1.2e-5 against the oracle's 3.1e-5 at K = 64).
-        slack = max(slack, 2.0)
     ref64 = O.ials_solver_step_f64(tgt0[rows], Xs[rows], oth0, None, omc, osc, CORES)
     nnz = np.diff(Xs.indptr)[rows]
     e_gpu, _ = rows_vs_float64(got, want, ref64)
-    assert_float64_bar(got, want, ref64, str(what), test=test or "fullsize", rtol=RTOL, slack=slack,
+    assert_float64_bar(got, want, ref64, str(what), test=test or "fullsize", rtol=RTOL, truncated=(kind != "CHOLESKY"),
                        worst_row=int(rows[int(np.argmax(e_gpu))]), worst_row_nnz=int(nnz[int(np.argmax(e_gpu))]))
     return float(e_gpu.max()), int((e_gpu >= RTOL).sum())
 
@@ -319,7 +314,7 @@ def test_ials_k128_c4_like_short_rows_vs_oracle(kind):
         want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
         assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
                           f"c4_small (200k x 20k) K=128 {kind} {'user' if side == 0 else 'item'} half, all rows",
-                          test="test_ials_k128_c4_like_short_rows_vs_oracle", slack=3.0)
+                          test="test_ials_k128_c4_like_short_rows_vs_oracle")
         assert np.isfinite(got).all()
 
 
@@ -414,7 +409,7 @@ def test_ials_k128_c4_full_matrix_vs_oracle(XC4, kind):
         assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
                           f"c4 FULL (10M x 1M, nnz={X.nnz}) K=128 {kind} {'user' if side == 0 else 'item'} half, "
                           f"{split.size} split rows + 64 longest + 20k random",
-                          test="test_ials_k128_c4_full_matrix_vs_oracle", slack=3.0)
+                          test="test_ials_k128_c4_full_matrix_vs_oracle")
         del got, want
 
 
@@ -502,25 +497,16 @@ def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
             rows = np.arange(Xs.shape[0])
             P = O.ials_gramian(oth0, omc.alpha0, CORES)
             want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
-        num = np.linalg.norm(got.astype(np.float64) - want, axis=1)
-        den = np.linalg.norm(want.astype(np.float64), axis=1)
-        err = num / np.maximum(den, 1e-6 * den.max())
-        far = np.flatnonzero(~(err < RTOL))
-        rec = dict(n_rows=int(len(rows)), worst_row_err=float(err.max()), median_row_err=float(np.median(err)),
-                   n_rows_over_1e_4=int(far.size), worst_vs_float64=None, oracle_vs_float64=None)
-        e_gpu = e_orc = None
-        if 0 < far.size <= max(50, 0.05 * len(rows)):
-            ref = ialspp_float64(Xs, rows[far], tgt0, oth0, 64)
-            nref = np.linalg.norm(ref, axis=1)
-            e_gpu = np.linalg.norm(got[far] - ref, axis=1) / nref
-            e_orc = np.linalg.norm(want[far] - ref, axis=1) / nref
-            rec.update(worst_vs_float64=float(e_gpu.max()), oracle_vs_float64=float(e_orc.max()))
-        record_parity("test_ialspp_ml20m_vs_oracle",
-                      f"ml20m K={K} iALS++ sub=64 direct={direct} {'user' if side == 0 else 'item'} half, "
-                      f"{'all' if K <= 256 else len(rows)} rows", **rec)
-        assert far.size <= max(50, 0.05 * len(rows)), (K, side, far.size, float(err.max()))
-        if far.size:
-            assert e_gpu.max() < 3 * RTOL, (K, side, float(e_gpu.max()))
-            assert (e_gpu >= RTOL).sum() <= max(2, FAR_FRACTION * len(rows)), (K, side, int((e_gpu >= RTOL).sum()))
-            assert e_gpu.max() <= max(2 * e_orc.max(), RTOL), (K, side, float(e_gpu.max()), float(e_orc.max()))
+        # EVERY row against the float64 evaluation of the same sweep (the oracle's sources with Real =
+        # double); one sweep is a truncated iteration: the distribution bar of conftest.assert_float64_bar
+        # (99.99 % quantile, count beyond RTOL, no row beyond 10 x the oracle's worst) - achieved in
+        # round 4: no row beyond RTOL on any of the eight comparisons
+        ref64 = O.ials_solver_step_f64(tgt0[rows], Xs[rows], oth0, None, omc, osc, CORES)
+        pin = np.random.default_rng(5 + side).choice(len(rows), size=16, replace=False)
+        indep = ialspp_float64(Xs, rows[pin], tgt0, oth0, 64)  # (the arbiter itself against plain numpy)
+        assert np.abs(ref64[pin] - indep).max() <= 1e-9 * max(1.0, np.abs(indep).max())
+        assert_float64_bar(got, want, ref64,
+                           f"ml20m K={K} iALS++ sub=64 direct={direct} {'user' if side == 0 else 'item'} half, "
+                           f"{'all' if K <= 256 else len(rows)} rows", test="test_ialspp_ml20m_vs_oracle",
+                           rtol=RTOL, truncated=True)
         assert np.isfinite(got).all()

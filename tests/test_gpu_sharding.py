@@ -87,25 +87,39 @@ def test_two_ranks_match_single_gpu(tmp_path, kind, equal, K):
     assert row_rel_err(r0["item"], ref.item) < 5e-4
 
 
-@pytest.mark.parametrize("extra", [["--shape", "small", "--balance", "equal"],
-                                   ["--shape", "small", "--balance", "cost", "--solver", "CG"],
-                                   ["--shape", "c4_small", "--K", "128", "--solver", "CG"]])
-def test_bench_two_ranks_control_flow(extra):
+@pytest.mark.parametrize("extra,env_extra,timed", [
+    (["--shape", "small", "--balance", "equal"], {}, "torch"),
+    (["--shape", "small", "--balance", "cost", "--solver", "CG"], {}, "torch"),
+    (["--shape", "c4_small", "--K", "128", "--solver", "CG"], {}, "torch"),
+    # the native path as the timed one: the RCCL-free peer-store transport (two processes, one GPU)
+    (["--shape", "small", "--balance", "equal"], {"IRSPACK_AMD_BENCH_COMM": "local"}, "native"),
+    (["--shape", "small", "--balance", "cost", "--solver", "CG"], {"IRSPACK_AMD_BENCH_COMM": "local"}, "native"),
+    # one rank cannot set the transport up -> BOTH ranks time the torch host loop, and say so
+    (["--shape", "small", "--balance", "equal"],
+     {"IRSPACK_AMD_BENCH_COMM": "local", "IRSPACK_AMD_TEST_FAIL_COMM_RANK": "1"}, "fallback"),
+    # one rank's first native epoch fails; the other's waits time out (5 s) -> both fall back
+    (["--shape", "small", "--balance", "equal"],
+     {"IRSPACK_AMD_BENCH_COMM": "local", "IRSPACK_AMD_TEST_FAIL_STEP_RANK": "0",
+      "IRSPACK_AMD_PEER_TIMEOUT_S": "5"}, "fallback")])
+def test_bench_two_ranks_control_flow(extra, env_extra, timed):
     """bench.py's N > 1 path (process group, shards, barrier + max-over-ranks timing, the
     per-phase compute / all-reduce / all-gather split, one JSON line from rank 0) with two ranks
     on one device over gloo: equal shards, cost-balanced shards, and the configs[3] invocation
     (`--shape c4 --K 128 --solver CG`, here its 1/50-scale matrix), whose longest row selects
-    the cost balance by itself."""
+    the cost balance by itself; the native path (irs_ials_sharded_step) timed over the peer-store
+    transport; and the collective fallback when one rank fails to create the transport or to run
+    its first native epoch - every rank then times the host loop and the line records why."""
     import json
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, IRSPACK_AMD_BENCH_BACKEND="gloo", IRSPACK_AMD_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, IRSPACK_AMD_BENCH_BACKEND="gloo", IRSPACK_AMD_BENCH_ONE_DEVICE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     out = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-         "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
          "--gpus", "2", "--steps", "2", "--warmup", "1", *extra],
         env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -120,6 +134,15 @@ def test_bench_two_ranks_control_flow(extra):
     assert c["compute_ms"] > 0 and c["allgather_ms"] > 0 and c["allreduce_ms"] >= 0
     assert 0 < c["exposed_comm_ms"] <= c["allreduce_ms"] + c["allgather_ms"] + 1e-6
     assert len(c["exchange"]) == 2 and c["overlap"] is False
+    pf = c["native_preflight"]
+    if timed == "torch":
+        assert pf is None and c["timed_path"] == "torch.distributed host loop"
+    elif timed == "native":
+        assert pf["created"] and pf["first_epoch"] and "error" not in pf
+        assert c["timed_path"].startswith("native") and "local" in c["timed_path"]
+    else:
+        assert not (pf["created"] and pf["first_epoch"]) and pf["error"]
+        assert c["timed_path"] == "torch.distributed host loop"
 
 
 def _knn_eval_worker(rank, world, port, out_dir):
@@ -228,7 +251,7 @@ def test_rccl_calls_on_library_buffers_world_size_one(tmp_path):
     assert (tmp_path / "rccl1.txt").read_text() == "ok"
 
 
-def _native_world1_worker(rank, kind, K, out_dir):
+def _native_world1_worker(rank, kind, K, out_dir, exchange="auto", transport="rccl"):
     from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
                                                       IALSSolverConfigBuilder, IALSTrainer,
                                                       SolverType)
@@ -240,9 +263,13 @@ def _native_world1_worker(rank, kind, K, out_dir):
     mc = IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(1e-2).build()
     sc = IALSSolverConfigBuilder().set_solver_type(SolverType[kind]).set_max_cg_steps(3).build()
     local = HipLocalSolver(mc, X, (0, U, 0, I), 0)
-    tr = ShardedIALSTrainer(local, [0, U], [0, I], native=True)
+    tr = ShardedIALSTrainer(local, [0, U], [0, I], native=transport, exchange=exchange)
+    assert tr.native and tr.native_error is None, tr.native_error
+    assert tr.native_transport == transport and tr.native_exchange == exchange
     ref = IALSTrainer(mc, X)
-    for _ in range(3):
+    assert tr.preflight_step(sc)
+    ref.step(sc)
+    for _ in range(2):
         tr.step(sc)
         ref.step(sc)
     np.testing.assert_array_equal(local.trainer.user, ref.user)
@@ -253,6 +280,18 @@ def _native_world1_worker(rank, kind, K, out_dir):
     tr.step(sc)
     ref.step(sc)
     np.testing.assert_array_equal(local.trainer.user, ref.user)
+    if transport == "rccl":  # the exchange can be switched between steps
+        for mode in ("mesh", "broadcast", "auto"):
+            tr.set_exchange(mode)
+            tr.step(sc)
+            ref.step(sc)
+            np.testing.assert_array_equal(local.trainer.item, ref.item)
+        try:
+            tr.set_exchange("peer")  # no peers mapped unless asked for at creation
+        except ValueError:
+            assert exchange != "peer"
+        else:
+            assert exchange == "peer"
     try:
         local.sharded_step(sc, [0, U - 1], [0, I])  # bounds that do not cover every row
     except ValueError:
@@ -264,26 +303,136 @@ def _native_world1_worker(rank, kind, K, out_dir):
         f.write("ok")
 
 
-@pytest.mark.parametrize("kind,K,exchange,chunks", [("CHOLESKY", 64, "allgather", 1), ("CG", 200, "allgather", 1),
-                                                   ("CHOLESKY", 64, "broadcast", 1), ("CHOLESKY", 64, "allgather", 3),
-                                                   ("CG", 200, "allgather", 2), ("CG", 128, "allgather", 4)])
-def test_native_sharded_step_world_size_one(tmp_path, kind, K, exchange, chunks, monkeypatch):
-    """``irs_ials_sharded_step`` (the epoch behind one C-ABI call, RCCL opened and called by the
-    library itself) on the one GPU of the box: world size 1 - communicator creation, the stream /
-    event plumbing and the Gramian prefetch run; the collectives are skipped.  The result must be
-    the unsharded trainer's, bit for bit, over three epochs (the prefetched Gramian of the next
-    epoch is used from the second one on), and a factor set from outside must invalidate it.
+@pytest.mark.parametrize("kind,K,exchange,chunks,transport", [
+    ("CHOLESKY", 64, "auto", 1, "rccl"), ("CG", 200, "auto", 1, "rccl"),
+    ("CHOLESKY", 64, "broadcast", 1, "rccl"), ("CHOLESKY", 64, "auto", 3, "rccl"),
+    ("CG", 200, "auto", 2, "rccl"), ("CG", 128, "auto", 4, "rccl"),
+    ("CHOLESKY", 64, "mesh", 1, "rccl"), ("CG", 128, "mesh", 3, "rccl"),
+    ("CHOLESKY", 64, "peer", 1, "rccl"), ("CG", 128, "peer", 2, "rccl"),
+    ("CHOLESKY", 64, "peer", 1, "local"), ("CG", 200, "peer", 3, "local")])
+def test_native_sharded_step_world_size_one(tmp_path, kind, K, exchange, chunks, transport, monkeypatch):
+    """``irs_ials_sharded_step`` (the epoch behind one C-ABI call, the transport opened and driven
+    by the library itself) on the one GPU of the box: world size 1 - communicator creation, the
+    collective set-up vote, the stream / event plumbing and the Gramian prefetch run.  The result
+    must be the unsharded trainer's, bit for bit, over three epochs (the prefetched Gramian of the
+    next epoch is used from the second one on), and a factor set from outside must invalidate it.
     The collectives themselves ARE issued (an all-reduce / all-gather / broadcast over one rank is
     the identity): the calls, buffers, counts, streams and events are those of a multi-GPU epoch.
-    "broadcast": the grouped in-place broadcasts of uneven shards, forced for the equal ones.
+    "broadcast": the grouped in-place broadcasts of uneven shards, forced for the equal ones;
+    "mesh": the send / receive group (empty over one rank); "peer": the signal / wait kernels and,
+    with transport "local", the mailbox all-reduce - no RCCL communicator at all.
     chunks > 1 (IRSPACK_AMD_SHARD_CHUNKS): the rows of the shard cut into chunks with task lists of
     their own, each exchanged behind its own solve: same bits (rows are independent).
     (In a spawned process like the other tests of this file: torch initialises the device there.)"""
     import torch.multiprocessing as mp
 
-    monkeypatch.setenv("IRSPACK_AMD_SHARD_EXCHANGE", exchange)
     if chunks > 1:  # the shard's rows solved and exchanged in chunks (chunk k + 1 solved while chunk k travels)
         monkeypatch.setenv("IRSPACK_AMD_SHARD_CHUNKS", str(chunks))
 
-    mp.spawn(_native_world1_worker, args=(kind, K, str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_native_world1_worker, args=(kind, K, str(tmp_path), exchange, transport), nprocs=1, join=True)
     assert (tmp_path / f"native_{kind}_{K}.txt").read_text() == "ok"
+
+
+def _local_transport_worker(rank, world, port, kind, K, out_dir, chunks):
+    import torch.distributed as dist
+
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, SolverType)
+    from irspack_amd.sharding import (HipLocalSolver, ShardedIALSTrainer, equal_shard_bounds,
+                                      shard_bounds)
+    from irspack_amd.synthetic import make_interactions
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["IRSPACK_AMD_PEER_TIMEOUT_S"] = "30"
+    if chunks > 1:
+        os.environ["IRSPACK_AMD_SHARD_CHUNKS"] = str(chunks)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X = make_interactions("small")
+    mc = IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(1e-2).build()
+    sc = (IALSSolverConfigBuilder().set_solver_type(SolverType[kind]).set_max_cg_steps(3).build())
+    ub, ib = shard_bounds(X, K, kind, world) if chunks == 1 else equal_shard_bounds(X, world)
+    shard = (ub[rank], ub[rank + 1], ib[rank], ib[rank + 1])
+    local = HipLocalSolver(mc, X, shard, 0)
+    tr = ShardedIALSTrainer(local, ub, ib, native="local", exchange="peer", watchdog_s=240)
+    assert tr.native, tr.native_error
+    assert tr.preflight_step(sc)
+    tr.step(sc)
+    tr.synchronize()
+    got_user, got_item = local.trainer.user, local.trainer.item
+    tr.close()
+    # the torch host loop (gloo) from the same start on a second solver: with two ranks the
+    # Gramian is a + b either way, so the two transports must agree bit for bit
+    os.environ.pop("IRSPACK_AMD_SHARD_CHUNKS", None)
+    local2 = HipLocalSolver(mc, X, shard, 0)
+    host = ShardedIALSTrainer(local2, ub, ib)
+    for _ in range(2):
+        host.step(sc)
+    host.synchronize()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), user=got_user, item=got_item,
+             host_user=local2.trainer.user, host_item=local2.trainer.item)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,K,chunks", [("CHOLESKY", 64, 1), ("CG", 128, 1), ("CG", 64, 3), ("IALSPP", 128, 1)])
+def test_peer_store_transport_two_processes_one_gpu(tmp_path, kind, K, chunks):
+    """The RCCL-free transport with TWO ranks (two processes sharing device 0, which RCCL refuses):
+    factor buffers, mailbox and flags exported with hipIpcGetMemHandle and mapped by the peer,
+    the solved rows STORED into the peer's replica by the push kernel, arrival signalled by
+    sequence numbers in mapped flag words, the K x K Gramian summed out of the mailbox slots in rank
+    order, the solver's error flag reduced the same way.  Two epochs (the second uses the
+    prefetched Gramian): replicas bit-identical, and bit-identical to the torch / gloo host loop
+    from the same start."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_local_transport_worker, args=(2, _free_port(), kind, K, str(tmp_path), chunks), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ("user", "item"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+        np.testing.assert_array_equal(r0[k], r0["host_" + k])
+    assert np.isfinite(r0["user"]).all() and np.abs(r0["user"]).max() > 0
+
+
+def _error_parity_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, SolverType)
+    from irspack_amd.sharding import HipLocalSolver, ShardedIALSTrainer, equal_shard_bounds
+    from irspack_amd.synthetic import make_interactions
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X = make_interactions("tiny").tolil()
+    X.rows[7], X.data[7] = [], []  # an empty user row in rank 0's shard: alpha0 = 0 makes its system the zero matrix
+    X = X.tocsr()
+    mc = IALSModelConfigBuilder().set_K(16).set_alpha0(0.0).set_reg(1e-3).build()
+    sc = IALSSolverConfigBuilder().set_solver_type(SolverType.CHOLESKY).build()
+    ub, ib = equal_shard_bounds(X, world)
+    local = HipLocalSolver(mc, X, (ub[rank], ub[rank + 1], ib[rank], ib[rank + 1]), 0)
+    tr = ShardedIALSTrainer(local, ub, ib, native="local", exchange="peer", watchdog_s=240)
+    assert tr.native, tr.native_error
+    msg = "none"
+    try:
+        tr.step(sc)
+    except RuntimeError as exc:
+        msg = str(exc)
+    with open(os.path.join(out_dir, f"err{rank}.txt"), "w") as f:
+        f.write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_solver_error_is_raised_on_every_rank(tmp_path):
+    """What the reference throws from inside a solve (hpp:316-318: LLT of a zero matrix, an empty
+    row at alpha0 = 0) happens on ONE rank's rows; the sharded step all-reduces the device error
+    flag, so both ranks raise the same RuntimeError instead of one raising and one waiting."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_error_parity_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = [(tmp_path / f"err{r}.txt").read_text() for r in range(2)]
+    assert msgs[0] == msgs[1] == "Cholesky decomposition failed."
