@@ -22,6 +22,7 @@ Objects on the line:
                   accuracy from exact three-way bf16 splits; not the headline path)
     knn           cosine / jaccard item-kNN top-100 (configs[2]); headline = wall-inclusive call
     evaluator     fused score + nDCG@20 over all users (K = 64)
+    fit           IALSTrainer(...) + 16 steps + factors to the host: the reference's learn() through the boundary
     k256          configs[4] on one GPU: K = 256 Cholesky + CG epochs and the fused nDCG@20
     c4            configs[3] shape on one GPU (10 M x 1 M, 95 M stored entries), K = 128, CG + Cholesky
 """
@@ -53,7 +54,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip every leg reported next to the headline metric")
-    ap.add_argument("--legs", default="ials_cg,ials_bf16x3,knn,evaluator,k256,c4",
+    ap.add_argument("--legs", default="ials_cg,ials_bf16x3,fit,knn,evaluator,k256,c4",
                     help="comma-separated secondary legs to run (N = 1)")
     ap.add_argument("--balance", default="auto", choices=["auto", "cost", "equal"],
                     help="N > 1 row shards: equal row blocks (one in-place all-gather) or "
@@ -225,6 +226,13 @@ def cpu_baseline(X, K, solver, budget_s):
         "kind": "port",
         "build": build,
         "cpu_gflops": value / (U + I) * flops / 1e9,
+        "cpu_gflops_per_thread": value / (U + I) * flops / 1e9 / cores,
+        "note": ("a LOWER BOUND of what these cores can do, not a target: a restatement with a register-"
+                 "blocked rank update and a plain LLT, one row per thread like the reference's loop - about "
+                 "1-2 GFLOP/s per thread, a few per cent of the cores' fp32 peak (an AVX-512 core at ~3 GHz "
+                 "peaks near 100 GFLOP/s); an Eigen build with blocked SYRK / LLT would be several times "
+                 "faster.  The GPU / CPU ratio this implies says nothing about kernel quality - "
+                 "roofline.frac does."),
         "parity_oracle_value": parity,
         "sample": (f"first {nu_} of {U} user rows + first {ni_} of {I} item rows of the same "
                    f"matrix (row order is random), one {solver} half-step each, {reps} pass(es), "
@@ -232,9 +240,15 @@ def cpu_baseline(X, K, solver, budget_s):
     }
 
 
-def pmc_traffic():
+PMC_WORKLOAD = "ml20m K=64"  # what the committed FETCH_SIZE / WRITE_SIZE passes ran (scripts/prof_bench.sh)
+
+
+def pmc_traffic(workload=PMC_WORKLOAD):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    written by scripts/summarize_prof.py with the guide's gfx950 corrections)."""
+    written by scripts/summarize_prof.py with the guide's gfx950 corrections) - ONLY for the workload
+    those passes ran: a leg on another shape or K gets no traffic figures rather than wrong ones."""
+    if workload != PMC_WORKLOAD:
+        return {}
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
@@ -276,8 +290,9 @@ def model_config(K):
             .set_init_stdev(0.1).set_random_seed(42).build())
 
 
-def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
-    """One solver on one matrix: updates/s + roofline with both terms."""
+def ials_leg(trainer, X, K, kind, steps, warmup, ceilings, workload=None):
+    """One solver on one matrix: updates/s + roofline with both terms.  `workload`: "<shape> K=<K>" when
+    a PMC pass of exactly this workload is committed (traffic_by_kernel is null otherwise)."""
     dt, kernels = time_epochs(trainer, solver_config(kind), steps, warmup)
     flops, byts = algorithmic_epoch(X, K, kind)
     U, I = X.shape
@@ -312,10 +327,38 @@ def ials_leg(trainer, X, K, kind, steps, warmup, ceilings):
                                scope="whole epoch (all kernels)",
                                algorithmic_gflop_per_epoch=flops / 1e9,
                                algorithmic_gbyte_per_epoch=byts / 1e9,
-                               traffic_by_kernel={k: v for k, v in pmc_traffic().items()
-                                                  if k.startswith("ials_") and ("cg" in k) == (kind == "CG")},
+                               traffic_by_kernel=({k: v for k, v in pmc_traffic(workload).items()
+                                                   if k.startswith("ials_") and ("cg" in k) == (kind == "CG")}
+                                                  or None),
                                **more),
     }
+
+
+def fit_leg(X, K, kind="CHOLESKY", epochs=16):
+    """`fit` THROUGH THE BOUNDARY: what the reference's `IALSRecommender.learn()` does with the core
+    (ials.py:92-131, base_earlystop.py:106-149): construct the trainer from the host CSR (copy,
+    transpose, task lists, the libstdc++ random stream of the initial factors, uploads), 16 `step`s,
+    both factor matrices back on the host.  Host clock around each part; the second of two fits (the
+    first pays one-off allocations)."""
+    from irspack_amd.recommenders._ials_core import IALSTrainer
+
+    sc = solver_config(kind)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        tr = IALSTrainer(model_config(K), X)
+        t1 = time.perf_counter()
+        for _ in range(epochs):
+            tr.step(sc)
+        t2 = time.perf_counter()
+        user, item = tr.user, tr.item
+        t3 = time.perf_counter()
+        best = {"solver": kind, "epochs": epochs, "fit_wall_s": t3 - t0, "create_s": t1 - t0,
+                "epochs_s": t2 - t1, "factors_to_host_s": t3 - t2,
+                "updates_per_s_through_the_boundary": (X.shape[0] + X.shape[1]) * epochs / (t3 - t0),
+                "factor_bytes": int(user.nbytes + item.nbytes)}
+        del tr, user, item
+    return best
 
 
 def ialspp_leg(trainer, X, K, steps, warmup):
@@ -354,7 +397,7 @@ def bf16x3_leg(X, K, steps, ceilings):
         tr = IALSTrainer(model_config(K), X)  # the switch is read when a trainer is created
     finally:
         del os.environ["IRSPACK_AMD_IALS_BF16X3"]
-    out = ials_leg(tr, X, K, "CHOLESKY", steps, 2, ceilings)
+    out = ials_leg(tr, X, K, "CHOLESKY", steps, 2, ceilings)  # (no PMC pass of this variant: no traffic figures)
     out["rank_update"] = ("bf16x3: v_mfma_f32_16x16x32_bf16 on exact 3-way splits of the fp32 values, "
                           "fp32 accumulate (opt-in, unit confidences, K <= 64)")
     return out
@@ -449,24 +492,33 @@ def evaluator_leg(X, trainer, K, ceilings):
     flops = 2.0 * K * (64.0 * 64.0 * st["tiles_scored"] + float(U) * st["sample_items"])
     # HBM side of what runs: the sample score block (written, masked, read) and the candidate lists
     byts = 2.0 * U * st["sample_items"] * 4 + 2.0 * U * 20 * 8
+    # Three clocks of the same call: the Python wall (fingerprint of the 80 MB mask + ctypes + the C
+    # call), the C call alone (host clock inside the library), and the DEVICE span (HIP events on the
+    # launch stream, first kernel -> last kernel done).  The roofline is priced on the device span: the
+    # host's share says nothing about the kernels.
+    span_s = max(st["device_span_ms"], 1e-6) * 1e-3
     return {
         "workload": (f"fused iALS k={K} scoring + nDCG@20 over {U} users x {I} items, fp32 scores; "
                      f"ground truth = 20 % per-row hold-out ({gt.nnz} entries), mask = the other 80 %"),
         "wall_s_first_call_incl_mask_upload": wall_first,
         "wall_s_incl_pcie": wall, "users_per_s": U / wall,
         "wall_s_sampled_mask_fingerprint": wall_sampled, "users_per_s_sampled_mask_fingerprint": U / wall_sampled,
-        "mask_check": ("default: every byte of the resident mask hashed per call (xxh3 / CRC-32); "
+        "library_call_ms": st["call_ms"], "device_span_ms": st["device_span_ms"],
+        "host_ms_outside_the_library": wall_sampled * 1e3 - st["call_ms"],
+        "mask_check": ("default: every byte of the resident mask hashed per call (irs_fingerprint, host threads); "
                        "EvaluatorCore.strict_mask_fingerprint = False: 1024-sample fingerprint"),
         "scores_per_s": U * float(I) / wall, "ndcg@20": m.as_dict()["ndcg"],
         "device_path": st,
         "model": "iALS fitted on the training entries (the mask) only: 3 CG epochs",
         "drop_in_block_path": block_path_leg(ev, trainer, mask),
         "tiles_scored_frac": st["tiles_scored"] / max(1, st["tiles_total"]),
-        "roofline": both_terms(flops, byts, wall, ceilings, bound="mfma",
-                               scope="whole call (host wall clock); after pruning the call is "
-                                     "launch / latency bound, not MFMA bound",
+        "roofline": both_terms(flops, byts, span_s, ceilings, bound=None,
+                               scope="device span of the call (HIP events, first kernel -> last kernel done; "
+                                     "includes the gaps in which the host reads the hard-row list back); "
+                                     "after pruning the call is launch / latency bound",
                                executed_gflop=flops / 1e9, dense_gflop=dense_flops / 1e9,
-                               dense_equivalent_tflops=dense_flops / wall / 1e12,
+                               dense_equivalent_tflops=dense_flops / span_s / 1e12,
+                               dense_equivalent_tflops_python_wall=dense_flops / wall / 1e12,
                                sample_block_gbyte_write_plus_read=byts / 1e9),
     }
 
@@ -515,8 +567,9 @@ def knn_leg(X, ceilings):
                      "note": "kernel time covers accumulate + epilogue + select + merge; "
                              "HBM side prices the reference's 4 B column id per multiply-add; "
                              "traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE of the tile kernel "
-                             "(profiles/r03_knn_pmc_hbm.json): the 2-byte column stream is "
-                             "re-read per target row from Infinity Cache / HBM"},
+                             "(profiles/pmc_traffic.json from the latest profiles/rNN_knn_pmc_hbm.json, "
+                             "same matrix): the 2-byte column stream is read once per column tile; "
+                             "short slices waste part of their 128-byte lines"},
         "out_nnz": int(S.nnz),
     }
     variants = {}
@@ -575,6 +628,16 @@ def c4_leg(full, ceilings):
            "generate_s": gen_s, "create_s": time.perf_counter() - t0}
     out["cg"] = ials_leg(tr, X, K, "CG", 5, 1, ceilings)
     out["cholesky"] = ials_leg(tr, X, K, "CHOLESKY", 3, 1, ceilings)
+    # fit through the boundary: the construction above + 16 CG epochs (the reference's default solver)
+    # + both factor matrices to the host
+    t0 = time.perf_counter()
+    user, item = tr.user, tr.item
+    d2h = time.perf_counter() - t0
+    out["fit"] = {"solver": "CG max_cg_steps=3", "epochs": 16, "create_s": out["create_s"],
+                  "epochs_s": 16 * out["cg"]["ms_per_epoch"] * 1e-3, "factors_to_host_s": d2h,
+                  "fit_wall_s": out["create_s"] + 16 * out["cg"]["ms_per_epoch"] * 1e-3 + d2h,
+                  "note": "create_s and factors_to_host_s measured, epochs_s = 16 x the measured epoch"}
+    del user, item
     return out
 
 
@@ -823,6 +886,11 @@ def main():
                 "spec_hbm_gbs": PEAK_HBM_GBS, "spec_f32_tflops": PEAK_F32_TFLOPS,
                 "copy_frac_of_spec": ceilings["copy_gbs"] / PEAK_HBM_GBS,
                 "mfma_f32_frac_of_spec": ceilings["mfma_f32_tflops"] / PEAK_F32_TFLOPS,
+                "copy_note": ("copy_gbs is what THIS library's plain copy kernel reaches (5.1-5.2 TB/s in rounds "
+                              "1-4); /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for a tuned "
+                              "copy, so every HBM-side frac_of_measured is ~20 % kinder than one priced "
+                              "on the guide's figure"),
+                "guide_copy_gbs": 6290.0,
                 "how": "irs_measure_ceilings: 1 GiB copy / triad, v_mfma_f32_16x16x4_f32 loop on "
                        "every SIMD, random-bank ds_add_u32 loop on every CU, random 256 / 512-byte row gather "
                        "out of a 1 GiB table; best of 3-5, HIP events"})
@@ -847,7 +915,7 @@ def main():
                                   avg_launch_ms=st["ms"] / st["launches"], launches=st["launches"],
                                   algorithmic_gflop_per_launch=flops / 1e9,
                                   algorithmic_gbyte_per_launch=byts / 1e9)
-            roofline["traffic"] = pmc_traffic().get(name)
+            roofline["traffic"] = pmc_traffic(f"{args.shape} K={K}").get(name) if world == 1 else None
         result = {
             "metric": "iALS user+item updates/sec at k=64, ML-20M-shape CSR",
             "value": value,
@@ -893,9 +961,11 @@ def main():
             other_leg = "ials_" + other.lower()
             if "ials_cg" in legs and other_leg not in legs:
                 legs.append(other_leg)
-            run(other_leg, lambda: ials_leg(local.trainer, X, K, other, args.steps, 2, ceilings))
+            run(other_leg, lambda: ials_leg(local.trainer, X, K, other, args.steps, 2, ceilings,
+                                            workload=f"{args.shape} K={K}"))
             if K <= 64 and args.solver == "CHOLESKY":
                 run("ials_bf16x3", lambda: bf16x3_leg(X, K, args.steps, ceilings))
+            run("fit", lambda: fit_leg(X, K, args.solver))
             if K <= 64:
                 run("knn", lambda: knn_leg(X, ceilings))
                 run("evaluator", lambda: evaluator_leg(X, local.trainer, K, ceilings))

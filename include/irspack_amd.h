@@ -37,9 +37,10 @@ typedef int32_t irs_status;
 #define IRS_INVALID_ARGUMENT 1
 #define IRS_RUNTIME_ERROR 2
 
-/* Layout version of the structs below: 2 since irs_ceilings grew the gather rates.  A binding
- * compares irs_abi_version() with the header it was written against before passing structs. */
-#define IRS_ABI_VERSION 2
+/* Layout version of the structs below: 2 since irs_ceilings grew the gather rates, 3 since
+ * irs_eval_stats carries the call's times.  A binding compares irs_abi_version() with the header it
+ * was written against before passing structs. */
+#define IRS_ABI_VERSION 3
 
 const char *irs_last_error(void);
 /* Library / device probe.  irs_device_count() returns 0 when no GPU is visible. */
@@ -368,6 +369,9 @@ typedef struct irs_eval_stats {
   int64_t tiles_total;  /* 64 x 64 score tiles of the user block */
   int64_t tiles_scored; /* tiles the scoring kernel computed (= tiles_total unless pruned) */
   int64_t sample_items; /* items of the threshold sample pass (0: none) */
+  double call_ms;        /* host clock around the whole C call (mask upload, launches, read-back) */
+  double device_span_ms; /* HIP events on the launch stream: first kernel of the call -> last one done
+                          * (includes the gaps in which the host reads the hard-row list back) */
 } irs_eval_stats;
 irs_status irs_eval_last_stats(irs_evaluator *e, irs_eval_stats *out);
 

@@ -69,6 +69,8 @@ class EvalStatsStruct(C.Structure):  # irs_eval_stats
         ("tiles_total", C.c_int64),
         ("tiles_scored", C.c_int64),
         ("sample_items", C.c_int64),
+        ("call_ms", C.c_double),
+        ("device_span_ms", C.c_double),
     ]
 
 
@@ -85,7 +87,7 @@ class CeilingsStruct(C.Structure):  # irs_ceilings
     ]
 
 
-ABI_VERSION = 2  # IRS_ABI_VERSION of include/irspack_amd.h
+ABI_VERSION = 3  # IRS_ABI_VERSION of include/irspack_amd.h
 # IRS_EXCHANGE_* of include/irspack_amd.h: how irs_ials_sharded_step moves the solved rows
 EXCHANGE_MODES = {"auto": 0, "broadcast": 1, "mesh": 2, "peer": 3}
 COMM_HANDLE_BYTES = 256

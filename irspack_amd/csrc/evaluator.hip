@@ -15,6 +15,7 @@
 // Per-user terms are folded by a fixed-order wave reduction (double), item counts with
 // int64 atomics.  The same kernel serves retrieve_recommend_from_score (no ground truth).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <memory>
@@ -1200,6 +1201,8 @@ struct irs_evaluator {
   DeviceBuffer<int32_t> mask_row;         // row of every mask entry (built with the bitmap)
   std::vector<int64_t> mask_ptr_host;     // host copy of the mask's row pointers
   irs_eval_stats stats{};  // of the last irs_eval_get_metrics_ials call
+  hipEvent_t ev_first = nullptr, ev_last = nullptr;  // span of that call's device work
+  bool span_open = false;
 };
 
 namespace {
@@ -1259,7 +1262,7 @@ template <class T> void launch_rank(EvalParams p, int64_t max_cand, hipStream_t 
   // the usual case first (all items are candidates, cutoff <= 64): one wave per row; the
   // rows it flags (and every row otherwise) go through the general kernel
   p.todo = nullptr;
-  static const bool wave_ok = [] {  // IRSPACK_AMD_EVAL_WAVE=0: general kernel only (debugging)
+  const bool wave_ok = [] {  // IRSPACK_AMD_EVAL_WAVE=0: general kernel only (read per call: tests toggle it)
     const char *e = std::getenv("IRSPACK_AMD_EVAL_WAVE");
     return !(e && e[0] == '0');
   }();
@@ -1327,6 +1330,7 @@ void begin_accumulate(irs_evaluator *e, hipStream_t s) {
 
 void finish_accumulate(irs_evaluator *e, irs_metrics *out, int64_t *item_cnt, hipStream_t s) {
   static_assert(sizeof(unsigned long long) == sizeof(int64_t), "");
+  if (e->span_open) IRS_HIP(hipEventRecord(e->ev_last, s));
   IRS_HIP(hipMemcpyAsync(out, e->metrics.ptr, sizeof(irs_metrics), hipMemcpyDeviceToHost, s));
   IRS_HIP(hipMemcpyAsync(item_cnt, e->item_cnt.ptr, e->n_items * sizeof(int64_t),
                          hipMemcpyDeviceToHost, s));
@@ -1527,7 +1531,7 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
   // hold nearly every user's threshold; IRSPACK_AMD_EVAL_SAMPLE overrides (multiples of 64).
   // The users it leaves without one (they have seen almost all of the sample) get a second
   // chance on EM_SAMPLE2 items.
-  static const int64_t env_sample = [] {
+  const int64_t env_sample = [] {  // (read per call: tests toggle it)
     const char *v = std::getenv("IRSPACK_AMD_EVAL_SAMPLE");
     return v ? std::max<int64_t>(64, std::atoll(v) / 64 * 64) : int64_t(0);
   }();
@@ -1913,6 +1917,8 @@ irs_status irs_eval_destroy(irs_evaluator *e) {
   return guard([&] {
     if (e) {
       (void)hipSetDevice(e->device);
+      if (e->ev_first) (void)hipEventDestroy(e->ev_first);
+      if (e->ev_last) (void)hipEventDestroy(e->ev_last);
       delete e;
     }
   });
@@ -2021,6 +2027,27 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
       throw std::runtime_error(irs_last_error());
     check_arg(dev == e->device, "evaluator and trainer live on different devices.");
     hipStream_t s = static_cast<hipStream_t>(sv);
+    const auto host_t0 = std::chrono::steady_clock::now();
+    if (!e->ev_first) {
+      IRS_HIP(hipEventCreate(&e->ev_first));
+      IRS_HIP(hipEventCreate(&e->ev_last));
+    }
+    IRS_HIP(hipEventRecord(e->ev_first, s));
+    e->span_open = true;
+    struct CloseSpan {  // the call's times, whichever path returns (irs_eval_stats: call_ms, device_span_ms)
+      irs_evaluator *e;
+      std::chrono::steady_clock::time_point t0;
+      ~CloseSpan() {
+        float ms = 0.0f;
+        if (e->span_open && hipEventElapsedTime(&ms, e->ev_first, e->ev_last) != hipSuccess) {
+          (void)hipGetLastError();
+          ms = 0.0f;
+        }
+        e->span_open = false;
+        e->stats.device_span_ms = ms;
+        e->stats.call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      }
+    } close_span{e, host_t0};
     begin_accumulate(e, s);
     const int64_t *d_mptr = nullptr;
     const int32_t *d_midx = nullptr;

@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "host_util.hpp"
+#include "mt_jump.hpp"
 
 namespace irs {
 namespace ials {
@@ -206,6 +207,10 @@ class Mt19937Bulk {
     mt_[0] = seed;
     for (uint32_t i = 1; i < N; i++) mt_[i] = 1812433253u * (mt_[i - 1] ^ (mt_[i - 1] >> 30)) + i;
   }
+  // an engine whose next block is regenerated from `window` (the raw state x_k .. x_{k+623}: mt_jump.hpp)
+  struct FromWindow {};
+  Mt19937Bulk(FromWindow, const uint32_t *window) { std::memcpy(mt_, window, sizeof(mt_)); }
+  const uint32_t *window() const { return mt_; }  // (meaningful right after construction)
   // the next `count` outputs of the engine
   IRS_MT_CLONES void fill(uint32_t *out, size_t count) {
     size_t done = 0;
@@ -251,8 +256,10 @@ class Mt19937Bulk {
 // Both matrices are drawn from generators with the SAME seed (hpp:718-719), so the shorter one
 // is a prefix of the longer one's stream: `n` rows are drawn once.
 // `block_attempts`: attempts per block of the parallel path (tests shrink it).
+// `jump_threshold`: matrices of at least that many values take the jump-ahead path (tests lower it).
 static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int64_t K, int64_t n,
-                                      size_t block_attempts = size_t(1) << 24) {
+                                      size_t block_attempts = size_t(1) << 24,
+                                      size_t jump_threshold = size_t(1) << 26) {
   std::vector<float> h(static_cast<size_t>(n) * K, 0.0f);
   if (!(init_stdev > 0)) return h;  // the reference leaves the matrix uninitialised; we zero it
   // std::sqrt(factor.cols()) takes the integral overload (hpp:68-69): the quotient is formed
@@ -282,6 +289,8 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
     float x, y, r2;
     bool ok;
   };
+  bool jump_resume = false;  // the jump path stopped short of the matrix: the engine goes on from here
+  uint32_t resume_window[mtjump::N];
   auto attempt = [&](uint32_t w0, uint32_t w1) {
     Attempt a;
     a.x = static_cast<float>(2.0f * canonical(w0) - 1.0);
@@ -290,8 +299,107 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
     a.ok = !(a.r2 > 1.0f || a.r2 == 0.0f);
     return a;
   };
-  const size_t BLK = std::max<size_t>(block_attempts, 1024);
   const int n_thr = static_cast<int>(std::max(1u, std::min(64u, std::thread::hardware_concurrency())));
+  struct Joiner {  // joins on every way out of a scope: an exception (thread creation can fail) must surface
+    std::vector<std::thread> th;  // as an irs_status error, not end in std::terminate on a joinable thread
+    ~Joiner() {
+      for (auto &t : th)
+        if (t.joinable()) t.join();
+    }
+  };
+  // Very large matrices (round 5): even the engine's words are generated in parallel.  MT19937 is linear
+  // over GF(2), so the state after J words is g_J(F) state with g_J = t^J mod the characteristic
+  // polynomial (mt_jump.hpp).  The stream is cut into blocks of 624 * 2^b words; block j's starting
+  // state is a jump of j blocks from the seed state, every thread regenerates ITS blocks twice - once to
+  // count the accepted attempts (the output position of an attempt is twice the number of accepted
+  // attempts before it), once to emit - and nothing but two counters per block is ever stored.  The
+  // number of attempts the matrix needs is estimated from the acceptance rate pi / 4 with a margin of
+  // > 100 standard deviations; should it fall short all the same, the block path below continues the
+  // stream where the last block ended.
+  size_t jumped_values = 0;   // values written by the jump path
+  if (total >= jump_threshold && n_thr >= 4) {
+    const double need_attempts = static_cast<double>((total + 1) / 2) / 0.78539816339 * 1.002 + 65536.0;
+    int b = 0;  // block = 624 * 2^b words = 312 * 2^b attempts: 2 - 4 blocks per thread (each costs one jump)
+    while (312.0 * static_cast<double>(uint64_t(1) << (b + 1)) * n_thr * 2 <= need_attempts && b < 30) b++;
+    const uint64_t block_words = 624ull << b, block_attempts_j = block_words / 2;
+    const uint64_t n_blocks = static_cast<uint64_t>(need_attempts / static_cast<double>(block_attempts_j)) + 1;
+    for (int i = 0; (uint64_t(1) << i) <= n_blocks; i++) (void)mtjump::pow_block(b + i);  // (the shared powers, once)
+    uint32_t seed_window[mtjump::N];
+    {
+      const Mt19937Bulk seeded(static_cast<uint32_t>(random_seed));
+      std::memcpy(seed_window, seeded.window(), sizeof(seed_window));
+    }
+    std::vector<uint32_t> windows(static_cast<size_t>(n_blocks + 1) * mtjump::N);  // (+ 1: where the stream goes on)
+    std::vector<uint64_t> accepted(n_blocks + 1, 0);
+    std::atomic<uint64_t> next{0};
+    constexpr size_t CH = 624 * 16;  // words per regeneration step
+    auto for_blocks = [&](auto &&body) {
+      next.store(0);
+      Joiner workers;
+      auto run = [&] {
+        for (;;) {
+          const uint64_t j = next.fetch_add(1);
+          if (j >= n_blocks) return;
+          body(j);
+        }
+      };
+      for (int k = 1; k < n_thr; k++) workers.th.emplace_back(run);
+      run();
+    };
+    // pass 1: every block's starting state and its number of accepted attempts
+    {
+      next.store(0);
+      Joiner workers;
+      auto run = [&] {
+        for (;;) {
+          const uint64_t j = next.fetch_add(1);
+          if (j > n_blocks) return;
+          uint32_t *w = windows.data() + static_cast<size_t>(j) * mtjump::N;
+          std::memcpy(w, seed_window, sizeof(seed_window));
+          if (j > 0) mtjump::apply(mtjump::pow_blocks(b, j), w);
+          if (j == n_blocks) continue;
+          Mt19937Bulk eng(Mt19937Bulk::FromWindow{}, w);
+          uint32_t buf[CH];
+          uint64_t c = 0;
+          for (uint64_t done = 0; done < block_words; done += CH) {
+            const size_t take = static_cast<size_t>(std::min<uint64_t>(CH, block_words - done));
+            eng.fill(buf, take);
+            for (size_t q = 0; q < take; q += 2) c += attempt(buf[q], buf[q + 1]).ok ? 1 : 0;
+          }
+          accepted[j + 1] = c;
+        }
+      };
+      for (int k = 1; k < n_thr; k++) workers.th.emplace_back(run);
+      run();
+    }
+    for (uint64_t j = 0; j < n_blocks; j++) accepted[j + 1] += accepted[j];
+    // pass 2: emit
+    for_blocks([&](uint64_t j) {
+      size_t pos = 2 * static_cast<size_t>(accepted[j]);
+      if (pos >= total) return;
+      Mt19937Bulk eng(Mt19937Bulk::FromWindow{}, windows.data() + static_cast<size_t>(j) * mtjump::N);
+      uint32_t buf[CH];
+      for (uint64_t done = 0; done < block_words && pos < total; done += CH) {
+        const size_t take = static_cast<size_t>(std::min<uint64_t>(CH, block_words - done));
+        eng.fill(buf, take);
+        for (size_t q = 0; q < take && pos < total; q += 2) {
+          const Attempt a = attempt(buf[q], buf[q + 1]);
+          if (!a.ok) continue;
+          const float mult = std::sqrt(-2 * std::log(a.r2) / a.r2);
+          h[pos] = a.y * mult * sd + 0.0f;
+          if (pos + 1 < total) h[pos + 1] = a.x * mult * sd + 0.0f;
+          pos += 2;
+        }
+      }
+    });
+    jumped_values = std::min<size_t>(total, 2 * static_cast<size_t>(accepted[n_blocks]));
+    if (jumped_values >= total) return h;
+    // (the estimate fell short - never seen: the block path goes on from the state behind the last block)
+    std::memcpy(seed_window, windows.data() + static_cast<size_t>(n_blocks) * mtjump::N, sizeof(seed_window));
+    jump_resume = true;
+    std::memcpy(resume_window, seed_window, sizeof(seed_window));
+  }
+  const size_t BLK = std::max<size_t>(block_attempts, 1024);
   // (sized to what the call needs, no zero fill: a 2^18-value factor used to allocate and clear
   // 128 MB per trainer)
   auto block_size = [&](size_t produced) {  // attempts of the block that starts at `produced`
@@ -299,23 +407,15 @@ static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int
     // ~78.5 % of the attempts are accepted; a short block at the end
     return std::min(BLK, static_cast<size_t>(want_pairs * 1.3) + 4096);
   };
-  Mt19937Bulk engine(static_cast<uint32_t>(random_seed));
+  Mt19937Bulk engine = jump_resume ? Mt19937Bulk(Mt19937Bulk::FromWindow{}, resume_window)
+                                   : Mt19937Bulk(static_cast<uint32_t>(random_seed));
   RawVector<uint32_t> buf[2];
-  const size_t first = block_size(0);
+  const size_t first = block_size(jumped_values);
   buf[0].resize(2 * first);
   engine.fill(buf[0].data(), 2 * first);
   std::vector<size_t> cnt(n_thr + 1);
-  size_t produced = 0, avail = first;  // attempts whose words are in buf[cur]
+  size_t produced = jumped_values, avail = first;  // attempts whose words are in buf[cur]
   int cur = 0;
-  // joins on every way out of a scope: an exception (thread creation can fail) must surface as an
-  // irs_status error, not end in std::terminate on a joinable std::thread
-  struct Joiner {
-    std::vector<std::thread> th;
-    ~Joiner() {
-      for (auto &t : th)
-        if (t.joinable()) t.join();
-    }
-  };
   while (produced < total) {
     // EVERY attempt in the buffer is evaluated (emission stops at `total`): a block that used
     // fewer than it holds would drop the unread words and leave the libstdc++ stream

@@ -375,6 +375,7 @@ struct irs_ials_trainer {
   DeviceBuffer<float> pp_pred;         // iALS++ prediction cache (CSR-indexed, padded)
   DeviceBuffer<int32_t> pp_llt_sink;   // iALS++ does not test the LLT status (hpp:495-497)
   DeviceBuffer<float> pp_pblk;         // iALS++ chain path: blocks of P in accumulator layout
+  DeviceBuffer<float> pp_px;           // iALS++ one-block sweep on the solve kernel: target @ P
   DeviceBuffer<float> gk_sys, gk_delta;  // general-size path (ials_gk_kernels.hpp): scratch systems
   // eigenbasis short-row path (ials_eig_kernels.hpp)
   DeviceBuffer<float> eig_Qrows, eig_Qcols, eig_lam, eig_stats, eig_table, eig_xt, eig_xt2;
@@ -1245,13 +1246,19 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     // One block that covers every dimension (subspace dimension >= K, the default at K <= 64):
     // the block step of hpp:436-502 is a Newton step of a quadratic, x - A^-1 (A x - b) with the
     // A and b of step_cholesky (hpp:289-324; the gradient P x + reg x + sum (c (x.v - 1) - bias) v
-    // is A x - b), i.e. the exact minimiser A^-1 b whatever x was, and further sweeps do not
-    // move it.  It is computed as that - the tuned rank-update + Cholesky kernel, no
-    // prediction pass - and agrees with the reference's two-step form to rounding.  Like the
-    // reference on this path (hpp:495-497) a failed factorisation is not reported.
+    // is A x - b).  It runs on the tuned rank-update + Cholesky kernel in the reference's own
+    // arithmetic FORM (round 5; RESID kernels, ials_kernels.hpp): the right-hand side is the
+    // negative gradient at the current row, built from the predictions v.x like hpp:455-474, the
+    // solve yields the step, the row moves by it.  (Rounds 2-4 computed the exact minimiser
+    // A^-1 b instead: the same number in exact arithmetic, but with kappa * 2^-24 of forward error
+    // where the reference's form has none - at the reference's DEFAULT alpha0 = 0 a row with
+    // fewer entries than K was up to 0.19 relative away from float64 where the reference is
+    // 3e-3, tests/test_gpu_operating_point.py.)  One sweep is then exactly the reference's; more
+    // sweeps repeat it like the reference does.  Like the reference on this path (hpp:495-497)
+    // a failed factorisation is not reported.
     pp_direct = t->opt_pp_direct && sc->ialspp_subspace_dimension > 1 &&
                 static_cast<uint64_t>(sc->ialspp_subspace_dimension) >= t->K &&
-                sc->ialspp_iteration >= 1;
+                sc->ialspp_iteration >= 1 && t->T <= 4 && target == t->factor[pidx].ptr;
     if (!pp_direct) {
       launch_ialspp(t, sd, other, target, pidx, sc);
       return;
@@ -1307,6 +1314,22 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   const bool unit = sd.unit && t->opt_unit && other == t->factor[1 - pidx].ptr &&
                     static_cast<uint64_t>(p.zero_row + 8) * t->KP * sizeof(float) < (uint64_t(1) << 32);
   const bool cg = sc->solver_type == IRS_SOLVER_CG;
+  auto pp_gramian_term = [&]() {
+    // the Gramian term of every row's gradient at once: (target @ P)[r] = P x_r (P is symmetric; its
+    // KP rows play the items of user_scores_kernel); R K^2 multiply-adds, ~1 % of the half-step
+    const int64_t R = sd.n_rows, KPl = t->KP;
+    t->pp_px.alloc(static_cast<size_t>(std::max<int64_t>(R, 1)) * KPl);
+    if (R > 0) {
+      const int64_t waves = ceil_div(R, 64) * ceil_div(KPl, 64);
+      IRS_DISPATCH_T(t->T, {
+        t->prof.launch("ials_ialspp_px", user_scores_kernel<16 * TT>, dim3(ceil_div(waves, 4)), dim3(256), 0, t->stream,
+                       static_cast<const float *>(target), static_cast<const float *>(t->P[pidx].ptr), int64_t(0), R,
+                       KPl, t->pp_px.ptr);
+      });
+    }
+    p.px = t->pp_px.ptr;
+  };
+  if (pp_direct) pp_gramian_term();
   // CG, short rows: the matrix-free kernel takes the tail of the longest-first task list
   int n_regular = sd.n_tasks;
   // short rows (<= 32 entries) of a side that has enough of them: Cholesky in its low-rank form /
@@ -1342,7 +1365,8 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     });
     t->prof.end(short_stream);
   };
-  const bool eig_cand = prior == nullptr && other == t->factor[1 - pidx].ptr && eig_begin(t, sd, pidx, cg);
+  const bool eig_cand = prior == nullptr && !pp_direct && other == t->factor[1 - pidx].ptr &&
+                        eig_begin(t, sd, pidx, cg);
   bool short_forked = false;
   if (eig_cand) {
     n_regular = sd.n_tasks - sd.n_short;  // (the long rows start now, beside the decomposition)
@@ -1434,7 +1458,11 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       if (n_regular > 0) {
         const dim3 grid(ceil_div(n_regular, SOLVE_WAVES)), block(64 * SOLVE_WAVES);
         const char *name = kNames[cg][0][pidx];
-        if (cg && unit)
+        if (pp_direct && unit)
+          t->prof.launch(name, ials_solve_kernel<TT, 0, 0, true, false, true>, grid, block, 0, t->stream, p);
+        else if (pp_direct)
+          t->prof.launch(name, ials_solve_kernel<TT, 0, 0, false, false, true>, grid, block, 0, t->stream, p);
+        else if (cg && unit)
           t->prof.launch(name, ials_solve_kernel<TT, 1, 0, true>, grid, block, 0, t->stream, p);
         else if (cg)
           t->prof.launch(name, ials_solve_kernel<TT, 1, 0>, grid, block, 0, t->stream, p);
@@ -1448,7 +1476,10 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       if (with_split && sd.n_split > 0) {
         fold_partials(G::PARTIAL_FLOATS);
         const dim3 grid(ceil_div(sd.n_split, SOLVE_WAVES)), block(64 * SOLVE_WAVES);
-        if (cg)
+        if (pp_direct)
+          t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 0, 1, false, false, true>, grid, block, 0,
+                         t->stream, p);
+        else if (cg)
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 1, 1>, grid, block, 0, t->stream, p);
         else
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 0, 1>, grid, block, 0, t->stream, p);
@@ -1486,6 +1517,12 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   IRS_HIP(hipGetLastError());
   };  // launch_dense
   launch_dense(sd.tasks.ptr, n_regular, true);
+  if (pp_direct) {  // the further sweeps of hpp:516-530, each a step from where the last one ended
+    for (uint64_t it = 1; it < sc->ialspp_iteration; it++) {
+      pp_gramian_term();
+      launch_dense(sd.tasks.ptr, n_regular, true);
+    }
+  }
   if (short_forked) {
     IRS_HIP(hipEventRecord(t->ev_join, t->stream2));
     IRS_HIP(hipStreamWaitEvent(t->stream, t->ev_join, 0));

@@ -46,13 +46,7 @@ __device__ __forceinline__ double row16_sum(double v) {
   v = step(v, std::integral_constant<int, 0x140>{});  // row_mirror
   return v;
 }
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
-  return v;
-}
+// (row16_sum(float): ials_kernels.hpp)
 
 struct EigOut {
   float *Qrows;   // [KP, KP]: row k = eigenvector k (natural dims)

@@ -108,6 +108,7 @@ struct SolveParams {
   int32_t zero_row;     // an all-zero row of `other` (UNIT kernels: entries past a row's end)
   const float *prior;   // feature prior [n_rows, KP] or null: rhs += reg_r * prior_r
                         // (step_cholesky_with_prior hpp:363, step_cg hpp:212-215)
+  const float *px = nullptr;  // RESID kernels (iALS++ with one block): target @ P, [n_rows, KP]
 };
 
 // The wave's index inside its workgroup as a SCALAR: `threadIdx.x >> 6` alone is a per-lane value to
@@ -126,6 +127,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// Sum over the 16 lanes of a row (lanes sharing lane >> 4), in every lane of the row: four DPP adds
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - after the first two steps
+// the quads are uniform, so the mirrors pair every lane with the other half's sum).
+__device__ __forceinline__ float row16_sum(float x) {
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value,
+                                                                  0xf, 0xf, false));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});
+  x += dpp(x, std::integral_constant<int, 0x4E>{});
+  x += dpp(x, std::integral_constant<int, 0x141>{});
+  x += dpp(x, std::integral_constant<int, 0x140>{});
+  return x;
 }
 
 template <int T> __device__ __forceinline__ void load_dims(const float *p, float (&v)[T]) {
@@ -217,13 +233,21 @@ __device__ __forceinline__ void mfma_tiles(const float (&cv)[T], const float (&v
 // see DESIGN 3.1).
 // LOWER: slot tix(i, j), i <= j, accumulates the tile (row block j, column block i) instead of
 // its transpose (the single-wave block Cholesky of ials_chol16.hpp works on lower tiles).
-template <int T, int NW = 1, int W = 0, int D = 8, bool UNIT = false, bool LOWER = false>
-__device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
-                                            const int32_t *__restrict__ indices,
-                                            const float *__restrict__ data, int begin,
-                                            int end, float bias,
-                                            f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW],
-                                            float (&bsum)[T], unsigned zero_row = 0) {
+// RESID (the one-block iALS++ sweep, hpp:436-502, on this kernel): the right-hand side becomes the
+// NEGATIVE GRADIENT at the current row x (`xr`, in the lanes' dims), built the way the reference
+// builds it - from the predictions: sum_q ((bias + c_q) - c_q (v_q . x)) v_q; the caller subtracts
+// P x + reg x.  Solving A delta = that and adding delta to x is the reference's own arithmetic: a
+// component of x that the row's entries do not see (fewer entries than K, alpha0 = 0) is removed by
+// the ridge term alone, to rounding of ITSELF - the direct solve A^-1 b leaves kappa * 2^-24 there.
+// Cost: T multiply-adds, four DPP adds and two more operations per sub-step.
+template <int T, int NW, int W, int D, bool UNIT, bool LOWER, bool RESID>
+__device__ __forceinline__ void syrk_gather_impl(const float *__restrict__ other,
+                                                 const int32_t *__restrict__ indices,
+                                                 const float *__restrict__ data, int begin,
+                                                 int end, float bias,
+                                                 f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW],
+                                                 float (&bsum)[T], unsigned zero_row,
+                                                 const float (&xr)[T]) {
   constexpr int KP = Geo<T>::KP;
   constexpr int NT = Geo<T>::NT;
   constexpr int TPW = (NT + NW - 1) / NW;
@@ -250,6 +274,14 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   // eight registers less than a second ring of weights, which is the difference between three and four
   // waves per SIMD.  Stored values are canonicalised on the host: -0.0 never comes from the data.)
   float v[D][T], vc[D];
+  // UNIT: b = (bias + 1) sum v is four adds per sub-step; two at a time as v_pk_add_f32 (the gathered
+  // dims sit in consecutive registers) - 2 of the 5 vector instructions a sub-step has beside its MFMAs
+  constexpr bool PK_RHS = UNIT && !RESID && T % 2 == 0;
+  f32x2 bpk[T / 2 > 0 ? T / 2 : 1];
+  if constexpr (PK_RHS) {
+#pragma unroll
+    for (int i = 0; i < T / 2; i++) bpk[i] = f32x2{bsum[2 * i], bsum[2 * i + 1]};
+  }
   // `all_valid` (a compile-time tag): the caller guarantees that the sub-step lies before the
   // row's last one, so no entry has to be neutralised (3 vector instructions less)
   auto fetch = [&](int k, int blk_idx, float blk_c, int j, int entry0, auto all_valid) {
@@ -302,16 +334,37 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
   auto consume = [&](int k, auto all_valid) {
     float cv[T];
     float w = 0.f;
-    if constexpr (!UNIT) {
+    if constexpr (RESID) {
+      float d = 0.f;  // the prediction v_q . x (hpp:455-457)
+#pragma unroll
+      for (int i = 0; i < T; i++) d = fmaf(v[k][i], xr[i], d);
+      d = row16_sum(d);
+      if constexpr (UNIT) {
+        w = (bias + 1.0f) - d;  // (an entry past the row's end gathered the zero row: its term vanishes)
+      } else {
+        w = fmaf(-vc[k], d, bias + vc[k]);
+        if constexpr (!decltype(all_valid)::value)
+          w = __builtin_bit_cast(unsigned, vc[k]) == 0x80000000u ? 0.f : w;
+      }
+    } else if constexpr (!UNIT) {
       w = bias + vc[k];
       if constexpr (!decltype(all_valid)::value)
         w = __builtin_bit_cast(unsigned, vc[k]) == 0x80000000u ? 0.f : w;
+    }
+    if constexpr (PK_RHS) {
+#pragma unroll
+      for (int i = 0; i < T / 2; i++) {
+        // (hipcc scalarises a <2 x float> add built from scalars; v_pk_add_f32 has no builtin)
+        const f32x2 pair{v[k][2 * i], v[k][2 * i + 1]};
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(bpk[i]) : "v"(bpk[i]), "v"(pair));
+      }
     }
 #pragma unroll
     for (int i = 0; i < T; i++) {
       if constexpr (UNIT) {
         cv[i] = v[k][i];
-        bsum[i] += v[k][i];
+        if constexpr (RESID) bsum[i] = fmaf(w, v[k][i], bsum[i]);
+        else if constexpr (!PK_RHS) bsum[i] += v[k][i];
       } else {
         cv[i] = vc[k] * v[k][i];
         bsum[i] = fmaf(w, v[k][i], bsum[i]);
@@ -409,13 +462,32 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
         if (base + D + k < rest) fetch(k, cur_i, cur_c, base + D + k, 4 * s0, std::false_type{});
     }
   }
+  if constexpr (PK_RHS) {
+#pragma unroll
+    for (int i = 0; i < T / 2; i++) {
+      bsum[2 * i] = bpk[i].x;
+      bsum[2 * i + 1] = bpk[i].y;
+    }
+  }
   // fold the four gathered-row groups: every lane ends with b[T*m + i]
 #pragma unroll
   for (int i = 0; i < T; i++) {
     bsum[i] += __shfl_xor(bsum[i], 16, 64);
     bsum[i] += __shfl_xor(bsum[i], 32, 64);
-    if constexpr (UNIT) bsum[i] *= bias + 1.0f;
+    if constexpr (UNIT && !RESID) bsum[i] *= bias + 1.0f;
   }
+}
+
+template <int T, int NW = 1, int W = 0, int D = 8, bool UNIT = false, bool LOWER = false>
+__device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
+                                            const int32_t *__restrict__ indices,
+                                            const float *__restrict__ data, int begin,
+                                            int end, float bias,
+                                            f32x4 (&acc)[(Geo<T>::NT + NW - 1) / NW],
+                                            float (&bsum)[T], unsigned zero_row = 0) {
+  const float none[T] = {};
+  syrk_gather_impl<T, NW, W, D, UNIT, LOWER, false>(other, indices, data, begin, end, bias, acc, bsum, zero_row,
+                                                    none);
 }
 
 // ---------------------------------------------------------------------------
@@ -1011,9 +1083,32 @@ __device__ unsigned long long ials_phase_clk[8 * 4096];
 #endif
 
 // BF16X3: the rank update of syrk_gather_bf16x3 (opt-in; UNIT, Cholesky, T == 4 only).
-template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false>
-__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? SOLVE_MIN_WAVES_PER_SIMD_K64 : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
+// RESID: rhs -= (P x)_row + reg x (hpp:459-466: the Gramian and ridge terms of the gradient); lane (g, m)
+// holds the dims T m .. T m + T - 1
+template <int T>
+__device__ __forceinline__ void resid_finish_rhs(const SolveParams &p, int row, const float (&xr)[T], float (&bsum)[T]) {
+  const int m = threadIdx.x & 15;
+  const float reg = p.reg[row];
+  float px[T];
+  load_dims<T>(p.px + static_cast<size_t>(row) * (16 * T) + T * m, px);
+#pragma unroll
+  for (int i = 0; i < T; i++) bsum[i] -= fmaf(reg, xr[i], px[i]);
+}
+// RESID: the solve left the step in the row (written by the lanes of group 0): x <- x + step
+template <int T> __device__ __forceinline__ void resid_add_step(float *xrow, const float (&xr)[T]) {
+  const int lane = threadIdx.x & 63;
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < T; i++) xrow[T * lane + i] += xr[i];
+  }
+}
+
+// RESID: the one-block iALS++ sweep (see syrk_gather_impl): right-hand side = negative gradient at the
+// current row, solution = the step; SOLVER 0, T <= 4.
+template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false, bool RESID = false>
+__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? (RESID && MODE == 0 ? (UNIT ? 3 : 4) : SOLVE_MIN_WAVES_PER_SIMD_K64) : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
   static_assert(!BF16X3 || (UNIT && SOLVER == 0 && T == 4 && MODE == 0), "bf16x3: unit-confidence Cholesky at K <= 64");
+  static_assert(!RESID || (SOLVER == 0 && T <= 4 && !BF16X3), "the gradient form: Cholesky at K <= 64");
   constexpr int WAVES = SOLVE_WAVES;
   using G = Geo<T>;
   // Cholesky: lower-form tiles + the 16-row block solve of ials_chol16.hpp
@@ -1046,12 +1141,14 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
 #pragma unroll
       for (int t = 0; t < G::NT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    float xr[T] = {};
+    if constexpr (RESID) load_dims<T>(p.target + static_cast<size_t>(task.row) * G::KP + T * (lane & 15), xr);
     if constexpr (BF16X3)
       syrk_gather_bf16x3<T>(p.other, p.indices, task.begin, task.end, p.bias, acc, bsum,
                             static_cast<unsigned>(p.zero_row));
     else
-      syrk_gather<T, 1, 0, RING, UNIT, LOWER>(p.other, p.indices, p.data, task.begin, task.end, p.bias,
-                                              acc, bsum, static_cast<unsigned>(p.zero_row));
+      syrk_gather_impl<T, 1, 0, RING, UNIT, LOWER, RESID>(p.other, p.indices, p.data, task.begin, task.end, p.bias,
+                                                          acc, bsum, static_cast<unsigned>(p.zero_row), xr);
     IPHASE(0);
     if (task.slot >= 0) {
       float *dst = p.partials + static_cast<size_t>(task.slot) * G::PARTIAL_FLOATS;
@@ -1065,11 +1162,14 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
       return;
     }
     add_prior<T>(p, task.row, bsum);
+    if constexpr (RESID) resid_finish_rhs<T>(p, task.row, xr, bsum);
     // with a prior an empty row is solved like any other (hpp:207): hide nnz == 0 from CG
     const int nnz_cg = p.prior ? max(task.end - task.begin, 1) : task.end - task.begin;
-    if constexpr (SOLVER == 0)
+    if constexpr (SOLVER == 0) {
       solve_row_cholesky16<T>(acc, bsum, p.reg[task.row], sm,
                               p.target + static_cast<size_t>(task.row) * G::KP, p.K, p.err_flag);
+      if constexpr (RESID) resid_add_step<T>(p.target + static_cast<size_t>(task.row) * G::KP, xr);
+    }
     else if constexpr (T == 8)
       solve_row_cg128<T>(acc, bsum, p.reg[task.row], sm,
                          p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
@@ -1110,9 +1210,16 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
       }
     }
     add_prior<T>(p, sr.row, bsum);
-    if constexpr (SOLVER == 0)
+    float xr[T] = {};
+    if constexpr (RESID) {
+      load_dims<T>(p.target + static_cast<size_t>(sr.row) * G::KP + T * (lane & 15), xr);
+      resid_finish_rhs<T>(p, sr.row, xr, bsum);
+    }
+    if constexpr (SOLVER == 0) {
       solve_row_cholesky16<T>(acc, bsum, p.reg[sr.row], sm,
                               p.target + static_cast<size_t>(sr.row) * G::KP, p.K, p.err_flag);
+      if constexpr (RESID) resid_add_step<T>(p.target + static_cast<size_t>(sr.row) * G::KP, xr);
+    }
     else if constexpr (T == 8)
       solve_row_cg128<T>(acc, bsum, p.reg[sr.row], sm,
                          p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,

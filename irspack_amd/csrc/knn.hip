@@ -1361,7 +1361,7 @@ extern "C" {
 
 // host threads of the target pass (IRSPACK_AMD_KNN_THREADS overrides)
 static int64_t host_thread_cap() {
-  static const int64_t cap = [] {
+  const int64_t cap = [] {  // (read per call: tests toggle it)
     const char *e = std::getenv("IRSPACK_AMD_KNN_THREADS");
     return e ? std::max<int64_t>(1, std::atoll(e)) : int64_t(32);
   }();

@@ -310,7 +310,8 @@ class EvaluatorCore:
         names = {0: "two_pass", 1: "emit", 2: "emit_bounded", 3: "single_pass"}
         return {"path": names.get(st.path, str(st.path)), "hard_rows": int(st.hard_rows),
                 "tiles_total": int(st.tiles_total), "tiles_scored": int(st.tiles_scored),
-                "sample_items": int(st.sample_items)}
+                "sample_items": int(st.sample_items), "call_ms": float(st.call_ms),
+                "device_span_ms": float(st.device_span_ms)}
 
     #: ``True`` (the default): EVERY byte of the mask is hashed on every ``get_metrics_ials``
     #: call (xxhash when installed, else CRC-32: ~15 ms for 20 M entries, next to a 2 ms device

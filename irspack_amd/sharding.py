@@ -206,67 +206,92 @@ class HipLocalSolver(LocalSolver):
         memory (``irs_comm_create_local``).  ``peers``: map every rank's factor buffers, mailbox
         and flags (``irs_comm_export`` / ``irs_comm_attach``, blobs gathered through
         ``torch.distributed``) - a must for "local", and what ``set_exchange("peer")`` needs on
-        an RCCL communicator; a mapping failure there only leaves ``peers_attached`` False."""
+        an RCCL communicator; a mapping failure there only leaves ``peers_attached`` False.
+
+        Collective-safe: whatever fails on this rank, it still takes part in EVERY exchange of the
+        set-up in the same order as the others (a rank with nothing to offer sends ``None``), the
+        ranks agree before the RCCL communicators are created (a rank missing from
+        ``ncclCommInitRank`` would leave the others waiting in it), and the error is raised only
+        at the end - on every rank that failed or depended on one that did."""
         import ctypes as C
 
         import torch.distributed as dist
 
         from ._lib import COMM_HANDLE_BYTES, check, lib
 
-        rank, world = _group_info(group)
-        if os.environ.get("IRSPACK_AMD_TEST_FAIL_COMM_RANK") == str(rank):  # fault injection (tests)
-            raise RuntimeError("injected failure of the communicator set-up on this rank")
-        h = C.c_void_p()
-        if transport == "local":
-            check(lib().irs_comm_create_local(C.c_int32(rank), C.c_int32(world),
-                                              C.c_int32(self.device.index), C.byref(h)))
-        elif transport == "rccl":
-            buf = (C.c_char * 256)()
-            if rank == 0:
-                check(lib().irs_comm_unique_id(buf))
-            if world > 1:
-                box = [bytes(buf)]
-                src = dist.get_global_rank(group, 0) if group is not None else 0
-                dist.broadcast_object_list(box, src=src, group=group)
-                buf = (C.c_char * 256).from_buffer_copy(box[0])
-            check(lib().irs_comm_create(buf, C.c_int32(rank), C.c_int32(world),
-                                        C.c_int32(self.device.index), C.byref(h)))
-        else:
+        if transport not in ("rccl", "local"):
             raise ValueError("transport must be 'rccl' or 'local'.")
-        self._comm = h
-        self.peers_attached = False
-        self.peers_error = None
-        if not peers and transport != "local":
-            return
-        # every rank takes part in the gather whatever happened to its own export: a rank that
-        # cannot export sends None and NOBODY attaches
-        blob, err = None, None
-        try:
-            mine = (C.c_char * COMM_HANDLE_BYTES)()
-            check(lib().irs_comm_export(h, self.trainer._h, mine))
-            blob = bytes(mine)
-        except (RuntimeError, ValueError) as exc:
-            err = repr(exc)
-        blobs = [blob]
-        if world > 1:
-            blobs = [None] * world
-            dist.all_gather_object(blobs, blob, group=group)
-        ok = all(b is not None for b in blobs)
-        if ok:
+        rank, world = _group_info(group)
+        src = dist.get_global_rank(group, 0) if (group is not None and world > 1) else 0
+
+        def gather(value):
+            if world == 1:
+                return [value]
+            out = [None] * world
+            dist.all_gather_object(out, value, group=group)
+            return out
+
+        err = None
+        id_bytes = None
+        if transport == "rccl":
+            if rank == 0:
+                try:
+                    buf = (C.c_char * 256)()
+                    check(lib().irs_comm_unique_id(buf))
+                    id_bytes = bytes(buf)
+                except (RuntimeError, ValueError) as exc:
+                    err = repr(exc)
+            if world > 1:
+                box = [id_bytes]
+                dist.broadcast_object_list(box, src=src, group=group)
+                id_bytes = box[0]
+            if id_bytes is None:
+                err = err or "group rank 0 could not make the RCCL id"
+        if os.environ.get("IRSPACK_AMD_TEST_FAIL_COMM_RANK") == str(rank):  # fault injection (tests)
+            err = err or "RuntimeError('injected failure of the communicator set-up on this rank')"
+        if not all(gather(err is None)):  # nobody enters ncclCommInitRank unless everybody will
+            err = err or "another rank could not start the communicator set-up"
+        h = C.c_void_p()
+        if err is None:
             try:
-                allb = (C.c_char * (COMM_HANDLE_BYTES * world)).from_buffer_copy(b"".join(blobs))
-                check(lib().irs_comm_attach(h, self.trainer._h, allb))
+                if transport == "local":
+                    check(lib().irs_comm_create_local(C.c_int32(rank), C.c_int32(world),
+                                                      C.c_int32(self.device.index), C.byref(h)))
+                else:
+                    check(lib().irs_comm_create((C.c_char * 256).from_buffer_copy(id_bytes), C.c_int32(rank),
+                                                C.c_int32(world), C.c_int32(self.device.index), C.byref(h)))
             except (RuntimeError, ValueError) as exc:
-                ok, err = False, repr(exc)
-        if world > 1:  # attached on every rank or on none
-            votes = [None] * world
-            dist.all_gather_object(votes, bool(ok), group=group)
+                err = repr(exc)
+        self._comm = h if err is None else None
+        self.peers_attached, self.peers_error = False, None
+        if peers or transport == "local":
+            blob, perr = None, err
+            if err is None:
+                try:
+                    mine = (C.c_char * COMM_HANDLE_BYTES)()
+                    check(lib().irs_comm_export(h, self.trainer._h, mine))
+                    blob = bytes(mine)
+                except (RuntimeError, ValueError) as exc:
+                    perr = repr(exc)
+            blobs = gather(blob)
+            ok = all(b is not None for b in blobs)
+            if ok:
+                try:
+                    allb = (C.c_char * (COMM_HANDLE_BYTES * world)).from_buffer_copy(b"".join(blobs))
+                    check(lib().irs_comm_attach(h, self.trainer._h, allb))
+                except (RuntimeError, ValueError) as exc:
+                    ok, perr = False, repr(exc)
+            elif perr is None:
+                perr = "another rank could not export its buffers"
+            votes = gather(bool(ok))  # attached on every rank or on none
             if ok and not all(votes):
-                ok, err = False, "another rank could not map the peers' memory"
-        self.peers_attached, self.peers_error = bool(ok), (None if ok else err)
-        if transport == "local" and not ok:
+                ok, perr = False, "another rank could not map the peers' memory"
+            self.peers_attached, self.peers_error = bool(ok), (None if ok else perr)
+            if transport == "local" and not ok:
+                err = err or f"peer stores are not available: {perr}"
+        if err is not None:
             self.close_comm()
-            raise RuntimeError(f"peer stores are not available: {err}")
+            raise RuntimeError(err)
 
     def set_exchange(self, mode: str) -> None:
         """How ``sharded_step`` moves the solved rows: "auto" (in-place all-gather / grouped

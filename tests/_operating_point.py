@@ -10,9 +10,9 @@ of IALSTrainer.hpp:273-331 / :170-271):
   * score distance on the row's OWN items  ||V_r x_gpu - V_r x_64|| / ||V_r x_64||  (`sco`) - what a
     recommender built on the factors observes; insensitive to the directions a rank-deficient A_r
     (fewer entries than K, alpha0 = 0) leaves to the ridge alone
-  * Cholesky only: the residual ||A_r x - b_r|| / ||b_r|| of the GPU's row and of the oracle's row
-    (`res`) - the backward error, which a correct factorisation keeps near float32 epsilon whatever
-    the conditioning
+  * Cholesky only: the normwise backward error ||A_r x - b_r|| / (||A_r|| ||x|| + ||b_r||) of the GPU's
+    row and of the oracle's row (`res`), which a backward-stable factorisation keeps near K 2^-24
+    whatever the conditioning
 and kappa_r, the 2-norm condition number of A_r (dense eigvalsh; only where asked for).
 """
 import os
@@ -152,16 +152,15 @@ def measure_side(t, side, Xs, tgt0, oth0, kind, alpha0, reg, nu, loss, cfg, kapp
     out["sco_gpu"] = own_item_score_err(Xs, other64, got, x64)
     out["sco_orc"] = own_item_score_err(Xs, other64, want, x64)
     out["finite"] = bool(np.isfinite(got).all())
+    out["orc_finite"] = bool(np.isfinite(want).all() and np.isfinite(x64).all())
     out["nnz"] = np.diff(Xs.indptr)
+    out["K"] = int(oth0.shape[1])
     if kind == "CHOLESKY":
         P64 = O.ials_gramian_f64(other64, omc.alpha0, CORES)
         regs = row_reg(Xs, oth0.shape[0], alpha0, reg, nu)
         b = rhs(Xs, other64, 0.0 if loss == "IALSPP" else alpha0)
-        bn = np.maximum(np.linalg.norm(b, axis=1), 1e-300)
+        bn = np.linalg.norm(b, axis=1)
         ne = np.diff(Xs.indptr) > 0
-        for name, x in (("gpu", got), ("orc", want)):
-            r = np.linalg.norm(apply_A(Xs, other64, P64, regs, x) - b, axis=1) / bn
-            out["res_" + name] = np.where(ne, r, 0.0)
         # an upper bound of kappa(A_r) for EVERY row: (lmax(P) + sum_j c_j |v_j|^2 + reg_r) / (lmin(P) + reg_r)
         w = np.linalg.eigvalsh(P64)
         s_r = np.zeros(Xs.shape[0])
@@ -169,6 +168,14 @@ def measure_side(t, side, Xs, tgt0, oth0, kind, alpha0, reg, nu, loss, cfg, kapp
         if nz.size:
             s_r[nz] = np.add.reduceat(Xs.data.astype(np.float64) * np.einsum("ij,ij->i", other64[Xs.indices],
                                                                               other64[Xs.indices]), Xs.indptr[nz])
+        # `res`: the normwise BACKWARD error ||A x - b|| / (||A|| ||x|| + ||b||) with ||A|| bounded from above
+        # by lmax(P) + sum_j c_j |v_j|^2 + reg_r - what a backward-stable solve keeps at ~K 2^-24 whatever
+        # the conditioning (||A x - b|| / ||b|| alone grows with ||A|| ||x|| / ||b||)
+        a_norm = max(float(w[-1]), 0.0) + s_r + regs
+        for name, x in (("gpu", got), ("orc", want)):
+            xn = np.linalg.norm(np.asarray(x, np.float64), axis=1)
+            r = np.linalg.norm(apply_A(Xs, other64, P64, regs, x) - b, axis=1) / np.maximum(a_norm * xn + bn, 1e-300)
+            out["res_" + name] = np.where(ne, r, 0.0)
         den = max(float(w[0]), 0.0) + regs
         out["kappa_bound"] = np.where(den > 0, (float(w[-1]) + s_r + regs) / np.where(den > 0, den, 1.0), np.inf)
         if kappa_rows:

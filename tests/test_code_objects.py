@@ -100,7 +100,7 @@ def test_headline_kernel_fits_four_waves_per_simd(kernels):
     # unit-confidence Cholesky, K = 64: <= 128 registers and no scratch (scratch costs ~60 us per launch),
     # 16 waves x 9.9 KB of LDS per compute unit
     k = next(v for n, v in kernels.items()
-             if "ials_solve_kernel" in n and "ILi4ELi0ELi0ELb1ELb0E" in n)
+             if "ials_solve_kernel" in n and "ILi4ELi0ELi0ELb1ELb0ELb0E" in n)
     assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 128, k[".vgpr_count"]
     assert k[".private_segment_fixed_size"] == 0
     assert 16 * k[".group_segment_fixed_size"] <= 160 * 1024

@@ -13,27 +13,31 @@ configs[3] short-row shape at alpha0 = 0 (the eigenbasis path at P = 0).
 Bars (machinery and definitions: tests/_operating_point.py; achieved distributions -> the parity log):
   A. error parity: the GPU raises iff the oracle raises, same exception type and message - over whole
      epochs from the seeded init and over the measured half-steps;
-  B. every factor finite;
-  C. CHOLESKY: backward error ||A x - b|| / ||b|| (float64) of the GPU's worst row <= max(2e-6, the
-     oracle's worst row); rows whose condition-number BOUND satisfies kappa * 2^-24 < 1e-4: factors
+  B. every factor finite (unless the oracle's own result is not: IALSPP at alpha0 = 0 with an empty row,
+     where the reference's unchecked LLT of the zero matrix yields NaN - then the GPU's must be too);
+  C. CHOLESKY: normwise backward error ||A x - b|| / (||A|| ||x|| + ||b||) (float64) of the GPU's worst row
+     <= max(2 K 2^-24 - the textbook bound of a backward-stable solve -, the oracle's worst row); rows
+     whose condition-number BOUND satisfies kappa * 2^-24 < 1e-4: factors
      within 1e-4 of float64, no exceptions; all rows: scores on the row's own items within
      max(1e-4, oracle's worst) of float64 (SURVEY section 7 "hard parts": where kappa * eps exceeds the
      tolerance the factors are compared through what a recommender observes);
   D. CG x 3 / IALSPP (truncated iterations: a row that has not converged amplifies ANY float32
      rounding, the oracle's as much as the GPU's): against float64, for factors and for own-item
-     scores, the GPU's 99.99 % quantile <= max(1e-4, the oracle's), the number of GPU rows over 1e-4
-     <= max(the oracle's count, 0.01 % of the rows), and no single row beyond 10 x max(1e-4, the
-     oracle's worst) - quantiles, not a ratio of two maxima.
+     scores, the GPU's 99.99 % quantile (with fewer than 10^5 rows: the quantile that leaves ten rows above
+     it, conftest.tail_quantile) <= max(1e-4, the oracle's), the number of GPU rows over 1e-4
+     <= max(0.01 % of the rows, the oracle's count + 3 standard deviations of a Poisson count of that
+     size: conftest.count_bar), and no single row beyond 10 x max(1e-4, the oracle's worst) -
+     quantiles and counts, not a ratio of two maxima.  (At alpha0 = 1, reg = 1e-4 three CG steps leave
+     most rows unconverged: 100,081 of 138,493 ML-20M user rows of the ORACLE are farther than 1e-4
+     from float64 at K = 4, and 100,112 of the GPU's.)
 """
-import math
-
 import numpy as np
 import pytest
 import scipy.sparse as sps
 
 import _operating_point as OP
 import oracle as O
-from conftest import record_parity
+from conftest import count_bar, record_parity, tail_quantile
 from irspack_amd.synthetic import holdout_split, make_interactions
 
 pytestmark = pytest.mark.gpu
@@ -53,11 +57,16 @@ def ml100k():
 @pytest.fixture(scope="module")
 def tiny_with_empty_rows():
     X = make_interactions("tiny").tolil()
-    for r in (0, 17, 299):  # empty user rows (the generator already leaves empty item rows)
+    for r in (0, 17, 299):  # empty user rows
         X.rows[r], X.data[r] = [], []
-    X = sps.csr_matrix(X.tocsr(), dtype=np.float32)
+    Xc = sps.csc_matrix(X.tocsr(), dtype=np.float32)
+    for c in (3, 101, 199):  # empty item rows
+        Xc.data[Xc.indptr[c]:Xc.indptr[c + 1]] = 0.0
+    Xc.eliminate_zeros()
+    X = sps.csr_matrix(Xc, dtype=np.float32)
+    X.sort_indices()
     Xt = OP.transpose_csr(X)
-    assert (np.diff(X.indptr) == 0).sum() >= 3 and (np.diff(Xt.indptr) == 0).sum() >= 1
+    assert (np.diff(X.indptr) == 0).sum() >= 3 and (np.diff(Xt.indptr) == 0).sum() >= 3
     return X, Xt
 
 
@@ -79,22 +88,33 @@ def check_side(m, kind, what, test):
     if m["gpu_exc"]:
         record_parity(test, what, raised=list(m["gpu_exc"]))
         return None
+    if not m["orc_finite"]:
+        # IALSPP does not test the LLT status (hpp:495-497): at alpha0 = 0 an empty row's zero system
+        # yields NaN, which the next Gramian (0 * NaN) spreads to every row - in the oracle, in its
+        # float64 build and on the GPU alike.  Parity of garbage: the GPU must not look healthier.
+        record_parity(test, what, non_finite_in_oracle=True, non_finite_on_gpu=not m["finite"])
+        assert kind == "IALSPP" and not m["finite"], what
+        return None
     s = OP.summary(m)
     record_parity(test, what, **s)
     assert m["finite"], what  # B
     n = m["fac_gpu"].size
     if kind == "CHOLESKY":  # C
-        assert s["res_gpu_worst"] <= max(2e-6, s["res_orc_worst"]), (what, s["res_gpu_worst"], s["res_orc_worst"])
+        K = int(m["K"])
+        assert s["res_gpu_worst"] <= max(2.0 * K * 2.0 ** -24, s["res_orc_worst"]), \
+            (what, s["res_gpu_worst"], s["res_orc_worst"])
         well = m["kappa_bound"] * 2.0 ** -24 < RTOL
         if well.any():
             assert m["fac_gpu"][well].max() <= RTOL, (what, float(m["fac_gpu"][well].max()))
         assert s["sco_gpu_worst"] <= max(RTOL, s["sco_orc_worst"]), (what, s["sco_gpu_worst"], s["sco_orc_worst"])
     else:  # D
-        allowed = math.ceil(1e-4 * n)
         for k in ("fac", "sco"):
             g, o = m[k + "_gpu"], m[k + "_orc"]
-            assert OP.q(g, 0.9999) <= max(RTOL, OP.q(o, 0.9999)), (what, k, OP.q(g, 0.9999), OP.q(o, 0.9999))
-            assert int((g >= RTOL).sum()) <= max(int((o >= RTOL).sum()), allowed), (what, k)
+            p = tail_quantile(n)
+            if p is not None:
+                assert OP.q(g, p) <= max(RTOL, OP.q(o, p)), (what, k, p, OP.q(g, p), OP.q(o, p))
+            assert int((g >= RTOL).sum()) <= count_bar(int((o >= RTOL).sum()), n), \
+                (what, k, int((g >= RTOL).sum()), int((o >= RTOL).sum()))
             assert g.max() <= 10.0 * max(RTOL, o.max()), (what, k, float(g.max()), float(o.max()))
     return s
 
@@ -149,11 +169,13 @@ def test_ml100k_defaults_after_eight_epochs(ml100k, kind, epochs_before):
                   epochs_before=epochs_before)
 
 
-ML20M_CASES = ([(K, kind, a, r) for K in (20, 64) for kind in ("CG", "CHOLESKY") for a, r in POINTS]
-               + [(K, kind, *DEFAULTS) for K in (4, 300) for kind in ("CG", "CHOLESKY")]
-               + [(4, "CG", 1.0, 1e-4), (300, "CG", 3e-3, 1e-4), (300, "CHOLESKY", 3e-3, 1e-4),
-                  (20, "IALSPP", *DEFAULTS), (64, "IALSPP", *DEFAULTS), (64, "IALSPP", 3e-3, 1e-4),
-                  (128, "IALSPP", *DEFAULTS)])
+# ML-20M: the defaults and the two opposite corners of the tune range for CG (the reference's default
+# solver) at K = 20 and 64; CHOLESKY and IALSPP at the defaults and at the corner where three CG steps are
+# farthest from converged (the oracle's float32 and float64 Cholesky passes take 25-80 s each here, so the
+# full product of the ML-100K tests is not repeated)
+ML20M_CASES = ([(K, "CG", a, r) for K in (20, 64) for a, r in [DEFAULTS, (3e-3, 1e-4), (1.0, 1e-1)]]
+               + [(4, "CG", *DEFAULTS), (4, "CG", 1.0, 1e-4), (20, "CHOLESKY", *DEFAULTS), (20, "CHOLESKY", 1.0, 1e-4),
+                  (64, "CHOLESKY", *DEFAULTS), (20, "IALSPP", *DEFAULTS), (64, "IALSPP", *DEFAULTS)])
 
 
 @pytest.mark.parametrize("K,kind,alpha0,reg", ML20M_CASES)
@@ -175,8 +197,7 @@ def test_c4_small_alpha0_zero(c4_small, K, kind):
         assert res["train_exc"][0] == ("RuntimeError", "Cholesky decomposition failed.")
 
 
-@pytest.mark.parametrize("alpha0,reg", [(3e-3, 1e-4), (1.0, 1e-1)])
-@pytest.mark.parametrize("kind", ["CG", "CHOLESKY"])
+@pytest.mark.parametrize("kind,alpha0,reg", [("CG", 3e-3, 1e-4), ("CG", 1.0, 1e-1), ("CHOLESKY", 3e-3, 1e-4)])
 def test_c4_small_tune_corners(c4_small, kind, alpha0, reg):
     run_and_check(*c4_small, "c4_small", 128, kind, alpha0, reg, "operating_point_c4_small_corners")
 
@@ -197,13 +218,25 @@ def oracle_metrics(user, item, X_train, X_test, cutoff):
     return m.as_dict()
 
 
+def observed_fit_rms(user, item, X):
+    """root mean square of (1 - x_u . y_i) over the stored entries of a binary matrix"""
+    rows = np.repeat(np.arange(X.shape[0]), np.diff(X.indptr))
+    s = np.einsum("ij,ij->i", user[rows].astype(np.float64), item[X.indices].astype(np.float64))
+    return float(np.sqrt(np.mean((1.0 - s) ** 2)))
+
+
 @pytest.mark.parametrize("solver_type", ["CG", "CHOLESKY", "IALSPP"])
-def test_sixteen_default_epochs_metrics_agree_with_oracle_fit(solver_type):
+def test_sixteen_default_epochs_reach_the_oracles_objective(solver_type):
     """`IALSRecommender(X_train).learn()` with the constructor defaults (K = 20, alpha0 = 0, reg = 1e-3,
-    16 epochs; ials.py:363-379, base_earlystop.py:106-149) on the ML-100K shape, scored by `Evaluator`:
-    ndcg@20 / recall@20 / hit@20 agree to 1e-3 with the same fit done by the CPU oracle and scored by the
-    oracle's evaluator.  (Truncated CG amplifies float32 rounding over 16 epochs, so single factors need
-    not agree; what the user of the model observes must.)"""
+    16 epochs; ials.py:363-379, base_earlystop.py:106-149) on the ML-100K shape.  At alpha0 = 0 the loss
+    has no term on the unobserved entries: every factorisation with x_u . y_i = 1 on the stored entries
+    is a minimiser, the 16-epoch map is not contractive, and what a held-out ranking sees is the
+    components the data does not determine - i.e. rounding.  Three CPU evaluations of the SAME algorithm
+    from the same start (the float32 parity oracle, its fma build, its float64 build) give ndcg@20 =
+    0.088 / 0.070 / 0.008 under CG here.  What every evaluation agrees on, and what is asserted: the
+    OBJECTIVE the fit minimises (`compute_loss`, hpp:826-917) to 1e-3 relative and the fit of the stored
+    entries (rms of 1 - x . y, ~2e-4) to 2 % - the CPU builds agree on both to 1e-4.  The held-out metrics
+    of the three parties are logged, not asserted."""
     from irspack_amd.evaluation.evaluator import Evaluator
     from irspack_amd.recommenders.ials import IALSRecommender
 
@@ -212,15 +245,48 @@ def test_sixteen_default_epochs_metrics_agree_with_oracle_fit(solver_type):
     rec = IALSRecommender(X_train, solver_type=solver_type)
     rec.learn()
     got = Evaluator(X_test, cutoff=20).get_scores(rec, [20])
-    user, item = oracle_fit(X_train, 20, 0.0, 1e-3, solver_type, 16)
-    want = oracle_metrics(user, item, X_train, X_test, 20)
-    rec_fields = {k: float(got[f"{k}@20"]) for k in ("ndcg", "recall", "hit", "map", "precision")}
+    _, sc, omc, osc = OP.configs(20, solver_type, 0.0, 1e-3)
+    o = O.IALSTrainer(omc, X_train)
+    for _ in range(16):
+        o.step(osc)
+    want = oracle_metrics(o.user, o.item, X_train, X_test, 20)
+    gpu_loss, orc_loss = rec.trainer.core_trainer.compute_loss(sc), o.compute_loss(osc)
+    gpu_rms = observed_fit_rms(rec.get_user_embedding(), rec.get_item_embedding(), X_train)
+    orc_rms = observed_fit_rms(o.user, o.item, X_train)
     record_parity("operating_point_learn_16_epochs", f"ml100k defaults {solver_type}",
-                  **{f"gpu_{k}": v for k, v in rec_fields.items()},
-                  **{f"oracle_{k}": float(want[k]) for k in rec_fields})
-    for k in ("ndcg", "recall", "hit"):
-        assert abs(rec_fields[k] - want[k]) <= 1e-3, (k, rec_fields[k], want[k])
-    assert rec_fields["ndcg"] > 0.05  # the model has learnt something
+                  gpu_loss=gpu_loss, oracle_loss=orc_loss, gpu_fit_rms=gpu_rms, oracle_fit_rms=orc_rms,
+                  gpu_ndcg=float(got["ndcg@20"]), oracle_ndcg=float(want["ndcg"]),
+                  gpu_recall=float(got["recall@20"]), oracle_recall=float(want["recall"]))
+    assert abs(gpu_loss - orc_loss) <= 1e-3 * abs(orc_loss), (gpu_loss, orc_loss)
+    assert abs(gpu_rms - orc_rms) <= 0.02 * orc_rms and gpu_rms < 1e-3, (gpu_rms, orc_rms)
+
+
+@pytest.mark.parametrize("alpha0,reg", [(3e-3, 1e-4), (0.1, 1e-3), (1.0, 1e-1)])
+@pytest.mark.parametrize("solver_type", ["CG", "CHOLESKY", "IALSPP"])
+def test_sixteen_epochs_in_the_tune_range_metrics_agree_with_oracle_fit(solver_type, alpha0, reg):
+    """The same 16-epoch `learn()` + `Evaluator` at points of `default_tune_range` (alpha0 > 0: the
+    unobserved entries enter the loss, the alternating map contracts, and the float32 parity oracle, its
+    fma build and its float64 build agree on ndcg@20 to 2e-4): ndcg@20 / recall@20 within 1e-3 of the oracle's
+    fit scored by the oracle's evaluator, hit@20 within three users."""
+    from irspack_amd.evaluation.evaluator import Evaluator
+    from irspack_amd.recommenders.ials import IALSRecommender
+
+    X = make_interactions("ml100k")
+    X_train, X_test = holdout_split(X, 0.2, seed=3)
+    rec = IALSRecommender(X_train, alpha0=alpha0, reg=reg, solver_type=solver_type)
+    rec.learn()
+    got = Evaluator(X_test, cutoff=20).get_scores(rec, [20])
+    user, item = oracle_fit(X_train, 20, alpha0, reg, solver_type, 16)
+    want = oracle_metrics(user, item, X_train, X_test, 20)
+    fields = {k: float(got[f"{k}@20"]) for k in ("ndcg", "recall", "hit", "map", "precision")}
+    record_parity("operating_point_learn_16_epochs", f"ml100k alpha0={alpha0} reg={reg} {solver_type}",
+                  **{f"gpu_{k}": v for k, v in fields.items()},
+                  **{f"oracle_{k}": float(want[k]) for k in fields})
+    for k in ("ndcg", "recall"):
+        assert abs(fields[k] - want[k]) <= 1e-3, (k, fields[k], want[k])
+    # hit@20 moves in steps of one user (1 / 941 = 1.06e-3): at most three users may differ
+    assert abs(fields["hit"] - want["hit"]) <= 3.0 / want["valid_user"] + 1e-12, (fields["hit"], want["hit"])
+    assert fields["ndcg"] > 0.02  # the model has learnt something
 
 
 def mf_example_data(n_users, n_items, n_components=5, random_state=1, density_target=0.3):
@@ -254,7 +320,9 @@ def test_docstring_example_sanity():
     (ndcg 0.43 .. 0.47).  The matrix is restated bit for bit (numpy's legacy RandomState) at density 0.5;
     the reference's split is its own C++ shuffle (the hold-out here is this repo's per-row splitter), so
     the bars are: hit@20 = 1.0, ndcg@20 within +- 0.05, recall@20 within +- 0.03, precision@20 within
-    +- 0.02 of the published line - and 1e-3 agreement with the oracle's fit on the same split."""
+    +- 0.02 of the published line - and 1e-2 agreement with the oracle's fit on the same split (alpha0 = 0:
+    not a contractive fit, see test_sixteen_default_epochs_reach_the_oracles_objective; the float32 oracle,
+    its fma build and its float64 build land on ndcg@20 = 0.6279 / 0.6283 / 0.6308 here)."""
     from irspack_amd.evaluation.evaluator import Evaluator
     from irspack_amd.recommenders.ials import IALSRecommender
 
@@ -273,4 +341,4 @@ def test_docstring_example_sanity():
     assert got["appeared_item@20"] == 30.0 and got["catalog_coverage@20"] == 1.0
     user, item = oracle_fit(X_train.astype(np.float32), 20, 0.0, 1e-3, "CG", 16)
     want = oracle_metrics(user, item, X_train, X_test, 20)
-    assert abs(got["ndcg@20"] - want["ndcg"]) <= 1e-3 and abs(got["recall@20"] - want["recall"]) <= 1e-3
+    assert abs(got["ndcg@20"] - want["ndcg"]) <= 1e-2 and abs(got["recall@20"] - want["recall"]) <= 2e-2
