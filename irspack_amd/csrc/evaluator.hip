@@ -2121,8 +2121,11 @@ irs_status irs_fingerprint(const void *data, int64_t n_bytes, uint64_t seed, uin
     const unsigned char *p = static_cast<const unsigned char *>(data);
     constexpr int64_t PIECE = int64_t(1) << 20;
     const int64_t n_pieces = ceil_div(n_bytes, PIECE);
-    const int n_thr = static_cast<int>(std::max<int64_t>(
+    int n_thr = static_cast<int>(std::max<int64_t>(
         1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()), n_pieces / 4 + 1})));
+    // (IRSPACK_AMD_FINGERPRINT_THREADS: tests force the thread count - the value must not depend on it)
+    if (const char *te = std::getenv("IRSPACK_AMD_FINGERPRINT_THREADS"))
+      n_thr = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(64, std::atoll(te))));
     auto mix = [](uint64_t h, uint64_t w) {
       h ^= w * 0x9E3779B97F4A7C15ull;
       h = (h << 29) | (h >> 35);

@@ -9,6 +9,9 @@
 #include <cstring>
 #include <random>
 #include <thread>
+#if defined(__linux__)
+#include <sys/mman.h>
+#endif
 
 #include "host_util.hpp"
 #include "mt_jump.hpp"
@@ -20,7 +23,9 @@ struct HostCsr {
   int64_t rows = 0, cols = 0;
   std::vector<int64_t> indptr;
   RawVector<int32_t> indices;  // (sized, then written: no zero fill of hundreds of MB)
-  RawVector<float> data;
+  RawVector<float> data;       // EMPTY when `unit` (every stored value is exactly 1: nothing to carry)
+  // known from the validation pass of host_csr (flags_known): every stored value == 1 / > 0
+  bool flags_known = false, unit = false, positive = false;
 };
 
 // Stored values as the device kernels take them: -0.0 becomes +0.0 (x + 0.0f; every other value,
@@ -44,29 +49,44 @@ static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
   for (int64_t r = 0; r < rows; r++) check_arg(indptr[r + 1] >= indptr[r], "malformed indptr.");
   // the two copies and the index check on a few host threads
   m.indices.resize(nnz);
-  m.data.resize(nnz);
   const int n_thr = static_cast<int>(std::max<int64_t>(
-      1, std::min<int64_t>({8, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz / 1000000 + 1})));
-  std::atomic<int> bad(0);
-  auto body = [&](int k) {
-    const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
-    if (e <= b) return;
-    std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
-    canonical_copy(m.data.data() + b, data + b, e - b);
-    int32_t lo = 0, hi = 0;
-    for (int64_t q = b; q < e; q++) {
-      lo = std::min(lo, indices[q]);
-      hi = std::max(hi, indices[q]);
-    }
-    if (lo < 0 || hi >= cols) bad.store(1);
-  };
-  {
+      1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz / 1000000 + 1})));
+  std::atomic<int> bad(0), not_unit(0), not_positive(0);
+  auto run = [&](auto &&body) {
     std::vector<std::thread> th;
     for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
     body(0);
     for (auto &w : th) w.join();
-  }
+  };
+  // pass 1: the index copy + range check, and what the values are (all exactly 1: binary interactions -
+  // then no copy of them is made at all; all positive)
+  run([&](int k) {
+    const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
+    if (e <= b) return;
+    std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
+    int32_t lo = 0, hi = 0;
+    bool one = true, pos = true;
+    for (int64_t q = b; q < e; q++) {
+      lo = std::min(lo, indices[q]);
+      hi = std::max(hi, indices[q]);
+      one &= data[q] == 1.0f;
+      pos &= data[q] > 0.0f;
+    }
+    if (lo < 0 || hi >= cols) bad.store(1);
+    if (!one) not_unit.store(1);
+    if (!pos) not_positive.store(1);
+  });
   check_arg(bad.load() == 0, "column index out of range.");
+  m.flags_known = true;
+  m.unit = not_unit.load() == 0;
+  m.positive = not_positive.load() == 0;
+  if (!m.unit) {
+    m.data.resize(nnz);
+    run([&](int k) {
+      const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
+      if (e > b) canonical_copy(m.data.data() + b, data + b, e - b);
+    });
+  }
   return m;
 }
 
@@ -135,7 +155,11 @@ static HostCsr transpose(const HostCsr &x) {
   t.indptr.assign(t.rows + 1, 0);
   const int64_t nnz = x.indptr[x.rows];
   t.indices.resize(nnz);
-  t.data.resize(nnz);
+  t.flags_known = x.flags_known;
+  t.unit = x.unit;
+  t.positive = x.positive;
+  const bool carry = !(x.flags_known && x.unit);  // (all ones: nothing to move)
+  if (carry) t.data.resize(nnz);
   const int64_t cols = x.cols;
   // threads: bounded by the counter memory (cols x threads x 8 B <= 256 MB) and the work
   int n_thr = static_cast<int>(std::max<int64_t>(
@@ -172,7 +196,7 @@ static HostCsr transpose(const HostCsr &x) {
       for (int64_t p = x.indptr[r]; p < x.indptr[r + 1]; p++) {
         const int64_t d = cur[x.indices[p]]++;
         t.indices[d] = static_cast<int32_t>(r);
-        t.data[d] = x.data[p];
+        if (carry) t.data[d] = x.data[p];
       }
   });
   return t;
@@ -257,11 +281,27 @@ class Mt19937Bulk {
 // is a prefix of the longer one's stream: `n` rows are drawn once.
 // `block_attempts`: attempts per block of the parallel path (tests shrink it).
 // `jump_threshold`: matrices of at least that many values take the jump-ahead path (tests lower it).
-static std::vector<float> draw_factor(float init_stdev, int32_t random_seed, int64_t K, int64_t n,
-                                      size_t block_attempts = size_t(1) << 24,
-                                      size_t jump_threshold = size_t(1) << 26) {
-  std::vector<float> h(static_cast<size_t>(n) * K, 0.0f);
-  if (!(init_stdev > 0)) return h;  // the reference leaves the matrix uninitialised; we zero it
+// (RawVector: the 5 GB of the 10 M x 128 matrix were zero-filled - and page-faulted - by ONE thread before a
+// single variate was written: 1 s of the 1.4 s the draw took; every element is written exactly once below.)
+static RawVector<float> draw_factor(float init_stdev, int32_t random_seed, int64_t K, int64_t n,
+                                    size_t block_attempts = size_t(1) << 24,
+                                    size_t jump_threshold = size_t(1) << 26) {
+  RawVector<float> h;
+  h.resize(static_cast<size_t>(n) * K);
+#if defined(__linux__)
+  // gigabytes first touched by dozens of threads at once: 2 MB pages where the kernel grants them (a
+  // million 4 KB faults contend for the address-space lock with every other allocating thread of the
+  // process - the CSR preparation runs beside this)
+  if (h.size() * sizeof(float) >= (size_t(64) << 20)) {
+    const uintptr_t b = (reinterpret_cast<uintptr_t>(h.data()) + 4095) & ~uintptr_t(4095);
+    const uintptr_t e = reinterpret_cast<uintptr_t>(h.data() + h.size()) & ~uintptr_t(4095);
+    if (e > b) (void)madvise(reinterpret_cast<void *>(b), e - b, MADV_HUGEPAGE);
+  }
+#endif
+  if (!(init_stdev > 0)) {  // the reference leaves the matrix uninitialised; we zero it
+    std::fill(h.begin(), h.end(), 0.0f);
+    return h;
+  }
   // std::sqrt(factor.cols()) takes the integral overload (hpp:68-69): the quotient is formed
   // in double and rounded to float once
   const float sd = static_cast<float>(static_cast<double>(init_stdev) / std::sqrt(static_cast<double>(K)));

@@ -12,6 +12,7 @@
 #include <numeric>
 #include <random>
 #include <sstream>
+#include <future>
 #include <thread>
 
 #include "common.hpp"
@@ -112,6 +113,9 @@ struct Side {
     if (share) {
       unit = share->unit;
       positive = share->positive;
+    } else if (m.flags_known) {  // (host_csr classified the values on its validation pass)
+      unit = m.unit;
+      positive = m.unit || m.positive;
     } else {
       unit = std::all_of(m.data.begin(), m.data.end(), [](float v) { return v == 1.0f; });
       positive = unit || std::all_of(m.data.begin(), m.data.end(), [](float v) { return v > 0.0f; });
@@ -202,7 +206,12 @@ struct Side {
       data.alloc(ne + 320);
       if (ne) {
         IRS_HIP(hipMemcpyAsync(indices.ptr, m.indices.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        IRS_HIP(hipMemcpyAsync(data.ptr, m.data.data(), ne * sizeof(float), hipMemcpyHostToDevice, s));
+        if (m.data.size() == ne) {
+          IRS_HIP(hipMemcpyAsync(data.ptr, m.data.data(), ne * sizeof(float), hipMemcpyHostToDevice, s));
+        } else {  // all ones (host_csr carried no values): written on the device, 80 MB less over PCIe per side
+          check_arg(m.flags_known && m.unit, "internal: a value array is missing.");
+          IRS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(data.ptr), 0x3f800000, ne, s));
+        }
       }
       IRS_HIP(hipMemsetAsync(indices.ptr + ne, 0, 320 * sizeof(int32_t), s));
       IRS_HIP(hipMemsetAsync(data.ptr + ne, 0, 320 * sizeof(float), s));
@@ -484,15 +493,17 @@ void alloc_common(irs_ials_trainer *t) {
   t->loss_sum.alloc(2);
 }
 
-void upload_factor(irs_ials_trainer *t, int which, const float *host) {
+// `s`: the stream of the copy (default: the trainer's; the constructor uploads beside its other work)
+void upload_factor(irs_ials_trainer *t, int which, const float *host, hipStream_t s = nullptr) {
+  if (!s) s = t->stream;
   t->gram_prefetched[0] = t->gram_prefetched[1] = false;  // (of irs_ials_sharded_step: the factors change)
   const int64_t n = t->rows_of(which);
-  t->factor[which].zero(t->stream);
+  t->factor[which].zero(s);
   if (n > 0)
     IRS_HIP(hipMemcpy2DAsync(t->factor[which].ptr, t->KP * sizeof(float), host,
                              t->K * sizeof(float), t->K * sizeof(float), n,
-                             hipMemcpyHostToDevice, t->stream));
-  IRS_HIP(hipStreamSynchronize(t->stream));
+                             hipMemcpyHostToDevice, s));
+  IRS_HIP(hipStreamSynchronize(s));
 }
 
 void download_factor(irs_ials_trainer *t, const float *dev, int64_t n, float *host) {
@@ -503,7 +514,7 @@ void download_factor(irs_ials_trainer *t, const float *dev, int64_t n, float *ho
 }
 
 void init_factor(irs_ials_trainer *t, int which) {
-  const std::vector<float> h = draw_factor(t->cfg.init_stdev, t->cfg.random_seed, t->K, t->rows_of(which));
+  const RawVector<float> h = draw_factor(t->cfg.init_stdev, t->cfg.random_seed, t->K, t->rows_of(which));
   upload_factor(t, which, h.data());
 }
 
@@ -1192,9 +1203,21 @@ void launch_mf_cg(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     t->prof.begin(pidx == 0 ? "ials_long_cg_user" : "ials_long_cg_item", ls);
     auto chain = [&](auto init, auto chunk, auto rowk) {
       hipLaunchKernelGGL(init, dim3(n_long), dim3(256), 0, ls, p);
+      // 2 (steps + 1) + 1 launches: 9 at the reference's default of three steps, 2 K + 3 for
+      // max_cg_steps = 0 (= K steps, hpp:232-234).  A caller's own, larger count is honoured - rows leave
+      // the iteration through the 1e-20 exits (hpp:238, 258) long before - but not blindly: every 64
+      // steps the rows' `done` flags come back, and the loop ends when every row has left.
+      std::vector<int32_t> done_host;
       for (int step = 0; step <= p.max_cg_steps; step++) {
         hipLaunchKernelGGL(chunk, dim3(sd.mf_n_chunks), dim3(256), 0, ls, p, step == 0 ? 1 : 0);
         hipLaunchKernelGGL(rowk, dim3(n_long), dim3(256), 0, ls, p, step);
+        if (step % 64 == 63 && step + 1 <= p.max_cg_steps) {
+          done_host.resize(static_cast<size_t>(n_long));
+          IRS_HIP(hipMemcpyAsync(done_host.data(), p.done, sizeof(int32_t) * static_cast<size_t>(n_long),
+                                 hipMemcpyDeviceToHost, ls));
+          IRS_HIP(hipStreamSynchronize(ls));
+          if (std::all_of(done_host.begin(), done_host.end(), [](int32_t d) { return d != 0; })) break;
+        }
       }
     };
     if (t->T == 12) chain(mf_long_init_kernel<192>, mf_chunk_kernel<192>, mf_row_kernel<192>);
@@ -1606,14 +1629,43 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     };
     // the initial factors (a sequential libstdc++ random stream, ~0.4 s for 10 M values) and the
     // transposed matrix are prepared on two host threads while this one sets the device up
-    std::vector<float> init_draw;
-    std::thread draw_thread([&] {
-      init_draw = draw_factor(config->init_stdev, config->random_seed, static_cast<int64_t>(config->K), std::max(n_users, n_items));
+    // ... and uploaded by that same thread as soon as the device buffers exist, beside the preparation
+    // and the uploads of the two CSR orientations (5.6 GB of factors at the 10 M x 1 M shape: 0.26 s
+    // that used to follow everything else)
+    RawVector<float> init_draw;
+    std::promise<irs_ials_trainer *> buffers_ready;  // null: the construction failed before the allocation
+    std::shared_future<irs_ials_trainer *> buffers = buffers_ready.get_future().share();
+    std::exception_ptr draw_error;
+    std::thread draw_thread([&, buffers] {
+      try {
+        init_draw = draw_factor(config->init_stdev, config->random_seed, static_cast<int64_t>(config->K),
+                                std::max(n_users, n_items));
+        irs_ials_trainer *tr = buffers.get();
+        if (!tr) return;
+        IRS_HIP(hipSetDevice(device));
+        hipStream_t us = nullptr;
+        IRS_HIP(hipStreamCreateWithFlags(&us, hipStreamNonBlocking));
+        struct StreamGuard {
+          hipStream_t s;
+          ~StreamGuard() { (void)hipStreamDestroy(s); }
+        } guard{us};
+        upload_factor(tr, 0, init_draw.data(), us);  // hpp:718-719: both sides from the same seed
+        upload_factor(tr, 1, init_draw.data(), us);
+      } catch (...) {
+        draw_error = std::current_exception();
+      }
     });
     struct Joiner {
       std::thread &t;
       ~Joiner() { if (t.joinable()) t.join(); }
     } draw_join{draw_thread};
+    struct ReleaseWaiter {  // (declared AFTER the joiner: runs first, so that a throw below cannot leave the
+      std::promise<irs_ials_trainer *> &p;  // draw thread waiting for buffers that will never come)
+      bool done = false;
+      ~ReleaseWaiter() {
+        if (!done) p.set_value(nullptr);
+      }
+    } release{buffers_ready};
     // A rank of a sharded run prepares only its own user rows of X and item rows of X^T (the
     // ranks together do the work once, not once each); the unsharded trainer keeps everything.
     const irs_ials_shard sh = shard ? *shard : irs_ials_shard{0, n_users, 0, n_items};
@@ -1647,7 +1699,10 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     t->device = device;
     t->shard = sh;
     t->whole = whole;
+    Joiner draw_join_before_trainer{draw_thread};  // (destroyed before `t`: the upload must not outlive its buffers)
     alloc_common(t.get());
+    buffers_ready.set_value(t.get());
+    release.done = true;
     mark("device alloc");
     // the two orientations are prepared and uploaded side by side (host preparation of one
     // overlaps the copies of the other)
@@ -1685,18 +1740,23 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     }
     t->has_X = true;
     draw_thread.join();
-    mark("draw (rest)");
-    upload_factor(t.get(), 0, init_draw.data());  // hpp:718-719: both sides from the same seed
-    upload_factor(t.get(), 1, init_draw.data());
-    mark("upload factors");
-    {  // the host staging goes back to the kernel on a thread of its own (munmap of ~0.3 GB)
-      auto *junk = new std::pair<HostCsr, HostCsr>();
-      junk->first.indices.swap(X.indices);
-      junk->first.data.swap(X.data);
-      junk->second.indices.swap(Xt.indices);
-      junk->second.data.swap(Xt.data);
+    if (draw_error) std::rethrow_exception(draw_error);
+    mark("draw + factors");
+    {  // the host staging goes back to the kernel on a thread of its own (munmap of ~0.3 GB - and of the
+       // 5 GB of initial factors at the 10 M x 1 M shape: 0.4 s that the caller used to wait for)
+      struct Junk {
+        HostCsr a, b;
+        RawVector<float> draw;
+      };
+      auto *junk = new Junk();
+      junk->a.indices.swap(X.indices);
+      junk->a.data.swap(X.data);
+      junk->b.indices.swap(Xt.indices);
+      junk->b.data.swap(Xt.data);
+      junk->draw.swap(init_draw);
       std::thread([junk] { delete junk; }).detach();
     }
+    mark("hand-off");
     *out = t.release();
   });
 }

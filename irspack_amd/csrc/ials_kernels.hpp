@@ -274,14 +274,9 @@ __device__ __forceinline__ void syrk_gather_impl(const float *__restrict__ other
   // eight registers less than a second ring of weights, which is the difference between three and four
   // waves per SIMD.  Stored values are canonicalised on the host: -0.0 never comes from the data.)
   float v[D][T], vc[D];
-  // UNIT: b = (bias + 1) sum v is four adds per sub-step; two at a time as v_pk_add_f32 (the gathered
-  // dims sit in consecutive registers) - 2 of the 5 vector instructions a sub-step has beside its MFMAs
-  constexpr bool PK_RHS = UNIT && !RESID && T % 2 == 0;
-  f32x2 bpk[T / 2 > 0 ? T / 2 : 1];
-  if constexpr (PK_RHS) {
-#pragma unroll
-    for (int i = 0; i < T / 2; i++) bpk[i] = f32x2{bsum[2 * i], bsum[2 * i + 1]};
-  }
+  // (Round 5: the four adds of the UNIT right-hand side as two v_pk_add_f32 - 3 instead of 5 vector
+  // instructions per sub-step beside the 10 MFMAs - changed nothing: 1.178 vs 1.175 ms for the user half.
+  // The adds already issue in the shadow of the matrix instructions; the form was not kept.)
   // `all_valid` (a compile-time tag): the caller guarantees that the sub-step lies before the
   // row's last one, so no entry has to be neutralised (3 vector instructions less)
   auto fetch = [&](int k, int blk_idx, float blk_c, int j, int entry0, auto all_valid) {
@@ -351,20 +346,12 @@ __device__ __forceinline__ void syrk_gather_impl(const float *__restrict__ other
       if constexpr (!decltype(all_valid)::value)
         w = __builtin_bit_cast(unsigned, vc[k]) == 0x80000000u ? 0.f : w;
     }
-    if constexpr (PK_RHS) {
-#pragma unroll
-      for (int i = 0; i < T / 2; i++) {
-        // (hipcc scalarises a <2 x float> add built from scalars; v_pk_add_f32 has no builtin)
-        const f32x2 pair{v[k][2 * i], v[k][2 * i + 1]};
-        asm("v_pk_add_f32 %0, %1, %2" : "=v"(bpk[i]) : "v"(bpk[i]), "v"(pair));
-      }
-    }
 #pragma unroll
     for (int i = 0; i < T; i++) {
       if constexpr (UNIT) {
         cv[i] = v[k][i];
         if constexpr (RESID) bsum[i] = fmaf(w, v[k][i], bsum[i]);
-        else if constexpr (!PK_RHS) bsum[i] += v[k][i];
+        else bsum[i] += v[k][i];
       } else {
         cv[i] = vc[k] * v[k][i];
         bsum[i] = fmaf(w, v[k][i], bsum[i]);
@@ -460,13 +447,6 @@ __device__ __forceinline__ void syrk_gather_impl(const float *__restrict__ other
 #pragma unroll
       for (int k = 0; k < D; k++)
         if (base + D + k < rest) fetch(k, cur_i, cur_c, base + D + k, 4 * s0, std::false_type{});
-    }
-  }
-  if constexpr (PK_RHS) {
-#pragma unroll
-    for (int i = 0; i < T / 2; i++) {
-      bsum[2 * i] = bpk[i].x;
-      bsum[2 * i + 1] = bpk[i].y;
     }
   }
   // fold the four gathered-row groups: every lane ends with b[T*m + i]

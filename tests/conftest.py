@@ -154,15 +154,6 @@ def count_bar(n_oracle: int, n_rows: int) -> int:
     return max(math.ceil(1e-4 * n_rows), n_oracle + math.ceil(3.0 * math.sqrt(max(n_oracle, 1))))
 
 
-def tail_quantile(n_rows: int):
-    """The quantile the truncated-iteration bar compares: 99.99 %, or - with fewer than 10^5 rows, where
-    that would be the maximum itself - the one that leaves ten rows above it; None below 100 rows (the
-    count bar and the 10 x bound on the worst row remain)."""
-    if n_rows < 100:
-        return None
-    return min(0.9999, 1.0 - 10.0 / n_rows)
-
-
 def assert_float64_bar(gpu, oracle32, ref64, what: str, test: str = "", rtol: float = 1e-4,
                        truncated: bool = False, **extra) -> None:
     """The factor-parity bar with float64 as the arbiter of EVERY row.  The achieved distributions
@@ -176,12 +167,12 @@ def assert_float64_bar(gpu, oracle32, ref64, what: str, test: str = "", rtol: fl
     converged on every row, and such a row amplifies any float32 rounding by its conditioning - the
     oracle's sequential sums as much as the GPU's tree sums, on different rows, run to run): a
     comparison of two maxima is a comparison of two extreme-value samples, so the bar is stated on the
-    distribution: the GPU's 99.99 % quantile (``tail_quantile``: with fewer than 10^5 rows the quantile
-    that leaves ten rows above it) <= max(rtol, the oracle's); the number of
-    GPU rows beyond rtol <= max(0.01 % of the rows, the oracle's count + three standard deviations of a
-    Poisson count of that size - two implementations with the SAME exceedance rate differ by that much,
-    ``count_bar``); and no single row beyond 10 x max(rtol, the oracle's worst row) (an outright wrong
-    row is O(1) away)."""
+    distribution, as COUNTS at two thresholds: the number of GPU rows beyond rtol, and the number beyond
+    10 rtol (the heavy tail), are each <= max(0.01 % of the rows, the oracle's count + three standard
+    deviations of a Poisson count of that size - two implementations with the SAME exceedance rate differ
+    by that much, ``count_bar``); and no single row lies beyond 10 x max(rtol, the oracle's worst row)
+    (an outright wrong row is O(1) away).  Quantiles are logged, not asserted: with 10^2 .. 10^5 rows the
+    upper quantiles of two float32 evaluations are single rows again."""
     e_gpu, e_orc = rows_vs_float64(gpu, oracle32, ref64)
     g32 = np.linalg.norm(np.asarray(gpu, np.float64) - np.asarray(oracle32, np.float64), axis=1)
     d32 = np.linalg.norm(np.asarray(oracle32, np.float64), axis=1)
@@ -202,11 +193,7 @@ def assert_float64_bar(gpu, oracle32, ref64, what: str, test: str = "", rtol: fl
     if not truncated:
         assert e_gpu.max() <= max(rtol, e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))
         return
-    import math
-
-    p = tail_quantile(e_gpu.size)
-    if p is not None:
-        assert q(e_gpu, p) <= max(rtol, q(e_orc, p)), (what, p, q(e_gpu, p), q(e_orc, p))
-    assert int((e_gpu >= rtol).sum()) <= count_bar(int((e_orc >= rtol).sum()), e_gpu.size), \
-        (what, int((e_gpu >= rtol).sum()), int((e_orc >= rtol).sum()))
+    for thr in (rtol, 10.0 * rtol):
+        assert int((e_gpu >= thr).sum()) <= count_bar(int((e_orc >= thr).sum()), e_gpu.size), \
+            (what, thr, int((e_gpu >= thr).sum()), int((e_orc >= thr).sum()))
     assert e_gpu.max() <= 10.0 * max(rtol, e_orc.max()), (what, float(e_gpu.max()), float(e_orc.max()))

@@ -3,6 +3,7 @@
 // irspack_amd/csrc/host_prep.hpp, and the kNN target pass helpers of knn_host_prep.hpp.  Built
 // and run by tests/test_host_sanitizers.py with -fsanitize=thread and -fsanitize=address,undefined.
 // Every multi-threaded result is compared with a sequential evaluation.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -70,6 +71,19 @@ int main() {
     CHECK(std::equal(ti.begin(), ti.end(), Xt.indices.begin()));
     CHECK(std::equal(td.begin(), td.end(), Xt.data.begin()));
   }
+  {  // binary interactions: the values are classified on the validation pass and never copied
+    CHECK(X.flags_known && !X.unit && X.positive && Xt.flags_known && !Xt.unit);
+    const std::vector<float> ones(nnz, 1.0f);
+    const ials::HostCsr U = ials::host_csr(rows, cols, indptr.data(), indices.data(), ones.data());
+    CHECK(U.flags_known && U.unit && U.positive && U.data.empty());
+    const ials::HostCsr Ut = ials::transpose(U);
+    CHECK(Ut.unit && Ut.data.empty() && Ut.indptr == Xt.indptr);
+    CHECK(std::equal(Ut.indices.begin(), Ut.indices.end(), Xt.indices.begin()));
+    std::vector<float> neg(ones);
+    neg[nnz / 2] = -0.0f;
+    const ials::HostCsr G = ials::host_csr(rows, cols, indptr.data(), indices.data(), neg.data());
+    CHECK(!G.unit && !G.positive && G.data.size() == static_cast<size_t>(nnz) && !std::signbit(G.data[nnz / 2]));
+  }
   {  // a rank's shard: rows [rb, re) of X and the columns [cb, ce) of X as rows of X^T
     const int64_t rb = 1000, re = 17000, cb = 100, ce = 2100;
     const ials::HostCsr S = ials::host_csr_rows(rows, cols, indptr.data(), indices.data(), data.data(), rb, re);
@@ -99,7 +113,7 @@ int main() {
     // (K = 10: blocks of 30,000 attempts, i.e. eight blocks with the producer thread one ahead)
     // (K = 33: the jump-ahead path - every thread regenerates its own blocks of the engine's stream from a
     // state computed by polynomial arithmetic over GF(2), mt_jump.hpp - forced by a low threshold)
-    const std::vector<float> par = K == 64   ? ials::draw_factor(stdev, 42, K, n)
+    const RawVector<float> par = K == 64   ? ials::draw_factor(stdev, 42, K, n)
                                    : K == 33 ? ials::draw_factor(stdev, 42, K, n, size_t(1) << 24, size_t(1) << 18)
                                              : ials::draw_factor(stdev, 42, K, n, 30000);
     CHECK(par.size() == static_cast<size_t>(n * K) && par.size() >= (size_t(1) << 18));

@@ -142,3 +142,44 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "liboracle" not in text and "orc_" not in text, f
+
+
+def test_fingerprint_is_independent_of_threads_and_sees_every_bit(monkeypatch):
+    """irs_fingerprint (the every-byte check of the evaluator's device-resident mask; host only): the same
+    value whatever the thread count (1 MiB pieces dealt round-robin, combined by a sum), for lengths around
+    the 32-byte stride and the piece size, for an empty buffer; a single flipped bit at the start, around
+    the stride, at a piece boundary and at the end changes it; a buffer and the same buffer with a zero
+    byte appended differ (the length is mixed in)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from irspack_amd import _lib
+
+    lib = _lib.lib()
+
+    def fp(buf: np.ndarray, seed: int = 7) -> int:
+        out = C.c_uint64(0)
+        ptr = buf.ctypes.data_as(C.c_void_p) if buf.size else None
+        _lib.check(lib.irs_fingerprint(ptr, C.c_int64(buf.size), C.c_uint64(seed), C.byref(out)))
+        return out.value
+
+    rng = np.random.default_rng(0)
+    MIB = 1 << 20
+    for n in (0, 1, 31, 32, 33, 63, 64, MIB - 1, MIB, MIB + 1, 5 * MIB + 3, 9 * MIB):
+        data = rng.integers(0, 256, size=n, dtype=np.uint8)
+        values = set()
+        for threads in ("1", "2", "5", "16"):
+            monkeypatch.setenv("IRSPACK_AMD_FINGERPRINT_THREADS", threads)
+            values.add(fp(data))
+        assert len(values) == 1, (n, values)
+        monkeypatch.delenv("IRSPACK_AMD_FINGERPRINT_THREADS")
+        base = fp(data)
+        assert base == values.pop() and fp(data, seed=8) != base
+        assert fp(np.concatenate([data, np.zeros(1, np.uint8)])) != base
+        for pos in {0, 30, 31, 32, 33, MIB - 1, MIB, n - 1}:
+            if 0 <= pos < n:
+                for bit in (0, 7):
+                    flipped = data.copy()
+                    flipped[pos] ^= np.uint8(1 << bit)
+                    assert fp(flipped) != base, (n, pos, bit)

@@ -83,11 +83,14 @@ def test_init_matches_libstdcxx_stream(K):
     np.testing.assert_array_equal(t.user[:29], t.item)  # hpp:718-719 same seed for both
 
 
-@pytest.mark.parametrize("rows,K", [(5000, 64), (7001, 40), (300001, 3)])
+@pytest.mark.parametrize("rows,K", [(5000, 64), (7001, 40), (300001, 3), (2_200_000, 32)])
 def test_parallel_init_stream_is_the_sequential_one(rows, K):
     """Above 2^18 values the initial factors are drawn by all host threads (attempt j of the
     polar method owns the engine words 2 j, 2 j + 1); the result must be libstdc++'s
-    sequential mt19937 + normal_distribution<float> stream bit for bit (hpp:64-76)."""
+    sequential mt19937 + normal_distribution<float> stream bit for bit (hpp:64-76).
+    2.2 M x 32 = 70 M values (above 2^26): the jump-ahead path - every thread regenerates its own
+    blocks of the ENGINE's stream from a state computed by polynomial arithmetic over GF(2)
+    (csrc/mt_jump.hpp)."""
     X = sps.csr_matrix((rows, 11), dtype=np.float32)
     mc, _ = build(K, init=0.1, seed=7)
     t = IALSTrainer(mc, X)

@@ -23,13 +23,13 @@ Bars (machinery and definitions: tests/_operating_point.py; achieved distributio
      tolerance the factors are compared through what a recommender observes);
   D. CG x 3 / IALSPP (truncated iterations: a row that has not converged amplifies ANY float32
      rounding, the oracle's as much as the GPU's): against float64, for factors and for own-item
-     scores, the GPU's 99.99 % quantile (with fewer than 10^5 rows: the quantile that leaves ten rows above
-     it, conftest.tail_quantile) <= max(1e-4, the oracle's), the number of GPU rows over 1e-4
-     <= max(0.01 % of the rows, the oracle's count + 3 standard deviations of a Poisson count of that
-     size: conftest.count_bar), and no single row beyond 10 x max(1e-4, the oracle's worst) -
-     quantiles and counts, not a ratio of two maxima.  (At alpha0 = 1, reg = 1e-4 three CG steps leave
-     most rows unconverged: 100,081 of 138,493 ML-20M user rows of the ORACLE are farther than 1e-4
-     from float64 at K = 4, and 100,112 of the GPU's.)
+     scores, as COUNTS at two thresholds - the number of GPU rows over 1e-4 and the number over 1e-3
+     are each <= max(0.01 % of the rows, the oracle's count + 3 standard deviations of a Poisson count
+     of that size: conftest.count_bar) - and no single row beyond 10 x max(1e-4, the oracle's worst).
+     Counts with their sampling error, not a ratio of two maxima or of two upper quantiles (which, with
+     10^2 .. 10^5 rows, are single rows again).  (At alpha0 = 1, reg = 1e-4 three CG steps leave most
+     rows unconverged: 100,081 of 138,493 ML-20M user rows of the ORACLE are farther than 1e-4 from
+     float64 at K = 4, and 100,112 of the GPU's.)
 """
 import numpy as np
 import pytest
@@ -37,7 +37,7 @@ import scipy.sparse as sps
 
 import _operating_point as OP
 import oracle as O
-from conftest import count_bar, record_parity, tail_quantile
+from conftest import count_bar, record_parity
 from irspack_amd.synthetic import holdout_split, make_interactions
 
 pytestmark = pytest.mark.gpu
@@ -110,11 +110,9 @@ def check_side(m, kind, what, test):
     else:  # D
         for k in ("fac", "sco"):
             g, o = m[k + "_gpu"], m[k + "_orc"]
-            p = tail_quantile(n)
-            if p is not None:
-                assert OP.q(g, p) <= max(RTOL, OP.q(o, p)), (what, k, p, OP.q(g, p), OP.q(o, p))
-            assert int((g >= RTOL).sum()) <= count_bar(int((o >= RTOL).sum()), n), \
-                (what, k, int((g >= RTOL).sum()), int((o >= RTOL).sum()))
+            for thr in (RTOL, 10.0 * RTOL):
+                assert int((g >= thr).sum()) <= count_bar(int((o >= thr).sum()), n), \
+                    (what, k, thr, int((g >= thr).sum()), int((o >= thr).sum()))
             assert g.max() <= 10.0 * max(RTOL, o.max()), (what, k, float(g.max()), float(o.max()))
     return s
 
