@@ -4,7 +4,9 @@
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -36,5 +38,26 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
   }
 };
 template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
+
+// fn(begin, end) over [0, n) on up to `max_threads` host threads (one call on this thread when n is
+// small); fn must not throw.
+template <class F> inline void parallel_ranges(int64_t n, F &&fn, int max_threads = 16, int64_t min_per_thread = 250000) {
+  const int64_t hw = static_cast<int64_t>(std::thread::hardware_concurrency());
+  const int n_thr = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({max_threads, hw, n / min_per_thread})));
+  if (n_thr <= 1) {
+    fn(int64_t(0), n);
+    return;
+  }
+  std::vector<std::thread> th;
+  struct Join {
+    std::vector<std::thread> &v;
+    ~Join() {
+      for (auto &t : v)
+        if (t.joinable()) t.join();
+    }
+  } join{th};
+  for (int k = 1; k < n_thr; k++) th.emplace_back([&, k] { fn(n * k / n_thr, n * (k + 1) / n_thr); });
+  fn(int64_t(0), n / n_thr);
+}
 
 }  // namespace irs

@@ -121,13 +121,16 @@ struct Side {
       positive = unit || std::all_of(m.data.begin(), m.data.end(), [](float v) { return v > 0.0f; });
     }
     std::vector<int32_t> ip32(m.rows + 1);
-    for (int64_t r = 0; r <= m.rows; r++) ip32[r] = static_cast<int32_t>(m.indptr[r]);
     std::vector<float> regs(m.rows);
-    for (int64_t r = 0; r < m.rows; r++) {
-      // Solver::compute_reg, hpp:117-120, evaluated in float like the reference
-      const int64_t nz = m.indptr[r + 1] - m.indptr[r];
-      regs[r] = cfg.reg * std::pow(cfg.alpha0 * m.cols + nz, cfg.nu);
-    }
+    ip32[m.rows] = static_cast<int32_t>(m.indptr[m.rows]);
+    parallel_ranges(m.rows, [&](int64_t r0, int64_t r1) {  // (10 M powf at the 10 M x 1 M shape)
+      for (int64_t r = r0; r < r1; r++) {
+        ip32[r] = static_cast<int32_t>(m.indptr[r]);
+        // Solver::compute_reg, hpp:117-120, evaluated in float like the reference
+        const int64_t nz = m.indptr[r + 1] - m.indptr[r];
+        regs[r] = cfg.reg * std::pow(cfg.alpha0 * m.cols + nz, cfg.nu);
+      }
+    });
     reg_min = 0.f;
     for (int64_t r = rb; r < re; r++) reg_min = r == rb ? regs[r] : std::min(reg_min, regs[r]);
     const int CH = chunk_size();

@@ -58,31 +58,27 @@ class IALSTrainer:
                  user_features: Any = None, item_features: Any = None,
                  lambda_user_feature: float = 0.0, lambda_item_feature: float = 0.0,
                  feature_warmup_epochs: int = 0) -> None:
-        X_train_all_f32 = X.astype(np.float32)
-        config = (
-            IALSModelConfigBuilder().set_K(n_components).set_init_stdev(init_std)
-            .set_alpha0(alpha0).set_reg(reg).set_nu(nu).set_loss_type(loss_type)
-            .set_random_seed(random_seed).set_lambda_user_feature(lambda_user_feature)
-            .set_lambda_item_feature(lambda_item_feature)
-            .set_feature_warmup_epochs(feature_warmup_epochs).build()
-        )
+        def solver(cg_steps: int, sweeps: int):
+            # the two solver configs differ only in how long they iterate (ials.py:103-131): one sweep /
+            # `max_cg_steps` while training, the prediction-time counts for fold-in
+            return (IALSSolverConfigBuilder().set_n_threads(n_threads).set_solver_type(solver_type)
+                    .set_max_cg_steps(cg_steps).set_ialspp_iteration(sweeps)
+                    .set_ialspp_subspace_dimension(ialspp_subspace_dimension).build())
+
+        model = IALSModelConfigBuilder()
+        for setter, value in (("set_K", n_components), ("set_init_stdev", init_std), ("set_alpha0", alpha0),
+                              ("set_reg", reg), ("set_nu", nu), ("set_loss_type", loss_type),
+                              ("set_random_seed", random_seed),
+                              ("set_lambda_user_feature", lambda_user_feature),
+                              ("set_lambda_item_feature", lambda_item_feature),
+                              ("set_feature_warmup_epochs", feature_warmup_epochs)):
+            getattr(model, setter)(value)
         self.feature_aware = user_features is not None or item_features is not None
-        self.solver_config = (
-            IALSSolverConfigBuilder().set_n_threads(n_threads).set_solver_type(solver_type)
-            .set_max_cg_steps(max_cg_steps).set_ialspp_iteration(1)
-            .set_ialspp_subspace_dimension(ialspp_subspace_dimension).build()
-        )
-        if self.feature_aware:
-            self.core_trainer = CoreTrainer(config, X_train_all_f32, user_features, item_features,
-                                            device=device)
-        else:
-            self.core_trainer = CoreTrainer(config, X_train_all_f32, device=device)
-        self.prediction_time_solver_config = (
-            IALSSolverConfigBuilder().set_n_threads(n_threads).set_solver_type(solver_type)
-            .set_max_cg_steps(prediction_time_max_cg_steps)
-            .set_ialspp_subspace_dimension(ialspp_subspace_dimension)
-            .set_ialspp_iteration(prediction_time_ialspp_iteration).build()
-        )
+        self.solver_config = solver(max_cg_steps, 1)
+        self.prediction_time_solver_config = solver(prediction_time_max_cg_steps,
+                                                    prediction_time_ialspp_iteration)
+        features = (user_features, item_features) if self.feature_aware else ()
+        self.core_trainer = CoreTrainer(model.build(), X.astype(np.float32), *features, device=device)
 
     _STATE_FIELDS = ("user", "item", "user_feature_weight", "item_feature_weight")
 
@@ -246,23 +242,25 @@ class IALSRecommender(BaseRecommender):
 
     def learn_with_evaluator(self, evaluator: Any, max_epoch: int = 128, validate_epoch: int = 5,
                              score_degradation_max: int = 5) -> None:
+        """base_earlystop.py:106-149 without the progress bar / Optuna hooks: every
+        ``validate_epoch`` epochs the evaluator scores the model; the best state is kept and
+        restored at the end, and ``score_degradation_max`` validations in a row without a new best
+        end the fit.  ``evaluator=None``: exactly ``max_epoch`` epochs."""
         self.start_learning()
-        best_score = -float("inf")
-        n_score_degradation = 0
-        for epoch in range(max_epoch):
+        best, misses = -float("inf"), 0
+        for done in range(1, max_epoch + 1):
             self.run_epoch()
-            if (epoch + 1) % validate_epoch or evaluator is None:
+            if evaluator is None or done % validate_epoch:
                 continue
-            target_score = evaluator.get_target_score(self)
-            if target_score > best_score:
-                best_score = target_score
+            score = evaluator.get_target_score(self)
+            if score > best:
+                best, misses = score, 0
                 self.save_state()
-                self.learnt_config["train_epochs"] = epoch + 1
-                n_score_degradation = 0
-            else:
-                n_score_degradation += 1
-                if n_score_degradation >= score_degradation_max:
-                    break
+                self.learnt_config["train_epochs"] = done
+                continue
+            misses += 1
+            if misses >= score_degradation_max:
+                break
         if evaluator is not None and self.best_state is not None:
             self.load_state()
 

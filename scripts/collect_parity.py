@@ -2,7 +2,7 @@
 `pytest -m gpu` run on the GPU box) into the tracked profiles/parity_rNN.json: the last
 record per (test, config), sorted, plus a per-test summary.
 
-    python scripts/collect_parity.py [gpurun_out/parity_gpu.jsonl] [profiles/parity_r04.json]
+    python scripts/collect_parity.py [gpurun_out/parity_gpu.jsonl] [profiles/parity_r05.json]
 """
 import json
 import os
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main() -> None:
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_gpu.jsonl")
-    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "parity_r04.json")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "parity_r05.json")
     last = {}
     with open(src) as f:
         for line in f:
@@ -38,6 +38,13 @@ def main() -> None:
                           ("oracle_f32_vs_f64_worst", "worst_oracle_vs_float64"),
                           ("oracle_f32_vs_f64_p999", "worst_oracle_p999_vs_float64"),
                           ("gpu_vs_oracle_f32_worst", "worst_row_err_vs_oracle"),
+                          # round 5: the operating-point tests (tests/_operating_point.py: summary)
+                          ("fac_gpu_worst", "worst_gpu_vs_float64"), ("fac_orc_worst", "worst_oracle_vs_float64"),
+                          ("sco_gpu_worst", "worst_gpu_own_item_scores_vs_float64"),
+                          ("sco_orc_worst", "worst_oracle_own_item_scores_vs_float64"),
+                          ("res_gpu_worst", "worst_gpu_backward_error"), ("res_orc_worst", "worst_oracle_backward_error"),
+                          ("n_fac_gpu_over_1e_4", "max_rows_gpu_over_1e-4_vs_float64"),
+                          ("n_fac_orc_over_1e_4", "max_rows_oracle_over_1e-4_vs_float64"),
                           ("n_rows_gpu_over_1e_4_vs_f64", "max_rows_gpu_over_1e-4_vs_float64"),
                           ("n_rows_oracle_over_1e_4_vs_f64", "max_rows_oracle_over_1e-4_vs_float64")):
             v = r.get(key)

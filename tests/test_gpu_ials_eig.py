@@ -150,10 +150,14 @@ def test_ill_conditioned_gramian_falls_back():
 
 
 @pytest.mark.parametrize("K", [128])
-def test_ialspp_with_one_block_takes_the_eigenbasis_cholesky(K):
-    """iALS++ whose one block covers every dimension is the direct solve (hpp:436-502 is a Newton
-    step of a quadratic): it goes through the same kernels as Cholesky, the eigenbasis path
-    included; equal to the oracle's two-step block form within 1e-4."""
+def test_ialspp_with_one_block_keeps_the_references_form(K):
+    """iALS++ whose one block covers every dimension.  Rounds 2-4 computed it as the direct solve
+    (hpp:436-502 is a Newton step of a quadratic) through the Cholesky kernels, the eigenbasis path
+    included; round 5 found that form kappa 2^-24 away from the reference's own arithmetic where the
+    reference's has no such error (DESIGN.md section 4), so it is gone: K <= 64 runs the reference's
+    gradient form on the tuned kernel, a block wider than 64 dims (this case: K = 128 with
+    ialspp_subspace_dimension = 128) the general block kernels - never the eigenbasis Cholesky.
+    Equal to the oracle's block form within 1e-4, empty rows included."""
     X = short_row_matrix(160_000 if K > 64 else 1_200_000, 300, 9, True)
     mc = (IALSModelConfigBuilder().set_K(K).set_alpha0(0.1).set_reg(2e-2).set_nu(1.0).set_init_stdev(0.1)
           .set_random_seed(42).build())
@@ -169,10 +173,10 @@ def test_ialspp_with_one_block_takes_the_eigenbasis_cholesky(K):
     t.finish_gramian_async(0)
     t.half_step_async(0, sc)
     t.synchronize()
-    assert t.last_half_step_used_eigenbasis()
-    # (an empty row: the direct solve gives exactly 0, the oracle's Newton step x0 - A^-1 (A x0)
-    # leaves rounding noise of ~1e-9 there - compared in absolute terms)
+    assert not t.last_half_step_used_eigenbasis()
+    # (an empty row: both forms leave rounding noise of ~1e-9 where the exact answer is 0 - compared in
+    # absolute terms)
     live = np.diff(X.indptr) > 0
     got = t.user
     assert row_rel_err(got[live], want[live]) < RTOL
-    assert np.abs(got[~live]).max() == 0.0 and np.abs(want[~live]).max() < 1e-6
+    assert np.abs(got[~live]).max() < 1e-6 and np.abs(want[~live]).max() < 1e-6
