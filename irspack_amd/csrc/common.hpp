@@ -99,4 +99,10 @@ template <class T> struct DeviceBuffer {
 void sort_pairs_f32(bool descending, const float *keys_in, float *keys_out, const int32_t *vals_in,
                     int32_t *vals_out, size_t n, DeviceBuffer<char> &tmp, hipStream_t s);
 
+// device_sort.hip: X^T of a device-resident CSR (stable: entries of a column stay in row order); t_count
+// (host) receives the stored entries per column; synchronises `s`
+void transpose_csr_device(const int32_t *indptr, const int32_t *indices, const float *data, int64_t rows,
+                          int64_t cols, int64_t nnz, int32_t *t_indices, float *t_data,
+                          std::vector<int32_t> &t_count, DeviceBuffer<char> &tmp, hipStream_t s);
+
 }  // namespace irs

@@ -100,6 +100,38 @@ struct Side {
   bool unit = false;  // every stored confidence is exactly 1 (UNIT kernels)
   bool positive = false;  // every stored confidence is > 0 (eigenbasis short-row kernels)
   float reg_min = 0.f;    // smallest per-row regulariser of the rows [row_begin, row_end)
+  bool entries_ready = false, indptr_ready = false;  // the device arrays were filled ahead of build()
+
+  // The gather pipeline loads whole 64-entry blocks up to two blocks past a row's end: 320 zero entries
+  // behind the arrays (set on the device; no padded host copies).
+  void alloc_entries(size_t ne, hipStream_t s) {
+    indices.alloc(ne + 320);
+    data.alloc(ne + 320);
+    IRS_HIP(hipMemsetAsync(indices.ptr + ne, 0, 320 * sizeof(int32_t), s));
+    IRS_HIP(hipMemsetAsync(data.ptr + ne, 0, 320 * sizeof(float), s));
+    entries_ready = true;
+  }
+  void upload_entries(const HostCsr &m, hipStream_t s) {
+    const size_t ne = static_cast<size_t>(m.indptr[m.rows]);
+    alloc_entries(ne, s);
+    if (ne) {
+      IRS_HIP(hipMemcpyAsync(indices.ptr, m.indices.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      if (m.data.size() == ne) {
+        IRS_HIP(hipMemcpyAsync(data.ptr, m.data.data(), ne * sizeof(float), hipMemcpyHostToDevice, s));
+      } else {  // all ones (host_csr carried no values): written on the device, 80 MB less over PCIe per side
+        check_arg(m.flags_known && m.unit, "internal: a value array is missing.");
+        IRS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(data.ptr), 0x3f800000, ne, s));
+      }
+    }
+    IRS_HIP(hipStreamSynchronize(s));
+  }
+  void upload_indptr(const HostCsr &m, hipStream_t s) {
+    std::vector<int32_t> ip32(m.rows + 1);
+    for (int64_t r = 0; r <= m.rows; r++) ip32[r] = static_cast<int32_t>(m.indptr[r]);
+    indptr.upload(ip32, s);
+    IRS_HIP(hipStreamSynchronize(s));
+    indptr_ready = true;
+  }
 
   // `share`: a Side already built from the same matrix - its device copies of the CSR arrays and
   // of the regulariser are borrowed (row chunks of a shard, irs_ials_sharded_step)
@@ -199,26 +231,8 @@ struct Side {
       indices.borrow(share->indices);
       data.borrow(share->data);
     } else {
-      indptr.upload(ip32, s);
-    }
-    if (!share) {
-      // the gather pipeline loads whole 64-entry blocks up to two blocks past a row's end:
-      // 320 zero entries behind the arrays (set on the device; no padded host copies)
-      const size_t ne = m.indices.size();
-      indices.alloc(ne + 320);
-      data.alloc(ne + 320);
-      if (ne) {
-        IRS_HIP(hipMemcpyAsync(indices.ptr, m.indices.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        if (m.data.size() == ne) {
-          IRS_HIP(hipMemcpyAsync(data.ptr, m.data.data(), ne * sizeof(float), hipMemcpyHostToDevice, s));
-        } else {  // all ones (host_csr carried no values): written on the device, 80 MB less over PCIe per side
-          check_arg(m.flags_known && m.unit, "internal: a value array is missing.");
-          IRS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(data.ptr), 0x3f800000, ne, s));
-        }
-      }
-      IRS_HIP(hipMemsetAsync(indices.ptr + ne, 0, 320 * sizeof(int32_t), s));
-      IRS_HIP(hipMemsetAsync(data.ptr + ne, 0, 320 * sizeof(float), s));
-      IRS_HIP(hipStreamSynchronize(s));
+      if (!indptr_ready) indptr.upload(ip32, s);
+      if (!entries_ready) upload_entries(m, s);
     }
     {
       std::vector<int32_t> order(re - rb);
@@ -1681,10 +1695,19 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
                       : host_csr_rows(n_users, n_items, indptr, indices, data, sh.user_begin,
                                       sh.user_end);
     mark("copy + validate");
+    // X^T (hpp:713).  An unsharded trainer uploads X once and transposes it ON THE DEVICE (round 5:
+    // device_sort.hip - a stable radix sort of the entry numbers by column + one gather; the host's
+    // 16-thread counting sort and the second 80 MB upload were ~15 of the 34 ms of an ML-20M
+    // construction); a rank of a sharded run keeps the host pass over its own columns.
+    // IRSPACK_AMD_IALS_HOST_TRANSPOSE=1: the host path for the unsharded trainer too (tests: the two
+    // must give the same X^T, entry for entry).
+    const bool device_transpose = whole && !env_flag("IRSPACK_AMD_IALS_HOST_TRANSPOSE", false) &&
+                                  X.indptr[n_users] > 0 && n_items > 0;
     HostCsr Xt;
     std::exception_ptr transpose_error;
     std::thread transpose_thread([&] {
       try {
+        if (device_transpose) return;
         Xt = whole ? transpose(X)
                    : transpose_cols(n_users, n_items, indptr, indices, data, sh.item_begin,
                                     sh.item_end);
@@ -1695,6 +1718,7 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     Joiner transpose_join{transpose_thread};
     require_device(device);
     auto t = std::make_unique<irs_ials_trainer>();
+    Joiner draw_join_before_trainer{draw_thread};  // (destroyed before `t`: the upload must not outlive its buffers)
     t->cfg = *config;
     t->K = static_cast<int64_t>(config->K);
     t->n_users = n_users;
@@ -1702,11 +1726,15 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     t->device = device;
     t->shard = sh;
     t->whole = whole;
-    Joiner draw_join_before_trainer{draw_thread};  // (destroyed before `t`: the upload must not outlive its buffers)
     alloc_common(t.get());
     buffers_ready.set_value(t.get());
     release.done = true;
     mark("device alloc");
+    if (device_transpose) {  // X on the device first: the item thread transposes it there
+      t->side[0].upload_entries(X, t->stream);
+      t->side[0].upload_indptr(X, t->stream);
+      mark("upload X");
+    }
     // the two orientations are prepared and uploaded side by side (host preparation of one
     // overlaps the copies of the other)
     std::exception_ptr item_error;
@@ -1715,13 +1743,56 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
         transpose_thread.join();
         if (transpose_error) std::rethrow_exception(transpose_error);
         IRS_HIP(hipSetDevice(device));
+        if (device_transpose) {
+          const int64_t nnz = X.indptr[n_users];
+          hipStream_t ts = nullptr;
+          IRS_HIP(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
+          struct StreamGuard {
+            hipStream_t s;
+            ~StreamGuard() { (void)hipStreamDestroy(s); }
+          } guard{ts};
+          Side &s0 = t->side[0], &s1 = t->side[1];
+          const auto tt0 = std::chrono::steady_clock::now();
+          s1.alloc_entries(static_cast<size_t>(nnz), ts);
+          std::vector<int32_t> count;
+          DeviceBuffer<char> scratch;
+          const bool values = !(X.flags_known && X.unit);
+          transpose_csr_device(s0.indptr.ptr, s0.indices.ptr, values ? s0.data.ptr : nullptr, n_users, n_items, nnz,
+                               s1.indices.ptr, values ? s1.data.ptr : nullptr, count, scratch, ts);
+          if (!values) {
+            IRS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s1.data.ptr), 0x3f800000,
+                                      static_cast<size_t>(nnz), ts));
+            IRS_HIP(hipStreamSynchronize(ts));
+          }
+          Xt.rows = n_items;
+          Xt.cols = n_users;
+          Xt.flags_known = X.flags_known;
+          Xt.unit = X.unit;
+          Xt.positive = X.positive;
+          Xt.indptr.assign(static_cast<size_t>(n_items) + 1, 0);
+          for (int64_t c = 0; c < n_items; c++) Xt.indptr[c + 1] = Xt.indptr[c] + count[c];
+          check_arg(Xt.indptr[n_items] == nnz, "internal: the device transpose lost entries.");
+          if (timing)
+            fprintf(stderr, "ials create (item thread) device transpose %8.2f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count());
+          if (!X.flags_known) {  // (host_csr always classifies; kept for callers that do not)
+            Xt.flags_known = true;
+            Xt.unit = false;
+            Xt.positive = false;
+          }
+        }
+        const auto tb0 = std::chrono::steady_clock::now();
         t->side[1].build(Xt, t->shard.item_begin, t->shard.item_end, t->cfg, t->stream);
+        if (timing)
+          fprintf(stderr, "ials create (item thread) side 1 build     %8.2f ms\n",
+                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
       } catch (...) {
         item_error = std::current_exception();
       }
     });
     Joiner item_join{item_thread};
     t->side[0].build(X, t->shard.user_begin, t->shard.user_end, t->cfg, t->stream);
+    mark("side 0 build");
     item_thread.join();
     if (item_error) std::rethrow_exception(item_error);
     mark("both sides");

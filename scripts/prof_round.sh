@@ -20,3 +20,6 @@ ls gpurun_out/prof | head -40
 # iALS++ with 64-dim blocks at K = 128 (chained passes)
 rm -rf gpurun_out/prof/pp_kt
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/pp_kt -- python3 scripts/quick_ials.py --shape ml20m --K 128 --solvers IALSPP --epochs 3 > gpurun_out/prof/pp_kt.log 2>&1
+# iALS++ with one block at K = 64: the gradient-form (RESID) variant of the solve kernel (round 5)
+rm -rf gpurun_out/prof/pp64_kt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/pp64_kt -- python3 scripts/quick_ials.py --shape ml20m --K 64 --solvers IALSPP --epochs 5 > gpurun_out/prof/pp64_kt.log 2>&1

@@ -70,7 +70,7 @@ def main():
                              min(d), max(d)])
     # secondary paths (scripts/prof_secondary.sh): kNN + evaluator trace, iALS++ trace, SQ counters
     for src, dst in (("sec_kt", "knn_eval"), ("pp_kt", "ialspp"), ("ef_kt_64", "eval_fused_k64"),
-                     ("ef_kt_256", "eval_fused_k256"), ("c4_kt", "c4")):
+                     ("ef_kt_256", "eval_fused_k256"), ("c4_kt", "c4"), ("pp64_kt", "ialspp_k64")):
         st = newest(os.path.join(SRC, src, "*", "*_kernel_stats.csv"))
         if st:
             shutil.copy(st[0], os.path.join(DST, f"{TAG}_{dst}_kernel_stats.csv"))

@@ -586,3 +586,28 @@ def test_k300_cholesky_failure_is_reported(X_small):
     t = IALSTrainer(mc, X_small)
     with pytest.raises(RuntimeError, match="Cholesky"):
         t.step(sc)
+
+
+@pytest.mark.parametrize("binary", [True, False])
+@pytest.mark.parametrize("shape", [(2000, 700, 0.05), (300, 5000, 0.01), (1, 40, 0.5), (50, 1, 0.5)])
+def test_device_transpose_is_the_host_transpose(shape, binary, monkeypatch):
+    """Round 5: an unsharded trainer uploads X once and builds X^T on the device (a stable radix sort of
+    the entry numbers by column + one gather, csrc/device_sort.hip) instead of the host's counting sort
+    and a second upload.  IRSPACK_AMD_IALS_HOST_TRANSPOSE=1 keeps the host path: both must produce the
+    SAME X^T, entry for entry - the item half-step sums a row's entries in stored order, so one epoch
+    from the same factors is bit-identical - for binary data (no value stream at all) and weighted
+    data, wide and tall matrices, a single row and a single column."""
+    n_u, n_i, dens = shape
+    X = random_csr(n_u, n_i, dens, 17, binary=binary, empty_rows=(0,) if n_u > 10 else ())
+    mc, _ = build(32, alpha0=0.1, reg=1e-2)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("IRSPACK_AMD_IALS_HOST_TRANSPOSE", mode)
+        t = IALSTrainer(mc, X)
+        for kind in ("CHOLESKY", "CG"):
+            sc, _ = solver(kind)
+            t.step(sc)
+        out[mode] = (t.user, t.item, t.compute_loss(sc))
+    np.testing.assert_array_equal(out["0"][0], out["1"][0])
+    np.testing.assert_array_equal(out["0"][1], out["1"][1])
+    assert out["0"][2] == out["1"][2]
