@@ -686,6 +686,58 @@ def _factor_digest(tr) -> float:
     return out
 
 
+def _exchange_ab(trainer, local, sc, barrier) -> dict:
+    """The row exchanges of the native RCCL path, A/B (every rank calls it; N > 1): a few untimed epochs
+    of `auto`, `mesh` and - if the peers' memory can be mapped - `peer` from the same factors (max over
+    ranks of the host clock around barrier + synchronize) and a digest of the factors each ends on.  The
+    exchange moves rows, it does not compute: a mode is eligible only if every replica ends on the
+    digest of `auto`; the fastest eligible mode is selected for the timed region
+    (IRSPACK_AMD_BENCH_EXCHANGE pins one)."""
+    import torch
+    import torch.distributed as dist
+
+    pinned = os.environ.get("IRSPACK_AMD_BENCH_EXCHANGE")
+    modes = ["auto", "mesh"] + (["peer"] if local.peers_attached or _try_attach_peers(local) else [])
+    ab_epochs = int(os.environ.get("IRSPACK_AMD_BENCH_AB_EPOCHS", "4"))
+    user0, item0 = local.trainer.user, local.trainer.item
+    out = {"epochs_each": ab_epochs, "modes": {}, "peers_mapped": bool(local.peers_attached),
+           "peers_error": getattr(local, "peers_error", None)}
+    for mode in modes:
+        rec = {}
+        try:
+            trainer.set_exchange(mode)
+            local.trainer.user, local.trainer.item = user0, item0
+            trainer.step(sc)  # (first use of a mode: connection set-up inside RCCL)
+            local.trainer.user, local.trainer.item = user0, item0
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(ab_epochs):
+                trainer.step(sc)
+            trainer.synchronize()
+            barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            rec["ms_per_epoch"] = float(dt.item()) / ab_epochs * 1e3
+            digest = _factor_digest(local.trainer)
+            lohi = torch.tensor([digest, -digest], dtype=torch.float64, device="cuda")
+            dist.all_reduce(lohi, op=dist.ReduceOp.MIN)  # min(d), -max(d): equal on every rank?
+            rec["digest"] = digest
+            rec["replicas_identical"] = bool(lohi[0].item() == -lohi[1].item())
+        except (RuntimeError, ValueError) as exc:  # (solver / argument errors: raised on every rank together)
+            rec["error"] = repr(exc)
+        out["modes"][mode] = rec
+    base = out["modes"]["auto"]
+    ok = [m for m, r in out["modes"].items()
+          if "error" not in r and r["replicas_identical"] and r["digest"] == base.get("digest")]
+    best = min(ok, key=lambda m: out["modes"][m]["ms_per_epoch"]) if ok else "auto"
+    choice = pinned if pinned in out["modes"] and pinned in ok else best
+    out["timed"] = choice
+    out["agree_with_auto"] = ok
+    trainer.set_exchange(choice)
+    local.trainer.user, local.trainer.item = user0, item0
+    return out
+
+
 def main():
     args = parse_args()
     import torch
@@ -699,14 +751,18 @@ def main():
     backend = os.environ.get("IRSPACK_AMD_BENCH_BACKEND", "nccl")
     if os.environ.get("IRSPACK_AMD_BENCH_ONE_DEVICE"):
         local_rank = 0
-    if world > 1:
+    # IRSPACK_AMD_BENCH_FORCE_DIST=1 (tests): the N > 1 code path - process group, native transport,
+    # preflight, exchange A/B, phase split - with ONE rank (RCCL accepts a world of one on one GPU)
+    multi = world > 1 or bool(os.environ.get("IRSPACK_AMD_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device (no CPU fallback).")
     torch.cuda.set_device(local_rank)
@@ -744,7 +800,7 @@ def main():
     # code 3 from the watchdog) and the line says which path was timed.  The per-phase split of the
     # line always comes from the host loop (a few extra, untimed epochs when the native path is timed).
     comm_choice = os.environ.get("IRSPACK_AMD_BENCH_COMM", "native")
-    want_native = world > 1 and comm_choice != "torch" and (backend == "nccl" or comm_choice == "local")
+    want_native = multi and comm_choice != "torch" and (backend == "nccl" or comm_choice == "local")
     overlap = bool(int(os.environ.get("IRSPACK_AMD_BENCH_OVERLAP", "0")))
     watchdog_s = float(os.environ.get("IRSPACK_AMD_BENCH_WATCHDOG_S", "600"))
     trainer = ShardedIALSTrainer(local, ub, ib, timing=False, overlap=overlap,
@@ -760,11 +816,11 @@ def main():
             preflight["error"] = trainer.native_error
         preflight["peers_mapped"] = bool(getattr(local, "peers_attached", False))
     native = bool(trainer.native)
-    if world > 1 and not native:  # the host loop is the timed path: it carries the phase marks itself
+    if multi and not native:  # the host loop is the timed path: it carries the phase marks itself
         trainer.timing = True
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -774,45 +830,10 @@ def main():
     # the fastest mode whose bits agree becomes the timed one (IRSPACK_AMD_BENCH_EXCHANGE pins it).
     exchange_ab = None
     if native and trainer.native_transport == "rccl":
-        pinned = os.environ.get("IRSPACK_AMD_BENCH_EXCHANGE")
-        modes = ["auto", "mesh"] + (["peer"] if local.peers_attached or _try_attach_peers(local) else [])
-        ab_epochs = int(os.environ.get("IRSPACK_AMD_BENCH_AB_EPOCHS", "4"))
-        user0, item0 = local.trainer.user, local.trainer.item
-        exchange_ab = {"epochs_each": ab_epochs, "modes": {}}
-        for mode in modes:
-            rec = {}
-            try:
-                trainer.set_exchange(mode)
-                local.trainer.user, local.trainer.item = user0, item0
-                trainer.step(sc)  # (first use of a mode: connection set-up inside RCCL)
-                local.trainer.user, local.trainer.item = user0, item0
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(ab_epochs):
-                    trainer.step(sc)
-                trainer.synchronize()
-                barrier()
-                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                rec["ms_per_epoch"] = float(dt.item()) / ab_epochs * 1e3
-                digest = _factor_digest(local.trainer)
-                lohi = torch.tensor([digest, -digest], dtype=torch.float64, device="cuda")
-                dist.all_reduce(lohi, op=dist.ReduceOp.MIN)  # min(d), -max(d): equal on every rank?
-                rec["digest"] = digest
-                rec["replicas_identical"] = bool(lohi[0].item() == -lohi[1].item())
-            except (RuntimeError, ValueError) as exc:  # (argument errors only: raised before any collective)
-                rec["error"] = repr(exc)
-            exchange_ab["modes"][mode] = rec
-        base = exchange_ab["modes"]["auto"]
-        ok = [m for m, r in exchange_ab["modes"].items()
-              if "error" not in r and r["replicas_identical"] and r["digest"] == base.get("digest")]
-        best = min(ok, key=lambda m: exchange_ab["modes"][m]["ms_per_epoch"]) if ok else "auto"
-        choice = pinned if pinned in exchange_ab["modes"] and pinned in ok else best
-        exchange_ab["timed"] = choice
-        exchange_ab["agree_with_auto"] = ok
-        trainer.set_exchange(choice)
-        local.trainer.user, local.trainer.item = user0, item0
-
+        try:
+            exchange_ab = _exchange_ab(trainer, local, sc, barrier)
+        except Exception as exc:  # (a defect of the A/B itself - the same on every rank - must not cost the headline)
+            exchange_ab = {"error": repr(exc), "timed": trainer.native_exchange}
     for _ in range(args.warmup):
         trainer.step(sc)
     trainer.synchronize()
@@ -838,7 +859,7 @@ def main():
         prof.setdefault(name, rec)  # (the dominant kernel keeps its timed-region figure)
     local.trainer.profile(False)
     comm = None
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -977,7 +998,7 @@ def main():
         # last: 256 busy host threads just before a GPU leg disturb its (host-clocked) timing
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(X, K, args.solver, args.cpu_seconds)
-    if world > 1:
+    if multi:
         dist.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)

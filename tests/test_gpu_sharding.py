@@ -145,6 +145,41 @@ def test_bench_two_ranks_control_flow(extra, env_extra, timed):
         assert c["timed_path"] == "torch.distributed host loop"
 
 
+def test_bench_rccl_path_with_one_rank():
+    """bench.py's N > 1 path over RCCL cannot run with two ranks on the one GPU of the box; with ONE rank
+    (IRSPACK_AMD_BENCH_FORCE_DIST=1: an RCCL process group of size 1) every line of it does run - the
+    library-owned communicators, the collective set-up vote, the preflight epoch, the exchange A/B over
+    `auto`, `mesh` and `peer` with its digests, the timed native region, the host-loop phase split and
+    the `comm` object of the line.  (What one rank cannot show is data on the wire.)"""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IRSPACK_AMD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", IRSPACK_AMD_BENCH_AB_EPOCHS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--shape", "small", "--balance", "equal", "--no-secondary", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    c = d["comm"]
+    assert c["native_preflight"] == {"requested": "rccl", "created": True, "first_epoch": True, "peers_mapped": False} \
+        or c["native_preflight"]["created"] and c["native_preflight"]["first_epoch"]
+    assert c["timed_path"].startswith("native") and "rccl" in c["timed_path"]
+    ab = c["exchange_ab"]
+    assert "error" not in ab, ab
+    assert set(ab["modes"]) == {"auto", "mesh", "peer"} and ab["peers_mapped"] is True
+    digests = {m: r["digest"] for m, r in ab["modes"].items()}
+    assert all("error" not in r and r["replicas_identical"] and r["ms_per_epoch"] > 0 for r in ab["modes"].values()), ab
+    assert len(set(digests.values())) == 1, digests  # the exchange moves rows, it does not compute
+    assert sorted(ab["agree_with_auto"]) == ["auto", "mesh", "peer"] and ab["timed"] in ab["modes"]
+
+
 def _knn_eval_worker(rank, world, port, out_dir):
     """Product kNN computer and evaluator sharded over two ranks on one device."""
     import pickle
