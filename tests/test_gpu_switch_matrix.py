@@ -5,7 +5,8 @@ Round 4's review: "42 switches select kernel variants ... each is tested once, n
 Here every iALS switch that selects a kernel family is flipped alone AND in pairs (the pairs are the
 combinations that can meet inside one launch: a fallback of one family landing on the fallback of
 another), across the K classes that route differently (<= 64 one wave per row, 128 the wave-128 kernel,
-200 a workgroup per row / matrix-free CG, 320 the general-size kernels), for the three solvers, on a
+200 a workgroup per row / matrix-free CG; the general-size kernels above 256 read no switch), for the
+three solvers, on a
 matrix with split rows, short rows and empty rows.  Bar: the float64 arbiter of conftest
 (``assert_float64_bar``), every row.  kNN and evaluator switches: singles and pairs against the oracle,
 indices / counters bit-exact.
@@ -66,7 +67,7 @@ def matrices():
 @pytest.mark.parametrize("case", IALS_CASES, ids=lambda c: "+".join(c))
 @pytest.mark.parametrize("K,kind,data", [(64, "CHOLESKY", "binary"), (64, "CG", "weighted"), (48, "IALSPP", "binary"),
                                          (128, "CHOLESKY", "weighted"), (128, "CG", "binary"), (128, "IALSPP", "weighted"),
-                                         (200, "CHOLESKY", "binary"), (200, "CG", "weighted"), (320, "CG", "binary")])
+                                         (200, "CHOLESKY", "binary"), (200, "CG", "weighted")])
 def test_ials_switches_alone_and_in_pairs(matrices, monkeypatch, case, K, kind, data):
     for name in case:
         for key, value in IALS_SWITCHES.get(name, {}).items():
