@@ -166,3 +166,59 @@ def test_no_dpp_read_within_two_wait_states_of_a_vector_write(tmp_path):
             del hist[:-4]
     assert n_dpp > 1000  # (the scan found the instructions it is about)
     assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain is not installed")
+def test_no_use_of_a_permute_result_before_its_wait(tmp_path):
+    """The gather loop of the solve kernels issues `ds_bpermute_b32` from inline assembly with an immediate
+    offset and places the `s_waitcnt lgkmcnt(0)` itself, one sub-step later (ials_kernels.hpp: perm_issue /
+    fetch_finish): the compiler does not know the result is in flight in between.  Should the register
+    allocator ever put a copy or a spill of that register there, the gathered index would be read before
+    the LDS unit delivered it - silently wrong rows, in one build and not in another.  This scan of every
+    kernel's disassembly (fall-through order) checks that no instruction touches the destination register of
+    a `ds_bpermute_b32` before the next wait that drains the LDS queue."""
+    import re
+    import subprocess
+
+    if not os.path.exists(LIB):
+        pytest.skip("libirspack_amd.so is not built")
+    data = open(LIB, "rb").read()
+    n_perm, bad = 0, []
+    for i, (_triple, image) in enumerate(_device_images(data)):
+        elf = tmp_path / f"image{i}.elf"
+        elf.write_bytes(image)
+        text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", str(elf)], capture_output=True,
+                              text=True, check=True).stdout
+        queue = []  # outstanding LDS / scalar-memory operations in issue order: (permute's register or None, line)
+        for line in text.split("\n"):
+            m = re.match(r"\s+([a-z_0-9]+)\s*(.*?)\s*(//.*)?$", line)
+            if not m or line.rstrip().endswith(":"):
+                queue.clear()  # a label: another basic block / kernel
+                continue
+            op, rest = m.group(1), m.group(2)
+            if op == "s_waitcnt":
+                # lgkmcnt(N): all but the N youngest operations of the queue have returned (LDS returns in order)
+                w = re.search(r"lgkmcnt\((\d+)\)", rest)
+                if w:
+                    del queue[:max(0, len(queue) - int(w.group(1)))]
+                elif rest.strip() in ("0", "0x0"):
+                    queue.clear()
+                continue
+            if op == "s_endpgm":
+                queue.clear()
+                continue
+            pending = {reg: where for reg, where in queue if reg is not None}
+            if pending:
+                used = set(_vregs(rest))
+                for reg, where in pending.items():
+                    if reg in used:
+                        bad.append((where, line.strip()))
+                        queue[:] = [(r, wl) for r, wl in queue if r != reg]
+            if op == "ds_bpermute_b32":
+                n_perm += 1
+                dst = _vregs(rest.split(",")[0])
+                queue.append((dst[0] if dst else None, line.strip()))
+            elif op.startswith("ds_") or op.startswith("s_load") or op.startswith("s_buffer_load"):
+                queue.append((None, line.strip()))
+    assert n_perm > 500  # (the scan found the instructions it is about)
+    assert not bad, bad[:5]
