@@ -26,6 +26,10 @@ struct HostCsr {
   RawVector<float> data;       // EMPTY when `unit` (every stored value is exactly 1: nothing to carry)
   // known from the validation pass of host_csr (flags_known): every stored value == 1 / > 0
   bool flags_known = false, unit = false, positive = false;
+  // host_csr(..., view = true): the caller's index array itself (validated in place, valid for the duration
+  // of the call that made it) instead of a copy in `indices` - nothing to allocate, fault in or unmap
+  const int32_t *indices_view = nullptr;
+  const int32_t *idx() const { return indices_view ? indices_view : indices.data(); }
 };
 
 // Stored values as the device kernels take them: -0.0 becomes +0.0 (x + 0.0f; every other value,
@@ -36,7 +40,7 @@ static inline void canonical_copy(float *dst, const float *src, int64_t n) {
 }
 
 static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
-                        const int32_t *indices, const float *data) {
+                        const int32_t *indices, const float *data, bool view = false) {
   check_arg(rows >= 0 && cols >= 0, "negative matrix shape.");
   check_arg(indptr != nullptr, "indptr is null.");
   HostCsr m;
@@ -48,7 +52,8 @@ static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
   check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31 (32-bit CSR like Eigen's).");
   for (int64_t r = 0; r < rows; r++) check_arg(indptr[r + 1] >= indptr[r], "malformed indptr.");
   // the two copies and the index check on a few host threads
-  m.indices.resize(nnz);
+  if (view) m.indices_view = indices;
+  else m.indices.resize(nnz);
   const int n_thr = static_cast<int>(std::max<int64_t>(
       1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz / 1000000 + 1})));
   std::atomic<int> bad(0), not_unit(0), not_positive(0);
@@ -63,7 +68,7 @@ static HostCsr host_csr(int64_t rows, int64_t cols, const int64_t *indptr,
   run([&](int k) {
     const int64_t b = nnz * k / n_thr, e = nnz * (k + 1) / n_thr;
     if (e <= b) return;
-    std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
+    if (!view) std::memcpy(m.indices.data() + b, indices + b, (e - b) * sizeof(int32_t));
     int32_t lo = 0, hi = 0;
     bool one = true, pos = true;
     for (int64_t q = b; q < e; q++) {
@@ -159,6 +164,7 @@ static HostCsr transpose(const HostCsr &x) {
   t.unit = x.unit;
   t.positive = x.positive;
   const bool carry = !(x.flags_known && x.unit);  // (all ones: nothing to move)
+  const int32_t *xi = x.idx();
   if (carry) t.data.resize(nnz);
   const int64_t cols = x.cols;
   // threads: bounded by the counter memory (cols x threads x 8 B <= 256 MB) and the work
@@ -178,7 +184,7 @@ static HostCsr transpose(const HostCsr &x) {
   };
   run([&](int k) {
     cnt[k].assign(cols, 0);
-    for (int64_t p = x.indptr[rb[k]]; p < x.indptr[rb[k + 1]]; p++) cnt[k][x.indices[p]]++;
+    for (int64_t p = x.indptr[rb[k]]; p < x.indptr[rb[k + 1]]; p++) cnt[k][xi[p]]++;
   });
   int64_t run_sum = 0;
   for (int64_t c = 0; c < cols; c++) {  // slot of (column c, thread k) = prefix in that order
@@ -194,7 +200,7 @@ static HostCsr transpose(const HostCsr &x) {
     std::vector<int64_t> &cur = cnt[k];
     for (int64_t r = rb[k]; r < rb[k + 1]; r++)
       for (int64_t p = x.indptr[r]; p < x.indptr[r + 1]; p++) {
-        const int64_t d = cur[x.indices[p]]++;
+        const int64_t d = cur[xi[p]]++;
         t.indices[d] = static_cast<int32_t>(r);
         if (carry) t.data[d] = x.data[p];
       }

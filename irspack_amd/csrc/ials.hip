@@ -115,7 +115,7 @@ struct Side {
     const size_t ne = static_cast<size_t>(m.indptr[m.rows]);
     alloc_entries(ne, s);
     if (ne) {
-      IRS_HIP(hipMemcpyAsync(indices.ptr, m.indices.data(), ne * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      IRS_HIP(hipMemcpyAsync(indices.ptr, m.idx(), ne * sizeof(int32_t), hipMemcpyHostToDevice, s));
       if (m.data.size() == ne) {
         IRS_HIP(hipMemcpyAsync(data.ptr, m.data.data(), ne * sizeof(float), hipMemcpyHostToDevice, s));
       } else {  // all ones (host_csr carried no values): written on the device, 80 MB less over PCIe per side
@@ -1691,7 +1691,7 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
               "shard out of range.");
     const bool whole = sh.user_begin == 0 && sh.user_end == n_users && sh.item_begin == 0 &&
                        sh.item_end == n_items;
-    HostCsr X = whole ? host_csr(n_users, n_items, indptr, indices, data)
+    HostCsr X = whole ? host_csr(n_users, n_items, indptr, indices, data, /*view=*/true)
                       : host_csr_rows(n_users, n_items, indptr, indices, data, sh.user_begin,
                                       sh.user_end);
     mark("copy + validate");

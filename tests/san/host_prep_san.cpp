@@ -71,6 +71,13 @@ int main() {
     CHECK(std::equal(ti.begin(), ti.end(), Xt.indices.begin()));
     CHECK(std::equal(td.begin(), td.end(), Xt.data.begin()));
   }
+  {  // view mode: the caller's index array is validated in place and not copied; same transpose
+    const ials::HostCsr V = ials::host_csr(rows, cols, indptr.data(), indices.data(), data.data(), true);
+    CHECK(V.indices.empty() && V.idx() == indices.data() && V.data.size() == static_cast<size_t>(nnz));
+    const ials::HostCsr Vt = ials::transpose(V);
+    CHECK(Vt.indptr == Xt.indptr && std::equal(Vt.indices.begin(), Vt.indices.end(), Xt.indices.begin()));
+    CHECK(std::equal(Vt.data.begin(), Vt.data.end(), Xt.data.begin()));
+  }
   {  // binary interactions: the values are classified on the validation pass and never copied
     CHECK(X.flags_known && !X.unit && X.positive && Xt.flags_known && !Xt.unit);
     const std::vector<float> ones(nnz, 1.0f);
