@@ -177,6 +177,9 @@ irs_status irs_ials_copy_rows_async(irs_ials_trainer *t, int32_t which,
  * (side 0: Gramian for the user solve = item rows of this shard). */
 irs_status irs_ials_partial_gramian_async(irs_ials_trainer *t, int32_t side);
 irs_status irs_ials_finish_gramian_async(irs_ials_trainer *t, int32_t side);
+/* The two in one call for a trainer that holds every row (nothing to all-reduce in between): the
+ * reduction writes the scaled Gramian in all its layouts itself, one launch less per half-epoch. */
+irs_status irs_ials_gramian_async(irs_ials_trainer *t, int32_t side);
 /* Solver::step (hpp:664-679) over this shard's rows of `side`. */
 irs_status irs_ials_half_step_async(irs_ials_trainer *t, int32_t side,
                                     const irs_ials_solver_config *sc);

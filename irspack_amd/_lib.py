@@ -116,6 +116,7 @@ EXPORTED_SYMBOLS = [
     "irs_ials_copy_rows_async",
     "irs_ials_partial_gramian_async",
     "irs_ials_finish_gramian_async",
+    "irs_ials_gramian_async",
     "irs_ials_half_step_async",
     "irs_ials_synchronize",
     "irs_comm_unique_id",

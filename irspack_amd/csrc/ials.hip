@@ -536,7 +536,9 @@ void init_factor(irs_ials_trainer *t, int which) {
 }
 
 // Gramian of `which` factors over rows [rb, re) into P_raw[dst] (unscaled).
-void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t re, int dst) {
+// `finish`: the reduce kernel also writes what launch_finish_gramian would (K <= 64; the caller then
+// skips that launch) - only where nothing (an all-reduce over ranks) sits between the two
+void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t re, int dst, bool finish = false) {
   const int64_t n = std::max<int64_t>(re - rb, 0);
   if (t->gk()) {  // K > 256: (64 x 64 block pair, row slab) units, slabs summed in order
     const int KP = t->KP, nb = KP / 64, nbp = nb * (nb + 1) / 2;
@@ -567,9 +569,16 @@ void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t 
       t->prof.launch("gramian_partial", gramian_partial_kernel<TT>, dim3(n_waves / 4), dim3(256), 0,
                      t->stream, static_cast<const float *>(t->factor[which].ptr), rb, re, per,
                      t->gram_partial.ptr);
-      t->prof.launch("gramian_reduce", gramian_reduce_kernel<TT>, dim3(ceil_div(G::NT * 256, 64)),
-                     dim3(256), 0, t->stream, static_cast<const float *>(t->gram_partial.ptr),
-                     n_waves / 4, t->P_raw[dst].ptr);
+      if (finish)
+        t->prof.launch("gramian_reduce", gramian_reduce_kernel<TT, true>, dim3(ceil_div(G::NT * 256, 64)),
+                       dim3(64 * GRAM_CHAINS), 0, t->stream, static_cast<const float *>(t->gram_partial.ptr),
+                       n_waves / 4, t->P_raw[dst].ptr, t->cfg.alpha0, t->P[dst].ptr, t->P_acc[dst].ptr,
+                       t->P_accL[dst].ptr);
+      else
+        t->prof.launch("gramian_reduce", gramian_reduce_kernel<TT>, dim3(ceil_div(G::NT * 256, 64)),
+                       dim3(64 * GRAM_CHAINS), 0, t->stream, static_cast<const float *>(t->gram_partial.ptr),
+                       n_waves / 4, t->P_raw[dst].ptr, 0.f, static_cast<float *>(nullptr),
+                       static_cast<float *>(nullptr), static_cast<float *>(nullptr));
     });
   } else {
     // four waves of a block share a slab of rows and split the tiles between them
@@ -587,8 +596,9 @@ void launch_partial_gramian(irs_ials_trainer *t, int which, int64_t rb, int64_t 
                          t->factor[which].ptr, rb, re, per_block, t->gram_partial.ptr);
       t->prof.end(t->stream);
       t->prof.begin("gramian_reduce", t->stream);
-      hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 64)), dim3(256),
-                         0, t->stream, t->gram_partial.ptr, n_blocks, t->P_raw[dst].ptr);
+      hipLaunchKernelGGL((gramian_reduce_kernel<TT>), dim3(ceil_div(G::NT * 256, 64)), dim3(64 * GRAM_CHAINS),
+                         0, t->stream, t->gram_partial.ptr, n_blocks, t->P_raw[dst].ptr, 0.f,
+                         static_cast<float *>(nullptr), static_cast<float *>(nullptr), static_cast<float *>(nullptr));
       t->prof.end(t->stream);
     });
   }
@@ -1603,8 +1613,9 @@ void full_gramian(irs_ials_trainer *t, int side) {
   t->gram_prefetched[side] = false;
   // side 0 (user solve) sums item rows; side 1 sums user rows.
   const int other = 1 - side;
-  launch_partial_gramian(t, other, 0, t->rows_of(other), side);
-  launch_finish_gramian(t, side);
+  const bool fused = t->T <= 4;  // (the one-wave-per-row family: reduce and finish in one launch)
+  launch_partial_gramian(t, other, 0, t->rows_of(other), side, fused);
+  if (!fused) launch_finish_gramian(t, side);
 }
 
 }  // namespace
@@ -1943,6 +1954,20 @@ irs_status irs_ials_finish_gramian_async(irs_ials_trainer *t, int32_t side) {
     check_arg(t && (side == 0 || side == 1), "bad argument.");
     IRS_HIP(hipSetDevice(t->device));
     launch_finish_gramian(t, side);
+  });
+}
+
+irs_status irs_ials_gramian_async(irs_ials_trainer *t, int32_t side) {
+  return guard([&] {
+    check_arg(t && (side == 0 || side == 1), "bad argument.");
+    const int other = 1 - side;
+    const int64_t rb = other == 0 ? t->shard.user_begin : t->shard.item_begin;
+    const int64_t re = other == 0 ? t->shard.user_end : t->shard.item_end;
+    check_arg(rb == 0 && re == t->rows_of(other),
+              "irs_ials_gramian_async needs every row of the other side on this trainer; a shard sums its "
+              "own rows (irs_ials_partial_gramian_async), all-reduces, then finishes.");
+    IRS_HIP(hipSetDevice(t->device));
+    full_gramian(t, side);
   });
 }
 

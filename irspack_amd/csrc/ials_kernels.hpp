@@ -1264,23 +1264,37 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float *__res
   }
 }
 
-// Sum the per-block partials (four interleaved chains per element, combined in
-// a fixed order) and write the row-major symmetric KP x KP matrix (unscaled).
-template <int T>
-__global__ __launch_bounds__(256) void gramian_reduce_kernel(const float *__restrict__ partial,
-                                                             int64_t n_parts,
-                                                             float *__restrict__ P_raw) {
+// Sum the per-block partials (GRAM_CHAINS interleaved chains per element, combined in a fixed
+// order) and write the row-major symmetric KP x KP matrix (unscaled).  Sixteen waves per element
+// group (round 5; four before): 16 instead of 64 dependent adds per thread behind as many loads -
+// the kernel was 12 us of latency for 2.6 MB of partials, twice per epoch.
+// FINISH (the unsharded epoch, where no all-reduce sits between the two): the thread that has summed
+// element e of the upper tiles also writes alpha0 times it to everything gramian_finish_kernel
+// derives from P_raw - the row-major P (both triangles), the accumulator layout (its own index e) and
+// the lower-form layout (the mirrored slot) - one launch and one dependent round trip less per side.
+constexpr int GRAM_CHAINS = 16;
+template <int T, bool FINISH = false>
+__global__ __launch_bounds__(64 * GRAM_CHAINS) void gramian_reduce_kernel(const float *__restrict__ partial,
+                                                                          int64_t n_parts,
+                                                                          float *__restrict__ P_raw,
+                                                                          float alpha0 = 0.f,
+                                                                          float *__restrict__ P = nullptr,
+                                                                          float *__restrict__ P_acc = nullptr,
+                                                                          float *__restrict__ P_accL = nullptr) {
   using G = Geo<T>;
-  __shared__ float part[4][64];
+  __shared__ float part[GRAM_CHAINS][64];
   const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int e = blockIdx.x * 64 + l;  // element of [NT][64][4]
   float s = 0.f;
   if (e < G::NT * 256)
-    for (int64_t w = q; w < n_parts; w += 4) s += partial[w * (G::NT * 256) + e];
+    for (int64_t w = q; w < n_parts; w += GRAM_CHAINS) s += partial[w * (G::NT * 256) + e];
   part[q][l] = s;
   __syncthreads();
   if (q != 0 || e >= G::NT * 256) return;
-  s = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+  s = 0.f;
+#pragma unroll
+  for (int c = 0; c < GRAM_CHAINS; c += 4)  // (a fixed order: bit-reproducible run to run)
+    s += (part[c][l] + part[c + 1][l]) + (part[c + 2][l] + part[c + 3][l]);
   const int t = e >> 8, lane = (e >> 2) & 63, r = e & 3;
   int ti = 0, tj = 0, c = t;
   for (int i = 0; i < T; i++) {
@@ -1291,6 +1305,15 @@ __global__ __launch_bounds__(256) void gramian_reduce_kernel(const float *__rest
   const int row = T * (4 * gg + r) + ti, col = T * m + tj;
   P_raw[row * G::KP + col] = s;
   if (ti != tj) P_raw[col * G::KP + row] = s;
+  if constexpr (FINISH) {
+    const float a = alpha0 * s;  // (the same product gramian_finish_kernel forms)
+    P[row * G::KP + col] = a;
+    if (ti != tj) P[col * G::KP + row] = a;
+    P_acc[e] = a;
+    // lower form: slot (ti, tj) holds the tile (row block tj, column block ti) = this tile transposed:
+    // element (col, row) lives in lane (m >> 2, 4 gg + r), register m & 3
+    P_accL[t * 256 + ((m >> 2) * 16 + (4 * gg + r)) * 4 + (m & 3)] = a;
+  }
 }
 
 // P = alpha0 * P_raw (hpp:113) in both row-major and accumulator layout.

@@ -675,6 +675,10 @@ class IALSTrainer:
     def partial_gramian_async(self, side: int) -> None:
         check(lib().irs_ials_partial_gramian_async(self._h, C.c_int32(side)))
 
+    def gramian_async(self, side: int) -> None:
+        """partial + finish in one call (a trainer that holds every row of the other side)"""
+        check(lib().irs_ials_gramian_async(self._h, C.c_int32(side)))
+
     def finish_gramian_async(self, side: int) -> None:
         check(lib().irs_ials_finish_gramian_async(self._h, C.c_int32(side)))
 

@@ -187,6 +187,10 @@ class HipLocalSolver(LocalSolver):
     def partial_gramian(self, side: int) -> None:
         self.trainer.partial_gramian_async(side)
 
+    def gramian(self, side: int) -> None:
+        """the whole Gramian of `side` in one call: for a solver that holds every row (world size 1)"""
+        self.trainer.gramian_async(side)
+
     def finish_gramian(self, side: int) -> None:
         self.trainer.finish_gramian_async(side)
 
@@ -634,12 +638,18 @@ class ShardedIALSTrainer:
             self._mark("start")
         # (1) Gramian of the other side: own rows, summed over ranks (K x K, latency bound) -
         #     unless the previous half-epoch already prefetched it
-        if not self._gram_ready[side]:
-            self._reduce_gramian(side, async_op=False)
+        if self.world == 1 and hasattr(local, "gramian"):
+            # nothing to sum over ranks: reduction and scaling in one launch (irs_ials_gramian_async)
+            local.gramian(side)
+            self._mark("gramian_ms")
             self._mark("allreduce_ms")
-        self._gram_ready[side] = False
-        local.finish_gramian(side)
-        self._mark("gramian_ms")
+        else:
+            if not self._gram_ready[side]:
+                self._reduce_gramian(side, async_op=False)
+                self._mark("allreduce_ms")
+            self._gram_ready[side] = False
+            local.finish_gramian(side)
+            self._mark("gramian_ms")
         # (2) solve this rank's rows of `side`
         local.half_step(side, solver_config)
         self._mark("solve_ms")

@@ -179,7 +179,8 @@ def test_profile_modes(X_small):
         if mode is False:
             assert prof == {}
         elif mode is True:
-            assert {"gramian_partial", "gramian_reduce", "gramian_finish"} <= set(prof)
+            # (round 5: an unsharded K <= 64 step reduces and scales the Gramian in one launch)
+            assert {"gramian_partial", "gramian_reduce"} <= set(prof) and "gramian_finish" not in prof
             assert prof["ials_solve_cholesky_user"]["launches"] == 2 == prof["ials_solve_cholesky_item"]["launches"]
         else:
             dominant = "ials_solve_cholesky_user" if X.shape[0] >= X.shape[1] else "ials_solve_cholesky_item"
