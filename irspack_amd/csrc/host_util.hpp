@@ -2,6 +2,7 @@
 // the multi-threaded host preparation (tests/san/host_prep_san.cpp).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <algorithm>
@@ -23,6 +24,12 @@ inline void check_arg(bool cond, const std::string &msg) {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// an IRSPACK_AMD_* switch: unset = `dflt`, else its integer value != 0
+inline bool env_flag(const char *name, bool dflt) {
+  const char *e = std::getenv(name);
+  return e ? std::atoi(e) != 0 : dflt;
+}
+
 // std::vector whose resize() leaves trivially constructible elements uninitialised: the big
 // host staging arrays (hundreds of MB) are written once right after they are sized, and the
 // value-initialising resize touched every page on one thread first (40 ms per 240 MB).
@@ -39,6 +46,28 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
 
+// body(k) for k in [0, n_thr) on n_thr host threads (k = 0 on the calling one); body must not throw.
+// The threads are started as a binary tree - thread k starts 2 k + 1 and 2 k + 2 before its own share -
+// so that the last one starts after log2(n_thr) thread creations instead of n_thr (30 us each: half a
+// millisecond for 20 threads, as much as a 4 M-entry pass takes).
+template <class F> inline void run_on_threads(int n_thr, F &&body) {
+  if (n_thr <= 1) {
+    body(0);
+    return;
+  }
+  struct Node {
+    static void run(int k, int n, F &body) {
+      std::thread left, right;
+      if (2 * k + 1 < n) left = std::thread([&body, k, n] { run(2 * k + 1, n, body); });
+      if (2 * k + 2 < n) right = std::thread([&body, k, n] { run(2 * k + 2, n, body); });
+      body(k);
+      if (left.joinable()) left.join();
+      if (right.joinable()) right.join();
+    }
+  };
+  Node::run(0, n_thr, body);
+}
+
 // fn(begin, end) over [0, n) on up to `max_threads` host threads (one call on this thread when n is
 // small); fn must not throw.
 template <class F> inline void parallel_ranges(int64_t n, F &&fn, int max_threads = 16, int64_t min_per_thread = 250000) {
@@ -48,16 +77,7 @@ template <class F> inline void parallel_ranges(int64_t n, F &&fn, int max_thread
     fn(int64_t(0), n);
     return;
   }
-  std::vector<std::thread> th;
-  struct Join {
-    std::vector<std::thread> &v;
-    ~Join() {
-      for (auto &t : v)
-        if (t.joinable()) t.join();
-    }
-  } join{th};
-  for (int k = 1; k < n_thr; k++) th.emplace_back([&, k] { fn(n * k / n_thr, n * (k + 1) / n_thr); });
-  fn(int64_t(0), n / n_thr);
+  run_on_threads(n_thr, [&](int k) { fn(n * k / n_thr, n * (k + 1) / n_thr); });
 }
 
 }  // namespace irs

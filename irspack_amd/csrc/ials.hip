@@ -909,10 +909,6 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
 //   IRSPACK_AMD_IALS_BF16X3=1   binary interactions, Cholesky, K <= 64 padded to 64: the rank update
 //                               on the bf16 matrix cores from exact three-way splits of the fp32
 //                               values (syrk_gather_bf16x3, ials_kernels.hpp); off by default
-static bool env_flag(const char *name, bool dflt) {
-  const char *e = std::getenv(name);
-  return e ? std::atoi(e) != 0 : dflt;
-}
 void read_switches(irs_ials_trainer *t) {
   t->opt_wave128 = env_flag("IRSPACK_AMD_IALS_WAVE128", true);
   t->opt_unit = env_flag("IRSPACK_AMD_IALS_UNIT", true);

@@ -1282,19 +1282,24 @@ __global__ __launch_bounds__(64 * GRAM_CHAINS) void gramian_reduce_kernel(const 
                                                                           float *__restrict__ P_acc = nullptr,
                                                                           float *__restrict__ P_accL = nullptr) {
   using G = Geo<T>;
-  __shared__ float part[GRAM_CHAINS][64];
+  __shared__ double part[GRAM_CHAINS][64];
   const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int e = blockIdx.x * 64 + l;  // element of [NT][64][4]
-  float s = 0.f;
+  // The partials are summed in float64 and rounded ONCE: the Gramian then carries the rounding of the
+  // matrix-core partial sums only (tens of rows each), not that of another few hundred float32 adds -
+  // a common-mode error of every row of the half-step (it decided the tail counts of the parity bars
+  // at alpha0 = 1, K = 4).  2.6 MB of partials: the float64 adds are not what this kernel waits for.
+  double sd = 0.0;
   if (e < G::NT * 256)
-    for (int64_t w = q; w < n_parts; w += GRAM_CHAINS) s += partial[w * (G::NT * 256) + e];
-  part[q][l] = s;
+    for (int64_t w = q; w < n_parts; w += GRAM_CHAINS) sd += static_cast<double>(partial[w * (G::NT * 256) + e]);
+  part[q][l] = sd;
   __syncthreads();
   if (q != 0 || e >= G::NT * 256) return;
-  s = 0.f;
+  sd = 0.0;
 #pragma unroll
   for (int c = 0; c < GRAM_CHAINS; c += 4)  // (a fixed order: bit-reproducible run to run)
-    s += (part[c][l] + part[c + 1][l]) + (part[c + 2][l] + part[c + 3][l]);
+    sd += (part[c][l] + part[c + 1][l]) + (part[c + 2][l] + part[c + 3][l]);
+  const float s = static_cast<float>(sd);
   const int t = e >> 8, lane = (e >> 2) & 63, r = e & 3;
   int ti = 0, tj = 0, c = t;
   for (int i = 0; i < T; i++) {

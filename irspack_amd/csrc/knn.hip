@@ -1355,6 +1355,28 @@ struct irs_knn_computer {
     DeviceBuffer<uint64_t> hi_stash;
     DeviceBuffer<int32_t> t_pop;
   } scratch;
+  // a compute call: set-up, the counts of the finished chunks and the end of the call; the kernels of its
+  // row chunks, one chunk after the other; the chunks' small inputs; the column indices (uploader
+  // thread); compaction + device-to-host copy of the chunks that are done.
+  // (Measured and dropped, round 5: the chunks' tile kernels on two or three streams in turn with the
+  // merges on a stream of their own, so that a chunk's last heavy pairs overlap the next chunk.  The
+  // ML-20M call went from 9.5 ms (four chunks, one stream) to 11.8 ms of device time: the 130 KB
+  // workgroups of two persistent kernels and the small merge blocks take each other's compute units.)
+  hipStream_t stream = nullptr, stream_k = nullptr, stream_in = nullptr, stream_up = nullptr, stream_out = nullptr;
+  hipEvent_t ev_in = nullptr, ev_setup = nullptr;
+  // the last result once more in page-locked host memory (kept between calls): the device-to-host copy
+  // runs at the link's rate at the end of the compute call, irs_knn_fetch is then a multi-threaded
+  // host copy into the caller's (pageable, usually untouched) arrays
+  char *stage = nullptr;
+  size_t stage_bytes = 0, stage_idx_offset = 0;  // values at 0, column indices at stage_idx_offset
+  bool staged = false;
+  ~irs_knn_computer() {
+    if (stage) (void)hipHostFree(stage);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_setup) (void)hipEventDestroy(ev_setup);
+    for (hipStream_t st : {stream, stream_k, stream_in, stream_up, stream_out})
+      if (st) (void)hipStreamDestroy(st);
+  }
 };
 
 extern "C" {
@@ -1706,9 +1728,15 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     }
     pt.mark("compute_W prologue");
     const bool binarise = c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
-    // One pass over the rows of the call, on several threads: index check, the per-row
-    // statistic of the epilogue, the multiply-add count that orders the launch, and whether the
-    // values are all ones / free of zeros (which accumulator the kernel may use).
+    // The rows of the call are taken in CHUNKS (contiguous row ranges of about equal entry counts, the
+    // first one half as long): per chunk one host pass on several threads - index check, the per-row
+    // statistic of the epilogue, the multiply-add count that orders the launch, whether the values
+    // are all ones / free of zeros (which accumulator the kernel may use) - then the chunk's launches.
+    // The pass over chunk k + 1 and the upload of its column indices (a second host thread) run
+    // while the device works on chunk k: of the 3 ms the pass takes on the ML-20M shape only the
+    // first chunk's share comes before the first kernel.  Every chunk chooses its kernel variant
+    // from its own rows (each variant gives the reference's values; section 3.4 of DESIGN.md).
+    // IRSPACK_AMD_KNN_CHUNKS overrides the count (1: the whole call at once; tests force small ones).
     std::vector<double> tstat(std::max<int64_t>(n, 1), 0.0);
     std::vector<double> tscale(std::max<int64_t>(n, 1), 1.0);
     // dense block: target row i is "popular item k" when item i is one and the row's pattern is the
@@ -1716,8 +1744,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     // from); any other row just takes the full walk
     const bool dense = c->pop_n > 0 && rows == c->N;
     std::vector<int32_t> tpop(dense ? std::max<int64_t>(n, 1) : 0, -1);
-    std::atomic<int> any_pop(0);
-    std::atomic<int64_t> skipped(0);  // multiply-adds the dense block stands for
     std::vector<int64_t> work(std::max<int64_t>(n, 1), 0);
     const int64_t e_begin = ip[row_begin], e_end = ip[row_end];
     check_arg(e_begin >= 0 && e_end >= e_begin, "malformed indptr.");
@@ -1726,396 +1752,544 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     // threads below cut [e_begin, e_end) by lower_bound, which on a non-monotone array yields
     // rows whose entries lie outside that range (an out-of-bounds host read instead of this error)
     for (int64_t i = row_begin; i < row_end; i++) check_arg(ip[i + 1] >= ip[i], "malformed indptr.");
-    std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0), any_wide(0);
     // IRSPACK_AMD_KNN_WIDE: 0 = never two limbs (A/B), 1 = every weighted row (tests); else by range
     const char *wide_env = std::getenv("IRSPACK_AMD_KNN_WIDE");
     const bool wide_ok = !(wide_env && wide_env[0] == '0');
     const double wide_ratio = (wide_env && wide_env[0] == '1') ? 0.0 : 2.3e5;
+    const int64_t out_k = std::min<int64_t>(top_k, c->N);
+    const bool have_work = n > 0 && out_k > 0 && c->N > 0;
+    const size_t ne = static_cast<size_t>(e_end - e_begin);
+    int n_chunks = 1;
+    {
+      const char *e = std::getenv("IRSPACK_AMD_KNN_CHUNKS");  // (read per call: tests toggle it)
+      if (e) n_chunks = std::min(64, std::max(1, std::atoi(e)));
+      else if (have_work && e_end - e_begin >= (int64_t(1) << 22) && n >= 4096) n_chunks = 3;
+      n_chunks = static_cast<int>(std::min<int64_t>(n_chunks, std::max<int64_t>(n, 1)));
+    }
+    const char *fw_env = std::getenv("IRSPACK_AMD_KNN_CHUNK_FIRST");
+    const double first_w = fw_env ? std::min(4.0, std::max(0.05, std::atof(fw_env))) : 1.0;
+    std::vector<int64_t> cb(n_chunks + 1);  // chunk k = rows [cb[k], cb[k + 1])
+    cb[0] = row_begin;
+    cb[n_chunks] = row_end;
+    for (int k = 1; k < n_chunks; k++) {
+      const int64_t e_cut = e_begin + static_cast<int64_t>(static_cast<double>(e_end - e_begin) * (k - 1.0 + first_w) / (n_chunks - 1.0 + first_w));
+      cb[k] = std::max<int64_t>(cb[k - 1], std::lower_bound(ip + row_begin, ip + row_end, e_cut) - ip);
+    }
     // The row pointers and column indices of the call's rows travel to the device on a second
-    // host thread while this one walks them (the values follow later, and only if the kernel
-    // reads them).  An index out of range is found by the walk below before any kernel runs.
+    // host thread, chunk by chunk, while this one walks them (the values follow later, and only if
+    // the kernel reads them).  An index out of range is found by the walk before its chunk's kernel runs.
     irs_knn_computer::Scratch &sc = c->scratch;
     std::string upload_error;
     std::thread uploader;
-    const bool have_work = n > 0 && std::min<int64_t>(top_k, c->N) > 0 && c->N > 0;
+    std::atomic<int> uploaded(0);  // chunks whose indices are on the device
     if (have_work) {
+      IRS_HIP(hipSetDevice(c->device));
+      if (!c->stream) {
+        IRS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        IRS_HIP(hipStreamCreateWithFlags(&c->stream_k, hipStreamNonBlocking));
+        IRS_HIP(hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking));
+        IRS_HIP(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
+        IRS_HIP(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
+        IRS_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        IRS_HIP(hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming));
+      }
+      sc.t_ptr.alloc(static_cast<size_t>(n) + 1);
+      sc.t_idx.alloc(std::max<size_t>(ne, 1));
       uploader = std::thread([&] {
         try {
           IRS_HIP(hipSetDevice(c->device));
           std::vector<int64_t> rel(n + 1);
           for (int64_t i = 0; i <= n; i++) rel[i] = ip[row_begin + i] - e_begin;
-          sc.t_ptr.upload(rel, nullptr);
-          sc.t_idx.upload(ix + e_begin, std::max<size_t>(static_cast<size_t>(e_end - e_begin), 1), nullptr);
-          IRS_HIP(hipStreamSynchronize(nullptr));  // `rel` goes out of scope
+          IRS_HIP(hipMemcpyAsync(sc.t_ptr.ptr, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+                                 c->stream_up));
+          for (int k = 0; k < n_chunks; k++) {
+            const int64_t q0 = ip[cb[k]], q1 = ip[cb[k + 1]];
+            if (q1 > q0)
+              IRS_HIP(hipMemcpyAsync(sc.t_idx.ptr + (q0 - e_begin), ix + q0,
+                                     static_cast<size_t>(q1 - q0) * sizeof(int32_t), hipMemcpyHostToDevice,
+                                     c->stream_up));
+            IRS_HIP(hipStreamSynchronize(c->stream_up));
+            uploaded.store(k + 1, std::memory_order_release);
+          }
         } catch (const std::exception &e) {
           upload_error = e.what();
+          (void)hipStreamSynchronize(c->stream_up);  // `rel` goes out of scope
+          uploaded.store(n_chunks, std::memory_order_release);
         }
       });
     }
-    struct Joiner {
+    // (declared after every host array the device work reads: on an exception the uploader is joined
+    // and the streams are drained before those arrays go)
+    struct Drain {
       std::thread &t;
-      ~Joiner() { if (t.joinable()) t.join(); }
-    } upload_join{uploader};
-    {
-      const int n_thr = static_cast<int>(std::max<int64_t>(
-          1, std::min<int64_t>({host_thread_cap(), static_cast<int64_t>(std::thread::hardware_concurrency()),
-                                (e_end - e_begin) / 200000 + 1})));
-      auto body = [&](int th) {
-        // contiguous row chunks of about equal entry counts
-        const int64_t lo_e = e_begin + (e_end - e_begin) * th / n_thr;
-        const int64_t hi_e = e_begin + (e_end - e_begin) * (th + 1) / n_thr;
-        int64_t r0 = std::lower_bound(ip + row_begin, ip + row_end, lo_e) - ip;
-        int64_t r1 = th + 1 == n_thr ? row_end : std::lower_bound(ip + row_begin, ip + row_end, hi_e) - ip;
-        if (th == 0) r0 = row_begin;
-        bool bad = false, ones = true, safe = true, positive = true;
-        // The usual case - every stored value of the chunk is exactly 1 (binary interactions) -
-        // is recognised by one tight pass over the values (a branch-free AND the compiler
-        // vectorises); the row loop then only walks the indices.
-        bool chunk_ones = true;
-        if (!binarise && r1 > r0) {
-          uint64_t diff = 0;
-          const uint64_t one_bits = 0x3ff0000000000000ull;
-          const uint64_t *vb = reinterpret_cast<const uint64_t *>(dv);
-          for (int64_t q = ip[r0]; q < ip[r1]; q++) diff |= vb[q] ^ one_bits;
-          chunk_ones = diff == 0;
-        }
-        const bool unit = binarise || chunk_ones;
-        for (int64_t i = r0; i < r1; i++) {
-          if (ip[i + 1] < ip[i]) { bad = true; break; }
-          double ss = 0, bound = 0, minprod = std::numeric_limits<double>::infinity();
-          int64_t w = 0;
-          if (unit) {
-            if (cols <= 0 && ip[i + 1] > ip[i]) { bad = true; break; }
-            int32_t lo_j = 0, hi_j = 0;  // running min / max: one range test per row
-            for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
-              const int32_t j = ix[q];
-              lo_j = std::min(lo_j, j);
-              hi_j = std::max(hi_j, j);
-              const int32_t jc = std::min(std::max(j, 0), static_cast<int32_t>(cols - 1));
-              w += c->xt_row_len[jc];
-              bound += c->xt_rowmax[jc];
-              if (c->xt_rowmin[jc] > 0.0) minprod = std::min(minprod, c->xt_rowmin[jc]);
-            }
-            if (lo_j < 0 || hi_j >= cols) { bad = true; break; }
-            ss = static_cast<double>(ip[i + 1] - ip[i]);
-            if (dense && c->pop_rank[i] >= 0) {
-              const int32_t k = c->pop_rank[i];
-              const int64_t len = c->pop_ptr[k + 1] - c->pop_ptr[k];
-              if (len == ip[i + 1] - ip[i] &&
-                  std::memcmp(ix + ip[i], c->pop_idx.data() + c->pop_ptr[k], static_cast<size_t>(len) * sizeof(int32_t)) == 0) {
-                tpop[i - row_begin] = k;
-                any_pop.store(1, std::memory_order_relaxed);
-                skipped.fetch_add(w, std::memory_order_relaxed);
-                w = 0;  // the walk of a popular row skips the popular columns
-                for (int64_t q = ip[i]; q < ip[i + 1]; q++) w += c->xt_row_len_np[ix[q]];
-                skipped.fetch_sub(w, std::memory_order_relaxed);
-              }
-            }
-          } else {
-            for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
-              const int32_t j = ix[q];
-              if (j < 0 || j >= cols) { bad = true; break; }
-              const double x = dv[q];  // similarities.hpp:113-118, 165-170
-              ss += x * x;
-              w += c->xt_row_len[j];
-              ones &= x == 1.0;
-              positive &= x > 0.0;
-              const double ax = std::fabs(x);
-              safe &= ax > 1e-150 && ax < 1e150;  // no stored zero, no underflow of x * y
-              bound += ax * c->xt_rowmax[j];      // >= |any sum of this product row|
-              if (ax > 0.0 && c->xt_rowmin[j] > 0.0) minprod = std::min(minprod, ax * c->xt_rowmin[j]);
-            }
-          }
-          if (bad) break;
-          switch (c->sim_type) {
-            case IRS_SIM_COSINE: tstat[i - row_begin] = std::sqrt(ss); break;             // :39
-            case IRS_SIM_ASYMMETRIC: tstat[i - row_begin] = std::pow(ss, c->alpha); break; // :78-79
-            case IRS_SIM_JACCARD:
-            case IRS_SIM_TVERSKY:
-              tstat[i - row_begin] = static_cast<double>(ip[i + 1] - ip[i]);            // :122, :174
-              break;
-            default: break;
-          }
-          work[i - row_begin] = w;
-          // fixed-point scale of the row: 2^s with bound * 2^s < 2^61
-          if (bound > 0 && std::isfinite(bound)) {
-            int ex = 0;
-            (void)std::frexp(bound, &ex);  // bound < 2^ex
-            tscale[i - row_begin] = std::ldexp(1.0, 61 - ex);
-            // One limb rounds every product to a multiple of 2^-s ~ bound 2^-61: 1e-13 of the row's
-            // smallest possible product as long as bound / minprod < 2.3e5.  Beyond that (weights
-            // over many decades, very long rows) the row is summed in two limbs (negative scale):
-            // twice the accumulation time, 2^-40 of the rounding step.
-            if (wide_ok && std::isfinite(minprod) && bound > wide_ratio * minprod) {
-              tscale[i - row_begin] = -tscale[i - row_begin];
-              any_wide.store(1, std::memory_order_relaxed);
-            }
-          }
-        }
-        if (!positive) not_positive.store(1);
-        if (bad) bad_index.store(1);
-        if (!ones) not_ones.store(1);
-        if (!safe) unsafe.store(1);
-      };
-      std::vector<std::thread> th;
-      for (int k = 1; k < n_thr; k++) th.emplace_back(body, k);
-      body(0);
-      for (auto &t : th) t.join();
-    }
-    check_arg(bad_index.load() == 0, "malformed matrix: column index out of range or indptr not monotone.");
-    const bool t_all_ones = not_ones.load() == 0, t_safe = unsafe.load() == 0;
-    pt.mark("target pass");
-    const int64_t out_k = std::min<int64_t>(top_k, c->N);
+      irs_knn_computer *c;
+      bool device;
+      ~Drain() {
+        if (t.joinable()) t.join();
+        if (device)
+          for (hipStream_t st : {c->stream_in, c->stream_k, c->stream_out, c->stream})
+            (void)hipStreamSynchronize(st);
+      }
+    };
     c->res_ptr.assign(n + 1, 0);
     c->res_nnz = 0;
+    c->staged = false;
     c->last_ms = 0;
     c->last_macs = 0;
+    c->last_walked = 0;
     *nnz_out = 0;
-    if (n == 0 || out_k == 0 || c->N == 0) return;
-    const int n_tiles = static_cast<int>(ceil_div(c->N, TILE));
+    const int n_tiles = static_cast<int>(ceil_div(std::max<int64_t>(c->N, 1), TILE));
     const bool big = out_k > TOPK_CAP;  // row merge by threshold select (knn_merge_big_kernel)
     const int64_t tile_k = std::min<int64_t>(out_k, TILE);
-    IRS_HIP(hipSetDevice(c->device));
-    hipStream_t s = nullptr;
-    // rows of the call, heaviest product row first (ids relative to row_begin)
-    for (int64_t i = 0; i < n; i++) c->last_macs += work[i];
-    c->last_macs += skipped.load();  // (the product's multiply-adds, however obtained)
-    std::vector<int32_t> order(n);
-    {  // Heaviest rows first, for the load balance of the persistent launch only (results do
-       // not depend on it): a counting sort by 1/64-octave of the work, rows of a bucket in
-       // row order - O(n) instead of a 1.2 ms comparison sort.
-      constexpr int NB = 64 * 64;
-      auto bucket = [&](int64_t w) {
-        const int b = static_cast<int>(std::log2(static_cast<double>(w) + 1.0) * 64.0);
-        return NB - 1 - std::min(std::max(b, 0), NB - 1);
-      };
-      std::vector<int32_t> start(NB + 1, 0);
-      std::vector<int32_t> bk(n);
-      for (int64_t i = 0; i < n; i++) {
-        bk[i] = bucket(work[i]);
-        start[bk[i] + 1]++;
+    std::vector<int32_t> order(std::max<int64_t>(n, 1));  // per chunk: its rows (chunk-relative ids), heaviest first
+    std::vector<double> ones_host;                        // (binarise: the values the kernel reads)
+    // per chunk: "its merged rows are in out_idx / out_val"; the call's device span lies between ev_first
+    // (before the first launch) and ev_last (after every chunk)
+    std::vector<hipEvent_t> ev_done(n_chunks, nullptr);
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    struct Events {
+      std::vector<hipEvent_t> &v;
+      hipEvent_t &a, &b;
+      ~Events() {
+        for (auto e : v) if (e) (void)hipEventDestroy(e);
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
       }
-      for (int b = 0; b < NB; b++) start[b + 1] += start[b];
-      for (int64_t i = 0; i < n; i++) order[start[bk[i]]++] = static_cast<int32_t>(i);
-    }
-    pt.mark("work + order");
+    } events_guard{ev_done, ev_first, ev_last};
+    std::vector<int32_t> slot_of(std::max<int64_t>(n, 1)), h_cnt(std::max<int64_t>(n, 1));
+    Drain drain{uploader, c, have_work};
+    hipStream_t s = c->stream, s_in = c->stream_in, s_out = c->stream_out;
     DeviceBuffer<int64_t> &t_ptr = sc.t_ptr;
-    DeviceBuffer<int32_t> &t_idx = sc.t_idx, &d_order = sc.order, &cand_idx = sc.cand_idx,
-                          &cand_cnt = sc.cand_cnt, &out_idx = sc.out_idx, &out_cnt = sc.out_cnt;
-    DeviceBuffer<double> &t_val = sc.t_val, &t_stat = sc.t_stat, &t_scale = sc.t_scale,
-                         &cand_val = sc.cand_val, &out_val = sc.out_val;
-    // which accumulator: 32-bit counts when every product is 1, else fp64 sums with the -0.0
-    // sentinel unless some product could be a zero
-    // (the sentinel of the fixed-point sums needs positive data: a sum must not return to the
-    // "untouched" pattern by cancellation)
-    const bool sentinel = c->xt_nonzero && t_safe && c->xt_positive && not_positive.load() == 0;
-    const bool acc32 = c->xt_all_ones && sentinel && t_all_ones;
-    {  // only the rows of the call travel; the values only if the kernel reads them
-      uploader.join();  // row pointers + column indices (started before the target pass)
-      if (!upload_error.empty()) throw std::runtime_error(upload_error);
-      const size_t ne = static_cast<size_t>(e_end - e_begin);
+    DeviceBuffer<int32_t> &t_idx = sc.t_idx, &d_order = sc.order, &out_idx = sc.out_idx, &out_cnt = sc.out_cnt;
+    DeviceBuffer<double> &t_val = sc.t_val, &t_stat = sc.t_stat, &t_scale = sc.t_scale, &out_val = sc.out_val;
+    int n_cu = 0;
+    size_t max_slots = 0;
+    bool use_stage = false;
+    if (have_work) {
+      int64_t max_rows = 0, max_entries = 0;
+      for (int k = 0; k < n_chunks; k++) {
+        max_rows = std::max(max_rows, cb[k + 1] - cb[k]);
+        max_entries = std::max(max_entries, ip[cb[k + 1]] - ip[cb[k]]);
+      }
+      if (binarise) ones_host.assign(static_cast<size_t>(max_entries), 1.0);  // (never resized: copies of it may be in flight)
+      max_slots = static_cast<size_t>(max_rows) * n_tiles;
+      t_stat.alloc(n);
+      t_scale.alloc(n);
+      d_order.alloc(n);
+      sc.slot_of.alloc(n);
+      sc.res_ptr.alloc(static_cast<size_t>(n) + 1);
+      // (every chunk has its own part of the candidate lists)
+      sc.cand_idx.alloc(static_cast<size_t>(n) * n_tiles * tile_k);
+      sc.cand_val.alloc(static_cast<size_t>(n) * n_tiles * tile_k);
+      sc.cand_cnt.alloc(static_cast<size_t>(n) * n_tiles);
+      const size_t cap = static_cast<size_t>(n) * out_k;  // entries the result can have
+      out_idx.alloc(cap);
+      out_val.alloc(cap);
+      out_cnt.alloc(n);
+      c->res_idx.alloc(cap);  // (the chunks are compacted as they finish, before the total is known)
+      c->res_val.alloc(cap);
+      // results of up to 1 GB also travel to a page-locked staging buffer, chunk by chunk as the chunks finish
+      // (IRSPACK_AMD_KNN_STAGE=0: irs_knn_fetch copies from the device into the caller's arrays, as before round 5)
+      const size_t bytes = cap * (sizeof(double) + sizeof(int32_t));
+      if (bytes <= (size_t(1) << 30) && env_flag("IRSPACK_AMD_KNN_STAGE", true)) {
+        if (c->stage_bytes < bytes) {
+          if (c->stage) (void)hipHostFree(c->stage);
+          c->stage = nullptr;
+          c->stage_bytes = 0;
+          if (hipHostMalloc(reinterpret_cast<void **>(&c->stage), bytes, hipHostMallocDefault) == hipSuccess)
+            c->stage_bytes = bytes;
+          else
+            (void)hipGetLastError();  // (no page-locked memory to be had: fetch from the device)
+        }
+        use_stage = c->stage_bytes >= bytes;
+        c->stage_idx_offset = cap * sizeof(double);
+      }
+      IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
+      // [3 k + 0] pairs, [3 k + 1] pairs of the redo list, [3 k + 2] length of the redo list of chunk k
+      sc.cursor.alloc(3 * static_cast<size_t>(n_chunks));
+      IRS_HIP(hipMemsetAsync(sc.cursor.ptr, 0, 3 * static_cast<size_t>(n_chunks) * sizeof(int32_t), s));
+      IRS_HIP(hipEventRecord(c->ev_setup, s));
+      IRS_HIP(hipStreamWaitEvent(c->stream_k, c->ev_setup, 0));
+      IRS_HIP(hipEventCreate(&ev_first));
+      IRS_HIP(hipEventCreate(&ev_last));
+    }
+    // A chunk whose kernels are done: its counts come back, its rows of the CSR get their places (the
+    // chunks are contiguous row ranges: the offsets continue from the chunk before), its winners are
+    // compacted on the device and copied to the staging buffer - all on a stream of its own beside the
+    // kernels of the later chunks.
+    int retired = 0;
+    bool ev_first_recorded = false;
+    auto retire = [&](int j) {
+      const int64_t rel0 = cb[j] - row_begin, nc = cb[j + 1] - cb[j];
+      if (nc <= 0 || !ev_done[j]) return;
+      // (the counts on the call's own stream, idle until the end: behind the earlier chunks' result copies
+      // on s_out - copy kernels that crawl while the tile kernels hold the compute units - this thread
+      // would wait milliseconds and launch the next chunk late)
+      IRS_HIP(hipStreamWaitEvent(s, ev_done[j], 0));
+      IRS_HIP(hipMemcpyAsync(h_cnt.data() + rel0, out_cnt.ptr + rel0, nc * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      IRS_HIP(hipStreamSynchronize(s));
+      IRS_HIP(hipStreamWaitEvent(s_out, ev_done[j], 0));
+      for (int64_t i = rel0; i < rel0 + nc; i++) c->res_ptr[i + 1] = c->res_ptr[i] + h_cnt[slot_of[i]];
+      const int64_t q0 = c->res_ptr[rel0], q1 = c->res_ptr[rel0 + nc];
+      if (q1 == q0) return;
+      IRS_HIP(hipMemcpyAsync(sc.res_ptr.ptr + rel0, c->res_ptr.data() + rel0, (nc + 1) * sizeof(int64_t),
+                             hipMemcpyHostToDevice, s_out));
+      hipLaunchKernelGGL(knn_compact_kernel, dim3(static_cast<unsigned>(ceil_div(nc, 4))), dim3(256), 0, s_out,
+                         out_idx.ptr, out_val.ptr, sc.slot_of.ptr + rel0, sc.res_ptr.ptr + rel0, nc,
+                         static_cast<int32_t>(out_k), c->res_idx.ptr, c->res_val.ptr);
+      IRS_HIP(hipGetLastError());
+      if (use_stage) {
+        IRS_HIP(hipMemcpyAsync(c->stage + static_cast<size_t>(q0) * sizeof(double), c->res_val.ptr + q0,
+                               static_cast<size_t>(q1 - q0) * sizeof(double), hipMemcpyDeviceToHost, s_out));
+        IRS_HIP(hipMemcpyAsync(c->stage + c->stage_idx_offset + static_cast<size_t>(q0) * sizeof(int32_t),
+                               c->res_idx.ptr + q0, static_cast<size_t>(q1 - q0) * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, s_out));
+      }
+    };
+    pt.mark("set-up");
+    for (int ck = 0; ck < n_chunks; ck++) {
+      const int64_t r_lo = cb[ck], r_hi = cb[ck + 1], nc = r_hi - r_lo, rel0 = r_lo - row_begin;
+      if (nc <= 0 && n > 0) continue;
+      const int64_t ce_begin = ip[r_lo], ce_end = ip[r_hi];
+      std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0), any_wide(0), any_pop(0);
+      std::atomic<int64_t> skipped(0);  // multiply-adds the dense block stands for
+      {
+        const int n_thr = static_cast<int>(std::max<int64_t>(
+            1, std::min<int64_t>({host_thread_cap(), static_cast<int64_t>(std::thread::hardware_concurrency()),
+                                  (ce_end - ce_begin) / 200000 + 1})));
+        auto body = [&](int th) {
+          // contiguous row chunks of about equal entry counts
+          const int64_t lo_e = ce_begin + (ce_end - ce_begin) * th / n_thr;
+          const int64_t hi_e = ce_begin + (ce_end - ce_begin) * (th + 1) / n_thr;
+          int64_t r0 = std::lower_bound(ip + r_lo, ip + r_hi, lo_e) - ip;
+          int64_t r1 = th + 1 == n_thr ? r_hi : std::lower_bound(ip + r_lo, ip + r_hi, hi_e) - ip;
+          if (th == 0) r0 = r_lo;
+          bool bad = false, ones = true, safe = true, positive = true;
+          // The usual case - every stored value of the chunk is exactly 1 (binary interactions) -
+          // is recognised by one tight pass over the values (a branch-free AND the compiler
+          // vectorises); the row loop then only walks the indices.
+          bool chunk_ones = true;
+          if (!binarise && r1 > r0) {
+            uint64_t diff = 0;
+            const uint64_t one_bits = 0x3ff0000000000000ull;
+            const uint64_t *vb = reinterpret_cast<const uint64_t *>(dv);
+            for (int64_t q = ip[r0]; q < ip[r1]; q++) diff |= vb[q] ^ one_bits;
+            chunk_ones = diff == 0;
+          }
+          const bool unit = binarise || chunk_ones;
+          for (int64_t i = r0; i < r1; i++) {
+            if (ip[i + 1] < ip[i]) { bad = true; break; }
+            double ss = 0, bound = 0, minprod = std::numeric_limits<double>::infinity();
+            int64_t w = 0;
+            if (unit) {
+              if (cols <= 0 && ip[i + 1] > ip[i]) { bad = true; break; }
+              int32_t lo_j = 0, hi_j = 0;  // running min / max: one range test per row
+              for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
+                const int32_t j = ix[q];
+                lo_j = std::min(lo_j, j);
+                hi_j = std::max(hi_j, j);
+                const int32_t jc = std::min(std::max(j, 0), static_cast<int32_t>(cols - 1));
+                w += c->xt_row_len[jc];
+                bound += c->xt_rowmax[jc];
+                if (c->xt_rowmin[jc] > 0.0) minprod = std::min(minprod, c->xt_rowmin[jc]);
+              }
+              if (lo_j < 0 || hi_j >= cols) { bad = true; break; }
+              ss = static_cast<double>(ip[i + 1] - ip[i]);
+              if (dense && c->pop_rank[i] >= 0) {
+                const int32_t k = c->pop_rank[i];
+                const int64_t len = c->pop_ptr[k + 1] - c->pop_ptr[k];
+                if (len == ip[i + 1] - ip[i] &&
+                    std::memcmp(ix + ip[i], c->pop_idx.data() + c->pop_ptr[k], static_cast<size_t>(len) * sizeof(int32_t)) == 0) {
+                  tpop[i - row_begin] = k;
+                  any_pop.store(1, std::memory_order_relaxed);
+                  skipped.fetch_add(w, std::memory_order_relaxed);
+                  w = 0;  // the walk of a popular row skips the popular columns
+                  for (int64_t q = ip[i]; q < ip[i + 1]; q++) w += c->xt_row_len_np[ix[q]];
+                  skipped.fetch_sub(w, std::memory_order_relaxed);
+                }
+              }
+            } else {
+              for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
+                const int32_t j = ix[q];
+                if (j < 0 || j >= cols) { bad = true; break; }
+                const double x = dv[q];  // similarities.hpp:113-118, 165-170
+                ss += x * x;
+                w += c->xt_row_len[j];
+                ones &= x == 1.0;
+                positive &= x > 0.0;
+                const double ax = std::fabs(x);
+                safe &= ax > 1e-150 && ax < 1e150;  // no stored zero, no underflow of x * y
+                bound += ax * c->xt_rowmax[j];      // >= |any sum of this product row|
+                if (ax > 0.0 && c->xt_rowmin[j] > 0.0) minprod = std::min(minprod, ax * c->xt_rowmin[j]);
+              }
+            }
+            if (bad) break;
+            switch (c->sim_type) {
+              case IRS_SIM_COSINE: tstat[i - row_begin] = std::sqrt(ss); break;             // :39
+              case IRS_SIM_ASYMMETRIC: tstat[i - row_begin] = std::pow(ss, c->alpha); break; // :78-79
+              case IRS_SIM_JACCARD:
+              case IRS_SIM_TVERSKY:
+                tstat[i - row_begin] = static_cast<double>(ip[i + 1] - ip[i]);            // :122, :174
+                break;
+              default: break;
+            }
+            work[i - row_begin] = w;
+            // fixed-point scale of the row: 2^s with bound * 2^s < 2^61
+            if (bound > 0 && std::isfinite(bound)) {
+              int ex = 0;
+              (void)std::frexp(bound, &ex);  // bound < 2^ex
+              tscale[i - row_begin] = std::ldexp(1.0, 61 - ex);
+              // One limb rounds every product to a multiple of 2^-s ~ bound 2^-61: 1e-13 of the row's
+              // smallest possible product as long as bound / minprod < 2.3e5.  Beyond that (weights
+              // over many decades, very long rows) the row is summed in two limbs (negative scale):
+              // twice the accumulation time, 2^-40 of the rounding step.
+              if (wide_ok && std::isfinite(minprod) && bound > wide_ratio * minprod) {
+                tscale[i - row_begin] = -tscale[i - row_begin];
+                any_wide.store(1, std::memory_order_relaxed);
+              }
+            }
+          }
+          if (!positive) not_positive.store(1);
+          if (bad) bad_index.store(1);
+          if (!ones) not_ones.store(1);
+          if (!safe) unsafe.store(1);
+        };
+        run_on_threads(n_thr, body);
+      }
+      check_arg(bad_index.load() == 0, "malformed matrix: column index out of range or indptr not monotone.");
+      const bool t_all_ones = not_ones.load() == 0, t_safe = unsafe.load() == 0;
+      pt.mark("target pass");
+      if (!have_work) continue;
+      // rows of the chunk, heaviest product row first (ids relative to the chunk's first row)
+      int64_t chunk_macs = 0;
+      for (int64_t i = 0; i < nc; i++) chunk_macs += work[rel0 + i];
+      chunk_macs += skipped.load();  // (the product's multiply-adds, however obtained)
+      c->last_macs += chunk_macs;
+      {  // Heaviest rows first, for the load balance of the persistent launch only (results do
+         // not depend on it): a counting sort by 1/64-octave of the work, rows of a bucket in
+         // row order - O(n) instead of a 1.2 ms comparison sort.
+        constexpr int NB = 64 * 64;
+        auto bucket = [&](int64_t w) {
+          const int b = static_cast<int>(std::log2(static_cast<double>(w) + 1.0) * 64.0);
+          return NB - 1 - std::min(std::max(b, 0), NB - 1);
+        };
+        std::vector<int32_t> start(NB + 1, 0);
+        std::vector<int32_t> bk(nc);
+        for (int64_t i = 0; i < nc; i++) {
+          bk[i] = bucket(work[rel0 + i]);
+          start[bk[i] + 1]++;
+        }
+        for (int b = 0; b < NB; b++) start[b + 1] += start[b];
+        for (int64_t i = 0; i < nc; i++) order[rel0 + start[bk[i]]++] = static_cast<int32_t>(i);
+      }
+      pt.mark("work + order");
+      // which accumulator: 32-bit counts when every product is 1, else fp64 sums with the -0.0
+      // sentinel unless some product could be a zero
+      // (the sentinel of the fixed-point sums needs positive data: a sum must not return to the
+      // "untouched" pattern by cancellation)
+      const bool sentinel = c->xt_nonzero && t_safe && c->xt_positive && not_positive.load() == 0;
+      const bool acc32 = c->xt_all_ones && sentinel && t_all_ones;
+      // the chunk's inputs, on their own stream (the kernels of the chunk before are still running on `s`)
+      const size_t cne = static_cast<size_t>(ce_end - ce_begin);
       if (acc32) {
         t_val.alloc(1);
-      } else if (binarise) {
-        std::vector<double> ones(std::max<size_t>(ne, 1), 1.0);
-        t_val.upload(ones, s);
-        IRS_HIP(hipStreamSynchronize(s));
       } else {
-        t_val.upload(dv + e_begin, std::max<size_t>(ne, 1), s);
+        t_val.alloc(std::max<size_t>(ne, 1));  // (whole call: the row pointers are relative to its first entry)
+        if (binarise) {
+          if (cne) IRS_HIP(hipMemcpyAsync(t_val.ptr + (ce_begin - e_begin), ones_host.data(), cne * sizeof(double),
+                                          hipMemcpyHostToDevice, s_in));
+        } else if (cne) {
+          IRS_HIP(hipMemcpyAsync(t_val.ptr + (ce_begin - e_begin), dv + ce_begin, cne * sizeof(double),
+                                 hipMemcpyHostToDevice, s_in));
+        }
       }
-      t_stat.upload(tstat, s);
-      t_scale.upload(tscale, s);
+      IRS_HIP(hipMemcpyAsync(t_stat.ptr + rel0, tstat.data() + rel0, nc * sizeof(double), hipMemcpyHostToDevice, s_in));
+      IRS_HIP(hipMemcpyAsync(t_scale.ptr + rel0, tscale.data() + rel0, nc * sizeof(double), hipMemcpyHostToDevice, s_in));
+      IRS_HIP(hipMemcpyAsync(d_order.ptr + rel0, order.data() + rel0, nc * sizeof(int32_t), hipMemcpyHostToDevice, s_in));
+      // (slots are work-ordered inside their chunk; the compaction reads the inverse map)
+      for (int64_t sl = 0; sl < nc; sl++) slot_of[rel0 + order[rel0 + sl]] = static_cast<int32_t>(rel0 + sl);
+      IRS_HIP(hipMemcpyAsync(sc.slot_of.ptr + rel0, slot_of.data() + rel0, nc * sizeof(int32_t), hipMemcpyHostToDevice, s_in));
+      const size_t slots = static_cast<size_t>(nc) * n_tiles;
+      Params p;
+      p.xt_tptr = c->xt_tptr.ptr;
+      p.xt_idx16 = c->xt_idx16.ptr;
+      p.xt_val = c->xt_val.ptr;
+      p.norms = c->norms.ptr;
+      p.t_ptr = t_ptr.ptr + rel0;  // (values relative to the CALL's first entry, like t_idx / t_val)
+      p.t_idx = t_idx.ptr;
+      p.t_val = t_val.ptr;
+      p.t_stat = t_stat.ptr + rel0;
+      p.t_scale = t_scale.ptr + rel0;
+      p.hi_stash = nullptr;
+      p.t_pop = nullptr;
+      p.pop_C = c->pop_C.ptr;
+      p.pop_col = c->pop_col.ptr;
+      p.pop_tile_ptr = c->pop_tile_ptr.ptr;
+      p.pop_n = c->pop_n;
+      p.xt_tptr_np = c->xt_tptr_np.ptr;
+      p.xt_idx16_np = c->xt_idx16_np.ptr;
+      if (dense && acc32 && any_pop.load()) {
+        sc.t_pop.alloc(n);
+        IRS_HIP(hipMemcpyAsync(sc.t_pop.ptr + rel0, tpop.data() + rel0, nc * sizeof(int32_t), hipMemcpyHostToDevice, s_in));
+        p.t_pop = sc.t_pop.ptr + rel0;
+      }
+      hipStream_t ks = c->stream_k;
+      IRS_HIP(hipEventRecord(c->ev_in, s_in));
+      IRS_HIP(hipStreamWaitEvent(ks, c->ev_in, 0));
+      c->last_walked += p.t_pop ? chunk_macs - skipped.load() : chunk_macs;  // added one by one
+      p.row_order = d_order.ptr + rel0;
+      p.n_rows = static_cast<int32_t>(nc);
+      p.n_tiles = n_tiles;
+      p.N = static_cast<int32_t>(c->N);
+      p.sim_type = c->sim_type;
+      p.normalize = c->normalize ? 1 : 0;
+      p.shrinkage = c->shrinkage;
+      p.alpha = c->alpha;
+      p.beta = c->beta;
+      p.shrink_f = static_cast<float>(c->shrinkage);
+      p.alpha_f = static_cast<float>(c->alpha);
+      p.beta_f = static_cast<float>(c->beta);
+      p.top_k = static_cast<int32_t>(out_k);
+      p.tile_k = static_cast<int32_t>(tile_k);
+      const size_t slot0 = static_cast<size_t>(rel0) * n_tiles;  // the chunk's first (row slot, tile) pair
+      p.cand_idx = sc.cand_idx.ptr + slot0 * tile_k;
+      p.cand_val = sc.cand_val.ptr + slot0 * tile_k;
+      p.cand_cnt = sc.cand_cnt.ptr + slot0;
+      p.out_idx = out_idx.ptr + static_cast<size_t>(rel0) * out_k;
+      p.out_val = out_val.ptr + static_cast<size_t>(rel0) * out_k;
+      p.out_cnt = out_cnt.ptr + rel0;
+      const size_t lds = TILE * sizeof(double) + (TILE / 32) * sizeof(uint32_t) +
+                         256 * sizeof(uint32_t) + 16 * sizeof(int32_t) + 64 * sizeof(double);
+      p.cursor = sc.cursor.ptr + 3 * ck;
+      p.redo_count = p.cursor + 2;
+      p.redo_list = nullptr;
+      p.redo = 0;
+      {  // merge buffer: all tiles' candidates at once when they fit, else rounds of MERGE_CAP
+        int64_t want = std::max<int64_t>(2 * out_k, std::min<int64_t>(int64_t(n_tiles) * out_k, MERGE_CAP));
+        int cap = 64;
+        while (cap < want) cap <<= 1;
+        p.merge_cap = std::min(cap, MERGE_CAP);
+      }
+      p.n_slots = static_cast<int32_t>(slots);
+      // persistent launch: one resident workgroup per CU (its LDS footprint allows no second)
+      const unsigned grid = static_cast<unsigned>(std::min<size_t>(slots, static_cast<size_t>(std::max(n_cu, 1))));
+      if (!acc32 && any_wide.load()) {  // first limbs of the wide-range pairs, one tile per resident workgroup
+        sc.hi_stash.alloc(static_cast<size_t>(std::max(n_cu, 1)) * TILE);
+        p.hi_stash = sc.hi_stash.ptr;
+      }
+      auto launch = [&](auto kernel) {
+        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    static_cast<int>(lds)));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(THREADS), lds, ks, p);
+      };
+      // the chunk's column indices must have arrived (the uploader works ahead of the walk)
+      while (uploaded.load(std::memory_order_acquire) <= ck) std::this_thread::yield();
+      if (!upload_error.empty()) throw std::runtime_error(upload_error);
+      pt.mark("uploads + flags");
+      if (!ev_first_recorded) {
+        IRS_HIP(hipEventRecord(ev_first, ks));
+        ev_first_recorded = true;
+      }
+      // IRSPACK_AMD_KNN_COMPACT=1 (opt-in, a measured NEGATIVE result): counts (binary data) on two
+      // 512-thread workgroups per CU with 66 KB of LDS each, so that one pair's epilogue / selection
+      // overlaps the other's accumulation.  Same results (tests/test_gpu_knn.py runs both), same
+      // time: 10.69 against 10.54 ms per ML-20M call - the phases of one pair do not leave the CU
+      // idle, they keep different units busy in turn (LDS atomics at 77 % of their rate, then fp64
+      // divisions), and two half-size workgroups issue the same instructions with 32 instead of 16
+      // keys per thread (128 registers, 51 spilled dwords).  DESIGN.md 3.4.
+      const char *compact_env = std::getenv("IRSPACK_AMD_KNN_COMPACT");  // (read per call: tests toggle it)
+      const bool compact = compact_env && compact_env[0] == '1';
+      if (c->xt_all_ones && acc32 && compact) {
+        const size_t lds_c = TILE * sizeof(uint32_t) + 64 * sizeof(uint32_t) + 256 * sizeof(uint32_t) +
+                             16 * sizeof(int32_t);
+        auto kernel = knn_tile_kernel<true, true, true, 512, true>;
+        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_c)));
+        const unsigned grid_c = static_cast<unsigned>(
+            std::min<size_t>(slots, 2 * static_cast<size_t>(std::max(n_cu, 1))));
+        hipLaunchKernelGGL(kernel, dim3(grid_c), dim3(512), lds_c, ks, p);
+      } else if (c->xt_all_ones) {
+        // counts + a similarity that ends in a division: selection on float32 approximations, exact
+        // fp64 values for the candidates only (knn_tile_kernel, FAST).  The error bound of the
+        // approximation needs non-negative terms in the denominator.  IRSPACK_AMD_KNN_FAST=0: A/B.
+        const char *fast_env = std::getenv("IRSPACK_AMD_KNN_FAST");  // (read per call: tests toggle it)
+        // (un-normalised cosine: the similarity IS the count - no division to save, but the 32-bit
+        // select and the candidate ranking replace the 64-bit select over every column)
+        const bool divides = c->sim_type == IRS_SIM_COSINE || c->sim_type == IRS_SIM_ASYMMETRIC ||
+                             c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
+        // (Tversky: norms(j) - v and target_norm - v are exact in float32 only for counts below
+        // 2^24; with larger ones and weights of 16 the approximation was measured at 2.1e-6 from the
+        // float64 value - tests/test_knn_approx_bound.py - too close to the candidate margin)
+        const bool tv_ok = c->sim_type != IRS_SIM_TVERSKY ||
+                           (p.alpha >= 0.0 && p.alpha <= 16.0 && p.beta >= 0.0 && p.beta <= 16.0 &&
+                            c->norm_max < 16777216.0 &&
+                            *std::max_element(tstat.begin() + rel0, tstat.begin() + rel0 + nc) < 16777216.0);
+        // (asymmetric cosine: norms are s^(1 - alpha) and s^alpha - inside [1, s] only for alpha in
+        // [0, 1]; outside, a float32 norm may underflow where the float64 one does not)
+        const bool as_ok = c->sim_type != IRS_SIM_ASYMMETRIC || (p.alpha >= 0.0 && p.alpha <= 1.0);
+        // (the candidate list holds FAST_CAP columns: a request for more than half of that would send
+        // most pairs to the redo list, i.e. accumulate them twice)
+        const bool fast = acc32 && !big && p.top_k <= FAST_CAP / 2 && divides && tv_ok && as_ok && p.shrinkage >= 0.0 &&
+                          p.shrinkage < 1e30 &&
+                          !(fast_env && fast_env[0] == '0');
+        if (fast) {
+          sc.redo_list.alloc(static_cast<size_t>(n) * n_tiles);
+          p.redo_list = sc.redo_list.ptr + slot0;
+          launch(knn_tile_kernel<true, true, true, THREADS, false, true>);
+          p.redo = 1;  // the pairs the approximate selection handed back (usually none), exactly
+          launch(knn_tile_kernel<true, true, true>);
+          p.redo = 0;
+        } else if (acc32) launch(knn_tile_kernel<true, true, true>);
+        else if (sentinel) launch(knn_tile_kernel<true, true>);
+        else launch(knn_tile_kernel<true, false>);
+      } else {
+        if (sentinel) launch(knn_tile_kernel<false, true>); else launch(knn_tile_kernel<false, false>);
+      }
+      if (big) {
+        hipLaunchKernelGGL(knn_merge_big_kernel, dim3(static_cast<unsigned>(nc)), dim3(256), 0, ks, p);
+      } else {
+        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_CAP * 20));
+        hipLaunchKernelGGL(knn_merge_kernel, dim3(static_cast<unsigned>(nc)), dim3(256),
+                           static_cast<size_t>(p.merge_cap) * 20, ks, p);
+      }
+      IRS_HIP(hipEventCreateWithFlags(&ev_done[ck], hipEventDisableTiming));
+      IRS_HIP(hipEventRecord(ev_done[ck], ks));
+      IRS_HIP(hipGetLastError());
+      pt.mark("launches");
+      // chunks that have finished meanwhile
+      while (retired < ck && (!ev_done[retired] || hipEventQuery(ev_done[retired]) == hipSuccess)) retire(retired++);
+      (void)hipGetLastError();  // (hipErrorNotReady of the query)
     }
-    d_order.upload(order, s);
-    const size_t slots = static_cast<size_t>(n) * n_tiles;
-    cand_idx.alloc(slots * tile_k);
-    cand_val.alloc(slots * tile_k);
-    cand_cnt.alloc(slots);
-    out_idx.alloc(static_cast<size_t>(n) * out_k);
-    out_val.alloc(static_cast<size_t>(n) * out_k);
-    out_cnt.alloc(n);
-    Params p;
-    p.xt_tptr = c->xt_tptr.ptr;
-    p.xt_idx16 = c->xt_idx16.ptr;
-    p.xt_val = c->xt_val.ptr;
-    p.norms = c->norms.ptr;
-    p.t_ptr = t_ptr.ptr;
-    p.t_idx = t_idx.ptr;
-    p.t_val = t_val.ptr;
-    p.t_stat = t_stat.ptr;
-    p.t_scale = t_scale.ptr;
-    p.hi_stash = nullptr;
-    p.t_pop = nullptr;
-    p.pop_C = c->pop_C.ptr;
-    p.pop_col = c->pop_col.ptr;
-    p.pop_tile_ptr = c->pop_tile_ptr.ptr;
-    p.pop_n = c->pop_n;
-    p.xt_tptr_np = c->xt_tptr_np.ptr;
-    p.xt_idx16_np = c->xt_idx16_np.ptr;
-    if (dense && acc32 && any_pop.load()) {
-      sc.t_pop.upload(tpop, s);
-      p.t_pop = sc.t_pop.ptr;
-    }
-    c->last_walked = p.t_pop ? c->last_macs - skipped.load() : c->last_macs;  // added one by one
-    p.row_order = d_order.ptr;
-    p.n_rows = static_cast<int32_t>(n);
-    p.n_tiles = n_tiles;
-    p.N = static_cast<int32_t>(c->N);
-    p.sim_type = c->sim_type;
-    p.normalize = c->normalize ? 1 : 0;
-    p.shrinkage = c->shrinkage;
-    p.alpha = c->alpha;
-    p.beta = c->beta;
-    p.shrink_f = static_cast<float>(c->shrinkage);
-    p.alpha_f = static_cast<float>(c->alpha);
-    p.beta_f = static_cast<float>(c->beta);
-    p.top_k = static_cast<int32_t>(out_k);
-    p.tile_k = static_cast<int32_t>(tile_k);
-    p.cand_idx = cand_idx.ptr;
-    p.cand_val = cand_val.ptr;
-    p.cand_cnt = cand_cnt.ptr;
-    p.out_idx = out_idx.ptr;
-    p.out_val = out_val.ptr;
-    p.out_cnt = out_cnt.ptr;
-    const size_t lds = TILE * sizeof(double) + (TILE / 32) * sizeof(uint32_t) +
-                       256 * sizeof(uint32_t) + 16 * sizeof(int32_t) + 64 * sizeof(double);
-    // persistent launch: one resident workgroup per CU (its LDS footprint allows no second)
-    int n_cu = 0;
-    IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-    DeviceBuffer<int32_t> &cursor = sc.cursor;
-    cursor.alloc(3);  // [0] pairs, [1] pairs of the redo list, [2] length of the redo list
-    IRS_HIP(hipMemsetAsync(cursor.ptr, 0, 3 * sizeof(int32_t), s));
-    p.cursor = cursor.ptr;
-    p.redo_count = cursor.ptr + 2;
-    p.redo_list = nullptr;
-    p.redo = 0;
-    {  // merge buffer: all tiles' candidates at once when they fit, else rounds of MERGE_CAP
-      int64_t want = std::max<int64_t>(2 * out_k, std::min<int64_t>(int64_t(n_tiles) * out_k, MERGE_CAP));
-      int cap = 64;
-      while (cap < want) cap <<= 1;
-      p.merge_cap = std::min(cap, MERGE_CAP);
-    }
-    p.n_slots = static_cast<int32_t>(slots);
-    const unsigned grid = static_cast<unsigned>(std::min<size_t>(slots, static_cast<size_t>(std::max(n_cu, 1))));
-    if (!acc32 && any_wide.load()) {  // first limbs of the wide-range pairs, one tile per resident workgroup
-      sc.hi_stash.alloc(static_cast<size_t>(grid) * TILE);
-      p.hi_stash = sc.hi_stash.ptr;
-    }
-    auto launch = [&](auto kernel) {
-      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(lds)));
-      hipLaunchKernelGGL(kernel, dim3(grid), dim3(THREADS), lds, s, p);
-    };
-    pt.mark("uploads + flags");
-    hipEvent_t ev0, ev1;
-    IRS_HIP(hipEventCreate(&ev0));
-    IRS_HIP(hipEventCreate(&ev1));
-    IRS_HIP(hipEventRecord(ev0, s));
-    // IRSPACK_AMD_KNN_COMPACT=1 (opt-in, a measured NEGATIVE result): counts (binary data) on two
-    // 512-thread workgroups per CU with 66 KB of LDS each, so that one pair's epilogue / selection
-    // overlaps the other's accumulation.  Same results (tests/test_gpu_knn.py runs both), same
-    // time: 10.69 against 10.54 ms per ML-20M call - the phases of one pair do not leave the CU
-    // idle, they keep different units busy in turn (LDS atomics at 77 % of their rate, then fp64
-    // divisions), and two half-size workgroups issue the same instructions with 32 instead of 16
-    // keys per thread (128 registers, 51 spilled dwords).  DESIGN.md 3.4.
-    const char *compact_env = std::getenv("IRSPACK_AMD_KNN_COMPACT");  // (read per call: tests toggle it)
-    const bool compact = compact_env && compact_env[0] == '1';
-    if (c->xt_all_ones && acc32 && compact) {
-      const size_t lds_c = TILE * sizeof(uint32_t) + 64 * sizeof(uint32_t) + 256 * sizeof(uint32_t) +
-                           16 * sizeof(int32_t);
-      auto kernel = knn_tile_kernel<true, true, true, 512, true>;
-      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_c)));
-      const unsigned grid_c = static_cast<unsigned>(
-          std::min<size_t>(slots, 2 * static_cast<size_t>(std::max(n_cu, 1))));
-      hipLaunchKernelGGL(kernel, dim3(grid_c), dim3(512), lds_c, s, p);
-    } else if (c->xt_all_ones) {
-      // counts + a similarity that ends in a division: selection on float32 approximations, exact
-      // fp64 values for the candidates only (knn_tile_kernel, FAST).  The error bound of the
-      // approximation needs non-negative terms in the denominator.  IRSPACK_AMD_KNN_FAST=0: A/B.
-      const char *fast_env = std::getenv("IRSPACK_AMD_KNN_FAST");  // (read per call: tests toggle it)
-      // (un-normalised cosine: the similarity IS the count - no division to save, but the 32-bit
-      // select and the candidate ranking replace the 64-bit select over every column)
-      const bool divides = c->sim_type == IRS_SIM_COSINE || c->sim_type == IRS_SIM_ASYMMETRIC ||
-                           c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
-      // (Tversky: norms(j) - v and target_norm - v are exact in float32 only for counts below
-      // 2^24; with larger ones and weights of 16 the approximation was measured at 2.1e-6 from the
-      // float64 value - tests/test_knn_approx_bound.py - too close to the candidate margin)
-      const bool tv_ok = c->sim_type != IRS_SIM_TVERSKY ||
-                         (p.alpha >= 0.0 && p.alpha <= 16.0 && p.beta >= 0.0 && p.beta <= 16.0 &&
-                          c->norm_max < 16777216.0 && *std::max_element(tstat.begin(), tstat.end()) < 16777216.0);
-      // (asymmetric cosine: norms are s^(1 - alpha) and s^alpha - inside [1, s] only for alpha in
-      // [0, 1]; outside, a float32 norm may underflow where the float64 one does not)
-      const bool as_ok = c->sim_type != IRS_SIM_ASYMMETRIC || (p.alpha >= 0.0 && p.alpha <= 1.0);
-      // (the candidate list holds FAST_CAP columns: a request for more than half of that would send
-      // most pairs to the redo list, i.e. accumulate them twice)
-      const bool fast = acc32 && !big && p.top_k <= FAST_CAP / 2 && divides && tv_ok && as_ok && p.shrinkage >= 0.0 &&
-                        p.shrinkage < 1e30 &&
-                        !(fast_env && fast_env[0] == '0');
-      if (fast) {
-        sc.redo_list.alloc(slots);
-        p.redo_list = sc.redo_list.ptr;
-        launch(knn_tile_kernel<true, true, true, THREADS, false, true>);
-        p.redo = 1;  // the pairs the approximate selection handed back (usually none), exactly
-        launch(knn_tile_kernel<true, true, true>);
-        p.redo = 0;
-      } else if (acc32) launch(knn_tile_kernel<true, true, true>);
-      else if (sentinel) launch(knn_tile_kernel<true, true>);
-      else launch(knn_tile_kernel<true, false>);
-    } else {
-      if (sentinel) launch(knn_tile_kernel<false, true>); else launch(knn_tile_kernel<false, false>);
-    }
-    if (big) {
-      hipLaunchKernelGGL(knn_merge_big_kernel, dim3(static_cast<unsigned>(n)), dim3(256), 0, s, p);
-    } else {
-      IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_merge_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_CAP * 20));
-      hipLaunchKernelGGL(knn_merge_kernel, dim3(static_cast<unsigned>(n)), dim3(256),
-                         static_cast<size_t>(p.merge_cap) * 20, s, p);
-    }
-    IRS_HIP(hipEventRecord(ev1, s));
-    IRS_HIP(hipGetLastError());
-    std::vector<int32_t> h_cnt(n);
-    IRS_HIP(hipMemcpyAsync(h_cnt.data(), out_cnt.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (!have_work) return;
+    for (; retired < n_chunks; retired++) retire(retired);  // (waits for each in turn)
+    for (int ck = 0; ck < n_chunks; ck++)
+      if (ev_done[ck]) IRS_HIP(hipStreamWaitEvent(s, ev_done[ck], 0));
+    IRS_HIP(hipEventRecord(ev_last, s));
+    IRS_HIP(hipStreamSynchronize(s_out));
     IRS_HIP(hipStreamSynchronize(s));
-    float ms = 0;
-    IRS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    c->last_ms = ms;
-    pt.mark("kernels + D2H");
+    if (ev_first_recorded) {  // first launch .. last merge, the waits for the host in between included
+      float ms = 0;
+      IRS_HIP(hipEventElapsedTime(&ms, ev_first, ev_last));
+      c->last_ms = ms;
+    }
+    c->res_nnz = c->res_ptr[n];
+    c->staged = use_stage && c->res_nnz > 0;
+    pt.mark("kernels + retire");
 #ifdef IRS_KNN_PHASES
     {
       unsigned long long h[8] = {0}, z[8] = {0};
       IRS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(knn_phase_clk), sizeof(h)));
       IRS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(knn_phase_clk), z, sizeof(z)));
-      fprintf(stderr, "knn phases (10 ns ticks, sum over %lld WGs): init %llu acc %llu bitmap %llu epi %llu select %llu write %llu\n",
-              static_cast<long long>(slots), h[0], h[1], h[2], h[3], h[4], h[5]);
+      fprintf(stderr, "knn phases (10 ns ticks, sum over the WGs): init %llu acc %llu bitmap %llu epi %llu select %llu write %llu\n",
+              h[0], h[1], h[2], h[3], h[4], h[5]);
       IRS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(knn_fast_stat), sizeof(h)));
       IRS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(knn_fast_stat), z, sizeof(z)));
       fprintf(stderr, "knn fast path: pairs %llu exact-path %llu candidates %llu; pairs with <= 128 / 256 / 512 / 1024 candidates: %llu %llu %llu %llu\n",
               h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
     }
 #endif
-    // the CSR in target-row order (slots are work-ordered), compacted on the device
-    std::vector<int32_t> slot_of(n);
-    for (int64_t sl = 0; sl < n; sl++) slot_of[order[sl]] = static_cast<int32_t>(sl);
-    for (int64_t i = 0; i < n; i++) c->res_ptr[i + 1] = c->res_ptr[i] + h_cnt[slot_of[i]];
-    c->res_nnz = c->res_ptr[n];
-    if (c->res_nnz > 0) {
-      DeviceBuffer<int32_t> &d_slot_of = sc.slot_of;
-      DeviceBuffer<int64_t> &d_res_ptr = sc.res_ptr;
-      d_slot_of.upload(slot_of, s);
-      d_res_ptr.upload(c->res_ptr, s);
-      c->res_idx.alloc(static_cast<size_t>(c->res_nnz));
-      c->res_val.alloc(static_cast<size_t>(c->res_nnz));
-      hipLaunchKernelGGL(knn_compact_kernel, dim3(static_cast<unsigned>(ceil_div(n, 4))), dim3(256), 0, s,
-                         out_idx.ptr, out_val.ptr, d_slot_of.ptr, d_res_ptr.ptr, n,
-                         static_cast<int32_t>(out_k), c->res_idx.ptr, c->res_val.ptr);
-      IRS_HIP(hipGetLastError());
-      IRS_HIP(hipStreamSynchronize(s));  // the scratch buffers of this call go out of scope
-    }
     *nnz_out = c->res_ptr[n];
     pt.mark("assemble");
   });
@@ -2125,7 +2299,15 @@ irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
   return guard([&] {
     check_arg(c && indptr, "null argument.");
     std::copy(c->res_ptr.begin(), c->res_ptr.end(), indptr);
-    if (c->res_nnz > 0) {  // device -> the caller's arrays, one copy each
+    if (c->res_nnz > 0 && c->staged) {  // page-locked copy of the result -> the caller's arrays
+      check_arg(indices && data, "null argument.");
+      const double *sv = reinterpret_cast<const double *>(c->stage);
+      const int32_t *si = reinterpret_cast<const int32_t *>(c->stage + c->stage_idx_offset);
+      parallel_ranges(c->res_nnz, [&](int64_t lo, int64_t hi) {
+        std::memcpy(data + lo, sv + lo, static_cast<size_t>(hi - lo) * sizeof(double));
+        std::memcpy(indices + lo, si + lo, static_cast<size_t>(hi - lo) * sizeof(int32_t));
+      }, 8, 200000);
+    } else if (c->res_nnz > 0) {  // device -> the caller's arrays, one copy each
       check_arg(indices && data, "null argument.");
       IRS_HIP(hipSetDevice(c->device));
       IRS_HIP(hipMemcpy(indices, c->res_idx.ptr, static_cast<size_t>(c->res_nnz) * sizeof(int32_t),

@@ -204,6 +204,8 @@ def summary(m):
         s["n_fac_orc_over_1e_4"] = int((m["fac_orc"] >= 1e-4).sum())
         s["n_sco_gpu_over_1e_4"] = int((m["sco_gpu"] >= 1e-4).sum())
         s["n_sco_orc_over_1e_4"] = int((m["sco_orc"] >= 1e-4).sum())
+        for k in ("fac_gpu", "fac_orc", "sco_gpu", "sco_orc"):  # (the second threshold of the count bars)
+            s["n_" + k + "_over_1e_3"] = int((m[k] >= 1e-3).sum())
     return s
 
 

@@ -512,3 +512,45 @@ def test_dense_block_of_popular_items(N, U, nnz, P, name, kwargs, monkeypatch):
     plain = g0.compute_similarity(Xt, 40)
     assert g0.dense_block_rows == 0
     assert_same_csr(plain, got, rtol=0)
+
+
+# ---------------------------------------------------------------- row chunks of one call (round 5)
+@pytest.mark.parametrize("chunks", ["1", "3", "7", "64"])
+@pytest.mark.parametrize("kind,kw", CASES)
+def test_row_chunks_of_a_call_are_transparent(kind, kw, chunks, monkeypatch):
+    """A call's rows are walked and launched in chunks so that the host pass and the uploads of chunk
+    k + 1 overlap the kernels of chunk k (IRSPACK_AMD_KNN_CHUNKS; 4 by default on large calls).  Every
+    chunk chooses its accumulator from its own rows: the first third of this target is binary (counts),
+    the rest weighted (fixed-point sums), three rows are empty, one chunk boundary falls on empty rows."""
+    monkeypatch.setenv("IRSPACK_AMD_KNN_CHUNKS", chunks)
+    Xt = sps.csr_matrix(X_many.T).tolil()
+    for r in (0, 170, 171, 511):
+        Xt.rows[r], Xt.data[r] = [], []
+    Xt = sps.csr_matrix(Xt)
+    g, o = make(kind, Xt, **dict(kw))
+    assert_same_csr(g.compute_similarity(Xt, 25), o.compute_similarity(Xt, 25), rtol=1e-12)
+    T = Xt.copy()
+    w = np.random.RandomState(3).uniform(0.5, 2.0, T.nnz)
+    w[: T.indptr[170]] = 1.0
+    T.data = w if kind in ("cosine", "asymmetric") else T.data
+    assert_same_csr(g.compute_similarity(T, 25), o.compute_similarity(T, 25), rtol=1e-12)
+    sel = (100, 400)
+    assert_same_csr(g.compute_similarity(T, 9, rows=sel), o.compute_similarity(T, 9)[sel[0]:sel[1]], rtol=1e-12)
+
+
+@pytest.mark.parametrize("chunks", ["1", "5"])
+def test_row_chunks_compute_w_and_errors(chunks, monkeypatch):
+    monkeypatch.setenv("IRSPACK_AMD_KNN_CHUNKS", chunks)
+    Xt = sps.csr_matrix(X_many.T)
+    g = K.RP3betaComputer(Xt, 0.8, 0.4, 1)
+    o = O.KNNComputer("rp3beta", Xt, alpha=0.8, beta=0.4, n_threads=1)
+    assert_same_csr(g.compute_W(Xt, 30), o.compute_W(Xt, 30), rtol=1e-11)
+    # an index out of range in the LAST chunk is an error although earlier chunks were already launched,
+    # and the computer stays usable
+    bad = Xt.copy()
+    bad.indices = bad.indices.copy()
+    bad.indices[-1] = Xt.shape[1] + 5
+    c = K.CosineSimilarityComputer(Xt, 0.0, True)
+    with pytest.raises(ValueError):
+        c.compute_similarity(bad, 10)
+    assert_same_csr(c.compute_similarity(Xt, 10), O.KNNComputer("cosine", Xt, 0.0, normalize=True, n_threads=1).compute_similarity(Xt, 10))

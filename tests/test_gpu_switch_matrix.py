@@ -95,9 +95,11 @@ KNN_SWITCHES = {
     "wide_on": {"IRSPACK_AMD_KNN_WIDE": "1"},
     "fast_off": {"IRSPACK_AMD_KNN_FAST": "0"},
     "threads_1": {"IRSPACK_AMD_KNN_THREADS": "1"},
+    "chunks_3": {"IRSPACK_AMD_KNN_CHUNKS": "3"},
 }
 KNN_CASES = ([("default",)] + [(k,) for k in KNN_SWITCHES]
-             + [p for p in itertools.combinations(["compact_on", "dense_on", "wide_on", "fast_off"], 2)])
+             + [p for p in itertools.combinations(["compact_on", "dense_on", "wide_on", "fast_off"], 2)]
+             + [("chunks_3", "dense_on"), ("chunks_3", "fast_off")])
 
 
 @pytest.mark.parametrize("case", KNN_CASES, ids=lambda c: "+".join(c))
