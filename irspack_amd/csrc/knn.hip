@@ -1728,14 +1728,17 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     }
     pt.mark("compute_W prologue");
     const bool binarise = c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
-    // The rows of the call are taken in CHUNKS (contiguous row ranges of about equal entry counts, the
-    // first one half as long): per chunk one host pass on several threads - index check, the per-row
-    // statistic of the epilogue, the multiply-add count that orders the launch, whether the values
-    // are all ones / free of zeros (which accumulator the kernel may use) - then the chunk's launches.
-    // The pass over chunk k + 1 and the upload of its column indices (a second host thread) run
-    // while the device works on chunk k: of the 3 ms the pass takes on the ML-20M shape only the
-    // first chunk's share comes before the first kernel.  Every chunk chooses its kernel variant
-    // from its own rows (each variant gives the reference's values; section 3.4 of DESIGN.md).
+    // The rows of the call are taken in CHUNKS (contiguous row ranges of about equal entry counts): per
+    // chunk one host pass on several threads - index check, the per-row statistic of the epilogue, the
+    // multiply-add count that orders the launch, whether the values are all ones / free of zeros (which
+    // accumulator the kernel may use) - then the chunk's launches.  The pass over chunk k + 1 and the
+    // upload of its column indices (a second host thread) run while the device works on chunk k: of
+    // the 2.3 ms the pass takes on the ML-20M shape only the first chunk's share comes before the first
+    // kernel, and a finished chunk's rows are compacted and copied to the host beside the later chunks'
+    // kernels.  Every chunk chooses its kernel variant from its own rows (each variant gives the
+    // reference's values; section 3.4 of DESIGN.md).  Three chunks on large calls: a chunk lasts at least
+    // as long as its heaviest (row, tile) pair - 2.1 of the ML-20M call's 8.4 ms - so more, shorter
+    // chunks lengthen the device time (4: +0.5 ms, 8: +6 ms) by more than they take off the start.
     // IRSPACK_AMD_KNN_CHUNKS overrides the count (1: the whole call at once; tests force small ones).
     std::vector<double> tstat(std::max<int64_t>(n, 1), 0.0);
     std::vector<double> tscale(std::max<int64_t>(n, 1), 1.0);
@@ -1766,13 +1769,11 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       else if (have_work && e_end - e_begin >= (int64_t(1) << 22) && n >= 4096) n_chunks = 3;
       n_chunks = static_cast<int>(std::min<int64_t>(n_chunks, std::max<int64_t>(n, 1)));
     }
-    const char *fw_env = std::getenv("IRSPACK_AMD_KNN_CHUNK_FIRST");
-    const double first_w = fw_env ? std::min(4.0, std::max(0.05, std::atof(fw_env))) : 1.0;
     std::vector<int64_t> cb(n_chunks + 1);  // chunk k = rows [cb[k], cb[k + 1])
     cb[0] = row_begin;
     cb[n_chunks] = row_end;
     for (int k = 1; k < n_chunks; k++) {
-      const int64_t e_cut = e_begin + static_cast<int64_t>(static_cast<double>(e_end - e_begin) * (k - 1.0 + first_w) / (n_chunks - 1.0 + first_w));
+      const int64_t e_cut = e_begin + static_cast<int64_t>(static_cast<double>(e_end - e_begin) * k / n_chunks);
       cb[k] = std::max<int64_t>(cb[k - 1], std::lower_bound(ip + row_begin, ip + row_end, e_cut) - ip);
     }
     // The row pointers and column indices of the call's rows travel to the device on a second
