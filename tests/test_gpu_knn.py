@@ -554,3 +554,36 @@ def test_row_chunks_compute_w_and_errors(chunks, monkeypatch):
     with pytest.raises(ValueError):
         c.compute_similarity(bad, 10)
     assert_same_csr(c.compute_similarity(Xt, 10), O.KNNComputer("cosine", Xt, 0.0, normalize=True, n_threads=1).compute_similarity(Xt, 10))
+
+
+# ---------------------------------------------------------------- construction on the device (round 5)
+@pytest.mark.parametrize("kind,kw", CASES)
+@pytest.mark.parametrize("shape", ["one_tile", "two_tiles"])
+def test_device_create_is_the_host_create(kind, kw, shape, monkeypatch):
+    """All-ones matrices: X_arg^T, its slice pointers and its packed offsets are built on the device from
+    the caller's arrays (no host copy / transpose); IRSPACK_AMD_KNN_DEVICE_CREATE=0 keeps the host
+    construction.  Same similarities bit for bit - empty rows and columns, one and two column tiles,
+    values that are not ones under Jaccard / Tversky (binarised) - and a weighted matrix falls back to the
+    host construction by itself."""
+    if shape == "one_tile":
+        Xt = sps.csr_matrix(X_many.T).tolil()
+        for r in (0, 200, 511):
+            Xt.rows[r], Xt.data[r] = [], []
+        Xt = sps.csr_matrix(Xt)
+    else:
+        Xt = power_law_items(900, 17000, 120000, 7)
+    if kind in ("jaccard", "tversky"):
+        Xt = Xt.copy()
+        Xt.data = np.random.RandomState(1).uniform(0.0, 3.0, Xt.nnz)  # (binarised by the similarity)
+    g_dev, o = make(kind, Xt, **dict(kw))
+    monkeypatch.setenv("IRSPACK_AMD_KNN_DEVICE_CREATE", "0")
+    g_host, _ = make(kind, Xt, **dict(kw))
+    monkeypatch.delenv("IRSPACK_AMD_KNN_DEVICE_CREATE")
+    a, b = g_dev.compute_similarity(Xt, 30), g_host.compute_similarity(Xt, 30)
+    assert_same_csr(a, b, rtol=0)
+    assert_same_csr(a, o.compute_similarity(Xt, 30), rtol=1e-12)
+    if kind in ("cosine", "asymmetric"):
+        W = Xt.copy()
+        W.data = np.random.RandomState(2).uniform(0.5, 2.0, W.nnz)
+        gw, ow = make(kind, W, **dict(kw))
+        assert_same_csr(gw.compute_similarity(W, 30), ow.compute_similarity(W, 30), rtol=1e-12)

@@ -96,10 +96,12 @@ KNN_SWITCHES = {
     "fast_off": {"IRSPACK_AMD_KNN_FAST": "0"},
     "threads_1": {"IRSPACK_AMD_KNN_THREADS": "1"},
     "chunks_3": {"IRSPACK_AMD_KNN_CHUNKS": "3"},
+    "host_create": {"IRSPACK_AMD_KNN_DEVICE_CREATE": "0"},
+    "stage_off": {"IRSPACK_AMD_KNN_STAGE": "0"},
 }
 KNN_CASES = ([("default",)] + [(k,) for k in KNN_SWITCHES]
              + [p for p in itertools.combinations(["compact_on", "dense_on", "wide_on", "fast_off"], 2)]
-             + [("chunks_3", "dense_on"), ("chunks_3", "fast_off")])
+             + [("chunks_3", "dense_on"), ("chunks_3", "fast_off"), ("chunks_3", "stage_off"), ("host_create", "wide_on")])
 
 
 @pytest.mark.parametrize("case", KNN_CASES, ids=lambda c: "+".join(c))
