@@ -104,5 +104,8 @@ void sort_pairs_f32(bool descending, const float *keys_in, float *keys_out, cons
 void transpose_csr_device(const int32_t *indptr, const int32_t *indices, const float *data, int64_t rows,
                           int64_t cols, int64_t nnz, int32_t *t_indices, float *t_data,
                           std::vector<int32_t> &t_count, DeviceBuffer<char> &tmp, hipStream_t s);
+void transpose_csr_device(const int32_t *indptr, const int32_t *indices, const double *data, int64_t rows,
+                          int64_t cols, int64_t nnz, int32_t *t_indices, double *t_data,
+                          std::vector<int32_t> &t_count, DeviceBuffer<char> &tmp, hipStream_t s);
 
 }  // namespace irs

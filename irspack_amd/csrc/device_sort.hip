@@ -2,7 +2,8 @@
 // unit because the rocPRIM headers are heavy:
 //   sort_pairs_f32        float keys: the item norms and the per-user pruning radii of the evaluator's
 //                         bounded path (~10^4 .. 10^6 keys per call)
-//   transpose_csr_device  X^T of a device-resident CSR (IALSTrainer's X.transpose(), hpp:713): a stable
+//   transpose_csr_device  X^T of a device-resident CSR (IALSTrainer's X.transpose(), hpp:713; the kNN
+//                         computers' X_arg^T, knn.hpp:30-41, float64 values): a stable
 //                         sort of the entry numbers by column + one gather - once per trainer
 // No reference counterpart.
 #include <cstring>
@@ -24,11 +25,12 @@ __global__ __launch_bounds__(256) void column_count_kernel(const int32_t *__rest
 }
 
 // entry q of X^T is entry perm[q] of X: its row = the row whose [indptr[r], indptr[r + 1]) holds perm[q]
+template <class V>
 __global__ __launch_bounds__(256) void transposed_entries_kernel(const int32_t *__restrict__ perm,
                                                                  const int32_t *__restrict__ indptr, int32_t rows,
-                                                                 const float *__restrict__ data, int64_t nnz,
+                                                                 const V *__restrict__ data, int64_t nnz,
                                                                  int32_t *__restrict__ t_indices,
-                                                                 float *__restrict__ t_data) {
+                                                                 V *__restrict__ t_data) {
   const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (q >= nnz) return;
   const int32_t p = perm[q];
@@ -48,9 +50,10 @@ __global__ __launch_bounds__(256) void transposed_entries_kernel(const int32_t *
 // t_data (device, nnz entries; t_data null when data is) and t_count (host: stored entries per column).
 // Entries of a column keep their row order (the radix sort is stable and the entries arrive in row
 // order): the result is the sequential counting-sort transpose, bit for bit.
-void transpose_csr_device(const int32_t *indptr, const int32_t *indices, const float *data, int64_t rows,
-                          int64_t cols, int64_t nnz, int32_t *t_indices, float *t_data,
-                          std::vector<int32_t> &t_count, DeviceBuffer<char> &tmp, hipStream_t s) {
+template <class V>
+static void transpose_csr_device_impl(const int32_t *indptr, const int32_t *indices, const V *data, int64_t rows,
+                                      int64_t cols, int64_t nnz, int32_t *t_indices, V *t_data,
+                                      std::vector<int32_t> &t_count, DeviceBuffer<char> &tmp, hipStream_t s) {
   t_count.assign(static_cast<size_t>(std::max<int64_t>(cols, 0)), 0);
   if (nnz == 0 || cols == 0) return;
   int end_bit = 1;
@@ -73,11 +76,22 @@ void transpose_csr_device(const int32_t *indptr, const int32_t *indices, const f
                      dim3(256), 0, s, indices, nnz, d_cnt);
   IRS_HIP(hipMemcpyAsync(t_count.data(), d_cnt, static_cast<size_t>(cols) * 4, hipMemcpyDeviceToHost, s));
   IRS_HIP(rocprim::radix_sort_pairs(tmp.ptr + o_sort, sort_bytes, indices, d_keys, entry, d_perm, n, 0, end_bit, s));
-  hipLaunchKernelGGL(transposed_entries_kernel, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(transposed_entries_kernel<V>, dim3(static_cast<unsigned>((nnz + 255) / 256)), dim3(256), 0, s,
                      static_cast<const int32_t *>(d_perm), indptr, static_cast<int32_t>(rows), data, nnz, t_indices,
                      t_data);
   IRS_HIP(hipGetLastError());
   IRS_HIP(hipStreamSynchronize(s));
+}
+
+void transpose_csr_device(const int32_t *indptr, const int32_t *indices, const float *data, int64_t rows,
+                          int64_t cols, int64_t nnz, int32_t *t_indices, float *t_data,
+                          std::vector<int32_t> &t_count, DeviceBuffer<char> &tmp, hipStream_t s) {
+  transpose_csr_device_impl<float>(indptr, indices, data, rows, cols, nnz, t_indices, t_data, t_count, tmp, s);
+}
+void transpose_csr_device(const int32_t *indptr, const int32_t *indices, const double *data, int64_t rows,
+                          int64_t cols, int64_t nnz, int32_t *t_indices, double *t_data,
+                          std::vector<int32_t> &t_count, DeviceBuffer<char> &tmp, hipStream_t s) {
+  transpose_csr_device_impl<double>(indptr, indices, data, rows, cols, nnz, t_indices, t_data, t_count, tmp, s);
 }
 
 void sort_pairs_f32(bool descending, const float *keys_in, float *keys_out, const int32_t *vals_in,

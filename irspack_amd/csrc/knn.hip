@@ -1264,6 +1264,23 @@ __global__ __launch_bounds__(256) void xt_slices_kernel(const uint32_t *__restri
   tptr[i] = lo;
 }
 
+// per feature row of X_arg^T: largest and smallest non-zero |x| (0 when the row has none): the bounds
+// the target pass builds the fixed-point scales from
+__global__ __launch_bounds__(256) void xt_row_range_kernel(const uint32_t *__restrict__ xt_ptr,
+                                                           const double *__restrict__ xt_val, int64_t n_rows,
+                                                           double *__restrict__ row_max, double *__restrict__ row_min) {
+  const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (u >= n_rows) return;
+  double mx = 0.0, mn = __longlong_as_double(0x7ff0000000000000ll);
+  for (uint32_t q = xt_ptr[u]; q < xt_ptr[u + 1]; q++) {
+    const double a = fabs(xt_val[q]);
+    mx = fmax(mx, a);
+    if (a > 0.0) mn = fmin(mn, a);
+  }
+  row_max[u] = mx;
+  row_min[u] = isfinite(mn) ? mn : 0.0;
+}
+
 // two tile-relative LDS byte offsets (column x 4, 16 bits each) per dword; zeros behind the last entry
 __global__ __launch_bounds__(256) void xt_pack16_kernel(const int32_t *__restrict__ t_idx, int64_t nnz,
                                                         int64_t n_words, uint32_t *__restrict__ idx_p) {
@@ -1480,14 +1497,15 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     for (int64_t i = 0; i < rows; i++) check_arg(indptr[i + 1] >= indptr[i], "malformed indptr.");
     const int64_t nnz_in = indptr[rows];
     check_arg(nnz_in == 0 || (indices && data), "bad matrix.");
-    // ---- All-ones matrices (binary interactions; Jaccard / Tversky whatever the values), round 5: the
-    // caller's arrays are validated and classified in place (no copy), the column indices travel to the
-    // device beside that pass, and X_arg^T, its slice pointers and its packed offsets are built THERE
-    // (stable radix sort of the entry numbers by column + one gather, two small kernels): 68 -> ~10 ms
-    // on the ML-20M shape, where the host spent 17 ms on the private copy, 29 ms on the transpose and
-    // 15 ms on slices + packing.  Bit-identical device arrays (test_device_create_is_the_host_create).
-    // Weighted matrices, P3alpha / RP3beta (values transformed) and the opt-in dense block keep the host
-    // path below.  IRSPACK_AMD_KNN_DEVICE_CREATE=0: host path for everything (A/B).
+    // ---- Cosine / asymmetric cosine / Jaccard / Tversky, round 5: the caller's arrays are validated and
+    // classified in place (no private copy), the column indices - and the values, if they are not all
+    // ones - travel to the device beside that pass, and X_arg^T, its slice pointers, its packed offsets
+    // and its per-row value ranges are built THERE (stable radix sort of the entry numbers by column +
+    // one gather, three small kernels): 68 -> 5 ms for binary interactions on the ML-20M shape, where the
+    // host spent 17 ms on the copy, 29 ms on the transpose and 15 ms on slices + packing.  Same
+    // similarities bit for bit (test_device_create_is_the_host_create).  P3alpha / RP3beta (values
+    // transformed first) and the opt-in dense block keep the host path below.
+    // IRSPACK_AMD_KNN_DEVICE_CREATE=0: host path for everything (A/B).
     const bool binarise_create = sim_type == IRS_SIM_JACCARD || sim_type == IRS_SIM_TVERSKY;
     const bool transforms = sim_type == IRS_SIM_P3ALPHA || sim_type == IRS_SIM_RP3BETA;
     const char *dense_env0 = std::getenv("IRSPACK_AMD_KNN_DENSE");
@@ -1498,8 +1516,10 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       require_device(device);
       IRS_HIP(hipSetDevice(device));
       DeviceBuffer<int32_t> d_indptr, d_indices, d_tidx;
+      DeviceBuffer<double> d_values;
       std::string upload_error;
-      std::thread uploader([&] {  // (pageable memory: the copy occupies a host thread)
+      std::atomic<int> kind(0);  // 0: not classified yet, 1: all ones, 2: weighted (the values travel too), 3: give up
+      std::thread uploader([&] {  // (pageable memory: the copies occupy a host thread)
         try {
           IRS_HIP(hipSetDevice(device));
           std::vector<int32_t> ip32(rows + 1);
@@ -1508,15 +1528,26 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
           d_indices.alloc(static_cast<size_t>(nnz_in));
           IRS_HIP(hipMemcpy(d_indptr.ptr, ip32.data(), ip32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
           IRS_HIP(hipMemcpy(d_indices.ptr, indices, static_cast<size_t>(nnz_in) * sizeof(int32_t), hipMemcpyHostToDevice));
+          int k = 0;
+          while ((k = kind.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+          if (k == 2) {
+            d_values.alloc(static_cast<size_t>(nnz_in));
+            IRS_HIP(hipMemcpy(d_values.ptr, data, static_cast<size_t>(nnz_in) * sizeof(double), hipMemcpyHostToDevice));
+          }
         } catch (const std::exception &e) {
           upload_error = e.what();
         }
       });
       struct Joiner {
         std::thread &t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-      } upload_join{uploader};
-      std::atomic<int> bad(0), not_ones(0);
+        std::atomic<int> &kind;
+        ~Joiner() {
+          int zero = 0;
+          kind.compare_exchange_strong(zero, 3);  // (an exception before the classification: the uploader must not wait)
+          if (t.joinable()) t.join();
+        }
+      } upload_join{uploader, kind};
+      std::atomic<int> bad(0), not_ones(0), not_safe(0), not_pos(0);
       {
         const int n_thr = static_cast<int>(std::max<int64_t>(
             1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz_in / 500000 + 1})));
@@ -1533,13 +1564,25 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
             const uint64_t one_bits = 0x3ff0000000000000ull;
             const uint64_t *vb = reinterpret_cast<const uint64_t *>(data);
             for (int64_t q = b; q < e; q++) diff |= vb[q] ^ one_bits;
-            if (diff) not_ones.store(1);
+            if (diff) {
+              not_ones.store(1);
+              bool safe = true, pos = true;
+              for (int64_t q = b; q < e; q++) {
+                const double v = data[q], a = std::fabs(v);
+                safe &= a > 1e-150 && a < 1e150;
+                pos &= v > 0.0;
+              }
+              if (!safe) not_safe.store(1);
+              if (!pos) not_pos.store(1);
+            }
           }
         });
       }
       check_arg(bad.load() == 0, "column index out of range.");
+      const bool weighted = not_ones.load() != 0;
+      kind.store(weighted ? 2 : 1, std::memory_order_release);
       pt.mark("create: validate");
-      if (not_ones.load() == 0) {
+      {
         auto c = std::make_unique<irs_knn_computer>();
         c->device = device;
         c->sim_type = sim_type;
@@ -1549,25 +1592,42 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         c->alpha = alpha;
         c->beta = beta;
         c->normalize = normalize != 0;
-        // the norms of rows of ones: sqrt / pow of the entry count (what the sums of 1.0 * 1.0 give)
+        // the norms (similarities.hpp:20-28, 61-72, 96-107, 143-159); rows of ones: sqrt / pow of the entry
+        // count, which is what their sums of 1.0 * 1.0 are
         std::vector<double> norms(rows, 0.0);
-        for (int64_t i = 0; i < rows; i++) {
-          const double cnt = static_cast<double>(indptr[i + 1] - indptr[i]);
-          switch (sim_type) {
-            case IRS_SIM_COSINE: norms[i] = std::sqrt(cnt); break;
-            case IRS_SIM_ASYMMETRIC: norms[i] = std::pow(cnt, 1 - alpha); break;
-            default: norms[i] = cnt; break;
-          }
+        {
+          const std::vector<int64_t> ipv(indptr, indptr + rows + 1);
+          for_rows_parallel(ipv, rows, [&](int64_t i) {
+            double ss = static_cast<double>(indptr[i + 1] - indptr[i]);
+            if (weighted) {
+              ss = 0;
+              for (int64_t q = indptr[i]; q < indptr[i + 1]; q++) ss += data[q] * data[q];
+            }
+            switch (sim_type) {
+              case IRS_SIM_COSINE: norms[i] = std::sqrt(ss); break;
+              case IRS_SIM_ASYMMETRIC: norms[i] = std::pow(ss, 1 - alpha); break;
+              default: norms[i] = ss; break;  // (Jaccard / Tversky: the entry count; never weighted)
+            }
+          });
         }
         uploader.join();
         if (!upload_error.empty()) throw std::runtime_error(upload_error);
-        pt.mark("create: upload");
+        pt.mark("create: norms + upload");
         hipStream_t s = nullptr;
         d_tidx.alloc(static_cast<size_t>(nnz_in));
+        const size_t padded = (static_cast<size_t>(nnz_in) + 256 + 1) & ~size_t(1);
         std::vector<int32_t> t_count;
         DeviceBuffer<char> tmp;
-        transpose_csr_device(d_indptr.ptr, d_indices.ptr, nullptr, rows, cols, nnz_in, d_tidx.ptr, nullptr, t_count,
-                             tmp, s);
+        if (weighted) {  // the transposed values straight into the padded value stream of the kernels
+          c->xt_val.alloc(padded);
+          IRS_HIP(hipMemsetAsync(c->xt_val.ptr + nnz_in, 0, (padded - static_cast<size_t>(nnz_in)) * sizeof(double), s));
+          transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(d_values.ptr), rows, cols,
+                               nnz_in, d_tidx.ptr, c->xt_val.ptr, t_count, tmp, s);
+        } else {
+          c->xt_val.alloc(2);  // (the ONES kernels never read the value stream)
+          transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(nullptr), rows, cols, nnz_in,
+                               d_tidx.ptr, static_cast<double *>(nullptr), t_count, tmp, s);
+        }
         pt.mark("create: transpose");
         const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
         std::vector<uint32_t> xt_ptr(static_cast<size_t>(cols) + 1, 0u);
@@ -1577,25 +1637,34 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         for (int64_t u = 0; u < cols; u++) {
           xt_ptr[u + 1] = xt_ptr[u] + static_cast<uint32_t>(t_count[u]);
           c->xt_row_len[u] = t_count[u];
-          if (t_count[u] > 0) c->xt_rowmax[u] = c->xt_rowmin[u] = 1.0;
+          if (!weighted && t_count[u] > 0) c->xt_rowmax[u] = c->xt_rowmin[u] = 1.0;
         }
         DeviceBuffer<uint32_t> d_xt_ptr;
+        DeviceBuffer<double> d_range;
         d_xt_ptr.upload(xt_ptr, s);
         c->xt_tptr.alloc(static_cast<size_t>(cols) * (n_tiles + 1));
         const int64_t n_pairs = cols * (n_tiles + 1);
         hipLaunchKernelGGL(xt_slices_kernel, dim3(static_cast<unsigned>(ceil_div(n_pairs, 256))), dim3(256), 0, s,
                            static_cast<const uint32_t *>(d_xt_ptr.ptr), static_cast<const int32_t *>(d_tidx.ptr), cols,
                            static_cast<int32_t>(n_tiles), c->xt_tptr.ptr);
-        const size_t padded = (static_cast<size_t>(nnz_in) + 256 + 1) & ~size_t(1);
         c->xt_idx16.alloc(padded / 2);
         hipLaunchKernelGGL(xt_pack16_kernel, dim3(static_cast<unsigned>(ceil_div(static_cast<int64_t>(padded / 2), 256))),
                            dim3(256), 0, s, static_cast<const int32_t *>(d_tidx.ptr), nnz_in,
                            static_cast<int64_t>(padded / 2), c->xt_idx16.ptr);
+        if (weighted) {
+          d_range.alloc(2 * static_cast<size_t>(cols));
+          hipLaunchKernelGGL(xt_row_range_kernel, dim3(static_cast<unsigned>(ceil_div(cols, 256))), dim3(256), 0, s,
+                             static_cast<const uint32_t *>(d_xt_ptr.ptr), static_cast<const double *>(c->xt_val.ptr), cols,
+                             d_range.ptr, d_range.ptr + cols);
+          IRS_HIP(hipMemcpyAsync(c->xt_rowmax.data(), d_range.ptr, static_cast<size_t>(cols) * sizeof(double),
+                                 hipMemcpyDeviceToHost, s));
+          IRS_HIP(hipMemcpyAsync(c->xt_rowmin.data(), d_range.ptr + cols, static_cast<size_t>(cols) * sizeof(double),
+                                 hipMemcpyDeviceToHost, s));
+        }
         IRS_HIP(hipGetLastError());
-        c->xt_all_ones = true;
-        c->xt_nonzero = true;
-        c->xt_positive = true;
-        c->xt_val.alloc(2);
+        c->xt_all_ones = !weighted;
+        c->xt_nonzero = not_safe.load() == 0;
+        c->xt_positive = not_pos.load() == 0;
         c->norm_max = norms.empty() ? 0.0 : *std::max_element(norms.begin(), norms.end());
         c->norms.upload(norms, s);
         IRS_HIP(hipStreamSynchronize(s));  // the host vectors and the device scratch go out of scope
@@ -1603,7 +1672,6 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         *out = c.release();
         return;
       }
-      // (weighted after all: the host path; the uploaded indices are dropped)
     }
     HostCsrD X = host_csr(rows, cols, indptr, indices, data);
     pt.mark("create: copy");

@@ -560,11 +560,10 @@ def test_row_chunks_compute_w_and_errors(chunks, monkeypatch):
 @pytest.mark.parametrize("kind,kw", CASES)
 @pytest.mark.parametrize("shape", ["one_tile", "two_tiles"])
 def test_device_create_is_the_host_create(kind, kw, shape, monkeypatch):
-    """All-ones matrices: X_arg^T, its slice pointers and its packed offsets are built on the device from
+    """X_arg^T, its slice pointers, packed offsets and per-row value ranges are built on the device from
     the caller's arrays (no host copy / transpose); IRSPACK_AMD_KNN_DEVICE_CREATE=0 keeps the host
     construction.  Same similarities bit for bit - empty rows and columns, one and two column tiles,
-    values that are not ones under Jaccard / Tversky (binarised) - and a weighted matrix falls back to the
-    host construction by itself."""
+    values that are not ones under Jaccard / Tversky (binarised), weighted matrices."""
     if shape == "one_tile":
         Xt = sps.csr_matrix(X_many.T).tolil()
         for r in (0, 200, 511):
@@ -582,8 +581,14 @@ def test_device_create_is_the_host_create(kind, kw, shape, monkeypatch):
     a, b = g_dev.compute_similarity(Xt, 30), g_host.compute_similarity(Xt, 30)
     assert_same_csr(a, b, rtol=0)
     assert_same_csr(a, o.compute_similarity(Xt, 30), rtol=1e-12)
-    if kind in ("cosine", "asymmetric"):
+    if kind in ("cosine", "asymmetric"):  # weighted: the values are transposed on the device too
         W = Xt.copy()
         W.data = np.random.RandomState(2).uniform(0.5, 2.0, W.nnz)
+        W.data[::7] = 1.0
         gw, ow = make(kind, W, **dict(kw))
-        assert_same_csr(gw.compute_similarity(W, 30), ow.compute_similarity(W, 30), rtol=1e-12)
+        monkeypatch.setenv("IRSPACK_AMD_KNN_DEVICE_CREATE", "0")
+        gw_host, _ = make(kind, W, **dict(kw))
+        monkeypatch.delenv("IRSPACK_AMD_KNN_DEVICE_CREATE")
+        aw = gw.compute_similarity(W, 30)
+        assert_same_csr(aw, gw_host.compute_similarity(W, 30), rtol=0)
+        assert_same_csr(aw, ow.compute_similarity(W, 30), rtol=1e-12)
