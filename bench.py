@@ -555,7 +555,7 @@ def knn_leg(X, ceilings):
         "item_pairs_per_s": I * float(I) / wall,
         "wall_s_incl_pcie": wall, "kernel_ms": ms,
         "item_pairs_per_s_kernel_only": I * float(I) / (ms * 1e-3),
-        "create_s": create_s, "macs": macs, "gmacs_per_s_kernel": gmacs,
+        "create_s": create_s, "fit_wall_s": create_s + wall, "macs": macs, "gmacs_per_s_kernel": gmacs,
         "roofline": {"bound": "lds_atomic", "achieved": gmacs, "peak": atomic_peak,
                      "unit": "G lane-atomics/s (measured ds_add_u32, random banks)",
                      "frac": (gmacs / atomic_peak) if atomic_peak else None,
@@ -564,7 +564,10 @@ def knn_leg(X, ceilings):
                      "hbm_side_gbs": macs * 4.0 / (ms * 1e-3) / 1e9,
                      "frac_hbm": macs * 4.0 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                      "traffic_gbs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
-                     "note": "kernel time covers accumulate + epilogue + select + merge; "
+                     "note": "kernel_ms = device span from the first launch to the last row merge of the call's "
+                             "three row chunks (accumulate + epilogue + select + merge; the host pass, the "
+                             "index upload and the result copy of one chunk run beside the kernels of another); "
+                             "fit_wall_s = the computer's construction (on the device since round 5) + one call; "
                              "HBM side prices the reference's 4 B column id per multiply-add; "
                              "traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE of the tile kernel "
                              "(profiles/pmc_traffic.json from the latest profiles/rNN_knn_pmc_hbm.json, "

@@ -1503,13 +1503,14 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     // and its per-row value ranges are built THERE (stable radix sort of the entry numbers by column +
     // one gather, three small kernels): 68 -> 5 ms for binary interactions on the ML-20M shape, where the
     // host spent 17 ms on the copy, 29 ms on the transpose and 15 ms on slices + packing.  Same
-    // similarities bit for bit (test_device_create_is_the_host_create).  P3alpha / RP3beta (values
-    // transformed first) and the opt-in dense block keep the host path below.
+    // similarities bit for bit (test_device_create_is_the_host_create).  P3alpha / RP3beta: the rows are
+    // pow-ed and normalised on the host first (libm's pow), into the one private array of this path.
+    // The opt-in dense block keeps the host path below.
     // IRSPACK_AMD_KNN_DEVICE_CREATE=0: host path for everything (A/B).
     const bool binarise_create = sim_type == IRS_SIM_JACCARD || sim_type == IRS_SIM_TVERSKY;
     const bool transforms = sim_type == IRS_SIM_P3ALPHA || sim_type == IRS_SIM_RP3BETA;
     const char *dense_env0 = std::getenv("IRSPACK_AMD_KNN_DENSE");
-    const bool device_candidate = !transforms && nnz_in > 0 && cols > 0 && nnz_in < (int64_t(1) << 31) - 1024 &&
+    const bool device_candidate = nnz_in > 0 && cols > 0 && nnz_in < (int64_t(1) << 31) - 1024 &&
                                   !(dense_env0 && dense_env0[0] == '1') &&
                                   env_flag("IRSPACK_AMD_KNN_DEVICE_CREATE", true);
     if (device_candidate) {
@@ -1517,6 +1518,11 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       IRS_HIP(hipSetDevice(device));
       DeviceBuffer<int32_t> d_indptr, d_indices, d_tidx;
       DeviceBuffer<double> d_values;
+      // P3alpha / RP3beta (similarities.hpp:198-222, 265-292): the rows pow-ed and normalised to sum 1, on
+      // the host (libm's pow: the values the oracle has) into the one private array of this path
+      const double *vals = data;
+      RawVector<double> tvals;
+      const std::vector<int64_t> ipv(indptr, indptr + rows + 1);
       std::string upload_error;
       std::atomic<int> kind(0);  // 0: not classified yet, 1: all ones, 2: weighted (the values travel too), 3: give up
       std::thread uploader([&] {  // (pageable memory: the copies occupy a host thread)
@@ -1532,7 +1538,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
           while ((k = kind.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
           if (k == 2) {
             d_values.alloc(static_cast<size_t>(nnz_in));
-            IRS_HIP(hipMemcpy(d_values.ptr, data, static_cast<size_t>(nnz_in) * sizeof(double), hipMemcpyHostToDevice));
+            IRS_HIP(hipMemcpy(d_values.ptr, vals, static_cast<size_t>(nnz_in) * sizeof(double), hipMemcpyHostToDevice));
           }
         } catch (const std::exception &e) {
           upload_error = e.what();
@@ -1548,6 +1554,19 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         }
       } upload_join{uploader, kind};
       std::atomic<int> bad(0), not_ones(0), not_safe(0), not_pos(0);
+      if (transforms) {
+        tvals.resize(static_cast<size_t>(nnz_in));
+        for_rows_parallel(ipv, rows, [&](int64_t i) {
+          double sum = 0;
+          for (int64_t q = indptr[i]; q < indptr[i + 1]; q++) {
+            tvals[q] = std::pow(data[q], alpha);
+            sum += tvals[q];
+          }
+          for (int64_t q = indptr[i]; q < indptr[i + 1]; q++) tvals[q] /= sum;
+        });
+        vals = tvals.data();
+        pt.mark("create: transform");
+      }
       {
         const int n_thr = static_cast<int>(std::max<int64_t>(
             1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()), nnz_in / 500000 + 1})));
@@ -1562,13 +1581,13 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
           if (!binarise_create) {  // (a branch-free pass the compiler vectorises)
             uint64_t diff = 0;
             const uint64_t one_bits = 0x3ff0000000000000ull;
-            const uint64_t *vb = reinterpret_cast<const uint64_t *>(data);
+            const uint64_t *vb = reinterpret_cast<const uint64_t *>(vals);
             for (int64_t q = b; q < e; q++) diff |= vb[q] ^ one_bits;
             if (diff) {
               not_ones.store(1);
               bool safe = true, pos = true;
               for (int64_t q = b; q < e; q++) {
-                const double v = data[q], a = std::fabs(v);
+                const double v = vals[q], a = std::fabs(v);
                 safe &= a > 1e-150 && a < 1e150;
                 pos &= v > 0.0;
               }
@@ -1595,8 +1614,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         // the norms (similarities.hpp:20-28, 61-72, 96-107, 143-159); rows of ones: sqrt / pow of the entry
         // count, which is what their sums of 1.0 * 1.0 are
         std::vector<double> norms(rows, 0.0);
-        {
-          const std::vector<int64_t> ipv(indptr, indptr + rows + 1);
+        if (!transforms)  // (P3alpha / RP3beta have none)
           for_rows_parallel(ipv, rows, [&](int64_t i) {
             double ss = static_cast<double>(indptr[i + 1] - indptr[i]);
             if (weighted) {
@@ -1609,7 +1627,6 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
               default: norms[i] = ss; break;  // (Jaccard / Tversky: the entry count; never weighted)
             }
           });
-        }
         uploader.join();
         if (!upload_error.empty()) throw std::runtime_error(upload_error);
         pt.mark("create: norms + upload");
@@ -1669,6 +1686,11 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         c->norms.upload(norms, s);
         IRS_HIP(hipStreamSynchronize(s));  // the host vectors and the device scratch go out of scope
         pt.mark("create: slices + pack");
+        if (!tvals.empty()) {  // (returning 160 MB to the system takes 10+ ms: not on the caller's clock)
+          auto *junk = new RawVector<double>();
+          junk->swap(tvals);
+          std::thread([junk] { delete junk; }).detach();
+        }
         *out = c.release();
         return;
       }

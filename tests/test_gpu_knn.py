@@ -592,3 +592,26 @@ def test_device_create_is_the_host_create(kind, kw, shape, monkeypatch):
         aw = gw.compute_similarity(W, 30)
         assert_same_csr(aw, gw_host.compute_similarity(W, 30), rtol=0)
         assert_same_csr(aw, ow.compute_similarity(W, 30), rtol=1e-12)
+
+
+@pytest.mark.parametrize("kind,alpha,beta", [("p3alpha", 0.5, 0.0), ("p3alpha", 1.0, 0.0), ("rp3beta", 0.7, 0.4)])
+def test_device_create_p3alpha_rp3beta(kind, alpha, beta, monkeypatch):
+    """compute_W computers: the rows are pow-ed and normalised on the host (libm), everything else of the
+    construction runs on the device - same W bit for bit as the host construction."""
+    Xt = sps.csr_matrix(X_many.T).tolil()
+    Xt.rows[3], Xt.data[3] = [], []
+    Xt = sps.csr_matrix(Xt)
+    Xt.data = np.random.RandomState(4).uniform(0.5, 3.0, Xt.nnz)
+
+    def both():
+        if kind == "p3alpha":
+            return K.P3alphaComputer(Xt, alpha), O.KNNComputer("p3alpha", Xt, alpha=alpha)
+        return K.RP3betaComputer(Xt, alpha, beta), O.KNNComputer("rp3beta", Xt, alpha=alpha, beta=beta)
+
+    g_dev, o = both()
+    monkeypatch.setenv("IRSPACK_AMD_KNN_DEVICE_CREATE", "0")
+    g_host, _ = both()
+    monkeypatch.delenv("IRSPACK_AMD_KNN_DEVICE_CREATE")
+    a = g_dev.compute_W(Xt, 40)
+    assert_same_csr(a, g_host.compute_W(Xt, 40), rtol=0)
+    assert_same_csr(a, o.compute_W(Xt, 40), rtol=1e-11)
