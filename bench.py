@@ -538,7 +538,11 @@ def knn_leg(X, ceilings):
     t0 = time.perf_counter()
     comp = CosineSimilarityComputer(Xt, 0.0, True)
     create_s = time.perf_counter() - t0
-    comp.compute_similarity(Xt, 100, rows=(0, 64))  # warm-up
+    # the first call of a fresh computer (what a one-off `learn()` pays: it also sizes the scratch, the result
+    # buffers and the page-locked staging buffer), then the steady state
+    t0 = time.perf_counter()
+    S = comp.compute_similarity(Xt, 100)
+    first_call_s = time.perf_counter() - t0
     walls = []
     S = None
     for _ in range(3):
@@ -555,7 +559,8 @@ def knn_leg(X, ceilings):
         "item_pairs_per_s": I * float(I) / wall,
         "wall_s_incl_pcie": wall, "kernel_ms": ms,
         "item_pairs_per_s_kernel_only": I * float(I) / (ms * 1e-3),
-        "create_s": create_s, "fit_wall_s": create_s + wall, "macs": macs, "gmacs_per_s_kernel": gmacs,
+        "create_s": create_s, "first_call_wall_s": first_call_s, "fit_wall_s": create_s + first_call_s,
+        "macs": macs, "gmacs_per_s_kernel": gmacs,
         "roofline": {"bound": "lds_atomic", "achieved": gmacs, "peak": atomic_peak,
                      "unit": "G lane-atomics/s (measured ds_add_u32, random banks)",
                      "frac": (gmacs / atomic_peak) if atomic_peak else None,
@@ -567,7 +572,8 @@ def knn_leg(X, ceilings):
                      "note": "kernel_ms = device span from the first launch to the last row merge of the call's "
                              "three row chunks (accumulate + epilogue + select + merge; the host pass, the "
                              "index upload and the result copy of one chunk run beside the kernels of another); "
-                             "fit_wall_s = the computer's construction (on the device since round 5) + one call; "
+                             "fit_wall_s = the computer's construction (on the device since round 5) + the FIRST call "
+                             "of that computer (buffers sized there), what one `learn()` of a kNN recommender costs; "
                              "HBM side prices the reference's 4 B column id per multiply-add; "
                              "traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE of the tile kernel "
                              "(profiles/pmc_traffic.json from the latest profiles/rNN_knn_pmc_hbm.json, "

@@ -75,6 +75,14 @@ template <class T> struct DeviceBuffer {
     count = other.count;
     owned = false;
   }
+  // n elements at `p` inside a larger allocation somebody else owns (an arena carved per call); alloc()
+  // must not be called on a view that is too small - it would leave the arena for memory of its own
+  void view(void *p, size_t n) {
+    release();
+    ptr = static_cast<T *>(p);
+    count = n;
+    owned = false;
+  }
   void alloc(size_t n) {
     if (n <= count && ptr && owned) return;
     release();

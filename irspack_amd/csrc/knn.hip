@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <numeric>
 
 #include "common.hpp"
@@ -1407,6 +1408,10 @@ struct irs_knn_computer {
     DeviceBuffer<double> t_val, t_stat, t_scale, cand_val, out_val;
     DeviceBuffer<uint64_t> hi_stash;
     DeviceBuffer<int32_t> t_pop;
+    // ONE allocation behind the buffers every call needs (carved per call; t_val / hi_stash / t_pop, which
+    // only some calls need, are allocations of their own): seventeen hipMalloc calls were 11 ms of the
+    // first call of a computer - and `learn()` of a kNN recommender makes exactly one call
+    DeviceBuffer<char> arena;
   } scratch;
   // a compute call: set-up, the counts of the finished chunks and the end of the call; the kernels of its
   // row chunks, one chunk after the other; the chunks' small inputs; the column indices (uploader
@@ -1423,6 +1428,7 @@ struct irs_knn_computer {
   char *stage = nullptr;
   size_t stage_bytes = 0, stage_idx_offset = 0;  // values at 0, column indices at stage_idx_offset
   bool staged = false;
+  int64_t n_calls = 0;  // compute calls so far
   ~irs_knn_computer() {
     if (stage) (void)hipHostFree(stage);
     if (ev_in) (void)hipEventDestroy(ev_in);
@@ -1431,6 +1437,27 @@ struct irs_knn_computer {
       if (st) (void)hipStreamDestroy(st);
   }
 };
+
+// The arena and the page-locked staging buffer of the last computer that was destroyed, per device: a
+// tuning loop constructs, uses once and drops one computer after the other, and mapping ~250 MB of
+// device memory (14 ms) + page-locking 32 MB (6 ms) cost more than the ML-20M call itself (11 ms).
+namespace {
+struct KnnBufferCache {
+  std::mutex mu;
+  struct Slot {
+    int device = -1;
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    char *stage = nullptr;
+    size_t stage_bytes = 0;
+    // (five stream creations are another 5 - 10 ms of a computer's first call)
+    hipStream_t streams[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_setup = nullptr;
+  } slot;
+  ~KnnBufferCache() {  // (process exit: the runtime may be gone already - nothing to free safely)
+  }
+} knn_buffer_cache;
+}  // namespace
 
 extern "C" {
 
@@ -1944,6 +1971,50 @@ irs_status irs_knn_destroy(irs_knn_computer *c) {
   return guard([&] {
     if (c) {
       (void)hipSetDevice(c->device);
+      {  // leave the larger buffers to the next computer on this device
+        for (hipStream_t st : {c->stream, c->stream_k, c->stream_in, c->stream_up, c->stream_out})
+          if (st) (void)hipStreamSynchronize(st);
+        std::lock_guard<std::mutex> lock(knn_buffer_cache.mu);
+        auto &slot = knn_buffer_cache.slot;
+        irs_knn_computer::Scratch &sc = c->scratch;
+        if (sc.arena.ptr && sc.arena.owned && (slot.device != c->device || sc.arena.count > slot.arena_bytes)) {
+          if (slot.arena) (void)hipFree(slot.arena);
+          slot.arena = sc.arena.ptr;
+          slot.arena_bytes = sc.arena.count;
+          sc.arena.ptr = nullptr;  // (the views into it die with the computer)
+          sc.arena.count = 0;
+          if (slot.device != c->device) {  // (what the slot holds belongs to another device)
+            if (slot.stage) (void)hipHostFree(slot.stage);
+            slot.stage = nullptr;
+            slot.stage_bytes = 0;
+            for (auto &st : slot.streams) {
+              if (st) (void)hipStreamDestroy(st);
+              st = nullptr;
+            }
+            if (slot.ev_in) (void)hipEventDestroy(slot.ev_in);
+            if (slot.ev_setup) (void)hipEventDestroy(slot.ev_setup);
+            slot.ev_in = slot.ev_setup = nullptr;
+          }
+          slot.device = c->device;
+        }
+        if (c->stream && slot.device == c->device && !slot.streams[0]) {
+          hipStream_t *mine[5] = {&c->stream, &c->stream_k, &c->stream_in, &c->stream_up, &c->stream_out};
+          for (int k = 0; k < 5; k++) {
+            slot.streams[k] = *mine[k];
+            *mine[k] = nullptr;
+          }
+          slot.ev_in = c->ev_in;
+          slot.ev_setup = c->ev_setup;
+          c->ev_in = c->ev_setup = nullptr;
+        }
+        if (c->stage && slot.device == c->device && c->stage_bytes > slot.stage_bytes) {
+          if (slot.stage) (void)hipHostFree(slot.stage);
+          slot.stage = c->stage;
+          slot.stage_bytes = c->stage_bytes;
+          c->stage = nullptr;
+          c->stage_bytes = 0;
+        }
+      }
       delete c;
     }
   });
@@ -2055,6 +2126,20 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     std::atomic<int> uploaded(0);  // chunks whose indices are on the device
     if (have_work) {
       IRS_HIP(hipSetDevice(c->device));
+      if (!c->stream) {  // (a dropped computer's streams first)
+        std::lock_guard<std::mutex> lock(knn_buffer_cache.mu);
+        auto &slot = knn_buffer_cache.slot;
+        if (slot.device == c->device && slot.streams[0]) {
+          hipStream_t *mine[5] = {&c->stream, &c->stream_k, &c->stream_in, &c->stream_up, &c->stream_out};
+          for (int k = 0; k < 5; k++) {
+            *mine[k] = slot.streams[k];
+            slot.streams[k] = nullptr;
+          }
+          c->ev_in = slot.ev_in;
+          c->ev_setup = slot.ev_setup;
+          slot.ev_in = slot.ev_setup = nullptr;
+        }
+      }
       if (!c->stream) {
         IRS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         IRS_HIP(hipStreamCreateWithFlags(&c->stream_k, hipStreamNonBlocking));
@@ -2064,8 +2149,65 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         IRS_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         IRS_HIP(hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming));
       }
-      sc.t_ptr.alloc(static_cast<size_t>(n) + 1);
-      sc.t_idx.alloc(std::max<size_t>(ne, 1));
+      {  // carve the call's buffers out of the arena (the last result, which lives there too, is gone now)
+        const size_t nn = static_cast<size_t>(n);
+        const size_t n_tiles_a = static_cast<size_t>(ceil_div(std::max<int64_t>(c->N, 1), TILE));
+        const size_t tile_k_a = static_cast<size_t>(std::min<int64_t>(out_k, TILE));
+        int64_t widest = 0;  // rows of the largest chunk: the candidate lists are one chunk's at a time
+        for (int k = 0; k < n_chunks; k++) widest = std::max(widest, cb[k + 1] - cb[k]);
+        const size_t slots_a = static_cast<size_t>(widest) * n_tiles_a, cap_a = nn * static_cast<size_t>(out_k);
+        size_t off = 0;
+        auto take = [&](size_t bytes) {
+          const size_t at = off;
+          off += (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+          return at;
+        };
+        const size_t o_t_ptr = take((nn + 1) * 8), o_t_idx = take(std::max<size_t>(ne, 1) * 4), o_stat = take(nn * 8),
+                     o_scale = take(nn * 8), o_order = take(nn * 4), o_slot = take(nn * 4),
+                     o_res_ptr = take((nn + 1) * 8), o_cidx = take(slots_a * tile_k_a * 4),
+                     o_cval = take(slots_a * tile_k_a * 8), o_ccnt = take(slots_a * 4), o_oidx = take(cap_a * 4),
+                     o_oval = take(cap_a * 8), o_ocnt = take(nn * 4), o_ridx = take(cap_a * 4),
+                     o_rval = take(cap_a * 8), o_cursor = take(3 * static_cast<size_t>(n_chunks) * 4),
+                     o_redo = take(slots_a * 4);
+        if (sc.arena.count < off) {  // (a dropped computer's buffers first)
+          std::lock_guard<std::mutex> lock(knn_buffer_cache.mu);
+          auto &slot = knn_buffer_cache.slot;
+          if (slot.device == c->device && slot.arena && slot.arena_bytes >= off) {
+            sc.arena.release();
+            sc.arena.ptr = slot.arena;
+            sc.arena.count = slot.arena_bytes;
+            sc.arena.owned = true;
+            slot.arena = nullptr;
+            slot.arena_bytes = 0;
+          }
+          if (slot.device == c->device && slot.stage && slot.stage_bytes > c->stage_bytes) {
+            if (c->stage) (void)hipHostFree(c->stage);
+            c->stage = slot.stage;
+            c->stage_bytes = slot.stage_bytes;
+            slot.stage = nullptr;
+            slot.stage_bytes = 0;
+          }
+        }
+        sc.arena.alloc(off);
+        char *base = sc.arena.ptr;
+        sc.t_ptr.view(base + o_t_ptr, nn + 1);
+        sc.t_idx.view(base + o_t_idx, std::max<size_t>(ne, 1));
+        sc.t_stat.view(base + o_stat, nn);
+        sc.t_scale.view(base + o_scale, nn);
+        sc.order.view(base + o_order, nn);
+        sc.slot_of.view(base + o_slot, nn);
+        sc.res_ptr.view(base + o_res_ptr, nn + 1);
+        sc.cand_idx.view(base + o_cidx, slots_a * tile_k_a);
+        sc.cand_val.view(base + o_cval, slots_a * tile_k_a);
+        sc.cand_cnt.view(base + o_ccnt, slots_a);
+        sc.out_idx.view(base + o_oidx, cap_a);
+        sc.out_val.view(base + o_oval, cap_a);
+        sc.out_cnt.view(base + o_ocnt, nn);
+        c->res_idx.view(base + o_ridx, cap_a);
+        c->res_val.view(base + o_rval, cap_a);
+        sc.cursor.view(base + o_cursor, 3 * static_cast<size_t>(n_chunks));
+        sc.redo_list.view(base + o_redo, slots_a);
+      }
       uploader = std::thread([&] {
         try {
           IRS_HIP(hipSetDevice(c->device));
@@ -2144,25 +2286,15 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       }
       if (binarise) ones_host.assign(static_cast<size_t>(max_entries), 1.0);  // (never resized: copies of it may be in flight)
       max_slots = static_cast<size_t>(max_rows) * n_tiles;
-      t_stat.alloc(n);
-      t_scale.alloc(n);
-      d_order.alloc(n);
-      sc.slot_of.alloc(n);
-      sc.res_ptr.alloc(static_cast<size_t>(n) + 1);
-      // (every chunk has its own part of the candidate lists)
-      sc.cand_idx.alloc(static_cast<size_t>(n) * n_tiles * tile_k);
-      sc.cand_val.alloc(static_cast<size_t>(n) * n_tiles * tile_k);
-      sc.cand_cnt.alloc(static_cast<size_t>(n) * n_tiles);
       const size_t cap = static_cast<size_t>(n) * out_k;  // entries the result can have
-      out_idx.alloc(cap);
-      out_val.alloc(cap);
-      out_cnt.alloc(n);
-      c->res_idx.alloc(cap);  // (the chunks are compacted as they finish, before the total is known)
-      c->res_val.alloc(cap);
+      // (c->res_idx / res_val hold `cap` entries: the chunks are compacted as they finish, before the total is known)
       // results of up to 1 GB also travel to a page-locked staging buffer, chunk by chunk as the chunks finish
       // (IRSPACK_AMD_KNN_STAGE=0: irs_knn_fetch copies from the device into the caller's arrays, as before round 5)
       const size_t bytes = cap * (sizeof(double) + sizeof(int32_t));
-      if (bytes <= (size_t(1) << 30) && env_flag("IRSPACK_AMD_KNN_STAGE", true)) {
+      // (not on a computer's FIRST call: page-locking 32 MB costs several milliseconds, more than the
+      // staged copy saves once - `learn()` of a kNN recommender makes exactly one call)
+      if (bytes <= (size_t(1) << 30) && (c->n_calls > 0 || c->stage_bytes >= bytes) &&
+          env_flag("IRSPACK_AMD_KNN_STAGE", true)) {
         if (c->stage_bytes < bytes) {
           if (c->stage) (void)hipHostFree(c->stage);
           c->stage = nullptr;
@@ -2177,7 +2309,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       }
       IRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
       // [3 k + 0] pairs, [3 k + 1] pairs of the redo list, [3 k + 2] length of the redo list of chunk k
-      sc.cursor.alloc(3 * static_cast<size_t>(n_chunks));
       IRS_HIP(hipMemsetAsync(sc.cursor.ptr, 0, 3 * static_cast<size_t>(n_chunks) * sizeof(int32_t), s));
       IRS_HIP(hipEventRecord(c->ev_setup, s));
       IRS_HIP(hipStreamWaitEvent(c->stream_k, c->ev_setup, 0));
@@ -2422,10 +2553,9 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       p.beta_f = static_cast<float>(c->beta);
       p.top_k = static_cast<int32_t>(out_k);
       p.tile_k = static_cast<int32_t>(tile_k);
-      const size_t slot0 = static_cast<size_t>(rel0) * n_tiles;  // the chunk's first (row slot, tile) pair
-      p.cand_idx = sc.cand_idx.ptr + slot0 * tile_k;
-      p.cand_val = sc.cand_val.ptr + slot0 * tile_k;
-      p.cand_cnt = sc.cand_cnt.ptr + slot0;
+      p.cand_idx = sc.cand_idx.ptr;  // (scratch of one chunk at a time: the chunks follow one another on the stream)
+      p.cand_val = sc.cand_val.ptr;
+      p.cand_cnt = sc.cand_cnt.ptr;
       p.out_idx = out_idx.ptr + static_cast<size_t>(rel0) * out_k;
       p.out_val = out_val.ptr + static_cast<size_t>(rel0) * out_k;
       p.out_cnt = out_cnt.ptr + rel0;
@@ -2505,8 +2635,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                           p.shrinkage < 1e30 &&
                           !(fast_env && fast_env[0] == '0');
         if (fast) {
-          sc.redo_list.alloc(static_cast<size_t>(n) * n_tiles);
-          p.redo_list = sc.redo_list.ptr + slot0;
+          p.redo_list = sc.redo_list.ptr;
           launch(knn_tile_kernel<true, true, true, THREADS, false, true>);
           p.redo = 1;  // the pairs the approximate selection handed back (usually none), exactly
           launch(knn_tile_kernel<true, true, true>);
@@ -2547,6 +2676,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     }
     c->res_nnz = c->res_ptr[n];
     c->staged = use_stage && c->res_nnz > 0;
+    c->n_calls++;
     pt.mark("kernels + retire");
 #ifdef IRS_KNN_PHASES
     {
