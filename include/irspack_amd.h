@@ -266,8 +266,10 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols,
 irs_status irs_knn_destroy(irs_knn_computer *c);
 /* compute_similarity(X, top_k) (knn.hpp:43-139) / compute_W (similarities.hpp:
  * 224-240, 294-324; as_w != 0, result still row-major [rows, N]).  Two calls:
- * compute runs the device work and reports nnz; fetch copies the CSR out.
- * row_begin/row_end select a shard of target rows (multi-GPU: rows are
+ * compute runs the device work and reports nnz; fetch copies the CSR out (from a
+ * page-locked copy the compute call made while its later row chunks were still
+ * running, or from the device).  The caller's arrays are read in place, never
+ * written.  row_begin/row_end select a shard of target rows (multi-GPU: rows are
  * independent, no collective). */
 irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            const int64_t *indptr, const int32_t *indices,
@@ -275,11 +277,11 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            int64_t row_begin, int64_t row_end, int64_t *nnz_out);
 irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
                          double *data);
-/* Seconds spent in device kernels of the last irs_knn_compute (HIP events) and
- * the number of multiply-adds it performed. */
 /* Measurement only: multiply-adds of the last call that were added one by one (the rest came out of
  * the dense block of the popular items, csrc/knn.hip), and the rows of that block (0: none). */
 irs_status irs_knn_last_walked(irs_knn_computer *c, int64_t *walked_macs, int32_t *dense_rows);
+/* Milliseconds of device time of the last irs_knn_compute (HIP events: first launch to last row merge of
+ * the call's row chunks) and the number of multiply-adds it performed. */
 irs_status irs_knn_last_stats(irs_knn_computer *c, double *kernel_ms,
                               int64_t *macs);
 /* remove_diagonal, cpp_source/util.hpp:211-226 (in place on `data`). */
