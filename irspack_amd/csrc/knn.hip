@@ -2255,7 +2255,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     const bool big = out_k > TOPK_CAP;  // row merge by threshold select (knn_merge_big_kernel)
     const int64_t tile_k = std::min<int64_t>(out_k, TILE);
     std::vector<int32_t> order(std::max<int64_t>(n, 1));  // per chunk: its rows (chunk-relative ids), heaviest first
-    std::vector<double> ones_host;                        // (binarise: the values the kernel reads)
+    std::vector<double> ones_host;  // (binarise on a path that reads values: sized once for the largest chunk
+    size_t ones_entries = 0;        //  - copies of it may be in flight, it must never move)
     // per chunk: "its merged rows are in out_idx / out_val"; the call's device span lies between ev_first
     // (before the first launch) and ev_last (after every chunk)
     std::vector<hipEvent_t> ev_done(n_chunks, nullptr);
@@ -2284,7 +2285,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         max_rows = std::max(max_rows, cb[k + 1] - cb[k]);
         max_entries = std::max(max_entries, ip[cb[k + 1]] - ip[cb[k]]);
       }
-      if (binarise) ones_host.assign(static_cast<size_t>(max_entries), 1.0);  // (never resized: copies of it may be in flight)
+      ones_entries = static_cast<size_t>(max_entries);
       max_slots = static_cast<size_t>(max_rows) * n_tiles;
       const size_t cap = static_cast<size_t>(n) * out_k;  // entries the result can have
       // (c->res_idx / res_val hold `cap` entries: the chunks are compacted as they finish, before the total is known)
@@ -2498,6 +2499,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       } else {
         t_val.alloc(std::max<size_t>(ne, 1));  // (whole call: the row pointers are relative to its first entry)
         if (binarise) {
+          if (ones_host.empty()) ones_host.assign(std::max<size_t>(ones_entries, 1), 1.0);
           if (cne) IRS_HIP(hipMemcpyAsync(t_val.ptr + (ce_begin - e_begin), ones_host.data(), cne * sizeof(double),
                                           hipMemcpyHostToDevice, s_in));
         } else if (cne) {
