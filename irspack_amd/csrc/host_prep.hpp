@@ -291,7 +291,7 @@ class Mt19937Bulk {
 // single variate was written: 1 s of the 1.4 s the draw took; every element is written exactly once below.)
 static RawVector<float> draw_factor(float init_stdev, int32_t random_seed, int64_t K, int64_t n,
                                     size_t block_attempts = size_t(1) << 24,
-                                    size_t jump_threshold = size_t(1) << 26) {
+                                    size_t jump_threshold = size_t(1) << 22) {
   RawVector<float> h;
   h.resize(static_cast<size_t>(n) * K);
 #if defined(__linux__)
@@ -353,7 +353,7 @@ static RawVector<float> draw_factor(float init_stdev, int32_t random_seed, int64
         if (t.joinable()) t.join();
     }
   };
-  // Very large matrices (round 5): even the engine's words are generated in parallel.  MT19937 is linear
+  // Matrices of 4 M values and more (round 5): even the engine's words are generated in parallel.  MT19937 is linear
   // over GF(2), so the state after J words is g_J(F) state with g_J = t^J mod the characteristic
   // polynomial (mt_jump.hpp).  The stream is cut into blocks of 624 * 2^b words; block j's starting
   // state is a jump of j blocks from the seed state, every thread regenerates ITS blocks twice - once to
@@ -365,8 +365,11 @@ static RawVector<float> draw_factor(float init_stdev, int32_t random_seed, int64
   size_t jumped_values = 0;   // values written by the jump path
   if (total >= jump_threshold && n_thr >= 4) {
     const double need_attempts = static_cast<double>((total + 1) / 2) / 0.78539816339 * 1.002 + 65536.0;
+    // threads of this path: a jump costs ~0.5 ms (one or two carry-less products + one Horner pass,
+    // mt_jump.hpp) - as much as generating 2^18 attempts' words twice - so no more threads than that pays
+    const int jt = static_cast<int>(std::max(4.0, std::min(static_cast<double>(n_thr), need_attempts / 262144.0)));
     int b = 0;  // block = 624 * 2^b words = 312 * 2^b attempts: 2 - 4 blocks per thread (each costs one jump)
-    while (312.0 * static_cast<double>(uint64_t(1) << (b + 1)) * n_thr * 2 <= need_attempts && b < 30) b++;
+    while (312.0 * static_cast<double>(uint64_t(1) << (b + 1)) * jt * 2 <= need_attempts && b < 30) b++;
     const uint64_t block_words = 624ull << b, block_attempts_j = block_words / 2;
     const uint64_t n_blocks = static_cast<uint64_t>(need_attempts / static_cast<double>(block_attempts_j)) + 1;
     for (int i = 0; (uint64_t(1) << i) <= n_blocks; i++) (void)mtjump::pow_block(b + i);  // (the shared powers, once)
@@ -379,24 +382,20 @@ static RawVector<float> draw_factor(float init_stdev, int32_t random_seed, int64
     std::vector<uint64_t> accepted(n_blocks + 1, 0);
     std::atomic<uint64_t> next{0};
     constexpr size_t CH = 624 * 16;  // words per regeneration step
-    auto for_blocks = [&](auto &&body) {
+    auto for_blocks = [&](auto &&body) {  // (threads started as a tree: host_util.hpp)
       next.store(0);
-      Joiner workers;
-      auto run = [&] {
+      run_on_threads(jt, [&](int) {
         for (;;) {
           const uint64_t j = next.fetch_add(1);
           if (j >= n_blocks) return;
           body(j);
         }
-      };
-      for (int k = 1; k < n_thr; k++) workers.th.emplace_back(run);
-      run();
+      });
     };
     // pass 1: every block's starting state and its number of accepted attempts
     {
       next.store(0);
-      Joiner workers;
-      auto run = [&] {
+      run_on_threads(jt, [&](int) {
         for (;;) {
           const uint64_t j = next.fetch_add(1);
           if (j > n_blocks) return;
@@ -414,9 +413,7 @@ static RawVector<float> draw_factor(float init_stdev, int32_t random_seed, int64
           }
           accepted[j + 1] = c;
         }
-      };
-      for (int k = 1; k < n_thr; k++) workers.th.emplace_back(run);
-      run();
+      });
     }
     for (uint64_t j = 0; j < n_blocks; j++) accepted[j + 1] += accepted[j];
     // pass 2: emit

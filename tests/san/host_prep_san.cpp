@@ -114,13 +114,15 @@ int main() {
     }
   }
   // ---- the parallel random stream is the sequential libstdc++ one, bit for bit (> 2^18 values)
-  for (const int64_t K : {int64_t(64), int64_t(10), int64_t(33)}) {
-    const int64_t n = K == 64 ? 6000 : K == 33 ? 20000 : 40000;
+  CHECK(mtjump::phi_low() == mtjump::phi_low_computed());  // (the tabulated characteristic polynomial)
+  for (const int64_t K : {int64_t(64), int64_t(10), int64_t(33), int64_t(70)}) {
+    // (K = 70: 4.9 M values - the jump-ahead path by the default threshold and thread / block policy)
+    const int64_t n = K == 64 ? 6000 : K == 33 ? 20000 : K == 70 ? 70000 : 40000;
     const float stdev = 0.1f;
     // (K = 10: blocks of 30,000 attempts, i.e. eight blocks with the producer thread one ahead)
     // (K = 33: the jump-ahead path - every thread regenerates its own blocks of the engine's stream from a
     // state computed by polynomial arithmetic over GF(2), mt_jump.hpp - forced by a low threshold)
-    const RawVector<float> par = K == 64   ? ials::draw_factor(stdev, 42, K, n)
+    const RawVector<float> par = (K == 64 || K == 70) ? ials::draw_factor(stdev, 42, K, n)
                                    : K == 33 ? ials::draw_factor(stdev, 42, K, n, size_t(1) << 24, size_t(1) << 18)
                                              : ials::draw_factor(stdev, 42, K, n, 30000);
     CHECK(par.size() == static_cast<size_t>(n * K) && par.size() >= (size_t(1) << 18));
