@@ -598,26 +598,27 @@ def knn_leg(X, ceilings):
                           "kernel_ms": other.last_kernel_ms,
                           "item_pairs_per_s_kernel_only": I * float(I) / (other.last_kernel_ms * 1e-3)}
         del other
-    # a weighted matrix (TF-IDF of the same interactions: the kNN recommenders' `feature_weighting`): 64-bit
-    # fixed-point sums, the float64 value stream beside the 2-byte columns, no approximate selection
-    from irspack_amd.utils import tf_idf_weight
+    # weighted matrices (the kNN recommenders' `feature_weighting`): 64-bit fixed-point sums, no approximate
+    # selection.  TF-IDF of binary interactions has ONE value per feature row of X_arg^T (the kernels then skip
+    # the float64 value stream, round 5); BM25 does not (8 more bytes per multiply-add beside the 2-byte column)
+    from irspack_amd.utils import okapi_BM_25_weight, tf_idf_weight
 
-    Xw = tf_idf_weight(Xt)
-    t0 = time.perf_counter()
-    wcomp = CosineSimilarityComputer(Xw, 0.0, True)
-    w_create = time.perf_counter() - t0
-    ws = []
-    for _ in range(3):
-        res = None
+    for wname, weigh in (("cosine_tfidf_weighted", tf_idf_weight), ("cosine_bm25_weighted", okapi_BM_25_weight)):
+        Xw = weigh(Xt)
         t0 = time.perf_counter()
-        res = wcomp.compute_similarity(Xw, 100)
-        ws.append(time.perf_counter() - t0)
-    del res
-    variants["cosine_tfidf_weighted"] = {"item_pairs_per_s": I * float(I) / min(ws), "wall_s_incl_pcie": min(ws),
-                                         "wall_s_three_calls": ws, "create_s": w_create,
-                                         "kernel_ms": wcomp.last_kernel_ms,
-                                         "item_pairs_per_s_kernel_only": I * float(I) / (wcomp.last_kernel_ms * 1e-3)}
-    del wcomp, Xw
+        wcomp = CosineSimilarityComputer(Xw, 0.0, True)
+        w_create = time.perf_counter() - t0
+        ws = []
+        for _ in range(3):
+            res = None
+            t0 = time.perf_counter()
+            res = wcomp.compute_similarity(Xw, 100)
+            ws.append(time.perf_counter() - t0)
+        del res
+        variants[wname] = {"item_pairs_per_s": I * float(I) / min(ws), "wall_s_incl_pcie": min(ws),
+                           "wall_s_three_calls": ws, "create_s": w_create, "kernel_ms": wcomp.last_kernel_ms,
+                           "item_pairs_per_s_kernel_only": I * float(I) / (wcomp.last_kernel_ms * 1e-3)}
+        del wcomp, Xw
     out["variants"] = variants
     return out
 

@@ -48,6 +48,11 @@ struct Params {
   const uint32_t *xt_tptr;
   const uint32_t *xt_idx16;  // tile-relative columns, 16 bits each, two per dword
   const double *xt_val;
+  // Not null: every feature row u of X_arg^T holds ONE value xt_rowval[u] in all its stored entries
+  // (TF-IDF of binary interactions: the weight is the row's idf).  The kernels then run their all-ones
+  // form on y' = x_u y - the same products x y, bit for bit - and never read the 8-byte value stream
+  // (four fifths of the bytes of a weighted walk).
+  const double *xt_rowval;
   const double *norms;  // per column j
   // target rows
   const int64_t *t_ptr;
@@ -328,6 +333,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     const int64_t qc = min(q, te - 1);  // te > tb here
     u = p.t_idx[qc];
     y = ACC32 ? 1.0 : p.t_val[qc];  // ACC32: the value stream is not uploaded
+    if (!ACC32 && ONES && p.xt_rowval != nullptr) y = __dmul_rn(p.xt_rowval[u], y);
   };
   auto load_bounds = [&](int64_t u, bool v, uint32_t &lo, int &len) {
     const uint32_t *tp = xt_tptr_l + u * tp_stride + tile;
@@ -485,7 +491,10 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
       const int64_t qDc = min(qD, te - 1);
       const int64_t uD = p.t_idx[qDc];
       double yD = 1.0;
-      if (!ACC32) yD = p.t_val[qDc];
+      if (!ACC32) {
+        yD = p.t_val[qDc];
+        if (ONES && p.xt_rowval != nullptr) yD = __dmul_rn(p.xt_rowval[uD], yD);  // (as in load_uy)
+      }
       const int jn = adv ? 0 : j + 1;
       const Batch nxt = make_batch(adv ? B.lo : A.lo, adv ? B.len : A.len, adv ? B.y : A.y,
                                    adv ? B.pin : A.pin, adv ? B.total : A.total, jn);
@@ -1267,19 +1276,27 @@ __global__ __launch_bounds__(256) void xt_slices_kernel(const uint32_t *__restri
 
 // per feature row of X_arg^T: largest and smallest non-zero |x| (0 when the row has none): the bounds
 // the target pass builds the fixed-point scales from
+// ... and the row's first value + whether any row holds two different ones (bit patterns compared)
 __global__ __launch_bounds__(256) void xt_row_range_kernel(const uint32_t *__restrict__ xt_ptr,
                                                            const double *__restrict__ xt_val, int64_t n_rows,
-                                                           double *__restrict__ row_max, double *__restrict__ row_min) {
+                                                           double *__restrict__ row_max, double *__restrict__ row_min,
+                                                           double *__restrict__ row_val, int32_t *__restrict__ not_const) {
   const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (u >= n_rows) return;
   double mx = 0.0, mn = __longlong_as_double(0x7ff0000000000000ll);
-  for (uint32_t q = xt_ptr[u]; q < xt_ptr[u + 1]; q++) {
-    const double a = fabs(xt_val[q]);
+  const uint32_t b = xt_ptr[u], e = xt_ptr[u + 1];
+  const double first = b < e ? xt_val[b] : 0.0;
+  bool same = true;
+  for (uint32_t q = b; q < e; q++) {
+    const double v = xt_val[q], a = fabs(v);
     mx = fmax(mx, a);
     if (a > 0.0) mn = fmin(mn, a);
+    same &= __double_as_longlong(v) == __double_as_longlong(first);
   }
   row_max[u] = mx;
   row_min[u] = isfinite(mn) ? mn : 0.0;
+  row_val[u] = first;
+  if (!same) atomicOr(not_const, 1);
 }
 
 // two tile-relative LDS byte offsets (column x 4, 16 bits each) per dword; zeros behind the last entry
@@ -1379,6 +1396,8 @@ struct irs_knn_computer {
   DeviceBuffer<uint32_t> xt_tptr;  // [n_features, n_tiles + 1], see Params
   DeviceBuffer<uint32_t> xt_idx16;
   DeviceBuffer<double> xt_val, norms;
+  DeviceBuffer<double> xt_rowval;  // see Params (allocated only when every feature row is constant)
+  bool xt_row_const = false;
   bool xt_all_ones = false;
   double norm_max = 0.0;  // largest column norm (the approximate selection needs counts below 2^24 for Tversky)
   bool xt_nonzero = false;  // |x| in (1e-150, 1e150) for every stored x
@@ -1695,11 +1714,17 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         hipLaunchKernelGGL(xt_pack16_kernel, dim3(static_cast<unsigned>(ceil_div(static_cast<int64_t>(padded / 2), 256))),
                            dim3(256), 0, s, static_cast<const int32_t *>(d_tidx.ptr), nnz_in,
                            static_cast<int64_t>(padded / 2), c->xt_idx16.ptr);
+        DeviceBuffer<int32_t> d_not_const;
+        int32_t not_const = 1;
         if (weighted) {
           d_range.alloc(2 * static_cast<size_t>(cols));
+          c->xt_rowval.alloc(static_cast<size_t>(cols));
+          d_not_const.alloc(1);
+          IRS_HIP(hipMemsetAsync(d_not_const.ptr, 0, sizeof(int32_t), s));
           hipLaunchKernelGGL(xt_row_range_kernel, dim3(static_cast<unsigned>(ceil_div(cols, 256))), dim3(256), 0, s,
                              static_cast<const uint32_t *>(d_xt_ptr.ptr), static_cast<const double *>(c->xt_val.ptr), cols,
-                             d_range.ptr, d_range.ptr + cols);
+                             d_range.ptr, d_range.ptr + cols, c->xt_rowval.ptr, d_not_const.ptr);
+          IRS_HIP(hipMemcpyAsync(&not_const, d_not_const.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, s));
           IRS_HIP(hipMemcpyAsync(c->xt_rowmax.data(), d_range.ptr, static_cast<size_t>(cols) * sizeof(double),
                                  hipMemcpyDeviceToHost, s));
           IRS_HIP(hipMemcpyAsync(c->xt_rowmin.data(), d_range.ptr + cols, static_cast<size_t>(cols) * sizeof(double),
@@ -1712,6 +1737,13 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         c->norm_max = norms.empty() ? 0.0 : *std::max_element(norms.begin(), norms.end());
         c->norms.upload(norms, s);
         IRS_HIP(hipStreamSynchronize(s));  // the host vectors and the device scratch go out of scope
+        if (weighted && not_const == 0) {  // one value per feature row: the value stream is not needed
+          c->xt_row_const = true;
+          c->xt_val.release();
+          c->xt_val.alloc(2);
+        } else {
+          c->xt_rowval.release();
+        }
         pt.mark("create: slices + pack");
         if (!tvals.empty()) {  // (returning 160 MB to the system takes 10+ ms: not on the caller's clock)
           auto *junk = new RawVector<double>();
@@ -2518,6 +2550,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       p.xt_tptr = c->xt_tptr.ptr;
       p.xt_idx16 = c->xt_idx16.ptr;
       p.xt_val = c->xt_val.ptr;
+      p.xt_rowval = c->xt_row_const ? c->xt_rowval.ptr : nullptr;
       p.norms = c->norms.ptr;
       p.t_ptr = t_ptr.ptr + rel0;  // (values relative to the CALL's first entry, like t_idx / t_val)
       p.t_idx = t_idx.ptr;
@@ -2645,6 +2678,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         } else if (acc32) launch(knn_tile_kernel<true, true, true>);
         else if (sentinel) launch(knn_tile_kernel<true, true>);
         else launch(knn_tile_kernel<true, false>);
+      } else if (c->xt_row_const) {  // (the all-ones kernels on y' = x_u y: Params::xt_rowval)
+        if (sentinel) launch(knn_tile_kernel<true, true>); else launch(knn_tile_kernel<true, false>);
       } else {
         if (sentinel) launch(knn_tile_kernel<false, true>); else launch(knn_tile_kernel<false, false>);
       }

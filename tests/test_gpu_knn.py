@@ -615,3 +615,30 @@ def test_device_create_p3alpha_rp3beta(kind, alpha, beta, monkeypatch):
     a = g_dev.compute_W(Xt, 40)
     assert_same_csr(a, g_host.compute_W(Xt, 40), rtol=0)
     assert_same_csr(a, o.compute_W(Xt, 40), rtol=1e-11)
+
+
+@pytest.mark.parametrize("kind,kw", [c for c in CASES if c[0] in ("cosine", "asymmetric")])
+@pytest.mark.parametrize("shape", ["one_tile", "two_tiles"])
+def test_row_constant_values_skip_the_value_stream(kind, kw, shape, monkeypatch):
+    """TF-IDF of binary interactions: every feature row of X_arg^T holds one value (its idf), found at
+    construction; the kernels then run their all-ones form on y' = x_u y and never read the float64 value
+    stream.  The same products x y: bit for bit the general weighted kernel's result (the host
+    construction keeps that one), one and two column tiles, a weighted AND a binary target."""
+    Xb = sps.csr_matrix(X_many.T) if shape == "one_tile" else power_law_items(900, 17000, 120000, 11)
+    Xw = tf_idf_weight(Xb)
+    g, o = make(kind, Xw, **dict(kw))
+    monkeypatch.setenv("IRSPACK_AMD_KNN_DEVICE_CREATE", "0")
+    g_general, _ = make(kind, Xw, **dict(kw))
+    monkeypatch.delenv("IRSPACK_AMD_KNN_DEVICE_CREATE")
+    for T in (Xw, Xb):
+        a = g.compute_similarity(T, 30)
+        assert_same_csr(a, g_general.compute_similarity(T, 30), rtol=0)
+        # against the oracle: the top-k VALUES of every row (idf weights of binary data produce sums that
+        # are equal in exact arithmetic; the oracle's sequential float64 sums break such ties by their
+        # rounding, the fixed-point sums by column - test_adversarial_exact_ties_with_weights)
+        want = sps.csr_matrix(o.compute_similarity(T, 30))
+        assert np.array_equal(a.indptr, want.indptr)
+        for r in range(0, a.shape[0], 7):
+            ga = np.sort(a.data[a.indptr[r]:a.indptr[r + 1]])
+            wa = np.sort(want.data[want.indptr[r]:want.indptr[r + 1]])
+            np.testing.assert_allclose(ga, wa, rtol=1e-12, atol=0)
