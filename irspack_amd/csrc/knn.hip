@@ -2172,15 +2172,11 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
           slot.ev_in = slot.ev_setup = nullptr;
         }
       }
-      if (!c->stream) {
-        IRS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        IRS_HIP(hipStreamCreateWithFlags(&c->stream_k, hipStreamNonBlocking));
-        IRS_HIP(hipStreamCreateWithFlags(&c->stream_in, hipStreamNonBlocking));
-        IRS_HIP(hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking));
-        IRS_HIP(hipStreamCreateWithFlags(&c->stream_out, hipStreamNonBlocking));
-        IRS_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-        IRS_HIP(hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming));
-      }
+      // (each on its own: a creation that failed half way must not leave a later call with null streams)
+      for (hipStream_t *st : {&c->stream, &c->stream_k, &c->stream_in, &c->stream_up, &c->stream_out})
+        if (!*st) IRS_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+      for (hipEvent_t *ev : {&c->ev_in, &c->ev_setup})
+        if (!*ev) IRS_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
       {  // carve the call's buffers out of the arena (the last result, which lives there too, is gone now)
         const size_t nn = static_cast<size_t>(n);
         const size_t n_tiles_a = static_cast<size_t>(ceil_div(std::max<int64_t>(c->N, 1), TILE));
