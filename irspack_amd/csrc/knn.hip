@@ -193,12 +193,9 @@ __device__ unsigned long long knn_phase_clk[8];
 // are counts, accumulated with 32-bit LDS atomics (one bank per lane instead of two: 1.5x the
 // fp64 atomic rate) in the upper half of the accumulator block and widened to fp64 in place
 // afterwards - the same values as the fp64 sums, which are exact for integers.
-// COMPACT (round 3; counts only): NT = 512 threads and 66 KB of LDS per workgroup - the TILE
-// 32-bit counters, the sinks, the select scratch; the similarities are NOT written back to LDS
-// (a winner's value is recovered from its order-preserving key, which is a bijection on the
-// non-NaN doubles) - so that TWO workgroups are resident per CU and one pair's epilogue /
-// selection (4 of the 10 ms of a call: fp64 divisions, global norm loads, barriers) overlaps the
-// other pair's accumulation (LDS atomics).
+// (A COMPACT form of the count path - 512 threads and 66 KB of LDS per workgroup, two workgroups per CU so
+// that one pair's epilogue / selection overlaps the other's accumulation - was built in round 3, measured
+// at 10.69 against 10.54 ms and kept as an opt-in; removed in round 5.  DESIGN.md 3.4 has the numbers.)
 // FAST (round 3; counts only, the four similarities that end in a division): the selection runs
 // on float32 APPROXIMATIONS of the similarities (8 vector instructions per column instead of the
 // ~45 of the un-fused fp64 epilogue, 32-bit keys), and only the columns that can still be among
@@ -209,28 +206,23 @@ __device__ unsigned long long knn_phase_clk[8];
 // top_k has approx >= t (1 - eps) / (1 + eps), t = the top_k-th largest approximation, so the
 // candidate set is a superset of the exact winners whatever the ties; when it does not fit
 // FAST_CAP entries (thousands of near-ties) the pair takes the exact path below.
-template <bool ONES, bool SENTINEL, bool ACC32 = false, int NT = THREADS, bool COMPACT = false, bool FAST = false>
-__global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p) {
+template <bool ONES, bool SENTINEL, bool ACC32 = false, bool FAST = false>
+__global__ __launch_bounds__(THREADS, 1) void knn_tile_kernel(Params p) {
   static_assert(!ACC32 || (ONES && SENTINEL), "counts need all-ones operands");
-  static_assert(!COMPACT || (ACC32 && NT == 512), "the compact layout holds counters only");
-  static_assert(!FAST || (ACC32 && !COMPACT), "the approximate selection is built for the count path");
-  constexpr int THREADS = NT;  // (shadows the namespace constant inside this kernel)
+  static_assert(!FAST || ACC32, "the approximate selection is built for the count path");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double *acc = reinterpret_cast<double *>(smem);                        // TILE (COMPACT: TILE counters)
-  // COMPACT: [TILE x u32 counters][64 x u32 sinks][256 x u32 hist][16 x i32 wave_cnt]
-  uint32_t *bits = COMPACT ? reinterpret_cast<uint32_t *>(smem + TILE * 4 + 256)
-                           : reinterpret_cast<uint32_t *>(acc + TILE);   // TILE / 32 (unused when COMPACT)
-  uint32_t *hist = COMPACT ? bits : bits + TILE / 32;                    // 256
+  double *acc = reinterpret_cast<double *>(smem);                        // TILE
+  uint32_t *bits = reinterpret_cast<uint32_t *>(acc + TILE);             // TILE / 32
+  uint32_t *hist = bits + TILE / 32;                                     // 256
   int32_t *wave_cnt = reinterpret_cast<int32_t *>(hist + 256);           // 16
   // one sink per lane for the lanes of a strip that lie outside their slice: the atomic is
-  // issued without a branch (ACC32 uses the idle upper half of the accumulator block; COMPACT
-  // the 256 bytes behind the counters)
+  // issued without a branch (ACC32 uses the idle upper half of the accumulator block)
   constexpr uint32_t SINK_BYTES = TILE * 8 + (TILE / 32) * 4 + 256 * 4 + 16 * 4;
   __shared__ uint64_t sh_prefix;
   __shared__ int32_t sh_need, sh_count, sh_total;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  constexpr int NW = NT / 64;
+  constexpr int NW = THREADS / 64;
   __shared__ int32_t sh_slot;
   // One workgroup per CU stays resident and draws (row slot, tile) pairs, heaviest rows
   // first, from a global counter: a 1024-thread / 130 KB workgroup costs ~20 us to launch
@@ -260,7 +252,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   uint32_t *cnt = reinterpret_cast<uint32_t *>(acc);  // ACC32: TILE counters
   // popular target row: the popular columns come from the dense block, the walk skips them
   int pr = -1;
-  if (ACC32 && !COMPACT && p.t_pop != nullptr) pr = __builtin_amdgcn_readfirstlane(p.t_pop[r]);
+  if (ACC32 && p.t_pop != nullptr) pr = __builtin_amdgcn_readfirstlane(p.t_pop[r]);
   const uint32_t *const xt_tptr_l = pr >= 0 ? p.xt_tptr_np : p.xt_tptr;
   const uint32_t *const xt_idx16_l = pr >= 0 ? p.xt_idx16_np : p.xt_idx16;
   if (ACC32) {
@@ -274,8 +266,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   } else {
     for (int i = tid; i < width; i += THREADS) acc[i] = SENTINEL ? -0.0 : 0.0;
   }
-  if (!COMPACT)
-    for (int i = tid; i < TILE / 32; i += THREADS) bits[i] = 0u;
+  for (int i = tid; i < TILE / 32; i += THREADS) bits[i] = 0u;
   __syncthreads();
   PHASE_MARK(0);
 
@@ -802,8 +793,8 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
   } else {
   uint64_t key[PER];
   have = 0;
-  uint32_t cv[(ACC32 && !COMPACT) ? PER : 1];
-  if (ACC32 && !COMPACT) {
+  uint32_t cv[ACC32 ? PER : 1];
+  if (ACC32) {
     // count i sits in the bytes of acc[i / 2]: every count is read before any sum is written
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -822,12 +813,8 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int i = cbase + 64 * (h + k);
-      if (COMPACT) {
-        const uint32_t c32 = cnt[min(i, TILE - 1)];  // (nothing overwrites the counters)
-        raw[k] = static_cast<double>(c32);
-        if (i < width && c32 != 0u) have |= 1u << (h + k);
-      } else if (ACC32) {
-        raw[k] = static_cast<double>(cv[(ACC32 && !COMPACT) ? h + k : 0]);
+      if (ACC32) {
+        raw[k] = static_cast<double>(cv[ACC32 ? h + k : 0]);
       } else {
         // fixed-point sum -> double (one rounding).  Sentinel: the accumulator started at the
         // bit pattern of -0.0 = INT64_MIN, the sum is the difference.
@@ -848,7 +835,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     for (int k = 0; k < 8; k++) {
       const double sv = epilogue(p, raw[k], nrm[k], tstat);
       key[h + k] = order_key(sv);
-      if (!COMPACT && ((have >> (h + k)) & 1u)) acc[cbase + 64 * (h + k)] = sv;
+      if ((have >> (h + k)) & 1u) acc[cbase + 64 * (h + k)] = sv;
     }
   }
   // stored entries of the tile, and the bits in which their keys differ (the radix select
@@ -1044,9 +1031,7 @@ __global__ __launch_bounds__(NT, COMPACT ? 4 : 1) void knn_tile_kernel(Params p)
     if (win) {
       const int pos = pos0 + __popcll(bal & lt_mask);
       cidx[pos] = c0 + cbase + 64 * k;
-      // COMPACT: the value back from its key (order_key is invertible: similarities of counts
-      // are finite and never -0.0)
-      cval[pos] = COMPACT ? key_to_double(key[k]) : acc[cbase + 64 * k];
+      cval[pos] = acc[cbase + 64 * k];
     }
     pos0 += __popcll(bal);
   }
@@ -2623,25 +2608,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         IRS_HIP(hipEventRecord(ev_first, ks));
         ev_first_recorded = true;
       }
-      // IRSPACK_AMD_KNN_COMPACT=1 (opt-in, a measured NEGATIVE result): counts (binary data) on two
-      // 512-thread workgroups per CU with 66 KB of LDS each, so that one pair's epilogue / selection
-      // overlaps the other's accumulation.  Same results (tests/test_gpu_knn.py runs both), same
-      // time: 10.69 against 10.54 ms per ML-20M call - the phases of one pair do not leave the CU
-      // idle, they keep different units busy in turn (LDS atomics at 77 % of their rate, then fp64
-      // divisions), and two half-size workgroups issue the same instructions with 32 instead of 16
-      // keys per thread (128 registers, 51 spilled dwords).  DESIGN.md 3.4.
-      const char *compact_env = std::getenv("IRSPACK_AMD_KNN_COMPACT");  // (read per call: tests toggle it)
-      const bool compact = compact_env && compact_env[0] == '1';
-      if (c->xt_all_ones && acc32 && compact) {
-        const size_t lds_c = TILE * sizeof(uint32_t) + 64 * sizeof(uint32_t) + 256 * sizeof(uint32_t) +
-                             16 * sizeof(int32_t);
-        auto kernel = knn_tile_kernel<true, true, true, 512, true>;
-        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_c)));
-        const unsigned grid_c = static_cast<unsigned>(
-            std::min<size_t>(slots, 2 * static_cast<size_t>(std::max(n_cu, 1))));
-        hipLaunchKernelGGL(kernel, dim3(grid_c), dim3(512), lds_c, ks, p);
-      } else if (c->xt_all_ones) {
+      if (c->xt_all_ones) {
         // counts + a similarity that ends in a division: selection on float32 approximations, exact
         // fp64 values for the candidates only (knn_tile_kernel, FAST).  The error bound of the
         // approximation needs non-negative terms in the denominator.  IRSPACK_AMD_KNN_FAST=0: A/B.
@@ -2667,7 +2634,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                           !(fast_env && fast_env[0] == '0');
         if (fast) {
           p.redo_list = sc.redo_list.ptr;
-          launch(knn_tile_kernel<true, true, true, THREADS, false, true>);
+          launch(knn_tile_kernel<true, true, true, true>);
           p.redo = 1;  // the pairs the approximate selection handed back (usually none), exactly
           launch(knn_tile_kernel<true, true, true>);
           p.redo = 0;

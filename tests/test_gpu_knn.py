@@ -255,12 +255,8 @@ def test_weighting_helpers_match_oracle():
             np.testing.assert_allclose(mine.toarray(), ref.toarray(), rtol=1e-13)
 
 
-@pytest.mark.parametrize("compact", ["0", "1"])
-def test_two_column_tiles(compact, monkeypatch):
+def test_two_column_tiles():
     # N > 16384 columns -> the product row is split over two LDS tiles and merged.
-    # compact = "1": the opt-in 512-thread / 66 KB kernel (two workgroups per CU; values recovered
-    # from the order-preserving keys) must give the same bits.
-    monkeypatch.setenv("IRSPACK_AMD_KNN_COMPACT", compact)
     rng2 = np.random.default_rng(5)
     N, U = 20000, 300
     rows = rng2.integers(0, U, size=60000)
