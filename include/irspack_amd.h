@@ -367,7 +367,7 @@ irs_status irs_fingerprint(const void *data, int64_t n_bytes, uint64_t seed, uin
 
 /* What the last irs_eval_get_metrics_ials call did (measurement only, no reference
  * counterpart).  path: 0 = score block + ranking (two passes), 1 = threshold-filtered
- * candidates, 2 = threshold-filtered with norm-bound pruning, 3 = single-pass streaming top-k. */
+ * candidates, 2 = threshold-filtered with norm-bound pruning (3, a single-pass variant, was removed in ABI 3's round). */
 typedef struct irs_eval_stats {
   int32_t path;
   int32_t hard_rows;    /* rows ranked from their full score row after the filtered pass */

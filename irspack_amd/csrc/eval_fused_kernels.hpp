@@ -1,27 +1,12 @@
-// Fused scoring + ranking for the iALS evaluator (irs_eval_get_metrics_ials): the
-// [users, items] score block is never written.  Replaces user_scores -> mask -> rank
-// (2 x 1.75 GB of HBM traffic per 16,384 users) for the usual call: every item a candidate,
-// cutoff <= 32.  Semantics: evaluator.cpp:292-367 (rank by (score desc, index asc) among the
-// scores != -inf) on scores bit-identical to user_scores_kernel's (the same MFMA sequence per
+// Kernels of the iALS evaluator's fused call (irs_eval_get_metrics_ials) that never write the
+// [users, items] score block: the mask as a bitmap (below) and the threshold-filtered "emit" path
+// (second half of this file).  Semantics: evaluator.cpp:292-367 (rank by (score desc, index asc) among
+// the scores != -inf) on scores bit-identical to user_scores_kernel's (the same MFMA sequence per
 // (user, item): k in ascending steps of 16, the four 4-slices of a step in order).
-//
-// fused_topk_kernel: one WAVE per (64-user tile, item chunk).  Per 64 x 64 score tile
-//   1. 16 MFMAs per k-step of 16, the user operands resident in registers for K <= 64;
-//   2. the tile goes to the wave's LDS slab, and lane l becomes USER l: it streams its 64
-//      scores (4-at-a-time maximum first) against its threshold tau - the cutoff-th best score
-//      it has kept so far - and appends what passes and is not masked to its own list in LDS
-//      (no atomics: a lane owns its user).  The mask (the training interactions) is a device
-//      bitmap, one 64-bit word per (user, item tile);
-//   3. a list that could overflow within the next 16 scores (CAP - 16 entries) is pruned by
-//      the whole wave: rank by (score desc, index asc), keep `cutoff`, new tau.
-//   The item range is cut into chunks (load balance: 2,164 user tiles on 1,024 wave slots); a
-//   chunk starts from tau = -inf but refreshes it from a per-user hint the other chunks raise
-//   (any chunk's cutoff-th best score is a lower bound of the user's final one).
-// fused_finish_kernel: one wave per user merges the chunks' lists (<= n_chunks x cutoff
-//   candidates), keeps the top `cutoff` exactly, and computes the metrics like
-//   rank_wave_kernel (sequential dcg / AP recurrences, evaluator.cpp:136-165).
-// A NaN / infinite score anywhere sets a flag and the host repeats the call on the unfused
-// path (NaN ordering is defined there).
+// (A single-pass variant - streaming top-k lists in LDS inside the scoring kernel, `fused_topk_kernel` +
+// `fused_finish_kernel`, IRSPACK_AMD_EVAL_FUSED=1 - was built in round 2, measured slower than the
+// two-pass path at every K (16.5 against 11.6 - 13.0 ms at K = 64: one wave per SIMD beside 39 KB of
+// LDS per wave) and then superseded by the emit path; deleted in round 5)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -38,291 +23,8 @@ typedef float fz_f32x4 __attribute__((ext_vector_type(4)));
 // would drain the operand loads that are in flight for the next tile.
 #define FZ_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-constexpr int FZ_CAP = 56;       // list entries per user and chunk
-constexpr int FZ_MAX_CUTOFF = 32;
-constexpr int FZ_SROW = 68;      // LDS row stride of the score tile (floats)
-// score tile | list scores (+64 dummy slots) | list items (+64 dummy slots)
-constexpr int FZ_LDS_PER_WAVE = 64 * FZ_SROW * 4 + (64 * FZ_CAP + 64) * 4 + (64 * FZ_CAP + 64) * 2;  // 39,296 B
-constexpr int FZ_MAX_CHUNKS = 16;
-
-struct FusedParams {
-  const float *user;      // [n_users, KP] (trainer's device buffer)
-  const float *item;      // [n_items, KP]
-  int64_t begin;          // first user of the call
-  int64_t rows;           // users of the call
-  int64_t n_items;
-  const uint64_t *mask_bits;  // [rows, words] bit j of word t: item 64 t + j is masked; or null
-  int64_t words;              // ceil(n_items / 64)
-  int32_t cutoff;
-  int32_t n_chunks;
-  int32_t tiles_per_chunk;    // item tiles (64 items) per chunk
-  float *cand_score;          // [rows, n_chunks, cutoff]
-  int32_t *cand_item;         // [rows, n_chunks, cutoff]
-  int32_t *cand_cnt;          // [rows, n_chunks]
-  int32_t *tau_hint;          // [rows] order-preserving int image of the best known threshold
-  int32_t *bad_flag;          // set when a score is NaN / infinite
-  const int32_t *n_masked;    // [rows] masked items per user (or null: none)
-};
-
-__device__ __forceinline__ int32_t fz_float_key(float s) {  // monotone float -> int
-  const int32_t b = __float_as_int(s);
-  return b >= 0 ? b : (b ^ 0x7fffffff);
-}
-__device__ __forceinline__ float fz_key_float(int32_t k) {
-  return __int_as_float(k >= 0 ? k : (k ^ 0x7fffffff));
-}
-
-// Rank the entries of user `u`'s list by (score desc, index asc), keep `keep`, sorted.
-// Whole wave: lane j holds entry j and compares it with every entry, broadcast from the
-// registers with v_readlane (no LDS latency in the loop); returns the new count and threshold
-// through lane-uniform values.
-__device__ __forceinline__ void fz_prune(float *lsc, uint16_t *lix, int u, int cnt, int keep,
-                                         int &cnt_out, float &tau_out) {
-  const int ln = threadIdx.x & 63;
-  float *sc = lsc + u * FZ_CAP;
-  uint16_t *ix = lix + u * FZ_CAP;
-  const float NEG_INF = -std::numeric_limits<float>::infinity();
-  const bool have = ln < cnt;
-  const float s = have ? sc[ln] : NEG_INF;
-  const int i = have ? ix[ln] : 0x7fffffff;
-  int rank = 0;
-  for (int k = 0; k < cnt; k++) {
-    const float sk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), k));
-    const int ik = __builtin_amdgcn_readlane(i, k);
-    rank += (sk > s || (sk == s && ik < i)) ? 1 : 0;
-  }
-  const int kept = min(cnt, keep);
-  if (have && rank < kept) {  // (every lane holds its entry in registers: no read is pending)
-    sc[rank] = s;
-    ix[rank] = static_cast<uint16_t>(i);
-  }
-  cnt_out = kept;
-  // the new threshold = the entry of rank keep - 1
-  const unsigned long long who = __ballot(have && rank == keep - 1);
-  tau_out = who ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), __ffsll(static_cast<long long>(who)) - 1))
-                : NEG_INF;
-  FZ_LDS_FENCE();
-}
-
-#ifdef FZ_PHASES
-__device__ unsigned long long fz_phase_clk[8];  // development: device-clock phase sums
-#define FZ_MARK(i) do { if (ln == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&fz_phase_clk[i], t_ - ph_t); ph_t = t_; } } while (0)
-#else
-#define FZ_MARK(i)
-#endif
-
-template <int KP, bool RESIDENT>
-__global__ __launch_bounds__(256, 1) void fused_topk_kernel(FusedParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fz_smem[];
-  const int wid = wave_index_in_block(), ln = threadIdx.x & 63;
-  const int g = ln >> 4, m = ln & 15;
-  unsigned char *slab = fz_smem + wid * FZ_LDS_PER_WAVE;
-  float *S = reinterpret_cast<float *>(slab);
-  float *lsc = S + 64 * FZ_SROW;
-  uint16_t *lix = reinterpret_cast<uint16_t *>(lsc + 64 * FZ_CAP + 64);
-  const float NEG_INF = -std::numeric_limits<float>::infinity();
-  // thresholds shared by the workgroup's four waves (see below); behind the four slabs
-  int32_t *hint_lds = reinterpret_cast<int32_t *>(fz_smem + 4 * FZ_LDS_PER_WAVE);
-  const bool shared_hints = p.n_chunks == 4;
-  if (threadIdx.x < 64) hint_lds[threadIdx.x] = static_cast<int32_t>(0x807fffffu);  // key of -inf
-  __syncthreads();
-
-  const int64_t n_user_tiles = (p.rows + 63) / 64;
-  const int64_t unit = static_cast<int64_t>(blockIdx.x) * 4 + wid;
-  if (unit >= n_user_tiles * p.n_chunks) return;
-  // consecutive units share the user tile: its chunks run at about the same time and feed
-  // each other's thresholds
-  const int64_t ut = unit / p.n_chunks;
-  const int ch = static_cast<int>(unit % p.n_chunks);
-  const int64_t item_tiles = (p.n_items + 63) / 64;
-  const int64_t t0 = static_cast<int64_t>(ch) * p.tiles_per_chunk;
-  const int64_t t1 = min(t0 + p.tiles_per_chunk, item_tiles);
-  const int64_t chunk_item0 = t0 * 64;
-
-  // lane l as user l of the tile
-  const int64_t my_row = ut * 64 + ln;          // row of the call
-  const bool my_valid = my_row < p.rows;
-  float tau = my_valid ? NEG_INF : std::numeric_limits<float>::infinity();
-  int cnt = 0;
-  const uint64_t *my_bits = p.mask_bits ? p.mask_bits + (my_valid ? my_row : 0) * p.words : nullptr;
-
-  // operand rows (as user_scores_kernel): user tile p' holds the users 16 p' + m, item tile q
-  // the items 4 m + q
-  const float *up[4];
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int64_t u = min(ut * 64 + q * 16 + m, p.rows - 1);
-    up[q] = p.user + (p.begin + u) * KP + 4 * g;
-  }
-  fz_f32x4 ares[RESIDENT ? KP / 16 : 1][4];
-  if constexpr (RESIDENT) {
-#pragma unroll
-    for (int k = 0; k < KP / 16; k++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) ares[k][q] = *reinterpret_cast<const fz_f32x4 *>(up[q] + 16 * k);
-  }
-  bool bad = false;
-#ifdef FZ_PHASES
-  unsigned long long ph_t = wall_clock64();
-#endif
-  // The operands of the next D k-steps (16 latent dims each) are always in flight, ACROSS
-  // tiles: one wave per SIMD has nobody to hide a load behind, so the first steps of the next
-  // tile are requested before this tile is staged, scanned and pruned.
-  constexpr int NS = KP / 16;            // k-steps per tile
-  constexpr int D = NS < 4 ? NS : 4;     // ring depth (NS is a multiple of D)
-  static_assert(NS % D == 0, "the ring must divide a tile's k-steps");
-  fz_f32x4 ra[RESIDENT ? 1 : D][4], rb[D][4];
-  auto item_ptrs = [&](int64_t tile, const float *(&ip)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int64_t i = min(tile * 64 + 4 * m + q, p.n_items - 1);
-      ip[q] = p.item + i * KP + 4 * g;
-    }
-  };
-  auto load_step = [&](const float *const (&ip)[4], int step, int slot) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if constexpr (!RESIDENT) ra[slot][q] = *reinterpret_cast<const fz_f32x4 *>(up[q] + 16 * step);
-      rb[slot][q] = *reinterpret_cast<const fz_f32x4 *>(ip[q] + 16 * step);
-    }
-  };
-  const float *ip_cur[4], *ip_nxt[4];
-  item_ptrs(t0, ip_cur);
-#pragma unroll
-  for (int s0 = 0; s0 < D; s0++) load_step(ip_cur, s0, s0);
-  uint64_t mword_next = (my_bits && t0 < t1) ? my_bits[t0] : 0ull;
-  for (int64_t it = t0; it < t1; it++) {
-    const uint64_t mword = mword_next;
-    if (my_bits) mword_next = my_bits[min(it + 1, t1 - 1)];  // unconditional: no drain of the ring
-    item_ptrs(min(it + 1, t1 - 1), ip_nxt);  // (the last tile prefetches itself: harmless)
-    // ---- 1. the 64 x 64 score tile (user_scores_kernel's MFMA order)
-    fz_f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) acc[a][b] = fz_f32x4{0.f, 0.f, 0.f, 0.f};
-    // (per accumulator the order stays x, y, z, w - user_scores_kernel's - but the four
-    // dependent MFMAs of one accumulator are issued 16 instructions apart: back to back they
-    // wait 40 cycles on each other instead of 32)
-    auto mfma_step = [&](const fz_f32x4 (&aa)[4], const fz_f32x4 (&bb)[4]) {
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[a][c], bb[b][c], acc[a][b], 0, 0, 0);
-    };
-#pragma unroll
-    for (int st = 0; st < NS; st++) {
-      if constexpr (RESIDENT) mfma_step(ares[st], rb[st % D]); else mfma_step(ra[st % D], rb[st % D]);
-      __builtin_amdgcn_sched_barrier(0);
-      // the slot is free: request step st + D (of this tile, or of the next one)
-      if (st + D < NS) load_step(ip_cur, st + D, st % D); else load_step(ip_nxt, st + D - NS, st % D);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) ip_cur[q] = ip_nxt[q];
-    FZ_MARK(0);
-    // ---- 2. tile -> LDS: row = user 16 a + 4 g + r, columns 4 m .. 4 m + 3 = items 4 m + q
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-        *reinterpret_cast<fz_f32x4 *>(S + (16 * a + 4 * g + r) * FZ_SROW + 4 * m) =
-            fz_f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
-    FZ_LDS_FENCE();
-    // every 8 tiles: a threshold another chunk of this user has reached
-    // a threshold another chunk of this user has reached: any chunk's cutoff-th best score is a
-    // lower bound of the user's final one.  The chunks of a user tile are the four waves of
-    // this workgroup when n_chunks == 4: they share through LDS; otherwise through a global
-    // array with plain loads / stores (a stale or lost value is only a weaker, still valid,
-    // bound)
-    if (shared_hints) {
-      tau = fmaxf(tau, fz_key_float(hint_lds[ln]));
-    } else if (my_valid) {
-      tau = fmaxf(tau, fz_key_float(__builtin_nontemporal_load(p.tau_hint + my_row)));
-    }
-    FZ_MARK(1);
-    const int valid_items = static_cast<int>(min<int64_t>(64, p.n_items - it * 64));
-    const int item_rel0 = static_cast<int>(it * 64 - chunk_item0);
-    // ---- 3. lane l scans user l's row, 16 scores at a time.  Branch-free: one wave per SIMD
-    //      has nobody to issue while it sits in a branch or a scalar dependency, so every score
-    //      is "appended" - to the list when it passes, to a per-lane dummy slot when not.
-    float fsum = 0.f;
-#ifndef FZ_NO_SCAN
-    const uint32_t mlo = static_cast<uint32_t>(mword), mhi = static_cast<uint32_t>(mword >> 32);
-#pragma unroll
-    for (int grp = 0; grp < 4; grp++) {
-      // lists that the next 16 scores could overflow are pruned first
-#ifdef FZ_NO_PRUNE
-      cnt = min(cnt, FZ_CAP - 16);
-#endif
-      unsigned long long need = __ballot(cnt > FZ_CAP - 16);
-      FZ_MARK(2);
-      while (need) {
-        const int u = __ffsll(static_cast<long long>(need)) - 1;
-        need &= need - 1;
-        const int cu = __builtin_amdgcn_readlane(cnt, u);
-        int c_new;
-        float t_new;
-        fz_prune(lsc, lix, u, cu, p.cutoff, c_new, t_new);
-        if (ln == u) {
-          cnt = c_new;
-          tau = fmaxf(tau, t_new);
-        }
-      }
-      FZ_MARK(3);
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        const fz_f32x4 v = *reinterpret_cast<const fz_f32x4 *>(S + ln * FZ_SROW + 16 * grp + 4 * jj);
-        fsum += (v.x + v.y) + (v.z + v.w);  // NaN / infinity anywhere poisons the sum
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const int j = 16 * grp + 4 * jj + c;  // compile time
-          const uint32_t mbit = (j < 32 ? mlo : mhi) & (1u << (j & 31));
-          const bool pass = v[c] >= tau && j < valid_items && mbit == 0u;
-          const int slot = pass ? ln * FZ_CAP + cnt : 64 * FZ_CAP + ln;
-          lsc[slot] = v[c];
-          lix[slot] = static_cast<uint16_t>(item_rel0 + j);
-          cnt += pass ? 1 : 0;
-        }
-      }
-    }
-#endif
-    bad |= !(fabsf(fsum) < 3.0e38f);
-    // publish this chunk's threshold (unconditional: no vector-memory operation under a branch)
-    if (shared_hints) {
-      atomicMax(hint_lds + ln, fz_float_key(tau == std::numeric_limits<float>::infinity() ? NEG_INF : tau));
-    } else {
-      __builtin_nontemporal_store(fz_float_key(tau), p.tau_hint + (my_valid ? my_row : p.rows));
-    }
-    FZ_MARK(2);
-    FZ_LDS_FENCE();  // the next tile overwrites S
-  }
-  if (__any(bad && my_valid)) {
-    if (ln == 0) atomicOr(p.bad_flag, 1);
-  }
-  FZ_MARK(4);
-  // ---- final prune of every user and hand-over
-  for (int u = 0; u < 64; u++) {
-    const int cu = __builtin_amdgcn_readlane(cnt, u);
-    int c_new;
-    float t_new;
-    fz_prune(lsc, lix, u, cu, p.cutoff, c_new, t_new);
-    if (ln == u) cnt = c_new;
-    const int64_t row = ut * 64 + u;
-    if (row < p.rows) {
-      const size_t base = (static_cast<size_t>(row) * p.n_chunks + ch) * p.cutoff;
-      if (ln < c_new) {
-        p.cand_score[base + ln] = lsc[u * FZ_CAP + ln];
-        p.cand_item[base + ln] = static_cast<int32_t>(chunk_item0) + lix[u * FZ_CAP + ln];
-      }
-      if (ln == 0) p.cand_cnt[static_cast<size_t>(row) * p.n_chunks + ch] = c_new;
-    }
-  }
-  FZ_MARK(5);
-}
+constexpr int FZ_MAX_CUTOFF = 32;  // largest cutoff of the fused paths
+constexpr int FZ_SROW = 68;        // LDS row stride of the score tile (floats)
 
 // mask CSR rows -> bitmap rows (the bitmap is zeroed by the host first), one wave per row
 __global__ __launch_bounds__(256) void mask_bitmap_kernel(const int64_t *__restrict__ mask_ptr,

@@ -785,74 +785,6 @@ __global__ __launch_bounds__(256) void rank_cand_slow_kernel(EvalParams p, EmitP
   wave_metrics_tail(p, row, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
 }
 
-// Fused path, second kernel: one wave per user.  Merges the item chunks' lists (each the
-// chunk's top `cutoff`, so their union contains the user's), ranks the union by (score desc,
-// index asc) and finishes like rank_wave_kernel.  n_rec = min(cutoff, rankable items):
-// every score of the fused path is finite (else the call is repeated unfused), so the
-// rankable items are the unmasked ones.
-__global__ __launch_bounds__(256) void fused_finish_kernel(EvalParams p, FusedParams f) {
-  __shared__ float cs[4][FZ_MAX_CHUNKS * FZ_MAX_CUTOFF];
-  __shared__ int32_t ci[4][FZ_MAX_CHUNKS * FZ_MAX_CUTOFF];
-  __shared__ int32_t sel[4][64];
-  const int ln = threadIdx.x & 63, wv = wave_index_in_block();
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + wv;
-  if (row >= p.rows) return;
-  const int64_t u = row + p.offset;
-  RowOut res{0, 0, 0, 0, 0, 0, 0};
-  const int gb = p.gt_ptr[u], ge = p.gt_ptr[u + 1];
-  const int n_gt = ge - gb;
-  int32_t *rec_row = p.rec_out + row * p.cutoff;
-  if (ln < p.cutoff) rec_row[ln] = -1;  // cutoff <= 32
-  if (n_gt == 0) {  // counted in total_user only (:316-321)
-    if (ln == 0) p.out[row] = res;
-    return;
-  }
-  int32_t gt_pref = -1;
-  double disc_pref = 0.0;
-  if (n_gt <= 64 && ln < n_gt) gt_pref = p.gt_idx[gb + ln];
-  if (ln < p.cutoff) disc_pref = p.disc[ln];
-  const double idcg_pref = p.idcg_prefix[min(n_gt, p.cutoff)];
-  // gather the chunks' lists
-  int total = 0;
-  for (int ch = 0; ch < f.n_chunks; ch++) {
-    const int c = f.cand_cnt[static_cast<size_t>(row) * f.n_chunks + ch];
-    const size_t base = (static_cast<size_t>(row) * f.n_chunks + ch) * f.cutoff;
-    if (ln < c) {
-      cs[wv][total + ln] = f.cand_score[base + ln];
-      ci[wv][total + ln] = f.cand_item[base + ln];
-    }
-    total += c;
-  }
-  __threadfence_block();
-  const int64_t n_rankable = f.n_items - (f.n_masked ? f.n_masked[row] : 0);
-  const int n_rec = static_cast<int>(min<int64_t>(p.cutoff, n_rankable));
-  res.valid = 1;
-  res.n_rec = n_rec;
-  if (n_rec == 0) {  // :132-135
-    if (ln == 0) p.out[row] = res;
-    return;
-  }
-  if (total < n_rec) {  // cannot happen for finite scores: have the host repeat the call
-    if (ln == 0) atomicOr(f.bad_flag, 2);
-    if (ln == 0) p.out[row] = res;
-    return;
-  }
-  for (int e = ln; e < total; e += 64) {
-    const float s = cs[wv][e];
-    const int32_t i = ci[wv][e];
-    int rank = 0;
-    for (int k = 0; k < total; k++) {
-      const float sk = cs[wv][k];
-      const int32_t ik = ci[wv][k];
-      rank += (sk > s || (sk == s && ik < i)) ? 1 : 0;
-    }
-    if (rank < n_rec) sel[wv][rank] = i;
-  }
-  __threadfence_block();
-  const int32_t mi = ln < n_rec ? sel[wv][ln] : 0x7fffffff;
-  wave_metrics_tail(p, row, ln, mi, n_rec, gb, ge, n_gt, gt_pref, disc_pref, idcg_pref, res, rec_row);
-}
-
 template <class T, int M>
 __global__ __launch_bounds__(256) void rank_wave_kernel(EvalParams p) {
   constexpr int U = 16;
@@ -1185,12 +1117,12 @@ struct irs_evaluator {
   DeviceBuffer<int32_t> mask_idx;
   int64_t mask_rows = -1;
   DeviceBuffer<float> fused_scores;  // score block of the two-pass path, kept between calls
-  // single-pass fused path (eval_fused_kernels.hpp): the cached mask as a bitmap + scratch
+  // fused call (eval_fused_kernels.hpp): the cached mask as a bitmap + scratch of the emit path
   DeviceBuffer<uint64_t> mask_bits;
   DeviceBuffer<int32_t> mask_count;
   int64_t mask_bits_rows = -1;  // rows the bitmap was built for (-1: none)
   DeviceBuffer<float> cand_score, tau;
-  DeviceBuffer<int32_t> cand_item, cand_cnt, tau_hint, bad_flag;
+  DeviceBuffer<int32_t> cand_item, cand_cnt, bad_flag;
   // bounded variant of the emit path: norms, the two sort permutations, per-tile limits
   DeviceBuffer<float> inorm, inorm_sorted, unorm, radius, radius_sorted, sample_item, hard_user;
   DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_prefix;
@@ -1338,135 +1270,8 @@ void finish_accumulate(irs_evaluator *e, irs_metrics *out, int64_t *item_cnt, hi
 }
 
 
-// IRSPACK_AMD_EVAL_FUSED=1 sends irs_eval_get_metrics_ials through the single-pass kernels of
-// eval_fused_kernels.hpp (the score block never reaches HBM).  It is exact (same tests as the
-// default) but, measured on the ML-20M shape, slower than the two-pass path (score block
-// written and read once): K = 64 16.5 ms against 11.6-13.0 ms, K = 256 29 ms against 21-23 ms
-// - with one wave per SIMD (39 KB of LDS per wave) the per-score selection code, ~2.1 k vector
-// instructions per 64 x 64 tile beside 256 MFMAs, issues at a fraction of the rate it needs.
-// Kept as an opt-in until the selection fits two waves per SIMD.
-bool fused_enabled() {
-  const char *e = std::getenv("IRSPACK_AMD_EVAL_FUSED");
-  return e ? std::atoi(e) != 0 : false;
-}
-
-// The single-pass path of irs_eval_get_metrics_ials (eval_fused_kernels.hpp).  Returns false
-// when the call is outside its domain (candidate lists, cutoff > 32, a bitmap that would not
-// fit, a non-finite score met on the way): the caller then runs the two-pass path.
 bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int64_t *d_mptr,
                         const int32_t *d_midx, hipStream_t s, bool cacheable = true);
-
-bool fused_single_pass(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t rows,
-                       const int64_t *d_mptr, const int32_t *d_midx, int64_t cutoff,
-                       int64_t offset, bool rwc, hipStream_t s) {
-  if (!fused_enabled() || e->rec_mode != 0 || cutoff > FZ_MAX_CUTOFF || rows <= 0) return false;
-  const float *user = nullptr, *item = nullptr;
-  int32_t KP = 0, dev = 0;
-  int64_t nu = 0, ni = 0;
-  void *sv = nullptr;
-  if (irs_ials_factors_device_(t, &user, &item, &KP, &nu, &ni, &sv, &dev) != IRS_OK)
-    throw std::runtime_error(irs_last_error());
-  if (KP > 256) return false;  // K > 256: the two-pass path (run-time-sized scoring kernel)
-  if (ni != e->n_items || ni < 64) return false;
-  const int64_t words = ceil_div(ni, 64);
-  const int64_t item_tiles = words;
-  // chunks: load balance (user tiles x chunks on 1024 wave slots), 16-bit chunk-relative ids
-  int64_t n_chunks = std::max<int64_t>(4, ceil_div(ni, 65472));
-  if (n_chunks > FZ_MAX_CHUNKS) return false;
-  const int64_t tiles_per_chunk = ceil_div(item_tiles, n_chunks);
-  n_chunks = ceil_div(item_tiles, tiles_per_chunk);
-  // mask bitmap (cached with the mask): rows x words x 8 B, at most 2 GiB
-  const uint64_t *bits = nullptr;
-  const int32_t *n_masked = nullptr;
-  if (d_mptr) {
-    if (!ensure_mask_bitmap(e, rows, words, d_mptr, d_midx, s)) return false;
-    bits = e->mask_bits.ptr;
-    n_masked = e->mask_count.ptr;
-  }
-  e->cand_score.alloc(static_cast<size_t>(rows) * n_chunks * cutoff);
-  e->cand_item.alloc(static_cast<size_t>(rows) * n_chunks * cutoff);
-  e->cand_cnt.alloc(static_cast<size_t>(rows) * n_chunks);
-  e->tau_hint.alloc(rows + 1);  // (+1: the slot the lanes past the last user store to)
-  e->bad_flag.alloc(1);
-  IRS_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->tau_hint.ptr),
-                            static_cast<int>(0x807fffffu), rows + 1, s));  // key of -inf
-  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, sizeof(int32_t), s));
-  FusedParams f;
-  f.user = user;
-  f.item = item;
-  f.begin = begin;
-  f.rows = rows;
-  f.n_items = ni;
-  f.mask_bits = bits;
-  f.words = words;
-  f.cutoff = static_cast<int32_t>(cutoff);
-  f.n_chunks = static_cast<int32_t>(n_chunks);
-  f.tiles_per_chunk = static_cast<int32_t>(tiles_per_chunk);
-  f.cand_score = e->cand_score.ptr;
-  f.cand_item = e->cand_item.ptr;
-  f.cand_cnt = e->cand_cnt.ptr;
-  f.tau_hint = e->tau_hint.ptr;
-  f.bad_flag = e->bad_flag.ptr;
-  f.n_masked = n_masked;
-  const int64_t units = ceil_div(rows, 64) * n_chunks;
-  const size_t lds = 4 * static_cast<size_t>(FZ_LDS_PER_WAVE) + 256;  // four slabs + shared thresholds
-  auto launch = [&](auto kernel) {
-    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ceil_div(units, 4))), dim3(256), lds, s, f);
-  };
-  switch (KP) {
-    case 16: launch(fused_topk_kernel<16, true>); break;
-    case 32: launch(fused_topk_kernel<32, true>); break;
-    case 64: launch(fused_topk_kernel<64, true>); break;
-    case 128: launch(fused_topk_kernel<128, false>); break;
-    case 192: launch(fused_topk_kernel<192, false>); break;
-    case 256: launch(fused_topk_kernel<256, false>); break;
-    default: return false;
-  }
-  e->row_out.alloc(rows);
-  e->rec_out.alloc(rows * cutoff);
-  EvalParams p;
-  p.scores = nullptr;
-  p.rows = rows;
-  p.n_items = e->n_items;
-  p.offset = offset;
-  p.gt_ptr = e->gt_ptr.ptr;
-  p.gt_idx = e->gt_idx.ptr;
-  p.rec_mode = 0;
-  p.rec_ptr = e->rec_ptr.ptr;
-  p.rec_items = e->rec_items.ptr;
-  p.cutoff = static_cast<int32_t>(cutoff);
-  p.retrieve = 0;
-  p.recall_with_cutoff = rwc ? 1 : 0;
-  p.disc = e->disc.ptr;
-  p.idcg_prefix = e->idcg_prefix.ptr;
-  p.out = e->row_out.ptr;
-  p.rec_out = e->rec_out.ptr;
-  p.item_cnt = e->item_cnt.ptr;
-  p.todo = nullptr;
-  hipLaunchKernelGGL(fused_finish_kernel, dim3(static_cast<unsigned>(ceil_div(rows, 4))), dim3(256), 0,
-                     s, p, f);
-  IRS_HIP(hipGetLastError());
-  int32_t bad = 0;
-  IRS_HIP(hipMemcpyAsync(&bad, e->bad_flag.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
-  IRS_HIP(hipStreamSynchronize(s));
-#ifdef FZ_PHASES
-  {
-    unsigned long long h[8] = {0}, z[8] = {0};
-    IRS_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(fz_phase_clk), sizeof(h)));
-    IRS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(fz_phase_clk), z, sizeof(z)));
-    fprintf(stderr, "fused phases (10 ns ticks summed over %lld waves): mfma %llu stage %llu scan %llu prune %llu tail %llu final %llu\n",
-            static_cast<long long>(units), h[0], h[1], h[2], h[3], h[4], h[5]);
-  }
-#endif
-  if (bad) return false;  // non-finite scores: the two-pass path defines their order
-  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
-                     e->metrics.ptr);
-  IRS_HIP(hipGetLastError());
-  return true;
-}
 
 // IRSPACK_AMD_EVAL_EMIT=0 switches the threshold-filtered path off (A/B against the two-pass one).
 bool emit_enabled() {
@@ -2069,15 +1874,8 @@ irs_status irs_eval_get_metrics_ials(irs_evaluator *e, irs_ials_trainer *t, int6
     begin_accumulate(e, s);  // (an abandoned attempt may have touched the sums)
     e->stats = irs_eval_stats{0, 0, ceil_div(rows, 64) * ceil_div(e->n_items, 64),
                               ceil_div(rows, 64) * ceil_div(e->n_items, 64), 0};
-    if (fused_single_pass(e, t, begin, rows, d_mptr, d_midx, cutoff, offset,
-                          recall_with_cutoff != 0, s)) {
-      e->stats.path = 3;
-      finish_accumulate(e, out, item_cnt, s);
-      return;
-    }
     DeviceBuffer<float> &scores = e->fused_scores;
     scores.alloc(static_cast<size_t>(std::min(BLOCK, std::max<int64_t>(rows, 1))) * e->n_items);
-    begin_accumulate(e, s);  // (a refused or abandoned single pass may have touched the sums)
     for (int64_t b = 0; b < rows; b += BLOCK) {
       const int64_t m = std::min(BLOCK, rows - b);
       if (irs_ials_scores_device_(t, begin + b, begin + b + m, scores.ptr, &sv, &dev) != IRS_OK)
@@ -2095,7 +1893,7 @@ irs_status irs_eval_cache_mask(irs_evaluator *e, int64_t rows, const int64_t *ma
                                const int32_t *mask_indices) {
   return guard([&] {
     check_arg(e != nullptr, "null argument.");
-    e->mask_bits_rows = -1;  // the bitmap of the single-pass path follows the cached mask
+    e->mask_bits_rows = -1;  // the bitmap follows the cached mask
     if (mask_indptr == nullptr || rows <= 0) {  // drop the cached mask
       e->mask_rows = -1;
       return;

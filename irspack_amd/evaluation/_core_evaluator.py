@@ -307,7 +307,7 @@ class EvaluatorCore:
 
         st = EvalStatsStruct()
         check(lib().irs_eval_last_stats(self._h, C.byref(st)))
-        names = {0: "two_pass", 1: "emit", 2: "emit_bounded", 3: "single_pass"}
+        names = {0: "two_pass", 1: "emit", 2: "emit_bounded"}
         return {"path": names.get(st.path, str(st.path)), "hard_rows": int(st.hard_rows),
                 "tiles_total": int(st.tiles_total), "tiles_scored": int(st.tiles_scored),
                 "sample_items": int(st.sample_items), "call_ms": float(st.call_ms),

@@ -161,11 +161,11 @@ def test_pickle_and_list_vs_list():
         assert m.as_dict()[k] == pytest.approx(a.as_dict()[k], rel=1e-9)
 
 
-@pytest.mark.parametrize("single_pass", ["0", "1"])
-def test_fused_ials_path_matches_block_path(single_pass, monkeypatch):
+@pytest.mark.parametrize("emit", ["1", "0"])
+def test_fused_ials_path_matches_block_path(emit, monkeypatch):
     # score + mask + rank on the device == user_scores -> mask -> get_metrics_f32
-    # (both device implementations: two-pass default, single-pass IRSPACK_AMD_EVAL_FUSED=1)
-    monkeypatch.setenv("IRSPACK_AMD_EVAL_FUSED", single_pass)
+    # (both device implementations: the threshold-filtered default and the two-pass one)
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_EMIT", emit)
     from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
                                                       IALSSolverConfigBuilder, IALSTrainer)
     from irspack_amd.synthetic import holdout_split, make_interactions

@@ -228,17 +228,15 @@ def test_evaluator_ndcg20_block_at_ml20m_width(X20):
                         ocore.get_metrics_f32(scores, cutoff, b, CORES))
 
 
-@pytest.mark.parametrize("path", ["emit", "two_pass", "single_pass"])
+@pytest.mark.parametrize("path", ["emit", "two_pass"])
 @pytest.mark.parametrize("K", [64, 256])
 def test_fused_evaluator_ml20m_vs_oracle(X20, K, path, monkeypatch):
     """configs[4] (K = 256) and the bench's secondary leg (K = 64): the fused device path
     (score + mask + rank without the block leaving the device) over 20,000 users, against the
-    oracle fed the same scores (user_scores) masked on the host.  All three implementations:
-    "emit" (default: sample thresholds, then only the candidates above them leave the scoring
-    kernel), "two_pass" (16,384-user score blocks in HBM, IRSPACK_AMD_EVAL_EMIT=0) and
-    "single_pass" (streaming top-k inside the scoring kernel, IRSPACK_AMD_EVAL_FUSED=1)."""
+    oracle fed the same scores (user_scores) masked on the host.  Both implementations: "emit"
+    (default: sample thresholds, then only the candidates above them leave the scoring kernel) and
+    "two_pass" (16,384-user score blocks in HBM, IRSPACK_AMD_EVAL_EMIT=0)."""
     monkeypatch.setenv("IRSPACK_AMD_EVAL_EMIT", "1" if path == "emit" else "0")
-    monkeypatch.setenv("IRSPACK_AMD_EVAL_FUSED", "1" if path == "single_pass" else "0")
     mc, sc, _, _ = configs(K, "CG")
     t = IALSTrainer(mc, X20)
     t.step(sc)

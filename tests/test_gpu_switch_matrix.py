@@ -130,7 +130,6 @@ def test_knn_switches_alone_and_in_pairs(monkeypatch, case, kind, binary):
 
 # ---------------------------------------------------------------- evaluator (fused iALS call)
 EVAL_SWITCHES = {
-    "fused_on": {"IRSPACK_AMD_EVAL_FUSED": "1"},
     "emit_off": {"IRSPACK_AMD_EVAL_EMIT": "0"},
     "bound_off": {"IRSPACK_AMD_EVAL_BOUND": "0"},
     "wave_off": {"IRSPACK_AMD_EVAL_WAVE": "0"},
@@ -139,7 +138,7 @@ EVAL_SWITCHES = {
     "block_512": {"IRSPACK_AMD_EVAL_BLOCK": "512"},
 }
 EVAL_CASES = ([("default",)] + [(k,) for k in EVAL_SWITCHES]
-              + [("fused_on", "emit_off"), ("emit_off", "block_512"), ("bound_off", "sample_64"),
+              + [("emit_off", "block_512"), ("bound_off", "sample_64"),
                  ("bound_off", "pass_rows_256"), ("wave_off", "emit_off"), ("sample_64", "pass_rows_256")])
 
 
