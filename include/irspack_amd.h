@@ -277,8 +277,9 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            int64_t row_begin, int64_t row_end, int64_t *nnz_out);
 irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
                          double *data);
-/* Measurement only: multiply-adds of the last call that were added one by one (the rest came out of
- * the dense block of the popular items, csrc/knn.hip), and the rows of that block (0: none). */
+/* Measurement only: multiply-adds of the last call that were added one by one, and the rows of the
+ * dense block of the popular items - an opt-in of rounds 4 - 5 that was removed: every multiply-add is
+ * added one by one and dense_rows is 0 (kept for ABI 3). */
 irs_status irs_knn_last_walked(irs_knn_computer *c, int64_t *walked_macs, int32_t *dense_rows);
 /* Milliseconds of device time of the last irs_knn_compute (HIP events: first launch to last row merge of
  * the call's row chunks) and the number of multiply-adds it performed. */

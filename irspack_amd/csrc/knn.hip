@@ -64,18 +64,6 @@ struct Params {
                               // row's products span a wide range - two limbs, see `hi_stash`
   uint64_t *hi_stash;         // [workgroups x TILE]: the first limbs of a wide-range pair while the
                               // second ones are accumulated
-  // Dense block of the popular items (counts only): a target row that IS popular
-  // item pop k (t_pop[r] = k >= 0) starts from pop_C[k][*] - its exact co-occurrence counts with
-  // the other popular items, one int8 matrix-core product at create time - and walks the slices
-  // WITHOUT the popular columns (xt_tptr_np / xt_idx16_np): about half of the multiply-adds of a
-  // power-law matrix lie between its ~2,000 most popular items.
-  const int32_t *t_pop;         // per target row of the call: popular index or -1; null: no dense block
-  const int32_t *pop_C;         // [pop_n, pop_n] counts, popular items in COLUMN order
-  const int32_t *pop_col;       // [pop_n] their columns, ascending
-  const int32_t *pop_tile_ptr;  // [n_tiles + 1] into pop_col
-  int32_t pop_n;
-  const uint32_t *xt_tptr_np;   // the slices without the popular columns
-  const uint32_t *xt_idx16_np;
   const int32_t *row_order;   // work-sorted list of target rows of this call
   int32_t n_rows;             // rows in this call
   int32_t n_tiles;
@@ -250,19 +238,10 @@ __global__ __launch_bounds__(THREADS, 1) void knn_tile_kernel(Params p) {
 #endif
 
   uint32_t *cnt = reinterpret_cast<uint32_t *>(acc);  // ACC32: TILE counters
-  // popular target row: the popular columns come from the dense block, the walk skips them
-  int pr = -1;
-  if (ACC32 && p.t_pop != nullptr) pr = __builtin_amdgcn_readfirstlane(p.t_pop[r]);
-  const uint32_t *const xt_tptr_l = pr >= 0 ? p.xt_tptr_np : p.xt_tptr;
-  const uint32_t *const xt_idx16_l = pr >= 0 ? p.xt_idx16_np : p.xt_idx16;
+  const uint32_t *const xt_tptr_l = p.xt_tptr;
+  const uint32_t *const xt_idx16_l = p.xt_idx16;
   if (ACC32) {
     for (int i = tid; i < width; i += THREADS) cnt[i] = 0u;
-    if (pr >= 0) {
-      __syncthreads();
-      const int32_t *crow = p.pop_C + static_cast<size_t>(pr) * p.pop_n;
-      for (int k = p.pop_tile_ptr[tile] + tid; k < p.pop_tile_ptr[tile + 1]; k += THREADS)
-        cnt[p.pop_col[k] - c0] = static_cast<uint32_t>(crow[k]);
-    }
   } else {
     for (int i = tid; i < width; i += THREADS) acc[i] = SENTINEL ? -0.0 : 0.0;
   }
@@ -1302,69 +1281,6 @@ static void check_lower(double x, double low, const char *name) {  // argcheck.h
   }
 }
 
-// ---- dense block of the popular items ------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-
-// A[k][u] = 1 for the stored entries of popular row k (rows of the computer's matrix, CSR)
-__global__ void pop_scatter_kernel(const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-                                   int32_t n_rows, int64_t ld, int8_t *__restrict__ A) {
-  const int k = blockIdx.x;
-  if (k >= n_rows) return;
-  for (int64_t q = ptr[k] + threadIdx.x; q < ptr[k + 1]; q += blockDim.x) A[k * ld + idx[q]] = 1;
-}
-
-// C = A A^T for the 0 / 1 int8 matrix A [P, ld] (P a multiple of 128, ld of 64): exact counts on
-// the matrix cores (v_mfma_i32_32x32x32_i8).  One workgroup per (128 x 128 tile pair I >= J, K
-// slab); wave w owns the 64 x 64 quadrant (w >> 1, w & 1) = 2 x 2 MFMA tiles.  Both operands of a
-// 32 x 32 x 32 step are 16 consecutive bytes of a row of A per lane (lane l: row l & 31, bytes
-// 16 (l >> 5) ..): the sum over k does not care how the k of a step are dealt to the lanes as long
-// as both operands use the same deal, and they do.  Slabs are added with integer atomics.
-__global__ __launch_bounds__(256) void pop_syrk_kernel(const int8_t *__restrict__ A, int32_t P, int64_t ld,
-                                                       int64_t slab, int32_t *__restrict__ C) {
-  const int nb = P / 128;
-  int pair = blockIdx.x, I = 0;
-  while (pair > I) { pair -= I + 1; I++; }
-  const int J = pair;
-  const int64_t k0 = static_cast<int64_t>(blockIdx.y) * slab, k1 = min(k0 + slab, ld);
-  const int w = wave_index_in_block(), lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int row_i = 128 * I + 64 * (w >> 1), row_j = 128 * J + 64 * (w & 1);
-  (void)nb;
-  i32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int v = 0; v < 16; v++) acc[a][b][v] = 0;
-  const int8_t *pi0 = A + static_cast<size_t>(row_i + r) * ld + 16 * h;
-  const int8_t *pi1 = pi0 + 32 * ld;
-  const int8_t *pj0 = A + static_cast<size_t>(row_j + r) * ld + 16 * h;
-  const int8_t *pj1 = pj0 + 32 * ld;
-  for (int64_t k = k0; k < k1; k += 32) {
-    const i32x4 a0 = *reinterpret_cast<const i32x4 *>(pi0 + k), a1 = *reinterpret_cast<const i32x4 *>(pi1 + k);
-    const i32x4 b0 = *reinterpret_cast<const i32x4 *>(pj0 + k), b1 = *reinterpret_cast<const i32x4 *>(pj1 + k);
-    acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
-  }
-  // C/D layout (dtype independent): col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int v = 0; v < 16; v++) {
-        const int i = row_i + 32 * a + (v & 3) + 8 * (v >> 2) + 4 * h, j = row_j + 32 * b + r;
-        const int val = acc[a][b][v];
-        if (val != 0) {
-          atomicAdd(&C[static_cast<size_t>(i) * P + j], val);
-          if (I != J) atomicAdd(&C[static_cast<size_t>(j) * P + i], val);
-        }
-      }
-}
-
 }  // namespace knn
 }  // namespace irs
 
@@ -1389,14 +1305,6 @@ struct irs_knn_computer {
   bool xt_positive = false; // every stored x > 0
   std::vector<double> xt_rowmax;  // host: max |x| per feature row (bound of a target row's sums)
   std::vector<double> xt_rowmin;  // host: min |x| per feature row (smallest product of a target row)
-  // dense block of the popular items (all-ones matrices; see Params)
-  int32_t pop_n = 0;
-  std::vector<int32_t> pop_rank;      // host, per item: popular index (column order) or -1
-  std::vector<int64_t> pop_ptr;       // host copy of the popular rows' patterns: a target row is
-  std::vector<int32_t> pop_idx;       //   "popular item k" only if its pattern equals this one
-  std::vector<int64_t> xt_row_len_np; // host: stored entries per feature row without the popular columns
-  DeviceBuffer<int32_t> pop_C, pop_col, pop_tile_ptr;
-  DeviceBuffer<uint32_t> xt_tptr_np, xt_idx16_np;
   // last result (host)
   std::vector<int64_t> res_ptr;
   DeviceBuffer<int32_t> res_idx;  // the last result stays on the device until irs_knn_fetch
@@ -1411,8 +1319,7 @@ struct irs_knn_computer {
     DeviceBuffer<int32_t> t_idx, order, cand_idx, cand_cnt, out_idx, out_cnt, cursor, slot_of, redo_list;
     DeviceBuffer<double> t_val, t_stat, t_scale, cand_val, out_val;
     DeviceBuffer<uint64_t> hi_stash;
-    DeviceBuffer<int32_t> t_pop;
-    // ONE allocation behind the buffers every call needs (carved per call; t_val / hi_stash / t_pop, which
+    // ONE allocation behind the buffers every call needs (carved per call; t_val / hi_stash, which
     // only some calls need, are allocations of their own): seventeen hipMalloc calls were 11 ms of the
     // first call of a computer - and `learn()` of a kNN recommender makes exactly one call
     DeviceBuffer<char> arena;
@@ -1536,13 +1443,10 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     // host spent 17 ms on the copy, 29 ms on the transpose and 15 ms on slices + packing.  Same
     // similarities bit for bit (test_device_create_is_the_host_create).  P3alpha / RP3beta: the rows are
     // pow-ed and normalised on the host first (libm's pow), into the one private array of this path.
-    // The opt-in dense block keeps the host path below.
     // IRSPACK_AMD_KNN_DEVICE_CREATE=0: host path for everything (A/B).
     const bool binarise_create = sim_type == IRS_SIM_JACCARD || sim_type == IRS_SIM_TVERSKY;
     const bool transforms = sim_type == IRS_SIM_P3ALPHA || sim_type == IRS_SIM_RP3BETA;
-    const char *dense_env0 = std::getenv("IRSPACK_AMD_KNN_DENSE");
     const bool device_candidate = nnz_in > 0 && cols > 0 && nnz_in < (int64_t(1) << 31) - 1024 &&
-                                  !(dense_env0 && dense_env0[0] == '1') &&
                                   env_flag("IRSPACK_AMD_KNN_DEVICE_CREATE", true);
     if (device_candidate) {
       require_device(device);
@@ -1871,102 +1775,6 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     c->norms.upload(norms, s);
     IRS_HIP(hipStreamSynchronize(s));
     pt.mark("create: pack+upload");
-    // ---- dense block of the popular items (all-ones matrices only: the counts are exact integers)
-    {
-      const char *dense_env = std::getenv("IRSPACK_AMD_KNN_DENSE");
-      const int64_t ld = ceil_div(cols, 64) * 64;
-      int64_t P = std::min<int64_t>(2048, rows / 4) / 128 * 128;
-      if (const char *pe = std::getenv("IRSPACK_AMD_KNN_DENSE_ROWS")) P = std::min<int64_t>(rows, std::atoll(pe)) / 128 * 128;
-      // OPT-IN (IRSPACK_AMD_KNN_DENSE=1), a measured near-negative result: on the
-      // ML-20M shape 2,048 popular items hold 60 % of the entries but only 25 % of the multiply-adds
-      // lie between them (53 % for 8,192: a 268 MB count matrix), and the walk's cost is per 128-entry
-      // STRIP, not per entry - a light user's slice is one strip with or without its popular items -
-      // so the tile kernel goes 8.52 -> 7.96 ms while irs_knn_create pays 33 ms for the block: a loss
-      // for the usual one compute call per computer.
-      const bool want = c->xt_all_ones && dense_env && dense_env[0] == '1' && P >= 128 &&
-                        (rows >= 4096 || std::getenv("IRSPACK_AMD_KNN_DENSE_ROWS")) && P * ld <= (int64_t(1) << 30);
-      if (want) {
-        // the P rows with the most stored entries (ties: lower row first), then in row (= column) order
-        std::vector<int32_t> byn(rows);
-        std::iota(byn.begin(), byn.end(), 0);
-        auto longer = [&](int32_t a, int32_t b) {
-          const int64_t na = X.indptr[a + 1] - X.indptr[a], nb = X.indptr[b + 1] - X.indptr[b];
-          return na != nb ? na > nb : a < b;
-        };
-        std::nth_element(byn.begin(), byn.begin() + P, byn.end(), longer);
-        std::vector<int32_t> pop(byn.begin(), byn.begin() + P);
-        std::sort(pop.begin(), pop.end());
-        int64_t pop_nnz = 0;
-        for (int32_t i : pop) pop_nnz += X.indptr[i + 1] - X.indptr[i];
-        // worth it only when the popular rows carry a good share of the entries (a power law)
-        if (pop_nnz * 5 >= xt_nnz) {
-          c->pop_n = static_cast<int32_t>(P);
-          c->pop_rank.assign(rows, -1);
-          c->pop_ptr.assign(P + 1, 0);
-          c->pop_idx.resize(pop_nnz);
-          for (int64_t k = 0; k < P; k++) {
-            const int32_t i = pop[k];
-            c->pop_rank[i] = static_cast<int32_t>(k);
-            c->pop_ptr[k + 1] = c->pop_ptr[k] + (X.indptr[i + 1] - X.indptr[i]);
-            std::copy(X.indices.begin() + X.indptr[i], X.indices.begin() + X.indptr[i + 1],
-                      c->pop_idx.begin() + c->pop_ptr[k]);
-          }
-          // C = A A^T on the device: A [P, ld] int8 is scratch of this block
-          DeviceBuffer<int64_t> d_ptr;
-          DeviceBuffer<int32_t> d_idx;
-          DeviceBuffer<int8_t> A;
-          d_ptr.upload(c->pop_ptr, s);
-          d_idx.upload(c->pop_idx, s);
-          A.alloc(static_cast<size_t>(P) * ld);
-          IRS_HIP(hipMemsetAsync(A.ptr, 0, static_cast<size_t>(P) * ld, s));
-          c->pop_C.alloc(static_cast<size_t>(P) * P);
-          IRS_HIP(hipMemsetAsync(c->pop_C.ptr, 0, static_cast<size_t>(P) * P * sizeof(int32_t), s));
-          hipLaunchKernelGGL(pop_scatter_kernel, dim3(static_cast<unsigned>(P)), dim3(256), 0, s, d_ptr.ptr, d_idx.ptr,
-                             static_cast<int32_t>(P), ld, A.ptr);
-          const int nb = static_cast<int>(P / 128);
-          const int64_t slab = 8192;
-          hipLaunchKernelGGL(pop_syrk_kernel, dim3(nb * (nb + 1) / 2, static_cast<unsigned>(ceil_div(ld, slab))),
-                             dim3(256), 0, s, A.ptr, static_cast<int32_t>(P), ld, slab, c->pop_C.ptr);
-          IRS_HIP(hipGetLastError());
-          // the slices without the popular columns, and the popular columns of every tile
-          std::vector<uint32_t> tptr_np(static_cast<size_t>(Xt.rows) * (n_tiles + 1));
-          std::vector<int64_t> np_ptr(Xt.rows + 1, 0);
-          c->xt_row_len_np.resize(Xt.rows);
-          for (int64_t u = 0; u < Xt.rows; u++) {
-            int64_t keep = 0;
-            for (int64_t q = Xt.indptr[u]; q < Xt.indptr[u + 1]; q++) keep += c->pop_rank[Xt.indices[q]] < 0;
-            c->xt_row_len_np[u] = keep;
-            np_ptr[u + 1] = np_ptr[u] + keep;
-          }
-          const size_t nnz_np = static_cast<size_t>(np_ptr[Xt.rows]), padded_np = (nnz_np + 256 + 1) & ~size_t(1);
-          std::vector<uint32_t> idx_np(padded_np / 2, 0u);
-          uint16_t *i16 = reinterpret_cast<uint16_t *>(idx_np.data());
-          on_threads([&](int k) {
-            for (int64_t u = blk[k]; u < blk[k + 1]; u++) {
-              int64_t w = np_ptr[u];
-              uint32_t *dst = tptr_np.data() + u * (n_tiles + 1);
-              int64_t t = 0;
-              for (int64_t q = Xt.indptr[u]; q < Xt.indptr[u + 1]; q++) {
-                const int32_t j = Xt.indices[q];
-                if (c->pop_rank[j] >= 0) continue;
-                for (; t <= j / TILE; t++) dst[t] = static_cast<uint32_t>(w);
-                i16[w++] = static_cast<uint16_t>((j % TILE) * 4);
-              }
-              for (; t <= n_tiles; t++) dst[t] = static_cast<uint32_t>(w);
-            }
-          });
-          c->xt_tptr_np.upload(tptr_np, s);
-          c->xt_idx16_np.upload(idx_np, s);
-          std::vector<int32_t> tile_ptr(n_tiles + 1);
-          for (int64_t t = 0; t <= n_tiles; t++)
-            tile_ptr[t] = static_cast<int32_t>(std::lower_bound(pop.begin(), pop.end(), static_cast<int32_t>(std::min<int64_t>(t * TILE, rows))) - pop.begin());
-          c->pop_col.upload(pop, s);
-          c->pop_tile_ptr.upload(tile_ptr, s);
-          IRS_HIP(hipStreamSynchronize(s));  // host vectors and the device scratch go out of scope
-        }
-      }
-    }
-    pt.mark("create: dense block");
     // (the host staging - half a gigabyte for 20 M entries - is released here rather than at
     // scope exit so that the phase shows up in the timing)
     // and on a thread of its own: returning 480 MB to the kernel (munmap) takes 56 ms, nothing
@@ -2100,11 +1908,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     // IRSPACK_AMD_KNN_CHUNKS overrides the count (1: the whole call at once; tests force small ones).
     std::vector<double> tstat(std::max<int64_t>(n, 1), 0.0);
     std::vector<double> tscale(std::max<int64_t>(n, 1), 1.0);
-    // dense block: target row i is "popular item k" when item i is one and the row's pattern is the
-    // computer's own row i (the usual call: compute_similarity(X, k) on the matrix it was built
-    // from); any other row just takes the full walk
-    const bool dense = c->pop_n > 0 && rows == c->N;
-    std::vector<int32_t> tpop(dense ? std::max<int64_t>(n, 1) : 0, -1);
     std::vector<int64_t> work(std::max<int64_t>(n, 1), 0);
     const int64_t e_begin = ip[row_begin], e_end = ip[row_end];
     check_arg(e_begin >= 0 && e_end >= e_begin, "malformed indptr.");
@@ -2367,8 +2170,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       const int64_t r_lo = cb[ck], r_hi = cb[ck + 1], nc = r_hi - r_lo, rel0 = r_lo - row_begin;
       if (nc <= 0 && n > 0) continue;
       const int64_t ce_begin = ip[r_lo], ce_end = ip[r_hi];
-      std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0), any_wide(0), any_pop(0);
-      std::atomic<int64_t> skipped(0);  // multiply-adds the dense block stands for
+      std::atomic<int> bad_index(0), not_ones(0), unsafe(0), not_positive(0), any_wide(0);
       {
         const int n_thr = static_cast<int>(std::max<int64_t>(
             1, std::min<int64_t>({host_thread_cap(), static_cast<int64_t>(std::thread::hardware_concurrency()),
@@ -2411,19 +2213,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
               }
               if (lo_j < 0 || hi_j >= cols) { bad = true; break; }
               ss = static_cast<double>(ip[i + 1] - ip[i]);
-              if (dense && c->pop_rank[i] >= 0) {
-                const int32_t k = c->pop_rank[i];
-                const int64_t len = c->pop_ptr[k + 1] - c->pop_ptr[k];
-                if (len == ip[i + 1] - ip[i] &&
-                    std::memcmp(ix + ip[i], c->pop_idx.data() + c->pop_ptr[k], static_cast<size_t>(len) * sizeof(int32_t)) == 0) {
-                  tpop[i - row_begin] = k;
-                  any_pop.store(1, std::memory_order_relaxed);
-                  skipped.fetch_add(w, std::memory_order_relaxed);
-                  w = 0;  // the walk of a popular row skips the popular columns
-                  for (int64_t q = ip[i]; q < ip[i + 1]; q++) w += c->xt_row_len_np[ix[q]];
-                  skipped.fetch_sub(w, std::memory_order_relaxed);
-                }
-              }
             } else {
               for (int64_t q = ip[i]; q < ip[i + 1]; q++) {
                 const int32_t j = ix[q];
@@ -2479,7 +2268,6 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       // rows of the chunk, heaviest product row first (ids relative to the chunk's first row)
       int64_t chunk_macs = 0;
       for (int64_t i = 0; i < nc; i++) chunk_macs += work[rel0 + i];
-      chunk_macs += skipped.load();  // (the product's multiply-adds, however obtained)
       c->last_macs += chunk_macs;
       {  // Heaviest rows first, for the load balance of the persistent launch only (results do
          // not depend on it): a counting sort by 1/64-octave of the work, rows of a bucket in
@@ -2539,22 +2327,10 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       p.t_stat = t_stat.ptr + rel0;
       p.t_scale = t_scale.ptr + rel0;
       p.hi_stash = nullptr;
-      p.t_pop = nullptr;
-      p.pop_C = c->pop_C.ptr;
-      p.pop_col = c->pop_col.ptr;
-      p.pop_tile_ptr = c->pop_tile_ptr.ptr;
-      p.pop_n = c->pop_n;
-      p.xt_tptr_np = c->xt_tptr_np.ptr;
-      p.xt_idx16_np = c->xt_idx16_np.ptr;
-      if (dense && acc32 && any_pop.load()) {
-        sc.t_pop.alloc(n);
-        IRS_HIP(hipMemcpyAsync(sc.t_pop.ptr + rel0, tpop.data() + rel0, nc * sizeof(int32_t), hipMemcpyHostToDevice, s_in));
-        p.t_pop = sc.t_pop.ptr + rel0;
-      }
       hipStream_t ks = c->stream_k;
       IRS_HIP(hipEventRecord(c->ev_in, s_in));
       IRS_HIP(hipStreamWaitEvent(ks, c->ev_in, 0));
-      c->last_walked += p.t_pop ? chunk_macs - skipped.load() : chunk_macs;  // added one by one
+      c->last_walked += chunk_macs;  // (every multiply-add is added one by one)
       p.row_order = d_order.ptr + rel0;
       p.n_rows = static_cast<int32_t>(nc);
       p.n_tiles = n_tiles;
@@ -2723,7 +2499,7 @@ irs_status irs_knn_last_walked(irs_knn_computer *c, int64_t *walked_macs, int32_
   return guard([&] {
     check_arg(c && walked_macs && dense_rows, "null argument.");
     *walked_macs = c->last_walked;
-    *dense_rows = c->pop_n;
+    *dense_rows = 0;  // (the dense block of the popular items was removed in round 5)
   });
 }
 

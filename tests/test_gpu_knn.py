@@ -473,43 +473,6 @@ def power_law_items(U, N, nnz, seed):
     return sps.csr_matrix(X.T)
 
 
-@pytest.mark.parametrize("N,U,nnz,P", [(700, 3000, 60000, 256), (20000, 2000, 150000, 512), (1300, 500, 30000, 128)])
-@pytest.mark.parametrize("name,kwargs", [("cosine", dict(shrinkage=0.0, normalize=False)),
-                                         ("cosine", dict(shrinkage=1.5, normalize=True)),
-                                         ("jaccard", dict(shrinkage=0.0)), ("tversky", dict(shrinkage=0.5, alpha=0.7, beta=1.3))])
-def test_dense_block_of_popular_items(N, U, nnz, P, name, kwargs, monkeypatch):
-    """The popular rows' counts with the popular columns come from ONE exact int8 matrix-core
-    product (pop_syrk_kernel) instead of LDS atomics, and their walk skips those columns: same
-    bits as the oracle - indices, tie order, values - for popular and other rows, one and two
-    column tiles, target row ranges; a target row that is NOT the computer's own row (a
-    different pattern at a popular item's position) takes the full walk."""
-    monkeypatch.setenv("IRSPACK_AMD_KNN_DENSE", "1")  # (opt-in: a measured near-negative result, DESIGN.md 3.4)
-    monkeypatch.setenv("IRSPACK_AMD_KNN_DENSE_ROWS", str(P))
-    Xt = power_law_items(U, N, nnz, N + P)
-    g, o = make(name, Xt, **kwargs)
-    got = g.compute_similarity(Xt, 40)
-    assert g.dense_block_rows == P and g.last_walked_macs < 0.85 * g.last_macs
-    assert_same_csr(got, o.compute_similarity(Xt, 40), rtol=1e-12)
-    # a row range, and top_k above the column count of a tile's winners
-    sel = (N // 3, N // 3 + 211)
-    assert_same_csr(g.compute_similarity(Xt, 300, rows=sel), o.compute_similarity(Xt, 300)[sel[0]:sel[1]], rtol=1e-12)
-    # another target matrix: the most popular item's row loses an entry, another row is emptied
-    T = Xt.tolil(copy=True)
-    heavy = int(np.argmax(np.diff(Xt.indptr)))
-    T.rows[heavy] = T.rows[heavy][1:]
-    T.data[heavy] = T.data[heavy][1:]
-    second = int(np.argsort(-np.diff(Xt.indptr))[1])
-    T.rows[second], T.data[second] = [], []
-    T = sps.csr_matrix(T)
-    assert_same_csr(g.compute_similarity(T, 25), o.compute_similarity(T, 25), rtol=1e-12)
-    # the switch: no dense block, same result
-    monkeypatch.setenv("IRSPACK_AMD_KNN_DENSE", "0")
-    g0, _ = make(name, Xt, **kwargs)
-    plain = g0.compute_similarity(Xt, 40)
-    assert g0.dense_block_rows == 0
-    assert_same_csr(plain, got, rtol=0)
-
-
 # ---------------------------------------------------------------- row chunks of one call (round 5)
 @pytest.mark.parametrize("chunks", ["1", "3", "7", "64"])
 @pytest.mark.parametrize("kind,kw", CASES)

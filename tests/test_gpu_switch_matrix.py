@@ -89,7 +89,6 @@ def test_ials_switches_alone_and_in_pairs(matrices, monkeypatch, case, K, kind, 
 
 # ---------------------------------------------------------------- kNN
 KNN_SWITCHES = {
-    "dense_on": {"IRSPACK_AMD_KNN_DENSE": "1", "IRSPACK_AMD_KNN_DENSE_ROWS": "64"},
     "wide_on": {"IRSPACK_AMD_KNN_WIDE": "1"},
     "fast_off": {"IRSPACK_AMD_KNN_FAST": "0"},
     "threads_1": {"IRSPACK_AMD_KNN_THREADS": "1"},
@@ -98,8 +97,8 @@ KNN_SWITCHES = {
     "stage_off": {"IRSPACK_AMD_KNN_STAGE": "0"},
 }
 KNN_CASES = ([("default",)] + [(k,) for k in KNN_SWITCHES]
-             + [p for p in itertools.combinations(["dense_on", "wide_on", "fast_off"], 2)]
-             + [("chunks_3", "dense_on"), ("chunks_3", "fast_off"), ("chunks_3", "stage_off"), ("host_create", "wide_on")])
+             + [p for p in itertools.combinations(["wide_on", "fast_off"], 2)]
+             + [("chunks_3", "fast_off"), ("chunks_3", "stage_off"), ("host_create", "wide_on")])
 
 
 @pytest.mark.parametrize("case", KNN_CASES, ids=lambda c: "+".join(c))
