@@ -24,7 +24,7 @@
 #include <cstring>
 #include <mutex>
 #include <vector>
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(IRS_MTJUMP_NO_CLMUL)
 #include <immintrin.h>
 #endif
 
@@ -177,7 +177,8 @@ inline bool reduce_sparse(uint64_t *c, size_t words) {
   return true;
 }
 
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(IRS_MTJUMP_NO_CLMUL)
+// (IRS_MTJUMP_NO_CLMUL: the portable product only - tests/san/mt_jump_check.cpp builds both)
 // the 39,873-bit product with the carry-less multiplier (312 x 312 64-bit products, 0.1 ms) where the
 // host has one; the shifted-copy loop below (one 313-word XOR per set coefficient of a: 1.4 ms) elsewhere
 __attribute__((target("pclmul,sse2"))) inline void product_clmul(const Poly &a, const Poly &b, uint64_t *c) {
@@ -222,7 +223,7 @@ inline Poly mulmod(const Poly &a, const Poly &b) {
     const uint64_t *at(int k) const { return v.data() + k * (PW + 1); }
   };
   std::vector<uint64_t> c(2 * PW + 2, 0);
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(IRS_MTJUMP_NO_CLMUL)
   if (have_clmul()) {
     product_clmul(a, b, c.data());
   } else

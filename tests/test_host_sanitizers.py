@@ -68,3 +68,21 @@ def test_cpu_oracle_under_sanitizers(san):
     assert r.returncode == 0, r.stderr[-4000:]
     assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     assert "oracle_san ok" in r.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+@pytest.mark.parametrize("portable", [False, True])
+def test_mt19937_jump_ahead_arithmetic(tmp_path, portable):
+    """Products modulo MT19937's characteristic polynomial against a bit-by-bit reference, the tabulated
+    polynomial against Berlekamp-Massey, jumps against the engine's own sequence - with the carry-less
+    multiplier and with the portable product a host without PCLMULQDQ takes (mt_jump.hpp)."""
+    exe = str(tmp_path / "mt_jump_check")
+    src = os.path.join(ROOT, "tests", "san", "mt_jump_check.cpp")
+    flags = ["-DIRS_MTJUMP_NO_CLMUL"] if portable else []
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", *flags, src, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mt_jump_check ok" in r.stdout
+    if portable:
+        assert "portable product" in r.stdout
