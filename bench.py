@@ -671,6 +671,111 @@ def c4_leg(full, ceilings):
     return out
 
 
+def _max_over_ranks(seconds):
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def knn_sharded_leg(X, device, barrier):
+    """configs[2] over N ranks (EVERY rank calls this): the target rows of the item-item product are
+    split into contiguous ranges of equal multiply-add count (sharding.similarity_row_bounds - the row
+    split of knn.hpp:54-71 with ranks in the place of threads), every rank holds the whole computer and
+    runs ``compute_similarity(rows=...)`` on its range; the CSR blocks are exchanged as host objects
+    and stacked on every rank.  No data-path collective.  ``item_pairs_per_s`` = I^2 / (max over ranks
+    of the wall of compute + exchange, between barriers); the compute-only maximum beside it."""
+    import scipy.sparse as sps
+    import torch.distributed as dist
+
+    from irspack_amd.recommenders._knn import CosineSimilarityComputer
+    from irspack_amd.sharding import sharded_similarity, similarity_row_bounds
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    U, I = X.shape
+    Xt = sps.csr_matrix(X.T, dtype=np.float64)
+    Xt.data[:] = 1.0
+    bounds = similarity_row_bounds(Xt, world)
+    comp = CosineSimilarityComputer(Xt, 0.0, True, device=device)
+    mine = (bounds[rank], bounds[rank + 1])
+    comp.compute_similarity(Xt, 100, rows=mine)  # the first call sizes scratch and staging buffers
+    walls, computes, S = [], [], None
+    for _ in range(3):
+        S = None
+        own = {}
+
+        def rows(b, e):
+            t0 = time.perf_counter()
+            blk = comp.compute_similarity(Xt, 100, rows=(b, e))
+            own["s"] = time.perf_counter() - t0
+            return blk
+
+        barrier()
+        t0 = time.perf_counter()
+        S = sharded_similarity(rows, I, bounds=bounds)
+        barrier()
+        walls.append(_max_over_ranks(time.perf_counter() - t0))
+        computes.append(_max_over_ranks(own["s"]))
+    wall, compute = min(walls), min(computes)
+    return {
+        "workload": f"cosine item-kNN top_k=100, {I} items x {U} users, binary interactions, fp64, "
+                    f"target rows over {world} rank(s)",
+        "item_pairs_per_s": I * float(I) / wall, "wall_s_max_over_ranks": wall,
+        "item_pairs_per_s_compute_only": I * float(I) / compute, "compute_s_max_over_ranks": compute,
+        "row_bounds": [int(b) for b in bounds], "balance": "equal multiply-add count per rank",
+        "kernel_ms_rank0": comp.last_kernel_ms, "macs_rank0": comp.last_macs,
+        "out_nnz": int(S.nnz), "scaling": "strong",
+        "exchange": "all_gather_object of the CSR blocks (host objects; every rank ends with the whole result)",
+    }
+
+
+def evaluator_sharded_leg(X, K, device, barrier):
+    """The fused evaluator over N ranks (EVERY rank calls this): users are split into equal contiguous
+    ranges (sharding.sharded_metrics), every rank scores and ranks its own users against the replicated
+    item factors and the ``Metrics`` are summed in rank order on the host (Metrics::merge,
+    evaluator.cpp:76-85).  The scored model is fitted by every rank on the training entries (3 CG epochs,
+    identical replicas) - outside the timed region."""
+    import torch.distributed as dist
+
+    from irspack_amd.evaluation._core_evaluator import EvaluatorCore, Metrics
+    from irspack_amd.recommenders._ials_core import IALSTrainer
+    from irspack_amd.sharding import even_bounds, sharded_metrics
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    U, I = X.shape
+    gt, mask = holdout(X)
+    trainer = IALSTrainer(model_config(K), mask, device=device)
+    for _ in range(3):
+        trainer.step(solver_config("CG"))
+    ev = EvaluatorCore(gt, [], device=device)
+    b = even_bounds(U, world)
+    my_mask = mask[b[rank]:b[rank + 1]]
+    type(ev).strict_mask_fingerprint = False  # (the mask is immutable here; see evaluator_leg)
+    try:
+        ev.get_metrics_ials(trainer, b[rank], b[rank + 1], my_mask, 20, b[rank], False)  # uploads the mask rows
+        walls, total = [], None
+        for _ in range(3):
+            barrier()
+            t0 = time.perf_counter()
+            total = sharded_metrics(lambda lo, hi: ev.get_metrics_ials(trainer, lo, hi, my_mask, 20, lo, False),
+                                    U, Metrics(I))
+            barrier()
+            walls.append(_max_over_ranks(time.perf_counter() - t0))
+    finally:
+        type(ev).strict_mask_fingerprint = True
+    wall = min(walls)
+    d = total.as_dict()
+    return {"workload": f"fused iALS k={K} scoring + nDCG@20, {U} users over {world} rank(s) x {I} items",
+            "users_per_s": U / wall, "wall_s_max_over_ranks": wall, "ndcg@20": d["ndcg"],
+            "valid_user": int(d["valid_user"]), "total_user": int(d["total_user"]), "scaling": "strong",
+            "exchange": "all_gather_object of one Metrics per rank, merged in rank order"}
+
+
 def _try_attach_peers(local) -> bool:
     """Maps the peers' factor buffers / mailboxes on an RCCL communicator that was created without
     them (collective: every rank calls it); False when any rank cannot."""
@@ -768,12 +873,57 @@ def _exchange_ab(trainer, local, sc, barrier) -> dict:
     return out
 
 
+def launch_ranks(args, argv):
+    """``python bench.py --gpus N`` (N > 1) WITHOUT an outer torch.distributed.run: start the N ranks as a
+    CHILD process - the launcher the driver itself uses - before this process has touched the GPU (no HIP
+    call, no ``torch.cuda.is_available()``; ``device_count()`` reads sysfs only), relay rank 0's JSON line
+    and return the child's exit code.  A box with fewer than N devices is refused (exit 2) rather than
+    benchmarked under the wrong ``n_gpus``; IRSPACK_AMD_BENCH_ONE_DEVICE=1 (tests: every rank on cuda:0
+    over gloo) lifts that check."""
+    import socket
+    import subprocess
+
+    if not os.environ.get("IRSPACK_AMD_BENCH_ONE_DEVICE"):
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for but this node shows {have} HIP device(s); "
+                  "refusing to print a line labelled with a GPU count that did not run", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # (stderr passes through)
+    lines = []
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{"):
+            lines.append(ln)
+        else:  # (launcher / library chatter on the children's stdout)
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(lines) != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    for ln in lines:
+        print(ln, flush=True)
+    return proc.returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); "
+                         "the line would carry a GPU count that did not run")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hooks (one-GPU boxes): IRSPACK_AMD_BENCH_BACKEND=gloo and
@@ -928,6 +1078,23 @@ def main():
                 "note": "solve_ms spread (max - min over ranks) = load imbalance; the collectives' "
                         "time includes waiting for the slowest rank"}
 
+    # N > 1: the kNN and evaluator legs sharded over the same ranks (north_star: item pairs/s at 1/2/4/8).
+    # Every rank takes part; a failing leg (the same exception on every rank: arguments, memory) is
+    # recorded instead of costing the headline line.
+    sharded_sec = {}
+    if multi and not args.no_secondary and K <= 64:
+        legs_n = [s for s in args.legs.split(",") if s]
+        for name, fn in (("knn", lambda: knn_sharded_leg(X, local_rank, barrier)),
+                         ("evaluator", lambda: evaluator_sharded_leg(X, K, local_rank, barrier))):
+            if name not in legs_n:
+                continue
+            t0 = time.perf_counter()
+            try:
+                sharded_sec[name] = fn()
+            except (RuntimeError, ValueError) as exc:
+                sharded_sec[name] = {"error": repr(exc)}
+            sharded_sec[name]["leg_wall_s"] = time.perf_counter() - t0
+
     result = None
     if rank == 0:
         ceilings = None
@@ -1025,6 +1192,8 @@ def main():
                 run("k256", lambda: k256_leg(X, ceilings))
                 run("c4", lambda: c4_leg(not args.c4_small, ceilings))
             result["secondary"] = sec
+        if sharded_sec:
+            result["secondary"] = sharded_sec
         # last: 256 busy host threads just before a GPU leg disturb its (host-clocked) timing
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(X, K, args.solver, args.cpu_seconds)

@@ -7,6 +7,7 @@
 #include <stdexcept>
 #include <algorithm>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -57,10 +58,27 @@ template <class F> inline void run_on_threads(int n_thr, F &&body) {
   }
   struct Node {
     static void run(int k, int n, F &body) {
+      // A thread that cannot be started (std::system_error: the process is out of threads) must not end
+      // in std::terminate inside a worker - its subtree runs here, on this thread, instead.
       std::thread left, right;
-      if (2 * k + 1 < n) left = std::thread([&body, k, n] { run(2 * k + 1, n, body); });
-      if (2 * k + 2 < n) right = std::thread([&body, k, n] { run(2 * k + 2, n, body); });
+      bool left_here = false, right_here = false;
+      if (2 * k + 1 < n) {
+        try {
+          left = std::thread([&body, k, n] { run(2 * k + 1, n, body); });
+        } catch (const std::system_error &) {
+          left_here = true;
+        }
+      }
+      if (2 * k + 2 < n) {
+        try {
+          right = std::thread([&body, k, n] { run(2 * k + 2, n, body); });
+        } catch (const std::system_error &) {
+          right_here = true;
+        }
+      }
       body(k);
+      if (left_here) run(2 * k + 1, n, body);
+      if (right_here) run(2 * k + 2, n, body);
       if (left.joinable()) left.join();
       if (right.joinable()) right.join();
     }

@@ -1363,17 +1363,20 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
   auto pp_gramian_term = [&]() {
     // the Gramian term of every row's gradient at once: (target @ P)[r] = P x_r (P is symmetric; its
     // KP rows play the items of user_scores_kernel); R K^2 multiply-adds, ~1 % of the half-step
-    const int64_t R = sd.n_rows, KPl = t->KP;
+    // Only the rows this Side solves, [row_begin, row_end): a rank of a sharded run (or a row chunk of
+    // irs_ials_sharded_step) must not repeat the product for the whole side, nor hold [n_rows, KP] for it.
+    // resid_finish_rhs reads px at the ABSOLUTE row, hence the base pointer shifted back by row_begin rows.
+    const int64_t rb = sd.row_begin, R = sd.row_end - sd.row_begin, KPl = t->KP;
     t->pp_px.alloc(static_cast<size_t>(std::max<int64_t>(R, 1)) * KPl);
     if (R > 0) {
       const int64_t waves = ceil_div(R, 64) * ceil_div(KPl, 64);
       IRS_DISPATCH_T(t->T, {
         t->prof.launch("ials_ialspp_px", user_scores_kernel<16 * TT>, dim3(ceil_div(waves, 4)), dim3(256), 0, t->stream,
-                       static_cast<const float *>(target), static_cast<const float *>(t->P[pidx].ptr), int64_t(0), R,
+                       static_cast<const float *>(target), static_cast<const float *>(t->P[pidx].ptr), rb, R,
                        KPl, t->pp_px.ptr);
       });
     }
-    p.px = t->pp_px.ptr;
+    p.px = t->pp_px.ptr - rb * KPl;
   };
   if (pp_direct) pp_gramian_term();
   // CG, short rows: the matrix-free kernel takes the tail of the longest-first task list
@@ -1725,7 +1728,20 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     Joiner transpose_join{transpose_thread};
     require_device(device);
     auto t = std::make_unique<irs_ials_trainer>();
-    Joiner draw_join_before_trainer{draw_thread};  // (destroyed before `t`: the upload must not outlive its buffers)
+    // (destroyed before `t`: the upload must not outlive its buffers.  It is also destroyed before `release`
+    // above, so when alloc_common throws - hipMalloc out of memory at the 10 M x 1 M shape - it has to
+    // fulfil the promise ITSELF before joining: the draw thread is blocked on it.)
+    struct ReleaseThenJoin {
+      std::thread &t;
+      ReleaseWaiter &r;
+      ~ReleaseThenJoin() {
+        if (!r.done) {
+          r.p.set_value(nullptr);
+          r.done = true;
+        }
+        if (t.joinable()) t.join();
+      }
+    } draw_join_before_trainer{draw_thread, release};
     t->cfg = *config;
     t->K = static_cast<int64_t>(config->K);
     t->n_users = n_users;
@@ -1733,6 +1749,8 @@ irs_status irs_ials_create(const irs_ials_model_config *config, int64_t n_users,
     t->device = device;
     t->shard = sh;
     t->whole = whole;
+    // (test hook: an allocation failure here must come back as IRS_RUNTIME_ERROR, not hang the draw thread)
+    if (env_flag("IRSPACK_AMD_TEST_FAIL_ALLOC", false)) throw std::runtime_error("injected allocation failure.");
     alloc_common(t.get());
     buffers_ready.set_value(t.get());
     release.done = true;
@@ -2334,10 +2352,17 @@ irs_status irs_ials_set_features(irs_ials_trainer *t, int32_t which, int64_t row
     hipStream_t s = t->stream;
     t->f_indptr[which].upload(to32(F.indptr), s);
     t->f_indices[which].upload(F.indices, s);
-    t->f_data[which].upload(F.data, s);
+    // host_csr / transpose carry NO values for an all-ones matrix (one-hot features: the usual input);
+    // feature_prior_kernel / feature_rhs_kernel read data[q] per stored entry, so the ones are made here
+    const size_t f_nnz = static_cast<size_t>(F.indptr[rows]);
+    std::vector<float> ones;
+    if (F.unit && f_nnz > 0) ones.assign(f_nnz, 1.0f);
+    if (F.unit) t->f_data[which].upload(ones, s);
+    else t->f_data[which].upload(F.data, s);
     t->ft_indptr[which].upload(to32(Ft.indptr), s);
     t->ft_indices[which].upload(Ft.indices, s);
-    t->ft_data[which].upload(Ft.data, s);
+    if (F.unit) t->ft_data[which].upload(ones, s);
+    else t->ft_data[which].upload(Ft.data, s);
     t->f_W[which].alloc(static_cast<size_t>(std::max<int64_t>(n_feat, 1)) * t->KP);
     t->f_rhs[which].alloc(static_cast<size_t>(std::max<int64_t>(n_feat, 1)) * t->KP);
     int64_t longest = 1;

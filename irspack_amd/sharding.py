@@ -335,12 +335,14 @@ class HipLocalSolver(LocalSolver):
             pass
 
 
-def run_with_watchdog(fn, timeout_s: float, what: str):
+def run_with_watchdog(fn, timeout_s: float, what: str, device: int = None):
     """``fn()`` on a worker thread; a call that has not returned after ``timeout_s`` seconds ends
     the PROCESS with exit code 3 (a collective that one rank never entered blocks the others
     inside the driver or on the device, where no exception can reach them: the launcher then
     takes the other ranks down, which is the only way such a job ever ends).  Exceptions of
-    ``fn`` are re-raised here."""
+    ``fn`` are re-raised here.  ``device``: the HIP device the worker binds first - the current
+    device is per THREAD and a new thread starts on device 0, where torch.distributed's object
+    collectives of every rank would otherwise be staged under the nccl backend."""
     import os
     import sys
     import threading
@@ -349,6 +351,11 @@ def run_with_watchdog(fn, timeout_s: float, what: str):
 
     def target():
         try:
+            if device is not None:
+                import torch
+
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(device)
             box["value"] = fn()
         except BaseException as exc:  # noqa: BLE001 - handed to the caller
             box["error"] = exc
@@ -445,7 +452,8 @@ class ShardedIALSTrainer:
             try:
                 run_with_watchdog(lambda: local.create_comm(group, transport=transport,
                                                             peers=(transport == "local" or exchange == "peer")),
-                                  self.watchdog_s, "creating the native communicators")
+                                  self.watchdog_s, "creating the native communicators",
+                                  device=getattr(local, "device", None))
                 local.set_exchange(exchange)
             except (RuntimeError, ValueError) as exc:
                 err = repr(exc)
@@ -507,7 +515,8 @@ class ShardedIALSTrainer:
         err = None
         try:
             run_with_watchdog(lambda: self.local.sharded_step(solver_config, self.bounds[0], self.bounds[1]),
-                              self.watchdog_s, "the first native sharded epoch")
+                              self.watchdog_s, "the first native sharded epoch",
+                              device=getattr(self.local, "device", None))
         except (RuntimeError, ValueError) as exc:
             err = repr(exc)
         if all_ranks_ok(err is None, self.group):
@@ -692,15 +701,33 @@ class ShardedIALSTrainer:
 # ---------------------------------------------------------------------------------------
 # kNN and evaluator: independent units, no data-path collective
 
-def sharded_similarity(compute_rows, n_rows: int, group=None) -> sps.csr_matrix:
+def similarity_row_bounds(X_target: sps.spmatrix, world: int) -> List[int]:
+    """Contiguous target-row ranges of ~equal multiply-add count for ``sharded_similarity``:
+    row i of ``X_target @ X_target.T`` (knn.hpp:43-83: the rows one thread / rank computes)
+    costs sum over its stored features f of nnz(column f) - a popular item's row is orders of
+    magnitude dearer than a tail item's, so equal ROW counts are balanced only when the row
+    order is random."""
+    Xr = sps.csr_matrix(X_target)
+    col_nnz = np.bincount(Xr.indices, minlength=Xr.shape[1]).astype(np.float64)
+    per_entry = col_nnz[Xr.indices]
+    cost = np.add.reduceat(np.concatenate([per_entry, [0.0]]), Xr.indptr[:-1].astype(np.int64))
+    cost[np.diff(Xr.indptr) == 0] = 0.0  # (reduceat repeats the next row's first entry on empty rows)
+    return balanced_bounds(cost + 1.0, world)
+
+
+def sharded_similarity(compute_rows, n_rows: int, group=None,
+                       bounds: Sequence[int] = None) -> sps.csr_matrix:
     """Item- / user-kNN over ``world`` ranks: rank r computes the target rows
-    ``even_bounds(n_rows, world)[r : r + 2]`` with ``compute_rows(begin, end)`` (a CSR
+    ``bounds[r : r + 2]`` (default ``even_bounds(n_rows, world)``; ``similarity_row_bounds``
+    balances the multiply-adds instead of the row count) with ``compute_rows(begin, end)`` (a CSR
     block, e.g. ``computer.compute_similarity(X, top_k, rows=(begin, end))``); the blocks are
     exchanged as host objects and stacked in rank order on every rank."""
     import torch.distributed as dist
 
     rank, world = _group_info(group)
-    b = even_bounds(n_rows, world)
+    b = even_bounds(n_rows, world) if bounds is None else [int(v) for v in bounds]
+    if len(b) != world + 1 or b[0] != 0 or b[-1] != n_rows or any(x > y for x, y in zip(b, b[1:])):
+        raise ValueError("bounds must be world + 1 non-decreasing row offsets from 0 to n_rows.")
     mine = sps.csr_matrix(compute_rows(b[rank], b[rank + 1]))
     if world == 1:
         return mine

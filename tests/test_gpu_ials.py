@@ -612,3 +612,28 @@ def test_device_transpose_is_the_host_transpose(shape, binary, monkeypatch):
     np.testing.assert_array_equal(out["0"][0], out["1"][0])
     np.testing.assert_array_equal(out["0"][1], out["1"][1])
     assert out["0"][2] == out["1"][2]
+
+
+def test_allocation_failure_in_create_is_an_error_not_a_hang():
+    """irs_ials_create draws the initial factors on a host thread that waits for the device buffers; when
+    the allocation throws (hipMalloc out of memory at the 10 M x 1 M shape) that thread has to be released
+    BEFORE it is joined.  Injected here (IRSPACK_AMD_TEST_FAIL_ALLOC=1), in a child process so that a
+    regression shows up as a timeout of this test rather than as a hung suite."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, scipy.sparse as sps\n"
+        "from irspack_amd.recommenders._ials_core import IALSModelConfigBuilder, IALSTrainer\n"
+        "X = sps.random(50, 40, density=0.2, format='csr', dtype=np.float32, random_state=1)\n"
+        "try:\n"
+        "    IALSTrainer(IALSModelConfigBuilder().set_K(16).build(), X)\n"
+        "except RuntimeError as exc:\n"
+        "    print('RuntimeError:', exc)\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, IRSPACK_AMD_TEST_FAIL_ALLOC="1", PYTHONPATH=root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RuntimeError: injected allocation failure." in out.stdout

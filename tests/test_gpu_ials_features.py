@@ -23,7 +23,7 @@ ITEM_F = np.array([[1, 0, 0.1], [0, 1, 0.2], [0.5, 0.2, 1], [-0.2, 0.8, 0.4]], d
 ALPHA0, REG, NU, LAM_U, LAM_I = 0.7, 0.03, 0.6, 0.11, 0.17
 
 
-def make(solver_type, max_cg_steps, feature_type, seed=0, warmup=0):
+def make(solver_type, max_cg_steps, feature_type, seed=0, warmup=0, USER_F=USER_F, ITEM_F=ITEM_F):
     mc = (IALSModelConfigBuilder().set_K(3).set_alpha0(ALPHA0).set_reg(REG).set_nu(NU)
           .set_init_stdev(0.1).set_random_seed(seed).set_loss_type(LossType.ORIGINAL)
           .set_lambda_user_feature(LAM_U).set_lambda_item_feature(LAM_I)
@@ -68,6 +68,40 @@ def solve_embeddings(histories, other, prior, reg_rows):
                 rhs = rhs + (ALPHA0 + value) * other[j]
         out.append(np.linalg.solve(lhs, rhs))
     return np.asarray(out)
+
+
+@pytest.mark.parametrize("feature_type", ["dense", "sparse"])
+def test_one_hot_feature_matrices(feature_type):
+    """All-ones (one-hot) feature matrices - the usual input of feature-aware iALS.  The host copy of an
+    all-ones CSR carries no value array (host_prep.hpp: `unit`), so the feature kernels' value streams have
+    to be made on the way to the device (round 5 left them unset: an out-of-bounds read).  Converged weights
+    against the float64 ridge closed form and the fold-in against the float64 block solve, as in
+    test_ials.py:152-153, 185-227."""
+    one_u = np.array([[1, 0], [0, 1], [1, 0]], dtype=np.float32)
+    one_i = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], dtype=np.float32)
+    t, sc, X = make("CHOLESKY", 3, feature_type, USER_F=one_u, ITEM_F=one_i)
+    for _ in range(500):
+        t.step(sc)
+    user, item = t.user.astype(np.float64), t.item.astype(np.float64)
+    uw, iw = t.user_feature_weight.astype(np.float64), t.item_feature_weight.astype(np.float64)
+    assert np.isfinite(user).all() and np.isfinite(item).all()
+    user_reg, item_reg = regs()
+    UF, IF = one_u.astype(np.float64), one_i.astype(np.float64)
+    exp_uw = np.linalg.solve(UF.T @ (user_reg[:, None] * UF) + LAM_U * np.eye(2),
+                             UF.T @ (user_reg[:, None] * user))
+    exp_iw = np.linalg.solve(IF.T @ (item_reg[:, None] * IF) + LAM_I * np.eye(3),
+                             IF.T @ (item_reg[:, None] * item))
+    np.testing.assert_allclose(uw, exp_uw, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(iw, exp_iw, rtol=2e-6, atol=2e-6)
+    fold = IALSSolverConfigBuilder().set_solver_type(SolverType.CHOLESKY).set_max_cg_steps(0).build()
+    uf = one_u if feature_type == "dense" else sps.csr_matrix(one_u)
+    itf = one_i if feature_type == "dense" else sps.csr_matrix(one_i)
+    np.testing.assert_allclose(t.transform_user_with_feature(X, uf, fold),
+                               solve_embeddings(INTERACTION, item, UF @ uw, user_reg), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(t.transform_item_with_feature(X, itf, fold),
+                               solve_embeddings(INTERACTION.T, user, IF @ iw, item_reg), rtol=2e-5, atol=2e-5)
+    # the converged factors also satisfy their own block equations with the prior F @ W
+    np.testing.assert_allclose(user, solve_embeddings(INTERACTION, item, UF @ uw, user_reg), rtol=2e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize(("solver_type", "max_cg_steps"), [("CHOLESKY", 3), ("CG", 0)])

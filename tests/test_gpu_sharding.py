@@ -88,7 +88,10 @@ def test_two_ranks_match_single_gpu(tmp_path, kind, equal, K):
 
 
 @pytest.mark.parametrize("extra,env_extra,timed", [
-    (["--shape", "small", "--balance", "equal"], {}, "torch"),
+    # `python bench.py --gpus 2` with NO outer launcher: bench.py starts its two ranks itself (a child
+    # torch.distributed.run, before the parent touches the GPU) and relays rank 0's line, which also
+    # carries the row-sharded kNN leg and the user-sharded evaluator leg
+    (["--shape", "small", "--balance", "equal", "--self-launch"], {}, "torch"),
     (["--shape", "small", "--balance", "cost", "--solver", "CG"], {}, "torch"),
     (["--shape", "c4_small", "--K", "128", "--solver", "CG"], {}, "torch"),
     # the native path as the timed one: the RCCL-free peer-store transport (two processes, one GPU)
@@ -117,15 +120,28 @@ def test_bench_two_ranks_control_flow(extra, env_extra, timed):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, IRSPACK_AMD_BENCH_BACKEND="gloo", IRSPACK_AMD_BENCH_ONE_DEVICE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    self_launch = "--self-launch" in extra
+    extra = [a for a in extra if a != "--self-launch"]
+    if self_launch:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        launcher = [sys.executable]
+    else:
+        extra = extra + ["--no-secondary"]
+        launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
     out = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
-         "--gpus", "2", "--steps", "2", "--warmup", "1", *extra],
+        [*launcher, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *extra],
         env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    if self_launch:
+        knn, ev = d["secondary"]["knn"], d["secondary"]["evaluator"]
+        assert "error" not in knn and "error" not in ev, (knn, ev)
+        assert knn["item_pairs_per_s"] > 0 and len(knn["row_bounds"]) == 3 and knn["out_nnz"] > 0
+        assert ev["users_per_s"] > 0 and 0 < ev["valid_user"] <= ev["total_user"] == 4000
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     assert "roofline" in d and d["roofline"]["frac"] > 0
     want_balance = "equal" if "equal" in extra else "cost"
