@@ -241,18 +241,45 @@ def cpu_baseline(X, K, solver, budget_s):
 
 
 PMC_WORKLOAD = "ml20m K=64"  # what the committed FETCH_SIZE / WRITE_SIZE passes ran (scripts/prof_bench.sh)
+# the sources that define the kernels whose traffic profiles/pmc_traffic.json records
+PMC_SOURCES = {"ials": ["ials.hip", "ials_kernels.hpp", "ials_chol16.hpp", "common.hpp"],
+               "knn": ["knn.hip", "common.hpp"]}
 
 
-def pmc_traffic(workload=PMC_WORKLOAD):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json,
-    written by scripts/summarize_prof.py with the guide's gfx950 corrections) - ONLY for the workload
-    those passes ran: a leg on another shape or K gets no traffic figures rather than wrong ones."""
+def kernel_source_sha16():
+    """sha256[:16] of the concatenated kernel sources per family: the key that ties a committed PMC figure
+    to the code it was measured on (scripts/summarize_prof.py writes it, pmc_traffic() compares it)."""
+    import hashlib
+
+    out = {}
+    for fam, files in PMC_SOURCES.items():
+        h = hashlib.sha256()
+        for f in files:
+            with open(os.path.join(ROOT, "irspack_amd", "csrc", f), "rb") as fh:
+                h.update(fh.read())
+        out[fam] = h.hexdigest()[:16]
+    return out
+
+
+def pmc_traffic(workload=PMC_WORKLOAD, family="ials"):
+    """HBM bytes from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    scripts/summarize_prof.py with the guide's gfx950 corrections): per LAUNCH for the ials_* kernels, per
+    compute_similarity CALL for knn_tile_kernel.  PMC counters cannot be collected inside this process, so the
+    figure is a committed one - and it is returned ONLY for the workload those passes ran AND while the
+    kernels' sources hash to what the passes ran on (`_provenance.sources_sha16`); otherwise `traffic` is
+    null rather than a number that no longer describes the code.  The line carries the provenance."""
     if workload != PMC_WORKLOAD:
         return {}
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         return {}
+    prov = d.get("_provenance") or {}
+    if (prov.get("sources_sha16") or {}).get(family) != kernel_source_sha16()[family]:
+        return {"_stale": {"reason": f"the {family} kernel sources changed since the PMC pass",
+                           "pass": prov.get("collected_at_git_head"), "sources_now": kernel_source_sha16()[family],
+                           "sources_at_pass": (prov.get("sources_sha16") or {}).get(family)}}
+    return d
 
 
 def time_epochs(trainer, sc, steps, warmup):
@@ -330,6 +357,8 @@ def ials_leg(trainer, X, K, kind, steps, warmup, ceilings, workload=None):
                                traffic_by_kernel=({k: v for k, v in pmc_traffic(workload).items()
                                                    if k.startswith("ials_") and ("cg" in k) == (kind == "CG")}
                                                   or None),
+                               traffic_provenance=(pmc_traffic(workload).get("_provenance")
+                                                   or pmc_traffic(workload).get("_stale")),
                                **more),
     }
 
@@ -553,7 +582,8 @@ def knn_leg(X, ceilings):
     wall, ms, macs = min(walls), comp.last_kernel_ms, comp.last_macs
     atomic_peak = (ceilings or {}).get("lds_atomic_u32_gops")
     gmacs = macs / ms / 1e6
-    traffic = pmc_traffic().get("knn_tile_kernel")
+    knn_pmc = pmc_traffic(family="knn")
+    traffic = knn_pmc.get("knn_tile_kernel")  # bytes per CALL (all launches of one compute_similarity)
     out = {
         "workload": f"cosine item-kNN top_k=100, {I} items x {U} users, binary interactions, fp64",
         "item_pairs_per_s": I * float(I) / wall,
@@ -569,15 +599,18 @@ def knn_leg(X, ceilings):
                      "hbm_side_gbs": macs * 4.0 / (ms * 1e-3) / 1e9,
                      "frac_hbm": macs * 4.0 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                      "traffic_gbs": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
+                     "traffic_over_algorithmic": (traffic / (macs * 2.0)) if traffic else None,
+                     "traffic_provenance": knn_pmc.get("_provenance") or knn_pmc.get("_stale"),
                      "note": "kernel_ms = device span from the first launch to the last row merge of the call's "
                              "three row chunks (accumulate + epilogue + select + merge; the host pass, the "
                              "index upload and the result copy of one chunk run beside the kernels of another); "
                              "fit_wall_s = the computer's construction (on the device since round 5) + the FIRST call "
                              "of that computer (buffers sized there), what one `learn()` of a kNN recommender costs; "
                              "HBM side prices the reference's 4 B column id per multiply-add; "
-                             "traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE of the tile kernel "
-                             "(profiles/pmc_traffic.json from the latest profiles/rNN_knn_pmc_hbm.json, "
-                             "same matrix): the 2-byte column stream is read once per column tile; "
+                             "traffic = rocprofv3 FETCH_SIZE + WRITE_SIZE of the tile kernel summed over the launches "
+                             "of ONE call (profiles/pmc_traffic.json from the latest profiles/rNN_knn_pmc_hbm.json, "
+                             "same matrix; null when knn.hip changed since that pass): the 2-byte column stream "
+                             "(algorithmic: 2 B per multiply-add) is read once per column tile; "
                              "short slices waste part of their 128-byte lines"},
         "out_nnz": int(S.nnz),
     }
@@ -620,6 +653,30 @@ def knn_leg(X, ceilings):
                            "item_pairs_per_s_kernel_only": I * float(I) / (wcomp.last_kernel_ms * 1e-3)}
         del wcomp, Xw
     out["variants"] = variants
+    # `learn()` END TO END from the scipy CSR a user holds (knn.py:67-80: weighting -> computer on
+    # X_weighted.T -> compute_similarity(X.T, top_k) -> remove_diagonal -> CSC): X.T goes to the library as the
+    # CSC view it is (no host transpose), the weighting is applied on the device on the way in (the weighted
+    # matrix never exists on the host), the target's columns are regrouped on host threads inside the call.
+    # The recommender's constructor (base.py:94-101: a float64 CSR copy, the reference's own Python) is timed
+    # beside it, not in it.  Minimum of three; the first (buffers, streams, page-locking) beside it.
+    from irspack_amd.recommenders.knn import CosineKNNRecommender
+
+    learn = {}
+    for scheme in ("NONE", "TF_IDF", "BM_25"):
+        t0 = time.perf_counter()
+        rec = CosineKNNRecommender(X, shrinkage=0.0, normalize=True, top_k=100, feature_weighting=scheme)
+        ctor = time.perf_counter() - t0
+        ws = []
+        for _ in range(3):
+            rec._W = None
+            t0 = time.perf_counter()
+            rec.learn()
+            ws.append(time.perf_counter() - t0)
+        learn[scheme] = {"learn_wall_s": min(ws), "learn_wall_s_three_calls": ws, "recommender_ctor_s": ctor,
+                         "item_pairs_per_s": I * float(I) / min(ws), "W_nnz": int(rec.W.nnz)}
+        del rec
+    out["learn"] = learn
+    out["learn_wall_s"] = learn["NONE"]["learn_wall_s"]
     return out
 
 
@@ -1133,7 +1190,10 @@ def main():
                                   avg_launch_ms=st["ms"] / st["launches"], launches=st["launches"],
                                   algorithmic_gflop_per_launch=flops / 1e9,
                                   algorithmic_gbyte_per_launch=byts / 1e9)
-            roofline["traffic"] = pmc_traffic(f"{args.shape} K={K}").get(name) if world == 1 else None
+            pmc = pmc_traffic(f"{args.shape} K={K}") if world == 1 else {}
+            roofline["traffic"] = pmc.get(name)
+            roofline["traffic_provenance"] = pmc.get("_provenance") or pmc.get("_stale") or (
+                "no PMC pass of this workload is committed" if world == 1 else "N > 1: per-rank shards, no pass")
         result = {
             "metric": "iALS user+item updates/sec at k=64, ML-20M-shape CSR",
             "value": value,

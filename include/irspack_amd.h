@@ -40,7 +40,7 @@ typedef int32_t irs_status;
 /* Layout version of the structs below: 2 since irs_ceilings grew the gather rates, 3 since
  * irs_eval_stats carries the call's times.  A binding compares irs_abi_version() with the header it
  * was written against before passing structs. */
-#define IRS_ABI_VERSION 3
+#define IRS_ABI_VERSION 4
 
 const char *irs_last_error(void);
 /* Library / device probe.  irs_device_count() returns 0 when no GPU is visible. */
@@ -254,26 +254,70 @@ irs_status irs_ials_profile_read(irs_ials_trainer *t, int32_t cap,
 
 typedef struct irs_knn_computer irs_knn_computer;
 
+/* How (indptr, indices, data) store a [rows, cols] sparse matrix.  The reference's binding takes
+ * either scipy layout (nanobind's Eigen caster converts: cpp_source/knn/wrapper.cpp:11-19 declares
+ * `const CSRMatrix &`, and irspack/recommenders/knn.py:77-79 passes `X_weighted.T` / `X_train_all.T`,
+ * which are CSC).  IRS_LAYOUT_CSC: the arrays are the compressed COLUMNS of the matrix, i.e. the CSR
+ * arrays of its transpose [cols, rows] - indptr has cols + 1 entries, indices are row numbers.  No
+ * host conversion: the library reads them as they are. */
+#define IRS_LAYOUT_CSR 0
+#define IRS_LAYOUT_CSC 1
+/* Feature weighting of the interaction matrix before a similarity computer is built on it
+ * (cpp_source/util.hpp:159-188 okapi_BM_25_weight, :190-209 tf_idf_weight; callers
+ * irspack/recommenders/knn.py:67-75, user_knn.py:62-72). */
+#define IRS_WEIGHT_NONE 0
+#define IRS_WEIGHT_TF_IDF 1
+#define IRS_WEIGHT_BM25 2
+/* Optional description of the arrays handed to irs_knn_create (null = CSR, no weighting).
+ * `weighting` is applied ON THE DEVICE, on the way in, to the matrix AS STORED - its compressed rows
+ * are the documents, `indices` the terms, exactly what tf_idf_weight / okapi_BM_25_weight do with a
+ * CSR matrix: `CosineSimilarityComputer(tf_idf_weight(X).T, ...)` of the reference is
+ * irs_knn_create(rows = X.cols, cols = X.rows, X's CSR arrays, {IRS_LAYOUT_CSC, IRS_WEIGHT_TF_IDF}),
+ * and the user-kNN `CosineSimilarityComputer(tf_idf_weight(X), ...)` is {IRS_LAYOUT_CSR,
+ * IRS_WEIGHT_TF_IDF} - the weighted matrix never exists on the host.  Jaccard / Tversky binarise their
+ * input (similarities.hpp:96-107, 143-159), which makes any weighting a no-op; P3alpha / RP3beta
+ * take no weighting (invalid argument). */
+typedef struct irs_knn_input {
+  int32_t layout;    /* IRS_LAYOUT_* */
+  int32_t weighting; /* IRS_WEIGHT_* */
+  int32_t smooth;    /* tf-idf: idf = log(N / (df + smooth)) (util.hpp:203; the Python default is 1) */
+  int32_t reserved;  /* 0 */
+  double k1, b;      /* BM25 (util.hpp:159; Python defaults 1.2, 0.75) */
+} irs_knn_input;
+
 /* *SimilarityComputer(X, shrinkage, [alpha, beta, normalize], n_threads,
  * max_chunk_size): similarities.hpp:20-28, 61-72, 96-107, 143-159, 198-222,
- * 265-292.  X is CSR float64 [N, n_features]. */
+ * 265-292.  X is float64 [rows = N, cols = n_features], stored as `input` says. */
 irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols,
                           const int64_t *indptr, const int32_t *indices,
-                          const double *data, double shrinkage, double alpha,
+                          const double *data, const irs_knn_input *input,
+                          double shrinkage, double alpha,
                           double beta, int32_t normalize, int64_t n_threads,
                           int64_t max_chunk_size, int32_t device,
                           irs_knn_computer **out);
+/* tf_idf_weight(X, smooth) / okapi_BM_25_weight(X, k1, b) on their own (util.hpp:159-209, bound at
+ * util.cpp:29-32): X is CSR float64 [rows, cols]; `out` (caller-allocated, nnz doubles) receives the
+ * weighted values in X's entry order (X's pattern is unchanged).  Column counts, row sums and the
+ * idf table (libm's log) are made on host threads, the per-entry pass runs on the device
+ * (knn_weight_kernel: one IEEE multiply for tf-idf; multiply, multiply, add, divide for BM25, each
+ * rounded once - the host loop's values bit for bit). */
+irs_status irs_knn_weight(int32_t weighting, int64_t rows, int64_t cols,
+                          const int64_t *indptr, const int32_t *indices,
+                          const double *data, double k1, double b, int32_t smooth,
+                          int32_t device, double *out);
 irs_status irs_knn_destroy(irs_knn_computer *c);
 /* compute_similarity(X, top_k) (knn.hpp:43-139) / compute_W (similarities.hpp:
  * 224-240, 294-324; as_w != 0, result still row-major [rows, N]).  Two calls:
  * compute runs the device work and reports nnz; fetch copies the CSR out (from a
  * page-locked copy the compute call made while its later row chunks were still
  * running, or from the device).  The caller's arrays are read in place, never
- * written.  row_begin/row_end select a shard of target rows (multi-GPU: rows are
+ * written.  `layout` (IRS_LAYOUT_*): how the arrays store the [rows, cols] target - knn.py:79 passes
+ * `X_train_all.T`, a CSC matrix; its columns are regrouped into rows on host threads inside the call (indices
+ * only when every value is 1).  row_begin/row_end select a shard of target rows (multi-GPU: rows are
  * independent, no collective). */
 irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            const int64_t *indptr, const int32_t *indices,
-                           const double *data, int64_t top_k, int32_t as_w,
+                           const double *data, int32_t layout, int64_t top_k, int32_t as_w,
                            int64_t row_begin, int64_t row_end, int64_t *nnz_out);
 irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
                          double *data);

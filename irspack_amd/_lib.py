@@ -87,7 +87,7 @@ class CeilingsStruct(C.Structure):  # irs_ceilings
     ]
 
 
-ABI_VERSION = 3  # IRS_ABI_VERSION of include/irspack_amd.h
+ABI_VERSION = 4  # IRS_ABI_VERSION of include/irspack_amd.h
 # IRS_EXCHANGE_* of include/irspack_amd.h: how irs_ials_sharded_step moves the solved rows
 EXCHANGE_MODES = {"auto": 0, "broadcast": 1, "mesh": 2, "peer": 3}
 COMM_HANDLE_BYTES = 256
@@ -133,6 +133,7 @@ EXPORTED_SYMBOLS = [
     "irs_ials_profile",
     "irs_ials_profile_read",
     "irs_knn_create",
+    "irs_knn_weight",
     "irs_knn_destroy",
     "irs_knn_compute",
     "irs_knn_fetch",
@@ -212,6 +213,42 @@ def default_device() -> int:
             except ValueError:
                 pass
     return 0
+
+
+LAYOUT_CSR, LAYOUT_CSC = 0, 1  # IRS_LAYOUT_* of include/irspack_amd.h
+WEIGHT_NONE, WEIGHT_TF_IDF, WEIGHT_BM25 = 0, 1, 2  # IRS_WEIGHT_*
+
+
+class KnnInputStruct(C.Structure):  # irs_knn_input
+    _fields_ = [
+        ("layout", C.c_int32),
+        ("weighting", C.c_int32),
+        ("smooth", C.c_int32),
+        ("reserved", C.c_int32),
+        ("k1", C.c_double),
+        ("b", C.c_double),
+    ]
+
+
+def sparse_arrays(X, dtype):
+    """scipy sparse -> (matrix, layout, indptr int64, indices int32, data dtype) WITHOUT changing the
+    layout: a CSC matrix (what ``X.T`` of a CSR is - a view of the same arrays) is handed to the library
+    as it is (IRS_LAYOUT_CSC), like nanobind's Eigen caster takes either; anything else becomes CSR.
+    Indices sorted (a transposed view inherits the flag of its base)."""
+    import scipy.sparse as sps
+
+    if sps.isspmatrix_csc(X):
+        layout = LAYOUT_CSC
+    else:
+        layout = LAYOUT_CSR
+        if not sps.isspmatrix_csr(X):
+            X = sps.csr_matrix(X)
+    if not X.has_sorted_indices:
+        X = X.sorted_indices()
+    indptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(X.indices, dtype=np.int32)
+    data = np.ascontiguousarray(X.data, dtype=dtype)
+    return X, layout, indptr, indices, data
 
 
 def csr_arrays(X, dtype):

@@ -1274,6 +1274,82 @@ __global__ __launch_bounds__(256) void xt_pack16_kernel(const int32_t *__restric
   idx_p[w] = lo | (hi << 16);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Feature weighting on the device (util.hpp:159-209; host tables: knn_host_prep.hpp weight_tables).
+// One wave per stored row of the matrix (its documents): w[q] = v * idf[col] (tf-idf, :206) or
+// idf[col] * (v * (k1 + 1)) / (v + reg[row]) (BM25, :183-184) - each operation rounded once, in the
+// reference's order (__dmul_rn / __dadd_rn / __ddiv_rn: no contraction), so the values are the host
+// loop's bit for bit.  `vals` null: every stored value is 1.  flags (or-ed): 1 some weight != 1,
+// 2 some |weight| outside (1e-150, 1e150) (or zero), 4 some weight <= 0 - what the host pass of
+// irs_knn_create derives from the caller's values when it does not weight.
+template <bool BM25>
+__global__ __launch_bounds__(256) void knn_weight_kernel(const int32_t *__restrict__ indptr,
+                                                         const int32_t *__restrict__ indices,
+                                                         const double *__restrict__ vals,
+                                                         const double *__restrict__ idf,
+                                                         const double *__restrict__ reg, double k1p1,
+                                                         int64_t n_rows, double *__restrict__ out,
+                                                         int32_t *__restrict__ flags) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
+  if (r >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int32_t b = indptr[r], e = indptr[r + 1];
+  const double rg = BM25 ? reg[r] : 0.0;
+  int32_t f = 0;
+  for (int32_t q = b + lane; q < e; q += 64) {
+    const double v = vals ? vals[q] : 1.0;
+    const double w = idf[indices[q]];
+    double o;
+    if (BM25) o = __ddiv_rn(__dmul_rn(w, __dmul_rn(v, k1p1)), __dadd_rn(v, rg));
+    else o = __dmul_rn(v, w);
+    out[q] = o;
+    const double a = fabs(o);
+    f |= (o != 1.0 ? 1 : 0) | (!(a > 1e-150 && a < 1e150) ? 2 : 0) | (!(o > 0.0) ? 4 : 0);
+  }
+  if (flags) {
+    f = (__ballot(f & 1) ? 1 : 0) | (__ballot(f & 2) ? 2 : 0) | (__ballot(f & 4) ? 4 : 0);  // wave-wide or
+    if (lane == 0 && f && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & f) != f)
+      atomicOr(flags, f);
+  }
+}
+
+// ss[r] = the squares of row r's values added one by one in storage order, product and sum rounded
+// separately (the `ss += x * x` loop of the norms, similarities.hpp:20-28 / :61-72, compiled without
+// contraction).  One wave per row: the lanes load and square a strip of 64 values, then every lane runs
+// the same 64-step chain over the strip's squares (lane broadcasts) - the order of the sum is the
+// sequential one, only the loads are parallel.  Entries past the row's end add +0.0, which changes no
+// partial sum (they are >= +0.0).
+__global__ __launch_bounds__(256) void knn_row_sumsq_kernel(const uint32_t *__restrict__ ptr,
+                                                            const double *__restrict__ vals, int64_t n_rows,
+                                                            double *__restrict__ ss) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
+  if (r >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t b = ptr[r], e = ptr[r + 1];
+  double sum = 0.0;
+  for (uint32_t q0 = b; q0 < e; q0 += 64) {
+    const uint32_t q = q0 + lane;
+    const double v = q < e ? vals[q] : 0.0;
+    const double sq = __dmul_rn(v, v);
+    const uint32_t n = min(64u, e - q0);
+    if (n == 64) {
+#pragma unroll
+      for (int j = 0; j < 64; j++) sum = __dadd_rn(sum, __shfl(sq, j));
+    } else {
+      for (uint32_t j = 0; j < n; j++) sum = __dadd_rn(sum, __shfl(sq, static_cast<int>(j)));
+    }
+  }
+  if (lane == 0) ss[r] = sum;
+}
+
+// the padded value stream of X_arg^T from values that are already on the device (zeros behind the last entry)
+__global__ __launch_bounds__(256) void knn_pad_copy_kernel(const double *__restrict__ src, int64_t nnz,
+                                                           int64_t padded, double *__restrict__ dst) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (q < padded) dst[q] = q < nnz ? src[q] : 0.0;
+}
+
 static void check_lower(double x, double low, const char *name) {  // argcheck.hpp:13-20
   if (x < low) {
     std::string msg = std::string(name) + " must be greater than or equal to  " + std::to_string(low);
@@ -1395,8 +1471,8 @@ struct PhaseTimer {
 };
 
 irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const int64_t *indptr,
-                          const int32_t *indices, const double *data, double shrinkage,
-                          double alpha, double beta, int32_t normalize, int64_t n_threads,
+                          const int32_t *indices, const double *data, const irs_knn_input *input,
+                          double shrinkage, double alpha, double beta, int32_t normalize, int64_t n_threads,
                           int64_t max_chunk_size, int32_t device, irs_knn_computer **out) {
   return guard([&] {
     check_arg(out != nullptr, "null argument.");
@@ -1429,11 +1505,18 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       default:
         throw std::invalid_argument("unknown similarity type.");
     }
+    int32_t layout = input ? input->layout : IRS_LAYOUT_CSR;
+    int32_t weighting = input ? input->weighting : IRS_WEIGHT_NONE;
+    check_arg(layout == IRS_LAYOUT_CSR || layout == IRS_LAYOUT_CSC, "unknown matrix layout.");
+    check_arg(weighting == IRS_WEIGHT_NONE || weighting == IRS_WEIGHT_TF_IDF || weighting == IRS_WEIGHT_BM25,
+              "unknown feature weighting.");
     check_arg(rows >= 0 && cols >= 0 && indptr, "bad matrix.");
-    check_arg(rows < (int64_t(1) << 31), "too many rows.");
-    check_arg(indptr[0] == 0 && indptr[rows] >= 0, "malformed indptr.");
-    for (int64_t i = 0; i < rows; i++) check_arg(indptr[i + 1] >= indptr[i], "malformed indptr.");
-    const int64_t nnz_in = indptr[rows];
+    check_arg(rows < (int64_t(1) << 31) && cols < (int64_t(1) << 31), "too many rows.");
+    // M: the matrix as the arrays store it - X_arg [rows, cols] itself, or X_arg^T for the CSC layout
+    int64_t m_rows = layout == IRS_LAYOUT_CSC ? cols : rows, m_cols = layout == IRS_LAYOUT_CSC ? rows : cols;
+    check_arg(indptr[0] == 0 && indptr[m_rows] >= 0, "malformed indptr.");
+    for (int64_t i = 0; i < m_rows; i++) check_arg(indptr[i + 1] >= indptr[i], "malformed indptr.");
+    const int64_t nnz_in = indptr[m_rows];
     check_arg(nnz_in == 0 || (indices && data), "bad matrix.");
     // ---- Cosine / asymmetric cosine / Jaccard / Tversky, round 5: the caller's arrays are validated and
     // classified in place (no private copy), the column indices - and the values, if they are not all
@@ -1448,24 +1531,63 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
     const bool transforms = sim_type == IRS_SIM_P3ALPHA || sim_type == IRS_SIM_RP3BETA;
     const bool device_candidate = nnz_in > 0 && cols > 0 && nnz_in < (int64_t(1) << 31) - 1024 &&
                                   env_flag("IRSPACK_AMD_KNN_DEVICE_CREATE", true);
+    check_arg(!(transforms && weighting != IRS_WEIGHT_NONE), "P3alpha / RP3beta take no feature weighting.");
+    if (binarise_create) weighting = IRS_WEIGHT_NONE;  // (every stored value becomes 1: similarities.hpp:96-107, 143-159)
+    // The paths that read X_arg's rows on the host (P3alpha / RP3beta's row normalisation; the host
+    // construction; empty matrices) get them: weighting and regrouping on host threads, into private arrays.
+    HostCsrD conv;
+    RawVector<double> conv_w;
+    if ((!device_candidate || transforms) && (layout == IRS_LAYOUT_CSC || weighting != IRS_WEIGHT_NONE)) {
+      std::atomic<int> bad_idx(0);
+      parallel_ranges(nnz_in, [&](int64_t b, int64_t e) {
+        int32_t lo = 0, hi = 0;
+        for (int64_t q = b; q < e; q++) {
+          lo = std::min(lo, indices[q]);
+          hi = std::max(hi, indices[q]);
+        }
+        if (e > b && (lo < 0 || hi >= m_cols)) bad_idx.store(1);
+      });
+      check_arg(bad_idx.load() == 0, "column index out of range.");
+      if (weighting != IRS_WEIGHT_NONE) {
+        const bool bm = weighting == IRS_WEIGHT_BM25;
+        const WeightTables wt = weight_tables(bm, m_rows, m_cols, indptr, indices, data, false, input->k1, input->b,
+                                              input->smooth != 0);
+        conv_w.resize(static_cast<size_t>(nnz_in));
+        weight_values_host(bm, wt, m_rows, indptr, indices, data, input->k1, conv_w.data());
+        data = conv_w.data();
+        weighting = IRS_WEIGHT_NONE;
+      }
+      if (layout == IRS_LAYOUT_CSC) {
+        conv = transpose_pattern(m_rows, m_cols, indptr, indices, data);
+        indptr = conv.indptr.data();
+        indices = conv.indices.data();
+        data = conv.data.data();
+        layout = IRS_LAYOUT_CSR;
+        m_rows = rows;
+        m_cols = cols;
+      }
+      pt.mark("create: host regroup");
+    }
     if (device_candidate) {
       require_device(device);
       IRS_HIP(hipSetDevice(device));
+      // M = the matrix as the arrays store it: X_arg itself (CSR layout) or X_arg^T (CSC layout)
+      const bool csc = layout == IRS_LAYOUT_CSC;
       DeviceBuffer<int32_t> d_indptr, d_indices, d_tidx;
       DeviceBuffer<double> d_values;
       // P3alpha / RP3beta (similarities.hpp:198-222, 265-292): the rows pow-ed and normalised to sum 1, on
       // the host (libm's pow: the values the oracle has) into the one private array of this path
       const double *vals = data;
       RawVector<double> tvals;
-      const std::vector<int64_t> ipv(indptr, indptr + rows + 1);
+      const std::vector<int64_t> ipv(indptr, indptr + m_rows + 1);
       std::string upload_error;
-      std::atomic<int> kind(0);  // 0: not classified yet, 1: all ones, 2: weighted (the values travel too), 3: give up
+      std::atomic<int> kind(0);  // 0: not classified yet, 1: all ones, 2: the values travel too, 3: give up
       std::thread uploader([&] {  // (pageable memory: the copies occupy a host thread)
         try {
           IRS_HIP(hipSetDevice(device));
-          std::vector<int32_t> ip32(rows + 1);
-          for (int64_t i = 0; i <= rows; i++) ip32[i] = static_cast<int32_t>(indptr[i]);
-          d_indptr.alloc(static_cast<size_t>(rows) + 1);
+          std::vector<int32_t> ip32(m_rows + 1);
+          for (int64_t i = 0; i <= m_rows; i++) ip32[i] = static_cast<int32_t>(indptr[i]);
+          d_indptr.alloc(static_cast<size_t>(m_rows) + 1);
           d_indices.alloc(static_cast<size_t>(nnz_in));
           IRS_HIP(hipMemcpy(d_indptr.ptr, ip32.data(), ip32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
           IRS_HIP(hipMemcpy(d_indices.ptr, indices, static_cast<size_t>(nnz_in) * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1491,7 +1613,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
       std::atomic<int> bad(0), not_ones(0), not_safe(0), not_pos(0);
       if (transforms) {
         tvals.resize(static_cast<size_t>(nnz_in));
-        for_rows_parallel(ipv, rows, [&](int64_t i) {
+        for_rows_parallel(ipv, m_rows, [&](int64_t i) {
           double sum = 0;
           for (int64_t q = indptr[i]; q < indptr[i + 1]; q++) {
             tvals[q] = std::pow(data[q], alpha);
@@ -1512,7 +1634,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
             lo = std::min(lo, indices[q]);
             hi = std::max(hi, indices[q]);
           }
-          if (e > b && (lo < 0 || hi >= cols)) bad.store(1);
+          if (e > b && (lo < 0 || hi >= m_cols)) bad.store(1);
           if (!binarise_create) {  // (a branch-free pass the compiler vectorises)
             uint64_t diff = 0;
             const uint64_t one_bits = 0x3ff0000000000000ull;
@@ -1533,9 +1655,18 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         });
       }
       check_arg(bad.load() == 0, "column index out of range.");
-      const bool weighted = not_ones.load() != 0;
-      kind.store(weighted ? 2 : 1, std::memory_order_release);
+      const bool input_ones = not_ones.load() == 0;  // (binarising similarities: always)
+      kind.store(input_ones ? 1 : 2, std::memory_order_release);
       pt.mark("create: validate");
+      // The feature weighting (util.hpp:159-209), fused: the two small tables on host threads while the
+      // uploads run, the per-entry pass on the device - the weighted matrix is never materialised on the host.
+      WeightTables wt;
+      const bool bm25 = weighting == IRS_WEIGHT_BM25;
+      if (weighting != IRS_WEIGHT_NONE) {
+        wt = weight_tables(bm25, m_rows, m_cols, indptr, indices, data, input_ones, input->k1, input->b,
+                           input->smooth != 0);
+        pt.mark("create: weight tables");
+      }
       {
         auto c = std::make_unique<irs_knn_computer>();
         c->device = device;
@@ -1547,40 +1678,142 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         c->beta = beta;
         c->normalize = normalize != 0;
         // the norms (similarities.hpp:20-28, 61-72, 96-107, 143-159); rows of ones: sqrt / pow of the entry
-        // count, which is what their sums of 1.0 * 1.0 are
+        // count, which is what their sums of 1.0 * 1.0 are.  From the caller's arrays on host threads when
+        // they hold X_arg's rows and nothing weights them; else from the device (below).
         std::vector<double> norms(rows, 0.0);
-        if (!transforms)  // (P3alpha / RP3beta have none)
-          for_rows_parallel(ipv, rows, [&](int64_t i) {
-            double ss = static_cast<double>(indptr[i + 1] - indptr[i]);
-            if (weighted) {
-              ss = 0;
-              for (int64_t q = indptr[i]; q < indptr[i + 1]; q++) ss += data[q] * data[q];
-            }
-            switch (sim_type) {
-              case IRS_SIM_COSINE: norms[i] = std::sqrt(ss); break;
-              case IRS_SIM_ASYMMETRIC: norms[i] = std::pow(ss, 1 - alpha); break;
-              default: norms[i] = ss; break;  // (Jaccard / Tversky: the entry count; never weighted)
-            }
-          });
+        auto finish_norm = [&](double ss) {
+          switch (sim_type) {
+            case IRS_SIM_COSINE: return std::sqrt(ss);
+            case IRS_SIM_ASYMMETRIC: return std::pow(ss, 1 - alpha);
+            default: return ss;  // (Jaccard / Tversky: the entry count; never weighted)
+          }
+        };
+        const bool norms_on_device = !transforms && (weighting != IRS_WEIGHT_NONE || (csc && !input_ones));
+        if (!transforms && !norms_on_device) {  // (P3alpha / RP3beta have none)
+          if (csc) {  // all ones: the entry count of every column of M
+            const std::vector<int64_t> cnt = column_counts(m_rows, m_cols, indptr, indices);
+            parallel_ranges(rows, [&](int64_t lo, int64_t hi) {
+              for (int64_t i = lo; i < hi; i++) norms[i] = finish_norm(static_cast<double>(cnt[i]));
+            }, 16, 20000);
+          } else {
+            for_rows_parallel(ipv, rows, [&](int64_t i) {
+              double ss = static_cast<double>(indptr[i + 1] - indptr[i]);
+              if (!input_ones) {
+                ss = 0;
+                for (int64_t q = indptr[i]; q < indptr[i + 1]; q++) ss += data[q] * data[q];
+              }
+              norms[i] = finish_norm(ss);
+            });
+          }
+        }
         uploader.join();
         if (!upload_error.empty()) throw std::runtime_error(upload_error);
         pt.mark("create: norms + upload");
         hipStream_t s = nullptr;
-        d_tidx.alloc(static_cast<size_t>(nnz_in));
+        bool weighted = !input_ones;  // does the value stream of the kernels carry anything but ones?
+        int32_t w_flags = 0;
+        if (weighting != IRS_WEIGHT_NONE) {
+          DeviceBuffer<double> d_idf, d_reg, d_w;
+          DeviceBuffer<int32_t> d_flags;
+          d_idf.upload(wt.idf, s);
+          if (bm25) d_reg.upload(wt.reg, s);
+          d_w.alloc(static_cast<size_t>(nnz_in));
+          d_flags.alloc(1);
+          IRS_HIP(hipMemsetAsync(d_flags.ptr, 0, sizeof(int32_t), s));
+          const double *in_vals = input_ones ? nullptr : d_values.ptr;
+          const dim3 grid(static_cast<unsigned>(ceil_div(m_rows, 4)));
+          if (bm25)
+            hipLaunchKernelGGL(knn_weight_kernel<true>, grid, dim3(256), 0, s, static_cast<const int32_t *>(d_indptr.ptr),
+                               static_cast<const int32_t *>(d_indices.ptr), in_vals, static_cast<const double *>(d_idf.ptr),
+                               static_cast<const double *>(d_reg.ptr), input->k1 + 1, m_rows, d_w.ptr, d_flags.ptr);
+          else
+            hipLaunchKernelGGL(knn_weight_kernel<false>, grid, dim3(256), 0, s, static_cast<const int32_t *>(d_indptr.ptr),
+                               static_cast<const int32_t *>(d_indices.ptr), in_vals, static_cast<const double *>(d_idf.ptr),
+                               static_cast<const double *>(nullptr), 0.0, m_rows, d_w.ptr, d_flags.ptr);
+          IRS_HIP(hipGetLastError());
+          IRS_HIP(hipMemcpyAsync(&w_flags, d_flags.ptr, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+          IRS_HIP(hipStreamSynchronize(s));
+          d_values.release();
+          d_values.ptr = d_w.ptr;  // (the weighted values take the place of the caller's)
+          d_values.count = d_w.count;
+          d_values.owned = true;
+          d_w.ptr = nullptr;
+          d_w.count = 0;
+          weighted = (w_flags & 1) != 0;
+          not_safe.store((w_flags & 2) ? 1 : 0);
+          not_pos.store((w_flags & 4) ? 1 : 0);
+          pt.mark("create: weight");
+        }
         const size_t padded = (static_cast<size_t>(nnz_in) + 256 + 1) & ~size_t(1);
         std::vector<int32_t> t_count;
         DeviceBuffer<char> tmp;
-        if (weighted) {  // the transposed values straight into the padded value stream of the kernels
-          c->xt_val.alloc(padded);
-          IRS_HIP(hipMemsetAsync(c->xt_val.ptr + nnz_in, 0, (padded - static_cast<size_t>(nnz_in)) * sizeof(double), s));
-          transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(d_values.ptr), rows, cols,
-                               nnz_in, d_tidx.ptr, c->xt_val.ptr, t_count, tmp, s);
-        } else {
-          c->xt_val.alloc(2);  // (the ONES kernels never read the value stream)
-          transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(nullptr), rows, cols, nnz_in,
-                               d_tidx.ptr, static_cast<double *>(nullptr), t_count, tmp, s);
+        DeviceBuffer<double> d_ss;
+        if (norms_on_device && !csc) {  // rows of X_arg as stored: before the transpose reorders the values
+          d_ss.alloc(static_cast<size_t>(std::max<int64_t>(rows, 1)));
+          hipLaunchKernelGGL(knn_row_sumsq_kernel, dim3(static_cast<unsigned>(ceil_div(rows, 4))), dim3(256), 0, s,
+                             reinterpret_cast<const uint32_t *>(d_indptr.ptr), static_cast<const double *>(d_values.ptr),
+                             rows, d_ss.ptr);
         }
-        pt.mark("create: transpose");
+        const int32_t *xt_idx_src = nullptr;  // column indices of X_arg^T's entries (device)
+        if (!csc) {
+          d_tidx.alloc(static_cast<size_t>(nnz_in));
+          if (weighted) {  // the transposed values straight into the padded value stream of the kernels
+            c->xt_val.alloc(padded);
+            IRS_HIP(hipMemsetAsync(c->xt_val.ptr + nnz_in, 0, (padded - static_cast<size_t>(nnz_in)) * sizeof(double), s));
+            transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(d_values.ptr), rows, cols,
+                                 nnz_in, d_tidx.ptr, c->xt_val.ptr, t_count, tmp, s);
+          } else {
+            c->xt_val.alloc(2);  // (the ONES kernels never read the value stream)
+            transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(nullptr), rows, cols, nnz_in,
+                                 d_tidx.ptr, static_cast<double *>(nullptr), t_count, tmp, s);
+          }
+          xt_idx_src = d_tidx.ptr;
+          pt.mark("create: transpose");
+        } else {
+          // CSC layout: the arrays ARE X_arg^T - nothing to transpose for the kernels' streams; only the
+          // norms of a weighted matrix need X_arg's rows together (their squares are added in row order)
+          t_count.resize(static_cast<size_t>(cols));
+          for (int64_t u = 0; u < cols; u++) t_count[u] = static_cast<int32_t>(indptr[u + 1] - indptr[u]);
+          if (weighted) {
+            c->xt_val.alloc(padded);
+            hipLaunchKernelGGL(knn_pad_copy_kernel, dim3(static_cast<unsigned>(ceil_div(static_cast<int64_t>(padded), 256))),
+                               dim3(256), 0, s, static_cast<const double *>(d_values.ptr), nnz_in,
+                               static_cast<int64_t>(padded), c->xt_val.ptr);
+          } else {
+            c->xt_val.alloc(2);
+          }
+          if (norms_on_device) {
+            DeviceBuffer<double> d_tval;
+            DeviceBuffer<uint32_t> d_rptr;
+            std::vector<int32_t> r_count;
+            d_tval.alloc(static_cast<size_t>(nnz_in));
+            d_tidx.alloc(static_cast<size_t>(nnz_in));
+            transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(d_values.ptr), m_rows, m_cols,
+                                 nnz_in, d_tidx.ptr, d_tval.ptr, r_count, tmp, s);
+            std::vector<uint32_t> rptr(static_cast<size_t>(rows) + 1, 0u);
+            for (int64_t i = 0; i < rows; i++) rptr[i + 1] = rptr[i] + static_cast<uint32_t>(r_count[i]);
+            d_rptr.upload(rptr, s);
+            d_ss.alloc(static_cast<size_t>(std::max<int64_t>(rows, 1)));
+            hipLaunchKernelGGL(knn_row_sumsq_kernel, dim3(static_cast<unsigned>(ceil_div(rows, 4))), dim3(256), 0, s,
+                               static_cast<const uint32_t *>(d_rptr.ptr), static_cast<const double *>(d_tval.ptr), rows,
+                               d_ss.ptr);
+            IRS_HIP(hipGetLastError());
+            IRS_HIP(hipStreamSynchronize(s));  // (rptr and the scratch go out of scope)
+          }
+          xt_idx_src = d_indices.ptr;
+          pt.mark("create: csc streams");
+        }
+        if (norms_on_device) {
+          std::vector<double> ss(static_cast<size_t>(rows), 0.0);
+          IRS_HIP(hipGetLastError());
+          if (rows > 0) IRS_HIP(hipMemcpyAsync(ss.data(), d_ss.ptr, static_cast<size_t>(rows) * sizeof(double),
+                                              hipMemcpyDeviceToHost, s));
+          IRS_HIP(hipStreamSynchronize(s));
+          parallel_ranges(rows, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) norms[i] = finish_norm(ss[i]);
+          }, 16, 20000);
+          pt.mark("create: device norms");
+        }
         const int64_t n_tiles = std::max<int64_t>(1, ceil_div(rows, TILE));
         std::vector<uint32_t> xt_ptr(static_cast<size_t>(cols) + 1, 0u);
         c->xt_row_len.resize(cols);
@@ -1597,11 +1830,11 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         c->xt_tptr.alloc(static_cast<size_t>(cols) * (n_tiles + 1));
         const int64_t n_pairs = cols * (n_tiles + 1);
         hipLaunchKernelGGL(xt_slices_kernel, dim3(static_cast<unsigned>(ceil_div(n_pairs, 256))), dim3(256), 0, s,
-                           static_cast<const uint32_t *>(d_xt_ptr.ptr), static_cast<const int32_t *>(d_tidx.ptr), cols,
+                           static_cast<const uint32_t *>(d_xt_ptr.ptr), xt_idx_src, cols,
                            static_cast<int32_t>(n_tiles), c->xt_tptr.ptr);
         c->xt_idx16.alloc(padded / 2);
         hipLaunchKernelGGL(xt_pack16_kernel, dim3(static_cast<unsigned>(ceil_div(static_cast<int64_t>(padded / 2), 256))),
-                           dim3(256), 0, s, static_cast<const int32_t *>(d_tidx.ptr), nnz_in,
+                           dim3(256), 0, s, xt_idx_src, nnz_in,
                            static_cast<int64_t>(padded / 2), c->xt_idx16.ptr);
         DeviceBuffer<int32_t> d_not_const;
         int32_t not_const = 1;
@@ -1792,6 +2025,109 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
   });
 }
 
+irs_status irs_knn_weight(int32_t weighting, int64_t rows, int64_t cols, const int64_t *indptr,
+                          const int32_t *indices, const double *data, double k1, double b, int32_t smooth,
+                          int32_t device, double *out) {
+  return guard([&] {
+    check_arg(weighting == IRS_WEIGHT_TF_IDF || weighting == IRS_WEIGHT_BM25, "unknown feature weighting.");
+    check_arg(rows >= 0 && cols >= 0 && indptr && indptr[0] == 0, "bad matrix.");
+    for (int64_t i = 0; i < rows; i++) check_arg(indptr[i + 1] >= indptr[i], "malformed indptr.");
+    const int64_t nnz = indptr[rows];
+    if (nnz == 0) return;
+    check_arg(indices && data && out, "bad matrix.");
+    check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31.");
+    PhaseTimer pt;
+    require_device(device);
+    IRS_HIP(hipSetDevice(device));
+    const bool bm25 = weighting == IRS_WEIGHT_BM25;
+    // the uploads (pageable memory: they occupy a host thread) beside the validation and the tables
+    DeviceBuffer<int32_t> d_indptr, d_indices;
+    DeviceBuffer<double> d_values, d_out;
+    std::string upload_error;
+    std::atomic<int> kind(0);  // 0: values not classified yet, 1: all ones, 2: they travel, 3: give up
+    std::thread uploader([&] {
+      try {
+        IRS_HIP(hipSetDevice(device));
+        std::vector<int32_t> ip32(rows + 1);
+        for (int64_t i = 0; i <= rows; i++) ip32[i] = static_cast<int32_t>(indptr[i]);
+        d_indptr.alloc(static_cast<size_t>(rows) + 1);
+        d_indices.alloc(static_cast<size_t>(nnz));
+        d_out.alloc(static_cast<size_t>(nnz));
+        IRS_HIP(hipMemcpy(d_indptr.ptr, ip32.data(), ip32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        IRS_HIP(hipMemcpy(d_indices.ptr, indices, static_cast<size_t>(nnz) * sizeof(int32_t), hipMemcpyHostToDevice));
+        int k = 0;
+        while ((k = kind.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+        if (k == 2) {
+          d_values.alloc(static_cast<size_t>(nnz));
+          IRS_HIP(hipMemcpy(d_values.ptr, data, static_cast<size_t>(nnz) * sizeof(double), hipMemcpyHostToDevice));
+        }
+      } catch (const std::exception &e) {
+        upload_error = e.what();
+      }
+    });
+    struct Joiner {
+      std::thread &t;
+      std::atomic<int> &kind;
+      ~Joiner() {
+        int zero = 0;
+        kind.compare_exchange_strong(zero, 3);
+        if (t.joinable()) t.join();
+      }
+    } upload_join{uploader, kind};
+    std::atomic<int> bad(0), not_ones(0);
+    parallel_ranges(nnz, [&](int64_t lo_q, int64_t hi_q) {
+      int32_t lo = 0, hi = 0;
+      uint64_t diff = 0;
+      const uint64_t *vb = reinterpret_cast<const uint64_t *>(data);
+      for (int64_t q = lo_q; q < hi_q; q++) {
+        lo = std::min(lo, indices[q]);
+        hi = std::max(hi, indices[q]);
+        diff |= vb[q] ^ 0x3ff0000000000000ull;
+      }
+      if (lo < 0 || hi >= cols) bad.store(1);
+      if (diff) not_ones.store(1);
+    });
+    check_arg(bad.load() == 0, "column index out of range.");
+    const bool ones = not_ones.load() == 0;
+    kind.store(ones ? 1 : 2, std::memory_order_release);
+    pt.mark("weight: validate");
+    const WeightTables wt = weight_tables(bm25, rows, cols, indptr, indices, data, ones, k1, b, smooth != 0);
+    pt.mark("weight: tables");
+    uploader.join();
+    if (!upload_error.empty()) throw std::runtime_error(upload_error);
+    hipStream_t s = nullptr;
+    DeviceBuffer<double> d_idf, d_reg;
+    d_idf.upload(wt.idf, s);
+    if (bm25) d_reg.upload(wt.reg, s);
+    const dim3 grid(static_cast<unsigned>(ceil_div(rows, 4)));
+    const double *in_vals = ones ? nullptr : d_values.ptr;
+    if (bm25)
+      hipLaunchKernelGGL(knn_weight_kernel<true>, grid, dim3(256), 0, s, static_cast<const int32_t *>(d_indptr.ptr),
+                         static_cast<const int32_t *>(d_indices.ptr), in_vals, static_cast<const double *>(d_idf.ptr),
+                         static_cast<const double *>(d_reg.ptr), k1 + 1, rows, d_out.ptr, static_cast<int32_t *>(nullptr));
+    else
+      hipLaunchKernelGGL(knn_weight_kernel<false>, grid, dim3(256), 0, s, static_cast<const int32_t *>(d_indptr.ptr),
+                         static_cast<const int32_t *>(d_indices.ptr), in_vals, static_cast<const double *>(d_idf.ptr),
+                         static_cast<const double *>(nullptr), 0.0, rows, d_out.ptr, static_cast<int32_t *>(nullptr));
+    IRS_HIP(hipGetLastError());
+    pt.mark("weight: upload + launch");
+    // the result into the caller's (pageable, usually untouched) array: a few device-to-host copies
+    // side by side - one pageable copy is staged through a single pinned bounce buffer by the runtime
+    const int n_copy = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(4, nnz / (int64_t(1) << 21))));
+    IRS_HIP(hipStreamSynchronize(s));
+    std::atomic<int> copy_failed(0);
+    run_on_threads(n_copy, [&](int k) {
+      const int64_t q0 = nnz * k / n_copy, q1 = nnz * (k + 1) / n_copy;
+      if (hipSetDevice(device) != hipSuccess ||
+          (q1 > q0 && hipMemcpy(out + q0, d_out.ptr + q0, static_cast<size_t>(q1 - q0) * sizeof(double),
+                                hipMemcpyDeviceToHost) != hipSuccess))
+        copy_failed.store(1);
+    });
+    if (copy_failed.load()) throw std::runtime_error("copying the weighted values to the host failed.");
+    pt.mark("weight: result copy");
+  });
+}
+
 irs_status irs_knn_destroy(irs_knn_computer *c) {
   return guard([&] {
     if (c) {
@@ -1847,7 +2183,7 @@ irs_status irs_knn_destroy(irs_knn_computer *c) {
 
 irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            const int64_t *indptr, const int32_t *indices, const double *data,
-                           int64_t top_k, int32_t as_w, int64_t row_begin, int64_t row_end,
+                           int32_t layout, int64_t top_k, int32_t as_w, int64_t row_begin, int64_t row_end,
                            int64_t *nnz_out) {
   return guard([&] {
     check_arg(c && nnz_out, "null argument.");
@@ -1857,6 +2193,42 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
     check_arg(rows >= 0 && cols >= 0 && indptr && indptr[0] == 0, "bad matrix.");
     check_arg(0 <= row_begin && row_begin <= row_end && row_end <= rows, "row range out of bounds.");
     const int64_t n = row_end - row_begin;
+    check_arg(layout == IRS_LAYOUT_CSR || layout == IRS_LAYOUT_CSC, "unknown matrix layout.");
+    // A CSC-layout target (knn.py:79 passes `X_train_all.T`): the arrays are the rows of target^T
+    // [cols, rows]; the call walks the target's ROWS, so its columns are regrouped here on host threads
+    // (a counting sort that keeps a row's entries in ascending column order), into private arrays - the
+    // indices only when every stored value is 1 or the similarity binarises them (the host pass and the
+    // kernels then never read a value).
+    HostCsrD regrouped;
+    bool target_unit = false;
+    if (layout == IRS_LAYOUT_CSC) {
+      check_arg(rows < (int64_t(1) << 31) && cols < (int64_t(1) << 31), "too many rows.");
+      for (int64_t u = 0; u < cols; u++) check_arg(indptr[u + 1] >= indptr[u], "malformed indptr.");
+      const int64_t t_nnz = indptr[cols];
+      check_arg(t_nnz < (int64_t(1) << 31), "nnz must be below 2^31.");
+      check_arg(t_nnz == 0 || (indices && data), "bad matrix.");
+      std::atomic<int> bad_idx(0), not_unit(0);
+      parallel_ranges(t_nnz, [&](int64_t b, int64_t e) {
+        int32_t lo = 0, hi = 0;
+        uint64_t diff = 0;
+        const uint64_t *vb = reinterpret_cast<const uint64_t *>(data);
+        for (int64_t q = b; q < e; q++) {
+          lo = std::min(lo, indices[q]);
+          hi = std::max(hi, indices[q]);
+          diff |= vb[q] ^ 0x3ff0000000000000ull;
+        }
+        if (e > b && (lo < 0 || hi >= rows)) bad_idx.store(1);
+        if (diff) not_unit.store(1);
+      });
+      check_arg(bad_idx.load() == 0, "malformed matrix: column index out of range or indptr not monotone.");
+      const bool sim_binarises = c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
+      target_unit = !as_w && (sim_binarises || not_unit.load() == 0);
+      regrouped = transpose_pattern(cols, rows, indptr, indices, target_unit ? nullptr : data);
+      indptr = regrouped.indptr.data();
+      indices = regrouped.indices.data();
+      data = target_unit ? nullptr : regrouped.data.data();
+      pt.mark("regroup columns");
+    }
     // --- target preparation (host; mirrors the prologues of compute_similarity_imple / compute_W).
     // Only compute_W transforms the values (a private copy); otherwise the caller's arrays are
     // read in place, and only the rows of this call are looked at.
@@ -1893,7 +2265,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       dv = T.data.data();
     }
     pt.mark("compute_W prologue");
-    const bool binarise = c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY;
+    // (binarise: the target's values count as 1 - the similarity says so, or a CSC-layout target was all ones)
+    const bool binarise = c->sim_type == IRS_SIM_JACCARD || c->sim_type == IRS_SIM_TVERSKY || target_unit;
     // The rows of the call are taken in CHUNKS (contiguous row ranges of about equal entry counts): per
     // chunk one host pass on several threads - index check, the per-row statistic of the epilogue, the
     // multiply-add count that orders the launch, whether the values are all ones / free of zeros (which

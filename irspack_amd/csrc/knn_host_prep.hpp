@@ -5,6 +5,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <thread>
 
@@ -129,6 +130,137 @@ static HostCsrD transpose(const HostCsrD &x) {
       }
   });
   return t;
+}
+
+
+// The pattern of X^T (no values) on several host threads: what a CSC-layout target needs when every
+// stored value is 1.  Same scheme as transpose() above; the entries of a column stay in row order.
+// `x_indices` must have been range-checked against x_cols.
+static HostCsrD transpose_pattern(int64_t x_rows, int64_t x_cols, const int64_t *x_indptr,
+                                  const int32_t *x_indices, const double *x_data /* null: pattern only */) {
+  HostCsrD t;
+  t.rows = x_cols;
+  t.cols = x_rows;
+  t.indptr.assign(t.rows + 1, 0);
+  const int64_t nnz = x_indptr[x_rows];
+  t.indices.resize(nnz);
+  if (x_data) t.data.resize(nnz);
+  const int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                            nnz / 1000000 + 1, (int64_t(1) << 25) / std::max<int64_t>(x_cols, 1)})));
+  std::vector<int64_t> row_lo(n_thr + 1, x_rows);
+  row_lo[0] = 0;
+  for (int k = 1; k < n_thr; k++)
+    row_lo[k] = std::lower_bound(x_indptr, x_indptr + x_rows, nnz * k / n_thr) - x_indptr;
+  std::vector<std::vector<int32_t>> cnt(n_thr);
+  run_on_threads(n_thr, [&](int k) {
+    auto &c = cnt[k];
+    c.assign(static_cast<size_t>(t.rows), 0);
+    for (int64_t q = x_indptr[row_lo[k]]; q < x_indptr[row_lo[k + 1]]; q++) c[x_indices[q]]++;
+  });
+  // slot of (column c, thread k) = prefix in that order; the threads' counters become write cursors
+  // relative to the column's first slot (32 bits: a column holds fewer than 2^31 entries)
+  int64_t pos = 0;
+  for (int64_t c = 0; c < t.rows; c++) {
+    t.indptr[c] = pos;
+    int32_t within = 0;
+    for (int k = 0; k < n_thr; k++) {
+      const int32_t here = cnt[k][c];
+      cnt[k][c] = within;
+      within += here;
+    }
+    pos += within;
+  }
+  t.indptr[t.rows] = pos;
+  run_on_threads(n_thr, [&](int k) {
+    auto &cur = cnt[k];
+    for (int64_t r = row_lo[k]; r < row_lo[k + 1]; r++)
+      for (int64_t q = x_indptr[r]; q < x_indptr[r + 1]; q++) {
+        const int32_t c = x_indices[q];
+        const int64_t d = t.indptr[c] + cur[c]++;
+        t.indices[d] = static_cast<int32_t>(r);
+        if (x_data) t.data[d] = x_data[q];
+      }
+  });
+  return t;
+}
+
+// Stored entries per column of a CSR (range-checked indices) on several host threads.
+static std::vector<int64_t> column_counts(int64_t rows, int64_t cols, const int64_t *indptr, const int32_t *indices) {
+  const int64_t nnz = indptr[rows];
+  const int n_thr = static_cast<int>(std::max<int64_t>(
+      1, std::min<int64_t>({16, static_cast<int64_t>(std::thread::hardware_concurrency()),
+                            nnz / 1000000 + 1, (int64_t(1) << 25) / std::max<int64_t>(cols, 1)})));
+  std::vector<std::vector<int32_t>> cnt(n_thr);
+  run_on_threads(n_thr, [&](int k) {
+    cnt[k].assign(static_cast<size_t>(cols), 0);
+    auto &c = cnt[k];
+    for (int64_t q = nnz * k / n_thr; q < nnz * (k + 1) / n_thr; q++) c[indices[q]]++;
+  });
+  std::vector<int64_t> out(static_cast<size_t>(cols), 0);
+  parallel_ranges(cols, [&](int64_t b, int64_t e) {
+    for (int k = 0; k < n_thr; k++)
+      for (int64_t c = b; c < e; c++) out[c] += cnt[k][c];
+  }, 16, 100000);
+  return out;
+}
+
+// The two tables of the feature weightings (util.hpp:159-209), from the matrix AS STORED (rows = documents):
+//   tf-idf : idf[c] = log(N / (df[c] + smooth))                                  (:196-203)
+//   BM25   : idf[c] = log(N / (df[c] + 1) + 1), reg[r] = k1 (1 - b + b dl[r] / avgdl),
+//            dl[r] = the row's values summed in entry order, avgdl = (dl summed in row order) / N   (:168-181)
+// Every operation is a single IEEE double operation in the order the reference's expression has
+// (this file is compiled with -ffp-contract=off); log is libm's.  `ones`: every stored value is 1.
+struct WeightTables {
+  std::vector<double> idf, reg;  // reg: BM25 only
+};
+static WeightTables weight_tables(bool bm25, int64_t rows, int64_t cols, const int64_t *indptr,
+                                  const int32_t *indices, const double *data, bool ones, double k1, double b,
+                                  bool smooth) {
+  WeightTables w;
+  const std::vector<int64_t> df = column_counts(rows, cols, indptr, indices);
+  w.idf.resize(static_cast<size_t>(cols));
+  const double N = static_cast<double>(rows);
+  if (!bm25) {
+    const double sm = smooth ? 1.0 : 0.0;
+    parallel_ranges(cols, [&](int64_t lo, int64_t hi) {
+      for (int64_t c = lo; c < hi; c++) w.idf[c] = std::log(N / (static_cast<double>(df[c]) + sm));
+    }, 16, 20000);
+    return w;
+  }
+  parallel_ranges(cols, [&](int64_t lo, int64_t hi) {
+    for (int64_t c = lo; c < hi; c++) w.idf[c] = std::log(N / (static_cast<double>(df[c]) + 1.0) + 1.0);
+  }, 16, 20000);
+  std::vector<double> dl(static_cast<size_t>(rows), 0.0);
+  parallel_ranges(rows, [&](int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; r++) {
+      double sum = 0.0;
+      if (ones) sum = static_cast<double>(indptr[r + 1] - indptr[r]);  // (a sum of 1.0s is exact)
+      else
+        for (int64_t q = indptr[r]; q < indptr[r + 1]; q++) sum += data[q];
+      dl[r] = sum;
+    }
+  }, 16, 20000);
+  double total = 0.0;
+  for (double v : dl) total += v;
+  const double avgdl = total / N;
+  w.reg.resize(static_cast<size_t>(rows));
+  parallel_ranges(rows, [&](int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; r++) w.reg[r] = k1 * (1 - b + b * dl[r] / avgdl);
+  }, 16, 20000);
+  return w;
+}
+
+// the per-entry pass of the weightings on the host (paths that never reach the device kernel)
+static void weight_values_host(bool bm25, const WeightTables &w, int64_t rows, const int64_t *indptr,
+                               const int32_t *indices, const double *data, double k1, double *out) {
+  const std::vector<int64_t> ip(indptr, indptr + rows + 1);
+  for_rows_parallel(ip, rows, [&](int64_t r) {
+    for (int64_t q = indptr[r]; q < indptr[r + 1]; q++) {
+      const double v = data[q];
+      out[q] = bm25 ? w.idf[indices[q]] * (v * (k1 + 1)) / (v + w.reg[r]) : v * w.idf[indices[q]];
+    }
+  });
 }
 
 }  // namespace knn

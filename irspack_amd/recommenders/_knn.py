@@ -1,8 +1,16 @@
 """Counterpart of the reference's nanobind module ``irspack.recommenders._knn``
 (/root/reference/cpp_source/knn/wrapper.cpp:11-66), backed by ``libirspack_amd.so``
-(irspack_amd/csrc/knn.hip).  Inputs are scipy sparse float64 (CSC is accepted and
-converted, like nanobind's Eigen caster does); results are CSR float64 with sorted
-indices (``compute_similarity``) or CSC (``compute_W``).
+(irspack_amd/csrc/knn.hip).  Inputs are scipy sparse float64, CSR or CSC - a CSC matrix
+(``X.T`` of the recommenders, knn.py:77-79) is handed over as it is with a layout flag, the
+library regroups what it needs itself; results are CSR float64 with sorted indices
+(``compute_similarity``) or CSC (``compute_W``).
+
+Not in the reference: the keyword-only ``weighting=`` of the cosine / asymmetric-cosine computers
+(``("TF_IDF", smooth)`` / ``("BM_25", k1, b)``): the feature weighting of knn.py:67-75 /
+user_knn.py:62-72 applied on the device on the way in - to the matrix as stored, i.e.
+``Computer(X.T, ..., weighting=w)`` is ``Computer(weight(X).T, ...)`` and ``Computer(X, ...,
+weighting=w)`` is ``Computer(weight(X), ...)`` - so that ``learn()`` never builds the weighted
+matrix on the host.
 """
 
 import ctypes as C
@@ -21,17 +29,31 @@ class _Computer:
     _sim_type = _COSINE
 
     def _create(self, X: Any, shrinkage: float, alpha: float, beta: float, normalize: bool,
-                n_threads: int, max_chunk_size: int, device: Optional[int]) -> None:
+                n_threads: int, max_chunk_size: int, device: Optional[int],
+                weighting: Optional[Tuple] = None) -> None:
         if n_threads < 0 or max_chunk_size < 0:
             raise TypeError("n_threads / max_chunk_size must be non-negative (size_t).")
-        Xc, indptr, indices, data = _lib.csr_arrays(X, np.float64)
+        Xc, layout, indptr, indices, data = _lib.sparse_arrays(X, np.float64)
         self._N, self._n_features = int(Xc.shape[0]), int(Xc.shape[1])
         self._device = _lib.default_device() if device is None else int(device)
+        # the stored matrix is the TRANSPOSE of X for a CSC input: the weighting's documents are its rows
+        spec = _lib.KnnInputStruct(layout=layout, weighting=_lib.WEIGHT_NONE, smooth=1, reserved=0, k1=1.2, b=0.75)
+        if weighting is not None:
+            kind = str(weighting[0]).upper()
+            if kind in ("TF_IDF", "TFIDF"):
+                spec.weighting = _lib.WEIGHT_TF_IDF
+                spec.smooth = 1 if (len(weighting) < 2 or weighting[1]) else 0
+            elif kind in ("BM_25", "BM25"):
+                spec.weighting = _lib.WEIGHT_BM25
+                spec.k1 = float(weighting[1]) if len(weighting) > 1 else 1.2
+                spec.b = float(weighting[2]) if len(weighting) > 2 else 0.75
+            elif kind != "NONE":
+                raise ValueError("weighting must be ('TF_IDF', smooth), ('BM_25', k1, b) or None.")
         h = C.c_void_p()
         check(
             lib().irs_knn_create(
                 C.c_int32(self._sim_type), C.c_int64(Xc.shape[0]), C.c_int64(Xc.shape[1]),
-                ptr(indptr, C.c_int64), ptr(indices, C.c_int32), ptr(data, C.c_double),
+                ptr(indptr, C.c_int64), ptr(indices, C.c_int32), ptr(data, C.c_double), C.byref(spec),
                 C.c_double(shrinkage), C.c_double(alpha), C.c_double(beta),
                 C.c_int32(1 if normalize else 0), C.c_int64(n_threads),
                 C.c_int64(max_chunk_size), C.c_int32(self._device), C.byref(h),
@@ -60,12 +82,15 @@ class _Computer:
                  rows: Optional[Tuple[int, int]] = None) -> sps.csr_matrix:
         if top_k < 0:
             raise TypeError("top_k must be non-negative (size_t).")
-        Xc, indptr, indices, data = _lib.csr_arrays(X, np.float64)
+        Xc, layout, indptr, indices, data = _lib.sparse_arrays(X, np.float64)
         rb, re = (0, Xc.shape[0]) if rows is None else rows
         n_tiles = max(1, -(-self._N // 16384))
         per_row = max(1, n_tiles * min(max(int(top_k), 1), self._N))
         batch = max(1, self._MAX_SLOT_ENTRIES // per_row)
         if re - rb > batch:  # rows are independent: stitch the batches
+            if layout == _lib.LAYOUT_CSC:  # (regrouped once here, not once per batch inside the library)
+                Xc = sps.csr_matrix(Xc)
+                Xc.sort_indices()
             parts, ms, macs = [], 0.0, 0
             for b in range(rb, re, batch):
                 parts.append(self._compute(Xc, top_k, as_w, (b, min(b + batch, re))))
@@ -79,7 +104,7 @@ class _Computer:
         check(
             lib().irs_knn_compute(
                 self._h, C.c_int64(Xc.shape[0]), C.c_int64(Xc.shape[1]), ptr(indptr, C.c_int64),
-                ptr(indices, C.c_int32), ptr(data, C.c_double), C.c_int64(top_k),
+                ptr(indices, C.c_int32), ptr(data, C.c_double), C.c_int32(layout), C.c_int64(top_k),
                 C.c_int32(1 if as_w else 0), C.c_int64(rb), C.c_int64(re), C.byref(nnz),
             )
         )
@@ -115,8 +140,9 @@ class CosineSimilarityComputer(_SimilarityComputer):  # wrapper.cpp:12-19, simil
     _sim_type = _COSINE
 
     def __init__(self, X: Any, shrinkage: float, normalize: bool, n_threads: int = 1,
-                 max_chunk_size: int = 128, *, device: Optional[int] = None) -> None:
-        self._create(X, shrinkage, 0.0, 0.0, bool(normalize), n_threads, max_chunk_size, device)
+                 max_chunk_size: int = 128, *, device: Optional[int] = None,
+                 weighting: Optional[Tuple] = None) -> None:
+        self._create(X, shrinkage, 0.0, 0.0, bool(normalize), n_threads, max_chunk_size, device, weighting)
 
 
 class JaccardSimilarityComputer(_SimilarityComputer):  # wrapper.cpp:21-29
@@ -139,8 +165,9 @@ class AsymmetricSimilarityComputer(_SimilarityComputer):  # wrapper.cpp:42-51
     _sim_type = _ASYMMETRIC
 
     def __init__(self, X: Any, shrinkage: float, alpha: float, n_threads: int = 1,
-                 max_chunk_size: int = 128, *, device: Optional[int] = None) -> None:
-        self._create(X, shrinkage, alpha, 0.0, False, n_threads, max_chunk_size, device)
+                 max_chunk_size: int = 128, *, device: Optional[int] = None,
+                 weighting: Optional[Tuple] = None) -> None:
+        self._create(X, shrinkage, alpha, 0.0, False, n_threads, max_chunk_size, device, weighting)
 
 
 class P3alphaComputer(_Computer):  # wrapper.cpp:53-58, similarities.hpp:186-251

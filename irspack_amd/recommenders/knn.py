@@ -12,7 +12,7 @@ import enum
 from typing import Any, Optional
 
 from .._threading import get_n_threads
-from ..utils import okapi_BM_25_weight, remove_diagonal, tf_idf_weight
+from ..utils import remove_diagonal
 from ._knn import (AsymmetricSimilarityComputer, CosineSimilarityComputer,
                    JaccardSimilarityComputer, P3alphaComputer, RP3betaComputer,
                    TverskyIndexComputer)
@@ -37,20 +37,28 @@ class BaseKNNRecommender(BaseSimilarityRecommender):
         self.bm25_b = bm25_b
         self.n_threads = get_n_threads(n_threads)
 
-    def _create_computer(self, X: Any):
+    def _create_computer(self, X: Any, weighting=None):
         raise NotImplementedError("")
 
-    def _learn(self) -> None:
+    def _weighting(self):
+        """knn.py:68-75 as the computer constructors' ``weighting=`` (applied on the device)."""
         if self.feature_weighting == FeatureWeightingScheme.NONE:
-            X_weighted = self.X_train_all
-        elif self.feature_weighting == FeatureWeightingScheme.TF_IDF:
-            X_weighted = tf_idf_weight(self.X_train_all)
-        elif self.feature_weighting == FeatureWeightingScheme.BM_25:
-            X_weighted = okapi_BM_25_weight(self.X_train_all, self.bm25_k1, self.bm25_b)
-        else:
-            raise RuntimeError("Unknown weighting scheme.")
-        computer = self._create_computer(X_weighted.T)
-        self._W = remove_diagonal(computer.compute_similarity(self.X_train_all.T, self.top_k)).tocsc()
+            return None
+        if self.feature_weighting == FeatureWeightingScheme.TF_IDF:
+            return ("TF_IDF", True)
+        if self.feature_weighting == FeatureWeightingScheme.BM_25:
+            return ("BM_25", self.bm25_k1, self.bm25_b)
+        raise RuntimeError("Unknown weighting scheme.")
+
+    def _learn(self) -> None:
+        # knn.py:67-80 - weighting -> computer on X_weighted.T -> compute_similarity(X.T) -> remove_diagonal
+        # -> CSC - with the first two steps as one device construction: X.T is a CSC view of the training
+        # matrix's own arrays (no host transpose), the weighting happens on the way in
+        Xt = self.X_train_all.T
+        if self.X_train_all.has_sorted_indices:  # (scipy's transposed view does not inherit the flag: a 20 M-entry rescan)
+            Xt.has_sorted_indices = True
+        computer = self._create_computer(Xt, self._weighting())
+        self._W = remove_diagonal(computer.compute_similarity(Xt, self.top_k)).tocsc()
 
 
 class CosineKNNRecommender(BaseKNNRecommender):  # knn.py:94-161
@@ -60,8 +68,8 @@ class CosineKNNRecommender(BaseKNNRecommender):  # knn.py:94-161
         super().__init__(X_train_all, shrinkage, top_k, n_threads, feature_weighting, bm25_k1, bm25_b)
         self.normalize = normalize
 
-    def _create_computer(self, X: Any) -> CosineSimilarityComputer:
-        return CosineSimilarityComputer(X, self.shrinkage, self.normalize, self.n_threads)
+    def _create_computer(self, X: Any, weighting=None) -> CosineSimilarityComputer:
+        return CosineSimilarityComputer(X, self.shrinkage, self.normalize, self.n_threads, weighting=weighting)
 
 
 class AsymmetricCosineKNNRecommender(BaseKNNRecommender):  # knn.py:168-235
@@ -71,8 +79,8 @@ class AsymmetricCosineKNNRecommender(BaseKNNRecommender):  # knn.py:168-235
         super().__init__(X_train_all, shrinkage, top_k, n_threads, feature_weighting, bm25_k1, bm25_b)
         self.alpha = alpha
 
-    def _create_computer(self, X: Any) -> AsymmetricSimilarityComputer:
-        return AsymmetricSimilarityComputer(X, self.shrinkage, self.alpha, self.n_threads)
+    def _create_computer(self, X: Any, weighting=None) -> AsymmetricSimilarityComputer:
+        return AsymmetricSimilarityComputer(X, self.shrinkage, self.alpha, self.n_threads, weighting=weighting)
 
 
 class JaccardKNNRecommender(BaseKNNRecommender):  # knn.py:238-270
@@ -80,8 +88,8 @@ class JaccardKNNRecommender(BaseKNNRecommender):  # knn.py:238-270
                  n_threads: Optional[int] = None) -> None:
         super().__init__(X_train_all, shrinkage, top_k, n_threads)
 
-    def _create_computer(self, X: Any) -> JaccardSimilarityComputer:
-        return JaccardSimilarityComputer(X, self.shrinkage, self.n_threads)
+    def _create_computer(self, X: Any, weighting=None) -> JaccardSimilarityComputer:
+        return JaccardSimilarityComputer(X, self.shrinkage, self.n_threads)  # (binarises: nothing to weight)
 
 
 class TverskyIndexKNNRecommender(BaseKNNRecommender):  # knn.py:273-326
@@ -91,7 +99,7 @@ class TverskyIndexKNNRecommender(BaseKNNRecommender):  # knn.py:273-326
         self.alpha = alpha
         self.beta = beta
 
-    def _create_computer(self, X: Any) -> TverskyIndexComputer:
+    def _create_computer(self, X: Any, weighting=None) -> TverskyIndexComputer:
         return TverskyIndexComputer(X, self.shrinkage, self.alpha, self.beta, self.n_threads)
 
 

@@ -11,7 +11,7 @@ computer built on ``X_weighted`` (users are the rows: no transpose, unlike item-
 from typing import Any, Optional
 
 from .._threading import get_n_threads
-from ..utils import okapi_BM_25_weight, remove_diagonal, tf_idf_weight
+from ..utils import remove_diagonal
 from ._knn import AsymmetricSimilarityComputer, CosineSimilarityComputer
 from .base import BaseUserSimilarityRecommender
 from .knn import FeatureWeightingScheme
@@ -29,21 +29,22 @@ class BaseUserKNNRecommender(BaseUserSimilarityRecommender):
         self.bm25_b = bm25_b
         self.n_threads = get_n_threads(n_threads)
 
-    def _create_computer(self, X: Any):
+    def _create_computer(self, X: Any, weighting=None):
         raise NotImplementedError("")
 
-    def _weighted(self) -> Any:
+    def _weighting(self):
+        """user_knn.py:62-72 as the computer constructors' ``weighting=`` (applied on the device)."""
         scheme = self.feature_weighting
         if scheme == FeatureWeightingScheme.NONE:
-            return self.X_train_all
+            return None
         if scheme == FeatureWeightingScheme.TF_IDF:
-            return tf_idf_weight(self.X_train_all)
+            return ("TF_IDF", True)
         if scheme == FeatureWeightingScheme.BM_25:
-            return okapi_BM_25_weight(self.X_train_all, self.bm25_k1, self.bm25_b)
+            return ("BM_25", self.bm25_k1, self.bm25_b)
         raise RuntimeError("Unknown weighting scheme.")
 
     def _learn(self) -> None:
-        computer = self._create_computer(self._weighted())
+        computer = self._create_computer(self.X_train_all, self._weighting())
         self.U_ = remove_diagonal(computer.compute_similarity(self.X_train_all, self.top_k))
 
 
@@ -54,8 +55,8 @@ class CosineUserKNNRecommender(BaseUserKNNRecommender):  # user_knn.py:81-148 (n
         super().__init__(X_train_all, shrinkage, top_k, n_threads, feature_weighting, bm25_k1, bm25_b)
         self.normalize = normalize
 
-    def _create_computer(self, X: Any) -> CosineSimilarityComputer:
-        return CosineSimilarityComputer(X, self.shrinkage, self.normalize, self.n_threads)
+    def _create_computer(self, X: Any, weighting=None) -> CosineSimilarityComputer:
+        return CosineSimilarityComputer(X, self.shrinkage, self.normalize, self.n_threads, weighting=weighting)
 
 
 class AsymmetricCosineUserKNNRecommender(BaseUserKNNRecommender):  # user_knn.py:155-218
@@ -65,5 +66,5 @@ class AsymmetricCosineUserKNNRecommender(BaseUserKNNRecommender):  # user_knn.py
         super().__init__(X_train_all, shrinkage, top_k, n_threads, feature_weighting, bm25_k1, bm25_b)
         self.alpha = alpha
 
-    def _create_computer(self, X: Any) -> AsymmetricSimilarityComputer:
-        return AsymmetricSimilarityComputer(X, self.shrinkage, self.alpha, self.n_threads)
+    def _create_computer(self, X: Any, weighting=None) -> AsymmetricSimilarityComputer:
+        return AsymmetricSimilarityComputer(X, self.shrinkage, self.alpha, self.n_threads, weighting=weighting)

@@ -1,10 +1,10 @@
 """The pieces of the reference's ``irspack.utils._util_cpp`` that the kNN path calls
 (/root/reference/cpp_source/util.hpp:158-226, util.cpp:14,29-32).
 
-``remove_diagonal`` and the serving top-k ``retrieve_recommend_from_score`` go through the
-C ABI; the two pre-weighting helpers are plain element-wise host transforms (float64 like
-the reference) written with numpy — they are data preparation, not part of the
-accelerated product.
+Everything goes through the C ABI: ``remove_diagonal``, the serving top-k
+``retrieve_recommend_from_score`` and the two feature weightings (``irs_knn_weight``; the kNN
+recommenders do not call them - they hand the weighting to the computer's constructor, which
+applies it on the device without a host copy of the weighted matrix).
 """
 
 from typing import List, Optional, Sequence, Tuple
@@ -35,33 +35,30 @@ def remove_diagonal(X) -> sps.csr_matrix:
     return out
 
 
-def tf_idf_weight(X, smooth: bool = True) -> sps.csr_matrix:
-    """util.hpp:190-209."""
-    Xc = sps.csr_matrix(X, dtype=np.float64)
-    Xc.sort_indices()
-    N = Xc.shape[0]
-    df = np.bincount(Xc.indices, minlength=Xc.shape[1]).astype(np.float64)
-    with np.errstate(divide="ignore"):
-        idf = np.log(N / (df + float(bool(smooth))))
-    out = Xc.copy()
-    out.data = out.data * idf[out.indices]
-    return out
+def _weight(X, scheme: int, k1: float, b: float, smooth: bool, device: Optional[int]) -> sps.csr_matrix:
+    """X's pattern with the weighted values: column counts, row sums and the idf table on host threads,
+    the per-entry pass on the device (``irs_knn_weight``; the values are the host loop's bit for bit)."""
+    Xc, indptr, indices, data = _lib.csr_arrays(X, np.float64)
+    out = np.empty(data.shape[0], dtype=np.float64)
+    if data.shape[0]:
+        check(lib().irs_knn_weight(
+            C.c_int32(scheme), C.c_int64(Xc.shape[0]), C.c_int64(Xc.shape[1]), ptr(indptr, C.c_int64),
+            ptr(indices, C.c_int32), ptr(data, C.c_double), C.c_double(k1), C.c_double(b),
+            C.c_int32(1 if smooth else 0), C.c_int32(_lib.default_device() if device is None else device),
+            ptr(out, C.c_double)))
+    res = sps.csr_matrix((out, Xc.indices.copy(), Xc.indptr.copy()), shape=Xc.shape)
+    res.has_sorted_indices = True
+    return res
 
 
-def okapi_BM_25_weight(X, k1: float = 1.2, b: float = 0.75) -> sps.csr_matrix:
-    """util.hpp:158-188."""
-    Xc = sps.csr_matrix(X, dtype=np.float64)
-    Xc.sort_indices()
-    N = Xc.shape[0]
-    df = np.bincount(Xc.indices, minlength=Xc.shape[1]).astype(np.float64)
-    doc_length = np.asarray(Xc.sum(axis=1)).ravel()
-    avgdl = doc_length.sum() / N
-    idf = np.log(N / (df + 1.0) + 1.0)
-    rows = np.repeat(np.arange(N), np.diff(Xc.indptr))
-    regularizer = k1 * (1 - b + b * doc_length[rows] / avgdl)
-    out = Xc.copy()
-    out.data = idf[out.indices] * (out.data * (k1 + 1)) / (out.data + regularizer)
-    return out
+def tf_idf_weight(X, smooth: bool = True, *, device: Optional[int] = None) -> sps.csr_matrix:
+    """util.hpp:190-209 (bound at util.cpp:29-32): ``x * log(N / (df + smooth))``."""
+    return _weight(X, _lib.WEIGHT_TF_IDF, 0.0, 0.0, bool(smooth), device)
+
+
+def okapi_BM_25_weight(X, k1: float = 1.2, b: float = 0.75, *, device: Optional[int] = None) -> sps.csr_matrix:
+    """util.hpp:158-188: ``idf * x (k1 + 1) / (x + k1 (1 - b + b dl / avgdl))``."""
+    return _weight(X, _lib.WEIGHT_BM25, float(k1), float(b), True, device)
 
 
 def _retrieve(score: np.ndarray, allowed_item_indices: Sequence[Sequence[int]], cutoff: int,

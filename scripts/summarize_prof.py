@@ -163,19 +163,35 @@ def main():
     kf = newest(os.path.join(SRC, "sec_fetch", "*", "*_counter_collection.csv"))
     kw = newest(os.path.join(SRC, "sec_write", "*", "*_counter_collection.csv"))
     if kf and kw:
+        # PER CALL: a compute_similarity call launches the tile kernel once per row chunk (three on the ML-20M
+        # shape); the profiled script makes KNN_CALLS full-matrix calls and nothing else that launches it
+        KNN_CALLS = 2  # scripts/quick_knn_eval.py: `for rep in range(2)`
+
         def knn_sum(path, counter):
-            best = collections.defaultdict(list)
+            per = collections.defaultdict(float)
             for r in csv.DictReader(open(path)):
                 if "knn_tile_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                    best[r["Dispatch_Id"]].append(float(r["Counter_Value"]))
-            per = sorted(sum(v) for v in best.values())
-            return per[-1] if per else 0.0  # the heaviest launch = a full-matrix call
-        fb, wb = knn_sum(kf[0], "FETCH_SIZE") * 1024 * 2, knn_sum(kw[0], "WRITE_SIZE") * 1024
+                    per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+            return sum(per.values()) / KNN_CALLS, len(per) / KNN_CALLS
+        (fk, launches), (wk, _) = knn_sum(kf[0], "FETCH_SIZE"), knn_sum(kw[0], "WRITE_SIZE")
+        fb, wb = fk * 1024 * 2, wk * 1024
         if fb > 0:
             traffic["knn_tile_kernel"] = fb + wb
             json.dump({"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
-                       "units": "FETCH_SIZE x 2 KiB (gfx950 correction), WRITE_SIZE x 1 KiB; heaviest launch"},
+                       "tile_kernel_launches_per_call": launches,
+                       "units": "FETCH_SIZE x 2 KiB (gfx950 correction), WRITE_SIZE x 1 KiB; summed over the "
+                                "launches of ONE compute_similarity call (all launches of the pass / calls made)"},
                       open(os.path.join(DST, f"{TAG}_knn_pmc_hbm.json"), "w"), indent=1)
+    # provenance: bench.py prints these figures only while the kernels' sources are the ones the passes ran
+    sys.path.insert(0, ROOT)
+    from bench import kernel_source_sha16  # noqa: E402
+
+    import subprocess
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    traffic["_provenance"] = {
+        "collected_at_git_head": head, "tag": TAG, "sources_sha16": kernel_source_sha16(),
+        "units": "HBM bytes (FETCH_SIZE x 2 KiB + WRITE_SIZE x 1 KiB): per LAUNCH for ials_*, per "
+                 "compute_similarity CALL for knn_tile_kernel"}
     json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 

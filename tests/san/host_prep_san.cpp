@@ -157,6 +157,47 @@ int main() {
       CHECK(norms[r] == s);
     }
   }
+  // ---- kNN, round 6: CSC-layout inputs (pattern-only and valued regrouping), column counts, the feature
+  // weightings' tables and their per-entry pass - against sequential restatements of util.hpp:159-209
+  {
+    std::vector<double> dd(data.begin(), data.end());
+    const knn::HostCsrD P = knn::transpose_pattern(rows, cols, indptr.data(), indices.data(), nullptr);
+    CHECK(P.indptr == Xt.indptr && P.data.empty());
+    CHECK(std::equal(P.indices.begin(), P.indices.end(), Xt.indices.begin()));
+    const knn::HostCsrD V = knn::transpose_pattern(rows, cols, indptr.data(), indices.data(), dd.data());
+    CHECK(std::equal(V.indices.begin(), V.indices.end(), Xt.indices.begin()));
+    for (int64_t p = 0; p < nnz; p++) CHECK(V.data[p] == static_cast<double>(Xt.data[p]));
+    const std::vector<int64_t> cnt = knn::column_counts(rows, cols, indptr.data(), indices.data());
+    for (int64_t c = 0; c < cols; c++) CHECK(cnt[c] == Xt.indptr[c + 1] - Xt.indptr[c]);
+    const double k1 = 1.3, b = 0.6;
+    for (const bool bm25 : {false, true}) {
+      const knn::WeightTables wt = knn::weight_tables(bm25, rows, cols, indptr.data(), indices.data(), dd.data(),
+                                                      false, k1, b, true);
+      std::vector<double> got(nnz), idf(cols, 0.0), dl(rows, 0.0);
+      knn::weight_values_host(bm25, wt, rows, indptr.data(), indices.data(), dd.data(), k1, got.data());
+      for (int64_t r = 0; r < rows; r++)
+        for (int64_t p = indptr[r]; p < indptr[r + 1]; p++) {
+          idf[indices[p]] += 1;
+          dl[r] += dd[p];
+        }
+      double total = 0;
+      for (double v : dl) total += v;
+      const double avgdl = total / rows;
+      for (auto &v : idf) v = bm25 ? std::log(rows / (v + 1.0) + 1.0) : std::log(rows / (v + 1.0));
+      for (int64_t r = 0; r < rows; r += 7) {
+        const double reg = k1 * (1 - b + b * dl[r] / avgdl);
+        for (int64_t p = indptr[r]; p < indptr[r + 1]; p++) {
+          const double want = bm25 ? idf[indices[p]] * (dd[p] * (k1 + 1)) / (dd[p] + reg) : dd[p] * idf[indices[p]];
+          CHECK(got[p] == want);
+        }
+      }
+    }
+    // all-ones input: the row sums are the entry counts
+    const std::vector<double> ones(nnz, 1.0);
+    const knn::WeightTables a = knn::weight_tables(true, rows, cols, indptr.data(), indices.data(), ones.data(), true, k1, b, true);
+    const knn::WeightTables c = knn::weight_tables(true, rows, cols, indptr.data(), indices.data(), ones.data(), false, k1, b, true);
+    CHECK(a.idf == c.idf && a.reg == c.reg);
+  }
   std::puts("host_prep_san ok");
   return 0;
 }

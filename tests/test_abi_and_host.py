@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     missing = sorted(s for s in declared if not hasattr(lib, s))
     assert not missing, missing
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.irs_abi_version() == 3  # IRS_ABI_VERSION: irs_ceilings grew in round 3, irs_eval_stats in round 5
+    assert lib.irs_abi_version() == 4  # IRS_ABI_VERSION: irs_ceilings grew in round 3, irs_eval_stats in round 5, irs_knn_input + layout in round 6
 
 
 def test_library_exports_nothing_but_the_declared_symbols():

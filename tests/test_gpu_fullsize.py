@@ -380,11 +380,11 @@ def test_ials_k320_ml20m_general_size_kernels_vs_oracle(X20, X20t, kind):
         assert np.isfinite(got).all()
         # (the oracle at K = 320 needs a minute for every row of the user side: every row above
         # 1024 entries, the 64 longest below that and 20,000 random rows of each side)
-        rows, _ = row_sample(Xs, 20_000, seed=60 + side, max_split=None if ALL_ROWS else 256)
+        rows, _ = row_sample(Xs, 20_000 if ALL_ROWS else 4_000, seed=60 + side, max_split=None if ALL_ROWS else 256)
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
         assert_rows_match(kind, got[rows], want, Xs, rows, tgt0, oth0,
                           f"ml20m K=320 (general-size kernels) {kind} {'user' if side == 0 else 'item'} half, "
-                          f"{len(rows)} rows (all above 1024 entries + 64 longest + 20k random)",
+                          f"{len(rows)} rows (rows above 1024 entries + 64 longest unsplit + random ones)",
                           test="test_ials_k320_ml20m_general_size_kernels_vs_oracle")
 
 
@@ -510,11 +510,9 @@ def test_ialspp_ml20m_vs_oracle(X20, X20t, K, direct, monkeypatch):
         got = t.user if side == 0 else t.item
         assert np.isfinite(got).all()
         if K > 256:  # (the oracle's K = 320 sweep over every row takes a minute: a row sample)
-            rows, _ = row_sample(Xs, 20_000, seed=70 + side, max_split=None if ALL_ROWS else 256)
-        elif K > 64:
-            rows, _ = rows_to_check(Xs, seed=70 + side)
+            rows, _ = row_sample(Xs, 20_000 if ALL_ROWS else 4_000, seed=70 + side, max_split=None if ALL_ROWS else 256)
         else:
-            rows = np.arange(Xs.shape[0])
+            rows, _ = rows_to_check(Xs, seed=70 + side)
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
         got = got[rows]
         # EVERY row against the float64 evaluation of the same sweep (the oracle's sources with Real =

@@ -249,10 +249,33 @@ def test_non_monotone_indptr_through_the_c_abi_is_an_error_not_a_wild_read():
 
 
 def test_weighting_helpers_match_oracle():
-    for X in (X_small, X_many_dense):
-        for mine, ref in ((tf_idf_weight(X), O.tf_idf_weight(X)),
-                          (okapi_BM_25_weight(X, 1.3, 0.6), O.okapi_BM_25_weight(X, 1.3, 0.6))):
-            np.testing.assert_allclose(mine.toarray(), ref.toarray(), rtol=1e-13)
+    """irs_knn_weight (tables on host threads with libm's log, per-entry pass on the device: one IEEE
+    operation per operation of util.hpp:183-184, :206, no contraction) against the oracle's sequential
+    loops: BIT FOR BIT, values and pattern - binary and real-valued matrices, empty rows and columns,
+    smooth on and off, a matrix large enough for several host threads and device blocks."""
+    big = power_law_items(3000, 1200, 400000, 3)
+    big_w = big.copy()
+    big_w.data = np.random.RandomState(5).uniform(0.0, 4.0, big_w.nnz)
+    holes = sps.csr_matrix(X_many).tolil()
+    for r in (0, 5, 887):
+        holes.rows[r], holes.data[r] = [], []
+    holes = sps.csr_matrix(holes)
+    for X in (X_small, X_many, X_many_dense, holes, big, big_w):
+        pairs = [(tf_idf_weight(X), O.tf_idf_weight(X)), (tf_idf_weight(X, False), O.tf_idf_weight(X, False)),
+                 (okapi_BM_25_weight(X, 1.3, 0.6), O.okapi_BM_25_weight(X, 1.3, 0.6)),
+                 (okapi_BM_25_weight(X), O.okapi_BM_25_weight(X))]
+        for mine, ref in pairs:
+            mine, ref = sps.csr_matrix(mine), sps.csr_matrix(ref)
+            ref.sort_indices()
+            np.testing.assert_array_equal(mine.indptr, ref.indptr)
+            np.testing.assert_array_equal(mine.indices, ref.indices)
+            np.testing.assert_array_equal(mine.data, ref.data)  # (inf where smooth=False meets df = N... never stored)
+    with pytest.raises(ValueError, match="column index out of range"):
+        bad = sps.csr_matrix(X_many)
+        bad = sps.csr_matrix((bad.data, bad.indices.copy(), bad.indptr), shape=bad.shape)
+        bad.indices[7] = 512
+        bad.has_sorted_indices = True
+        tf_idf_weight(bad)
 
 
 def test_two_column_tiles():
@@ -601,3 +624,103 @@ def test_row_constant_values_skip_the_value_stream(kind, kw, shape, monkeypatch)
             ga = np.sort(a.data[a.indptr[r]:a.indptr[r + 1]])
             wa = np.sort(want.data[want.indptr[r]:want.indptr[r + 1]])
             np.testing.assert_allclose(ga, wa, rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------- CSC inputs and fused weighting (round 6)
+def _weighted_copy(X, seed):
+    W = X.copy()
+    W.data = np.random.RandomState(seed).uniform(0.5, 2.0, W.nnz)
+    W.data[::5] = 1.0
+    return W
+
+
+@pytest.mark.parametrize("kind,kw", CASES)
+@pytest.mark.parametrize("shape", ["one_tile", "two_tiles"])
+def test_csc_layout_is_the_csr_layout(kind, kw, shape, monkeypatch):
+    """The reference's recommenders pass ``X.T`` - a CSC matrix - to the computers (knn.py:77-79).  The
+    library takes the CSC arrays as they are (IRS_LAYOUT_CSC): for the constructor they ARE X_arg^T (no
+    transpose at all; the norms of a weighted matrix from a device regrouping, their squares added in row
+    order), for ``compute_similarity`` the target's columns are regrouped on host threads.  Same result
+    BIT FOR BIT as the CSR input of the same matrix: binary and weighted values, every similarity, empty
+    rows / columns, one and two column tiles, a row range, and the host construction
+    (IRSPACK_AMD_KNN_DEVICE_CREATE=0)."""
+    if shape == "one_tile":
+        Xt = sps.csr_matrix(X_many.T).tolil()
+        for r in (0, 200, 511):
+            Xt.rows[r], Xt.data[r] = [], []
+        Xt = sps.csr_matrix(Xt)
+    else:
+        Xt = power_law_items(900, 17000, 120000, 7)
+    for M in (Xt, _weighted_copy(Xt, 3)):
+        M_csc = sps.csc_matrix(M)
+        M_csc.sort_indices()
+        g_csr, o = make(kind, M, **dict(kw))
+        g_csc, _ = make(kind, M_csc, **dict(kw))
+        want = g_csr.compute_similarity(M, 30)
+        assert_same_csr(want, o.compute_similarity(M, 30), rtol=1e-12)
+        assert_same_csr(g_csc.compute_similarity(M, 30), want, rtol=0)       # CSC constructor, CSR target
+        assert_same_csr(g_csr.compute_similarity(M_csc, 30), want, rtol=0)   # CSR constructor, CSC target
+        assert_same_csr(g_csc.compute_similarity(M_csc, 30), want, rtol=0)
+        part = g_csc.compute_similarity(M_csc, 30, rows=(100, 300))
+        assert_same_csr(part, want[100:300], rtol=0)
+        monkeypatch.setenv("IRSPACK_AMD_KNN_DEVICE_CREATE", "0")
+        g_host, _ = make(kind, M_csc, **dict(kw))
+        monkeypatch.delenv("IRSPACK_AMD_KNN_DEVICE_CREATE")
+        assert_same_csr(g_host.compute_similarity(M_csc, 30), want, rtol=0)
+
+
+@pytest.mark.parametrize("kind,alpha,beta", [("p3alpha", 0.5, 0.0), ("rp3beta", 0.7, 0.4)])
+def test_csc_layout_compute_w(kind, alpha, beta):
+    """P3alpha / RP3beta recommenders pass ``X.T`` (CSC) to the constructor and to compute_W
+    (p3.py:61-68, rp3.py:68-76): regrouped on host threads with their values."""
+    Xt = sps.csr_matrix(X_many.T).copy()
+    Xt.data = np.random.RandomState(4).uniform(0.5, 3.0, Xt.nnz)
+    Xc = sps.csc_matrix(Xt)
+    Xc.sort_indices()
+    mk = (lambda M: K.P3alphaComputer(M, alpha)) if kind == "p3alpha" else (lambda M: K.RP3betaComputer(M, alpha, beta))
+    want = sps.csr_matrix(mk(Xt).compute_W(Xt, 40))
+    for ctor_in, target in ((Xc, Xt), (Xt, Xc), (Xc, Xc)):
+        assert_same_csr(sps.csr_matrix(mk(ctor_in).compute_W(target, 40)), want, rtol=0)
+
+
+@pytest.mark.parametrize("kind,kw", [c for c in CASES if c[0] in ("cosine", "asymmetric")])
+@pytest.mark.parametrize("scheme", [("TF_IDF", True), ("TF_IDF", False), ("BM_25", 1.2, 0.75), ("BM_25", 0.7, 0.3)])
+@pytest.mark.parametrize("values", ["binary", "real"])
+def test_fused_weighting_is_the_host_weighting(kind, kw, scheme, values):
+    """``Computer(X.T, weighting=w)`` (item-kNN: knn.py:67-77) and ``Computer(X, weighting=w)`` (user-kNN:
+    user_knn.py:62-74) weight the stored matrix on the device while it is uploaded; the similarities are
+    those of a computer built on the oracle's weighted matrix BIT FOR BIT (same weights - one IEEE
+    operation each -, norms added in the same order), and match the oracle's computer to 1e-12."""
+    X = power_law_items(700, 2500, 60000, 21).T.tocsr()  # [users, items]
+    X.sort_indices()
+    if values == "real":
+        X = X.copy()
+        X.data = np.random.RandomState(8).uniform(0.2, 5.0, X.nnz)
+    Xw = O.tf_idf_weight(X, scheme[1]) if scheme[0] == "TF_IDF" else O.okapi_BM_25_weight(X, scheme[1], scheme[2])
+    Xw.sort_indices()
+    # item-kNN orientation: the computer sees X_w.T, the target is the unweighted X.T
+    plain, o = make(kind, sps.csr_matrix(Xw.T), **dict(kw))
+    want = plain.compute_similarity(sps.csr_matrix(X.T), 25)
+    assert_same_csr(want, o.compute_similarity(sps.csr_matrix(X.T), 25), rtol=1e-12)
+    if kind == "cosine":
+        fused = K.CosineSimilarityComputer(X.T, kw["shrinkage"], kw["normalize"], weighting=scheme)
+    else:
+        fused = K.AsymmetricSimilarityComputer(X.T, kw["shrinkage"], kw["alpha"], weighting=scheme)
+    assert_same_csr(fused.compute_similarity(X.T, 25), want, rtol=0)
+    # user-kNN orientation: the computer sees X_w, the target is X (CSR layout, weighting over its own rows)
+    plain_u, _ = make(kind, Xw, **dict(kw))
+    want_u = plain_u.compute_similarity(X, 25)
+    if kind == "cosine":
+        fused_u = K.CosineSimilarityComputer(X, kw["shrinkage"], kw["normalize"], weighting=scheme)
+    else:
+        fused_u = K.AsymmetricSimilarityComputer(X, kw["shrinkage"], kw["alpha"], weighting=scheme)
+    assert_same_csr(fused_u.compute_similarity(X, 25), want_u, rtol=0)
+
+
+def test_fused_weighting_argument_errors():
+    X = sps.csr_matrix(X_many)
+    with pytest.raises(ValueError, match="weighting"):
+        K.CosineSimilarityComputer(X.T, 0.0, True, weighting=("LOG",))
+    # Jaccard / Tversky binarise their input: they take no weighting argument at all
+    with pytest.raises(TypeError):
+        K.JaccardSimilarityComputer(X.T, 0.0, weighting=("TF_IDF", True))
