@@ -321,6 +321,14 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
                            int64_t row_begin, int64_t row_end, int64_t *nnz_out);
 irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
                          double *data);
+/* The last result once more, as the compressed COLUMNS of the [rows of the call, N] matrix (col_ptr
+ * int64[N + 1], row numbers relative to the call's first row, ascending in every column) - what
+ * `remove_diagonal(result).tocsc()` of irspack/recommenders/knn.py:78-80 builds on the host (util.hpp:211-226
+ * + scipy's conversion, ~50 ms for the ML-20M result), regrouped on the device instead.
+ * zero_diagonal_row0 >= 0: the stored entries whose column equals zero_diagonal_row0 + their row are set to
+ * 0.0 and KEPT (remove_diagonal; pass the call's row_begin, 0 for a whole matrix); < 0: values unchanged. */
+irs_status irs_knn_fetch_csc(irs_knn_computer *c, int64_t zero_diagonal_row0, int64_t *col_ptr,
+                             int32_t *row_idx, double *data);
 /* Measurement only: multiply-adds of the last call that were added one by one, and the rows of the
  * dense block of the popular items - an opt-in of rounds 4 - 5 that was removed: every multiply-add is
  * added one by one and dense_rows is 0 (kept for ABI 3). */

@@ -137,6 +137,7 @@ EXPORTED_SYMBOLS = [
     "irs_knn_destroy",
     "irs_knn_compute",
     "irs_knn_fetch",
+    "irs_knn_fetch_csc",
     "irs_knn_last_stats",
     "irs_knn_last_walked",
     "irs_remove_diagonal",

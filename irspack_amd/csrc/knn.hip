@@ -54,6 +54,10 @@ struct Params {
   // (four fifths of the bytes of a weighted walk).
   const double *xt_rowval;
   const double *norms;  // per column j
+  // Not null: the sums of column j are multiplied by col_scale[j] (one rounding) before the similarity's
+  // epilogue - the column factor of a SEPARABLE weighting w[u][j] = rowval[u] * col_scale[j] (tf-idf / BM25 of
+  // binary interactions, fused at construction: DESIGN 3.4).  Exact kernels only (never FAST).
+  const double *col_scale;
   // target rows
   const int64_t *t_ptr;
   const int32_t *t_idx;
@@ -810,6 +814,11 @@ __global__ __launch_bounds__(THREADS, 1) void knn_tile_kernel(Params p) {
         if (i < width && st) have |= 1u << (h + k);
       }
     }
+    if (!FAST && p.col_scale != nullptr) {  // (block-uniform)
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        raw[k] = __dmul_rn(raw[k], p.col_scale[c0 + min(cbase + 64 * (h + k), width - 1)]);
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const double sv = epilogue(p, raw[k], nrm[k], tstat);
@@ -1350,6 +1359,25 @@ __global__ __launch_bounds__(256) void knn_pad_copy_kernel(const double *__restr
   if (q < padded) dst[q] = q < nnz ? src[q] : 0.0;
 }
 
+
+// remove_diagonal (util.hpp:211-226) on the TRANSPOSED result: column c's entries hold ascending row numbers;
+// the one whose row is c - row0 (if stored) is set to 0.0 and kept.  One thread per column.
+__global__ __launch_bounds__(256) void knn_zero_diagonal_csc_kernel(const int32_t *__restrict__ col_ptr,
+                                                                    const int32_t *__restrict__ row_idx,
+                                                                    int64_t n_cols, int64_t row0,
+                                                                    double *__restrict__ val) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= n_cols) return;
+  const int64_t want = c - row0;
+  int32_t lo = col_ptr[c], hi = col_ptr[c + 1];
+  while (lo < hi) {
+    const int32_t mid = lo + ((hi - lo) >> 1);
+    if (row_idx[mid] < want) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lo < col_ptr[c + 1] && row_idx[lo] == want) val[lo] = 0.0;
+}
+
 static void check_lower(double x, double low, const char *name) {  // argcheck.hpp:13-20
   if (x < low) {
     std::string msg = std::string(name) + " must be greater than or equal to  " + std::to_string(low);
@@ -1376,6 +1404,8 @@ struct irs_knn_computer {
   DeviceBuffer<double> xt_rowval;  // see Params (allocated only when every feature row is constant)
   bool xt_row_const = false;
   bool xt_all_ones = false;
+  DeviceBuffer<double> col_scale;  // see Params (allocated only for a separable fused weighting)
+  bool col_scaled = false;
   double norm_max = 0.0;  // largest column norm (the approximate selection needs counts below 2^24 for Tversky)
   bool xt_nonzero = false;  // |x| in (1e-150, 1e150) for every stored x
   bool xt_positive = false; // every stored x > 0
@@ -1744,6 +1774,31 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
           not_pos.store((w_flags & 4) ? 1 : 0);
           pt.mark("create: weight");
         }
+        // SEPARABLE weightings.  On binary interactions both weightings factor over the stored matrix M
+        // (rows r = documents, columns t = terms): tf-idf w[r][t] = idf[t] (util.hpp:206 with x = 1), BM25
+        // w[r][t] = (idf[t] (k1 + 1)) / (1 + reg[r]) (:183-184).  The kernels then never read a value stream:
+        // the factor that belongs to X_arg^T's ROWS (the features) becomes `xt_rowval` - the all-ones kernels
+        // on y' = x_u y, round 5 - and the factor that belongs to its COLUMNS (the computer's items / users)
+        // becomes `col_scale`, applied to the finished sum with one rounding.  Pure tf-idf of an item-kNN
+        // (CSC layout: idf belongs to the columns) therefore runs the exact COUNT kernel.  The sums differ
+        // from the sums of the individually rounded weights by rounding only (<= 2 ulp per term, far inside
+        // the 1e-12 of the parity bar; columns whose weights and counts are equal tie EXACTLY and are ordered
+        // by column - DESIGN 3.4, `test_separable_weighting`).  The norms still come from the individually
+        // rounded weights (d_values), like the reference's.  IRSPACK_AMD_KNN_SEPARABLE=0: the general form (A/B).
+        const bool separable = weighting != IRS_WEIGHT_NONE && input_ones && env_flag("IRSPACK_AMD_KNN_SEPARABLE", true);
+        std::vector<double> sep_rowval, sep_colscale;  // (empty: that factor is 1)
+        if (separable) {
+          const double k1p1 = bm25 ? input->k1 + 1 : 1.0;
+          std::vector<double> &term_f = csc ? sep_colscale : sep_rowval;  // per column of M
+          std::vector<double> &doc_f = csc ? sep_rowval : sep_colscale;   // per row of M
+          term_f.resize(static_cast<size_t>(m_cols));
+          for (int64_t t = 0; t < m_cols; t++) term_f[t] = bm25 ? wt.idf[t] * k1p1 : wt.idf[t];
+          if (bm25) {
+            doc_f.resize(static_cast<size_t>(m_rows));
+            for (int64_t r = 0; r < m_rows; r++) doc_f[r] = 1.0 / (1.0 + wt.reg[r]);
+          }
+        }
+        const bool stream_vals = weighted && !separable;  // do the kernels read a float64 value per entry?
         const size_t padded = (static_cast<size_t>(nnz_in) + 256 + 1) & ~size_t(1);
         std::vector<int32_t> t_count;
         DeviceBuffer<char> tmp;
@@ -1757,7 +1812,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         const int32_t *xt_idx_src = nullptr;  // column indices of X_arg^T's entries (device)
         if (!csc) {
           d_tidx.alloc(static_cast<size_t>(nnz_in));
-          if (weighted) {  // the transposed values straight into the padded value stream of the kernels
+          if (stream_vals) {  // the transposed values straight into the padded value stream of the kernels
             c->xt_val.alloc(padded);
             IRS_HIP(hipMemsetAsync(c->xt_val.ptr + nnz_in, 0, (padded - static_cast<size_t>(nnz_in)) * sizeof(double), s));
             transpose_csr_device(d_indptr.ptr, d_indices.ptr, static_cast<const double *>(d_values.ptr), rows, cols,
@@ -1774,7 +1829,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
           // norms of a weighted matrix need X_arg's rows together (their squares are added in row order)
           t_count.resize(static_cast<size_t>(cols));
           for (int64_t u = 0; u < cols; u++) t_count[u] = static_cast<int32_t>(indptr[u + 1] - indptr[u]);
-          if (weighted) {
+          if (stream_vals) {
             c->xt_val.alloc(padded);
             hipLaunchKernelGGL(knn_pad_copy_kernel, dim3(static_cast<unsigned>(ceil_div(static_cast<int64_t>(padded), 256))),
                                dim3(256), 0, s, static_cast<const double *>(d_values.ptr), nnz_in,
@@ -1822,7 +1877,8 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
         for (int64_t u = 0; u < cols; u++) {
           xt_ptr[u + 1] = xt_ptr[u] + static_cast<uint32_t>(t_count[u]);
           c->xt_row_len[u] = t_count[u];
-          if (!weighted && t_count[u] > 0) c->xt_rowmax[u] = c->xt_rowmin[u] = 1.0;
+          if (!stream_vals && t_count[u] > 0)
+            c->xt_rowmax[u] = c->xt_rowmin[u] = sep_rowval.empty() ? 1.0 : std::fabs(sep_rowval[u]);
         }
         DeviceBuffer<uint32_t> d_xt_ptr;
         DeviceBuffer<double> d_range;
@@ -1838,7 +1894,7 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
                            static_cast<int64_t>(padded / 2), c->xt_idx16.ptr);
         DeviceBuffer<int32_t> d_not_const;
         int32_t not_const = 1;
-        if (weighted) {
+        if (stream_vals) {
           d_range.alloc(2 * static_cast<size_t>(cols));
           c->xt_rowval.alloc(static_cast<size_t>(cols));
           d_not_const.alloc(1);
@@ -1853,17 +1909,35 @@ irs_status irs_knn_create(int32_t sim_type, int64_t rows, int64_t cols, const in
                                  hipMemcpyDeviceToHost, s));
         }
         IRS_HIP(hipGetLastError());
-        c->xt_all_ones = !weighted;
+        c->xt_all_ones = !stream_vals && sep_rowval.empty();
         c->xt_nonzero = not_safe.load() == 0;
         c->xt_positive = not_pos.load() == 0;
+        if (separable) {  // (the flags describe what the kernels multiply: the row factors)
+          bool safe = true, pos = true;
+          for (const double v : sep_rowval) {
+            const double a = std::fabs(v);
+            safe &= a > 1e-150 && a < 1e150;
+            pos &= v > 0.0;
+          }
+          c->xt_nonzero = safe;
+          c->xt_positive = pos;
+          if (!sep_rowval.empty()) {
+            c->xt_row_const = true;
+            c->xt_rowval.upload(sep_rowval, s);
+          }
+          if (!sep_colscale.empty()) {
+            c->col_scaled = true;
+            c->col_scale.upload(sep_colscale, s);
+          }
+        }
         c->norm_max = norms.empty() ? 0.0 : *std::max_element(norms.begin(), norms.end());
         c->norms.upload(norms, s);
         IRS_HIP(hipStreamSynchronize(s));  // the host vectors and the device scratch go out of scope
-        if (weighted && not_const == 0) {  // one value per feature row: the value stream is not needed
+        if (stream_vals && not_const == 0) {  // one value per feature row: the value stream is not needed
           c->xt_row_const = true;
           c->xt_val.release();
           c->xt_val.alloc(2);
-        } else {
+        } else if (!c->xt_row_const) {
           c->xt_rowval.release();
         }
         pt.mark("create: slices + pack");
@@ -2694,6 +2768,7 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
       p.xt_val = c->xt_val.ptr;
       p.xt_rowval = c->xt_row_const ? c->xt_rowval.ptr : nullptr;
       p.norms = c->norms.ptr;
+      p.col_scale = c->col_scaled ? c->col_scale.ptr : nullptr;
       p.t_ptr = t_ptr.ptr + rel0;  // (values relative to the CALL's first entry, like t_idx / t_val)
       p.t_idx = t_idx.ptr;
       p.t_val = t_val.ptr;
@@ -2778,7 +2853,8 @@ irs_status irs_knn_compute(irs_knn_computer *c, int64_t rows, int64_t cols,
         const bool as_ok = c->sim_type != IRS_SIM_ASYMMETRIC || (p.alpha >= 0.0 && p.alpha <= 1.0);
         // (the candidate list holds FAST_CAP columns: a request for more than half of that would send
         // most pairs to the redo list, i.e. accumulate them twice)
-        const bool fast = acc32 && !big && p.top_k <= FAST_CAP / 2 && divides && tv_ok && as_ok && p.shrinkage >= 0.0 &&
+        // (a column scale - a separable weighting - may be zero or negative: exact values for every column)
+        const bool fast = acc32 && !c->col_scaled && !big && p.top_k <= FAST_CAP / 2 && divides && tv_ok && as_ok && p.shrinkage >= 0.0 &&
                           p.shrinkage < 1e30 &&
                           !(fast_env && fast_env[0] == '0');
         if (fast) {
@@ -2865,6 +2941,54 @@ irs_status irs_knn_fetch(irs_knn_computer *c, int64_t *indptr, int32_t *indices,
       IRS_HIP(hipMemcpy(data, c->res_val.ptr, static_cast<size_t>(c->res_nnz) * sizeof(double),
                         hipMemcpyDeviceToHost));
     }
+  });
+}
+
+irs_status irs_knn_fetch_csc(irs_knn_computer *c, int64_t zero_diagonal_row0, int64_t *col_ptr, int32_t *row_idx,
+                             double *data) {
+  return guard([&] {
+    check_arg(c && col_ptr, "null argument.");
+    const int64_t n = static_cast<int64_t>(c->res_ptr.size()) - 1, N = c->N, nnz = c->res_nnz;
+    std::fill(col_ptr, col_ptr + N + 1, int64_t(0));
+    if (nnz <= 0) return;
+    check_arg(row_idx && data, "null argument.");
+    check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31.");
+    IRS_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;  // (idle: the compute call that made the result has returned)
+    std::vector<int32_t> rp(static_cast<size_t>(n) + 1);
+    for (int64_t i = 0; i <= n; i++) rp[i] = static_cast<int32_t>(c->res_ptr[i]);
+    DeviceBuffer<int32_t> d_rp, d_tidx, d_cp;
+    DeviceBuffer<double> d_tval;
+    DeviceBuffer<char> tmp;
+    d_rp.upload(rp, s);
+    d_tidx.alloc(static_cast<size_t>(nnz));
+    d_tval.alloc(static_cast<size_t>(nnz));
+    std::vector<int32_t> t_count;
+    transpose_csr_device(d_rp.ptr, c->res_idx.ptr, static_cast<const double *>(c->res_val.ptr), n, N, nnz, d_tidx.ptr,
+                         d_tval.ptr, t_count, tmp, s);
+    for (int64_t j = 0; j < N; j++) col_ptr[j + 1] = col_ptr[j] + t_count[j];
+    if (zero_diagonal_row0 >= 0) {
+      std::vector<int32_t> cp(static_cast<size_t>(N) + 1);
+      for (int64_t j = 0; j <= N; j++) cp[j] = static_cast<int32_t>(col_ptr[j]);
+      d_cp.upload(cp, s);
+      hipLaunchKernelGGL(knn_zero_diagonal_csc_kernel, dim3(static_cast<unsigned>(ceil_div(N, 256))), dim3(256), 0, s,
+                         static_cast<const int32_t *>(d_cp.ptr), static_cast<const int32_t *>(d_tidx.ptr), N,
+                         zero_diagonal_row0, d_tval.ptr);
+      IRS_HIP(hipGetLastError());
+      IRS_HIP(hipStreamSynchronize(s));  // (cp goes out of scope)
+    }
+    // into the caller's pageable arrays: a few copies side by side (see irs_knn_weight)
+    const int n_copy = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(4, nnz / (int64_t(1) << 20))));
+    std::atomic<int> failed(0);
+    run_on_threads(n_copy, [&](int k) {
+      const int64_t q0 = nnz * k / n_copy, q1 = nnz * (k + 1) / n_copy;
+      if (q1 <= q0) return;
+      if (hipSetDevice(c->device) != hipSuccess ||
+          hipMemcpy(data + q0, d_tval.ptr + q0, static_cast<size_t>(q1 - q0) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(row_idx + q0, d_tidx.ptr + q0, static_cast<size_t>(q1 - q0) * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        failed.store(1);
+    });
+    if (failed.load()) throw std::runtime_error("copying the result to the host failed.");
   });
 }
 

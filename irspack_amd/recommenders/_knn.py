@@ -79,7 +79,7 @@ class _Computer:
     _MAX_SLOT_ENTRIES = 1 << 26
 
     def _compute(self, X: Any, top_k: int, as_w: bool,
-                 rows: Optional[Tuple[int, int]] = None) -> sps.csr_matrix:
+                 rows: Optional[Tuple[int, int]] = None, csc_zero_diagonal: bool = False):
         if top_k < 0:
             raise TypeError("top_k must be non-negative (size_t).")
         Xc, layout, indptr, indices, data = _lib.sparse_arrays(X, np.float64)
@@ -87,6 +87,10 @@ class _Computer:
         n_tiles = max(1, -(-self._N // 16384))
         per_row = max(1, n_tiles * min(max(int(top_k), 1), self._N))
         batch = max(1, self._MAX_SLOT_ENTRIES // per_row)
+        if re - rb > batch and csc_zero_diagonal:  # (huge catalogues: the host conversion of the stitched result)
+            from ..utils import remove_diagonal
+
+            return remove_diagonal(self._compute(X, top_k, as_w, rows)).tocsc()
         if re - rb > batch:  # rows are independent: stitch the batches
             if layout == _lib.LAYOUT_CSC:  # (regrouped once here, not once per batch inside the library)
                 Xc = sps.csr_matrix(Xc)
@@ -108,11 +112,16 @@ class _Computer:
                 C.c_int32(1 if as_w else 0), C.c_int64(rb), C.c_int64(re), C.byref(nnz),
             )
         )
-        o_ptr = np.empty(re - rb + 1, dtype=np.int64)
         o_idx = np.empty(max(nnz.value, 1), dtype=np.int32)
         o_val = np.empty(max(nnz.value, 1), dtype=np.float64)
-        check(lib().irs_knn_fetch(self._h, ptr(o_ptr, C.c_int64), ptr(o_idx, C.c_int32),
-                                  ptr(o_val, C.c_double)))
+        if csc_zero_diagonal:
+            o_ptr = np.empty(self._N + 1, dtype=np.int64)
+            check(lib().irs_knn_fetch_csc(self._h, C.c_int64(rb), ptr(o_ptr, C.c_int64), ptr(o_idx, C.c_int32),
+                                          ptr(o_val, C.c_double)))
+        else:
+            o_ptr = np.empty(re - rb + 1, dtype=np.int64)
+            check(lib().irs_knn_fetch(self._h, ptr(o_ptr, C.c_int64), ptr(o_idx, C.c_int32),
+                                      ptr(o_val, C.c_double)))
         ms = C.c_double(0)
         macs = C.c_int64(0)
         check(lib().irs_knn_last_stats(self._h, C.byref(ms), C.byref(macs)))
@@ -121,8 +130,12 @@ class _Computer:
         check(lib().irs_knn_last_walked(self._h, C.byref(walked), C.byref(dense_rows)))
         #: (measurement) multiply-adds added one by one / rows of the dense popular block
         self.last_walked_macs, self.dense_block_rows = int(walked.value), int(dense_rows.value)
-        res = sps.csr_matrix((o_val[: nnz.value], o_idx[: nnz.value], o_ptr),
-                             shape=(re - rb, self._N))
+        if csc_zero_diagonal:
+            res = sps.csc_matrix((o_val[: nnz.value], o_idx[: nnz.value], o_ptr.astype(np.int32)),
+                                 shape=(re - rb, self._N))
+        else:
+            res = sps.csr_matrix((o_val[: nnz.value], o_idx[: nnz.value], o_ptr),
+                                 shape=(re - rb, self._N))
         res.has_sorted_indices = True
         return res
 
@@ -134,6 +147,15 @@ class _SimilarityComputer(_Computer):
         call to a shard of target rows — rows are independent, so a multi-GPU run
         concatenates the shards."""
         return self._compute(X, top_k, False, rows)
+
+    def compute_similarity_without_diagonal_csc(self, X: Any, top_k: int) -> sps.csc_matrix:
+        """``remove_diagonal(self.compute_similarity(X, top_k)).tocsc()`` - the last two steps of the kNN
+        recommenders' ``_learn`` (knn.py:78-80) - with the regrouping into columns and the zeroed
+        (kept) diagonal done on the device before the result travels (``irs_knn_fetch_csc``).  The same
+        matrix entry for entry.  Not in the reference."""
+        if X.shape[0] != self._N:
+            raise ValueError("X must be square")  # (remove_diagonal's check, util.hpp:213)
+        return self._compute(X, top_k, False, None, csc_zero_diagonal=True)
 
 
 class CosineSimilarityComputer(_SimilarityComputer):  # wrapper.cpp:12-19, similarities.hpp:6-47

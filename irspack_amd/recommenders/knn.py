@@ -12,7 +12,6 @@ import enum
 from typing import Any, Optional
 
 from .._threading import get_n_threads
-from ..utils import remove_diagonal
 from ._knn import (AsymmetricSimilarityComputer, CosineSimilarityComputer,
                    JaccardSimilarityComputer, P3alphaComputer, RP3betaComputer,
                    TverskyIndexComputer)
@@ -58,7 +57,8 @@ class BaseKNNRecommender(BaseSimilarityRecommender):
         if self.X_train_all.has_sorted_indices:  # (scipy's transposed view does not inherit the flag: a 20 M-entry rescan)
             Xt.has_sorted_indices = True
         computer = self._create_computer(Xt, self._weighting())
-        self._W = remove_diagonal(computer.compute_similarity(Xt, self.top_k)).tocsc()
+        # (= remove_diagonal(computer.compute_similarity(Xt, top_k)).tocsc(), regrouped on the device)
+        self._W = computer.compute_similarity_without_diagonal_csc(Xt, self.top_k)
 
 
 class CosineKNNRecommender(BaseKNNRecommender):  # knn.py:94-161

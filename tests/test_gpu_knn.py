@@ -686,7 +686,7 @@ def test_csc_layout_compute_w(kind, alpha, beta):
 @pytest.mark.parametrize("kind,kw", [c for c in CASES if c[0] in ("cosine", "asymmetric")])
 @pytest.mark.parametrize("scheme", [("TF_IDF", True), ("TF_IDF", False), ("BM_25", 1.2, 0.75), ("BM_25", 0.7, 0.3)])
 @pytest.mark.parametrize("values", ["binary", "real"])
-def test_fused_weighting_is_the_host_weighting(kind, kw, scheme, values):
+def test_fused_weighting_is_the_host_weighting(kind, kw, scheme, values, monkeypatch):
     """``Computer(X.T, weighting=w)`` (item-kNN: knn.py:67-77) and ``Computer(X, weighting=w)`` (user-kNN:
     user_knn.py:62-74) weight the stored matrix on the device while it is uploaded; the similarities are
     those of a computer built on the oracle's weighted matrix BIT FOR BIT (same weights - one IEEE
@@ -699,6 +699,9 @@ def test_fused_weighting_is_the_host_weighting(kind, kw, scheme, values):
     Xw = O.tf_idf_weight(X, scheme[1]) if scheme[0] == "TF_IDF" else O.okapi_BM_25_weight(X, scheme[1], scheme[2])
     Xw.sort_indices()
     # item-kNN orientation: the computer sees X_w.T, the target is the unweighted X.T
+    # (binary interactions would take the separable form - one factor per feature row, one per column, see
+    # test_separable_weighting: same values to rounding, not bit for bit; here the general form)
+    monkeypatch.setenv("IRSPACK_AMD_KNN_SEPARABLE", "0")
     plain, o = make(kind, sps.csr_matrix(Xw.T), **dict(kw))
     want = plain.compute_similarity(sps.csr_matrix(X.T), 25)
     assert_same_csr(want, o.compute_similarity(sps.csr_matrix(X.T), 25), rtol=1e-12)
@@ -724,3 +727,111 @@ def test_fused_weighting_argument_errors():
     # Jaccard / Tversky binarise their input: they take no weighting argument at all
     with pytest.raises(TypeError):
         K.JaccardSimilarityComputer(X.T, 0.0, weighting=("TF_IDF", True))
+
+
+@pytest.mark.parametrize("kind,kw", [CASES[0], CASES[3], CASES[5]])
+@pytest.mark.parametrize("shape", ["one_tile", "two_tiles", "tiny"])
+def test_result_as_csc_without_diagonal(kind, kw, shape):
+    """``remove_diagonal(compute_similarity(X, k)).tocsc()`` (knn.py:78-80) regrouped on the device
+    (irs_knn_fetch_csc): the same CSC matrix entry for entry - explicit zeros on the diagonal kept
+    (util.hpp:211-226), row numbers ascending in every column, empty columns, an empty result."""
+    if shape == "one_tile":
+        Xt = sps.csr_matrix(X_many.T)
+    elif shape == "two_tiles":
+        Xt = power_law_items(900, 17000, 120000, 7)
+    else:
+        Xt = sps.csr_matrix(X_small.T)
+    for M in (Xt, _weighted_copy(Xt, 9)):
+        g, _ = make(kind, M, **dict(kw))
+        for top_k in (30, 1, 0):
+            want = remove_diagonal(g.compute_similarity(M, top_k)).tocsc()
+            want.sort_indices()
+            got = g.compute_similarity_without_diagonal_csc(M, top_k)
+            assert sps.isspmatrix_csc(got) and got.shape == want.shape
+            np.testing.assert_array_equal(got.indptr, want.indptr)
+            np.testing.assert_array_equal(got.indices, want.indices)
+            np.testing.assert_array_equal(got.data, want.data)
+            if top_k == 30:
+                assert (got.diagonal() == 0).all() and got.nnz == want.nnz
+    with pytest.raises(ValueError, match="square"):
+        g.compute_similarity_without_diagonal_csc(M[:2], 3)
+
+
+def assert_same_topk_up_to_rounding(got, want, rtol=1e-12):
+    """Two top-k results whose sums were rounded differently: per row the same values to `rtol` (sorted),
+    and the same columns except where a column's value is within `rtol` of another candidate's (a tie in
+    exact arithmetic may be broken either way by the last bit)."""
+    got, want = sps.csr_matrix(got), sps.csr_matrix(want)
+    np.testing.assert_array_equal(got.indptr, want.indptr)
+    for r in range(got.shape[0]):
+        sl = slice(got.indptr[r], got.indptr[r + 1])
+        gv, wv = got.data[sl], want.data[sl]
+        np.testing.assert_allclose(np.sort(gv), np.sort(wv), rtol=rtol, atol=0)
+        gi, wi = got.indices[sl], want.indices[sl]
+        if np.array_equal(gi, wi):
+            continue
+        allv = np.concatenate([gv, wv])
+        for j in np.setxor1d(gi, wi):
+            v = gv[gi == j][0] if j in gi else wv[wi == j][0]
+            near = np.sum(np.abs(allv - v) <= rtol * max(abs(v), 1e-300))
+            assert near >= 3, (r, int(j), float(v))  # itself (once or twice) + at least one rival within rounding
+
+
+@pytest.mark.parametrize("scheme", [("TF_IDF", True), ("BM_25", 1.2, 0.75)])
+@pytest.mark.parametrize("orient", ["item", "user"])
+@pytest.mark.parametrize("kind,kw", [CASES[0], CASES[1], CASES[2], CASES[5]])
+def test_separable_weighting(kind, kw, scheme, orient, monkeypatch):
+    """tf-idf / BM25 of BINARY interactions factor into (a factor per document) x (a factor per term): the
+    fused constructor keeps the two factors instead of a float64 value per entry - pure tf-idf of an item-kNN
+    runs the exact COUNT kernel and scales the finished counts per column.  Against (a) the general weighted
+    form of the same computer (IRSPACK_AMD_KNN_SEPARABLE=0) and (b) the oracle on the oracle-weighted matrix:
+    values to 1e-12; columns identical except between candidates that agree to 1e-12 (ties in exact
+    arithmetic - equal idf and equal counts - are EXACT ties in the separable form and come out by ascending
+    column, knn.hpp:119-129; sums of individually rounded weights break them by their last bits)."""
+    X = power_law_items(600, 1800, 40000, 33).T.tocsr()  # [users, items], binary
+    X.sort_indices()
+    Xw = O.tf_idf_weight(X, scheme[1]) if scheme[0] == "TF_IDF" else O.okapi_BM_25_weight(X, scheme[1], scheme[2])
+    Xw.sort_indices()
+    arg, target, ow = (X.T, X.T, sps.csr_matrix(Xw.T)) if orient == "item" else (X, X, Xw)
+
+    def fused():
+        if kind == "cosine":
+            return K.CosineSimilarityComputer(arg, kw["shrinkage"], kw["normalize"], weighting=scheme)
+        return K.AsymmetricSimilarityComputer(arg, kw["shrinkage"], kw["alpha"], weighting=scheme)
+
+    sep = fused().compute_similarity(target, 20)
+    monkeypatch.setenv("IRSPACK_AMD_KNN_SEPARABLE", "0")
+    general = fused().compute_similarity(target, 20)
+    monkeypatch.delenv("IRSPACK_AMD_KNN_SEPARABLE")
+    assert_same_topk_up_to_rounding(sep, general)
+    _, o = make(kind, ow, **dict(kw))
+    assert_same_topk_up_to_rounding(sep, o.compute_similarity(sps.csr_matrix(target), 20))
+
+
+def test_separable_weighting_tie_order_known_answer():
+    """The 4 x 5 tie matrix of tests/recommenders/test_knn.py:144-165 with tf-idf weights, top_k = 2: the
+    separable form's value of column j is fl(count_ij * idf_j) through the un-fused cosine epilogue - restated
+    here in numpy operation by operation - and candidates of equal value come out by ascending column."""
+    X = sps.csr_matrix(np.asarray([[1, 1, 1, 0, 0], [1, 1, 0, 1, 0], [1, 0, 1, 1, 0], [0, 1, 1, 1, 1]], dtype=float))
+    Xw = O.tf_idf_weight(X, True)
+    idf = np.log(X.shape[0] / (np.bincount(X.indices, minlength=5) + 1.0))
+    Wd, Xd = Xw.toarray(), X.toarray()
+    norms = np.empty(5)
+    for j in range(5):
+        ss = 0.0
+        for u in range(4):  # stored entries of column j in row order
+            if Xd[u, j]:
+                ss += Wd[u, j] * Wd[u, j]
+        norms[j] = np.sqrt(ss)
+    tnorm = np.sqrt(Xd.sum(axis=0))
+    counts = Xd.T @ Xd
+    got = K.CosineSimilarityComputer(X.T, 0.0, True, weighting=("TF_IDF", True)).compute_similarity(X.T, 2)
+    got.sort_indices()
+    for i in range(5):
+        cols = np.flatnonzero(counts[i] > 0)
+        vals = (counts[i, cols] * idf[cols]) / (norms[cols] * tnorm[i] + 0.0 + 1e-6)
+        order = np.lexsort((cols, -vals))[:2]
+        sel = np.sort(cols[order])
+        sl = slice(got.indptr[i], got.indptr[i + 1])
+        np.testing.assert_array_equal(got.indices[sl], sel)
+        np.testing.assert_array_equal(got.data[sl], vals[np.searchsorted(cols, sel)])
