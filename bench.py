@@ -18,8 +18,8 @@ Objects on the line:
                 built offline) on this box's host cores, bounded row sample, N = 1 only
   secondary     N = 1 only, each leg time-boxed and independent:
     ials_cg       the reference's DEFAULT solver (CG, 3 steps) on the same matrix
-    ials_bf16x3   the Cholesky epoch again with the OPT-IN bf16x3 rank update (fp32-equivalent
-                  accuracy from exact three-way bf16 splits; not the headline path)
+    ials_f32_mfma the Cholesky epoch again with the rank update on the fp32-input matrix instruction
+                  (the headline path until round 5; IRSPACK_AMD_IALS_BF16X3=0)
     knn           cosine / jaccard item-kNN top-100 (configs[2]); headline = wall-inclusive call
     evaluator     fused score + nDCG@20 over all users (K = 64)
     fit           IALSTrainer(...) + 16 steps + factors to the host: the reference's learn() through the boundary
@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip every leg reported next to the headline metric")
-    ap.add_argument("--legs", default="ials_cg,ials_bf16x3,fit,knn,evaluator,k256,c4",
+    ap.add_argument("--legs", default="ials_cg,ials_f32_mfma,fit,knn,evaluator,k256,c4",
                     help="comma-separated secondary legs to run (N = 1)")
     ap.add_argument("--balance", default="auto", choices=["auto", "cost", "equal"],
                     help="N > 1 row shards: equal row blocks (one in-place all-gather) or "
@@ -413,22 +413,21 @@ def ialspp_leg(trainer, X, K, steps, warmup):
             "algorithmic_gflop_per_epoch": flops / 1e9}
 
 
-def bf16x3_leg(X, K, steps, ceilings):
-    """NOT the headline path: the same Cholesky epoch with the opt-in rank update on the bf16
-    matrix cores (IRSPACK_AMD_IALS_BF16X3=1: every fp32 factor value split exactly into three
-    bf16 terms, six partial products accumulated in fp32 - fp32-equivalent accuracy, checked
-    by tests/test_gpu_fullsize.py).  Reported so that the two rank updates can be compared on
-    the driver's own box; its roofline is still priced against the fp32 peak."""
+def f32_mfma_leg(X, K, steps, ceilings):
+    """The same Cholesky epoch with the rank update on the fp32-INPUT matrix instruction
+    (v_mfma_f32_16x16x4_f32; IRSPACK_AMD_IALS_BF16X3=0) - the headline path of rounds 1-5, beside the
+    headline's default (round 6: the bf16 matrix cores on exact three-way splits of the fp32 values, six
+    fp32-exact partial products per product, fp32 accumulate), so that the two rank updates can be compared
+    on the driver's own box.  Both are priced against the fp32 peak on the same algorithmic flops."""
     from irspack_amd.recommenders._ials_core import IALSTrainer
 
-    os.environ["IRSPACK_AMD_IALS_BF16X3"] = "1"
+    os.environ["IRSPACK_AMD_IALS_BF16X3"] = "0"
     try:
         tr = IALSTrainer(model_config(K), X)  # the switch is read when a trainer is created
     finally:
         del os.environ["IRSPACK_AMD_IALS_BF16X3"]
-    out = ials_leg(tr, X, K, "CHOLESKY", steps, 2, ceilings)  # (no PMC pass of this variant: no traffic figures)
-    out["rank_update"] = ("bf16x3: v_mfma_f32_16x16x32_bf16 on exact 3-way splits of the fp32 values, "
-                          "fp32 accumulate (opt-in, unit confidences, K <= 64)")
+    out = ials_leg(tr, X, K, "CHOLESKY", steps, 2, ceilings)  # (the committed PMC pass is of the default path)
+    out["rank_update"] = "fp32: v_mfma_f32_16x16x4_f32, one triangle of 16 x 16 tiles (IRSPACK_AMD_IALS_BF16X3=0)"
     return out
 
 
@@ -1190,6 +1189,27 @@ def main():
                                   avg_launch_ms=st["ms"] / st["launches"], launches=st["launches"],
                                   algorithmic_gflop_per_launch=flops / 1e9,
                                   algorithmic_gbyte_per_launch=byts / 1e9)
+            # which matrix instruction the rank update runs on: binary interactions, Cholesky,
+            # 48 < K <= 64 -> the bf16 matrix cores on exact three-way splits (fp32-exact partial products,
+            # fp32 accumulate) unless IRSPACK_AMD_IALS_BF16X3=0; `frac` stays priced on the ALGORITHMIC fp32
+            # flops against the fp32 peak, the executed bf16 flops are shown against the bf16 peak beside it
+            bf16x3 = (args.solver == "CHOLESKY" and 48 < K <= 64 and bool(np.all(X.data == 1.0))
+                      and os.environ.get("IRSPACK_AMD_IALS_BF16X3", "1") != "0"
+                      and os.environ.get("IRSPACK_AMD_IALS_UNIT", "1") != "0")
+            if bf16x3:
+                groups = float(np.ceil(np.diff(Xs.indptr[b:e + 1]) / 32.0).sum())  # 32-entry groups walked
+                executed = groups * 60 * 16384.0  # 10 tiles x 6 partial products x v_mfma_f32_16x16x32_bf16
+                roofline["rank_update"] = {
+                    "form": "bf16x3: v_mfma_f32_16x16x32_bf16 on exact 3-way bf16 splits of the fp32 factors, "
+                            "6 fp32-exact partial products per product, fp32 accumulate (IRSPACK_AMD_IALS_BF16X3=0: "
+                            "v_mfma_f32_16x16x4_f32, leg secondary.ials_f32_mfma)",
+                    "executed_bf16_tflops": executed / t_launch / 1e12, "peak_bf16_tflops": 2500.0,
+                    "frac_bf16_peak": executed / t_launch / 1e12 / 2500.0,
+                    "accuracy": "every row of both benchmark half-steps vs the float64 solve: worst 1.1e-5 (user) / "
+                                "1.9e-6 (item), the float32 oracle 3.8e-5 / 5.7e-5 (tests/test_gpu_fullsize.py, "
+                                "profiles/parity_r06.json)"}
+            else:
+                roofline["rank_update"] = {"form": "fp32: v_mfma_f32_16x16x4_f32, one triangle of 16 x 16 tiles"}
             pmc = pmc_traffic(f"{args.shape} K={K}") if world == 1 else {}
             roofline["traffic"] = pmc.get(name)
             roofline["traffic_provenance"] = pmc.get("_provenance") or pmc.get("_stale") or (
@@ -1242,7 +1262,7 @@ def main():
             run(other_leg, lambda: ials_leg(local.trainer, X, K, other, args.steps, 2, ceilings,
                                             workload=f"{args.shape} K={K}"))
             if K <= 64 and args.solver == "CHOLESKY":
-                run("ials_bf16x3", lambda: bf16x3_leg(X, K, args.steps, ceilings))
+                run("ials_f32_mfma", lambda: f32_mfma_leg(X, K, args.steps, ceilings))
             run("fit", lambda: fit_leg(X, K, args.solver))
             if K <= 64:
                 run("knn", lambda: knn_leg(X, ceilings))

@@ -906,9 +906,10 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
 //   IRSPACK_AMD_IALS_UNIT=0     keeps binary interactions on the general rank-update code
 //   IRSPACK_AMD_IALS_SHORT=0    sends the short rows of a CG step through the general kernels
 //   IRSPACK_AMD_IALS_WG16=0     Cholesky at K > 64 on the first-generation kernels (4-row panels)
-//   IRSPACK_AMD_IALS_BF16X3=1   binary interactions, Cholesky, K <= 64 padded to 64: the rank update
-//                               on the bf16 matrix cores from exact three-way splits of the fp32
-//                               values (syrk_gather_bf16x3, ials_kernels.hpp); off by default
+//   IRSPACK_AMD_IALS_BF16X3=0   binary interactions, Cholesky, 48 < K <= 64: the rank update back on the
+//                               fp32-input matrix instruction.  Default (round 6): the bf16 matrix cores
+//                               on exact three-way splits of the fp32 values, six fp32-exact partial
+//                               products per product, fp32 accumulate (syrk_gather_bf16x3, ials_kernels.hpp)
 void read_switches(irs_ials_trainer *t) {
   t->opt_wave128 = env_flag("IRSPACK_AMD_IALS_WAVE128", true);
   t->opt_unit = env_flag("IRSPACK_AMD_IALS_UNIT", true);
@@ -918,7 +919,7 @@ void read_switches(irs_ials_trainer *t) {
   t->opt_pp_chain = env_flag("IRSPACK_AMD_IALSPP_CHAIN", true);
   t->opt_pp_fork = env_flag("IRSPACK_AMD_IALSPP_FORK", true);
   t->opt_wg16 = env_flag("IRSPACK_AMD_IALS_WG16", true);
-  t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", false);
+  t->opt_bf16x3 = env_flag("IRSPACK_AMD_IALS_BF16X3", true);
   t->opt_eig = env_flag("IRSPACK_AMD_IALS_EIG", true);
   t->opt_mf = env_flag("IRSPACK_AMD_IALS_MF", true);
 }

@@ -472,8 +472,11 @@ __device__ __forceinline__ void syrk_gather(const float *__restrict__ other,
 
 // ---------------------------------------------------------------------------
 // The same rank update on the bf16 matrix cores with fp32-equivalent accuracy ("bf16x3"):
-// unit confidences only (binary interactions), lower-form tiles.  Opt-in
-// (IRSPACK_AMD_IALS_BF16X3=1), not the default and not the benchmark's headline path.
+// unit confidences only (binary interactions), lower-form tiles.  The DEFAULT rank update of binary
+// interactions at K <= 64 under the Cholesky solver since round 6 (IRSPACK_AMD_IALS_BF16X3=0 keeps the
+// fp32-input matrix instruction): on all 165,237 rows of the ML-20M benchmark half-steps its factors are
+// CLOSER to the float64 solve than the float32 oracle's (worst row 1.1e-5 / 1.9e-6 against 3.8e-5 / 5.7e-5,
+// profiles/parity_r06.json) - the six partial products are exact in fp32, only their accumulation rounds.
 //
 // v_mfma_f32_16x16x32_bf16 contracts 32 stored entries in 16 cycles where
 // v_mfma_f32_16x16x4_f32 contracts 4 in 32 (MI355X_MICROARCH.md: the fp32-input MFMA runs at
@@ -564,18 +567,24 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
   int cur = ip[0], nxt = ip[64];
   issue(0, cur, 0, 0);
   issue(1, cur, 1, 0);
-  for (int g0 = 0; g0 < ngroups; g0 += 2) {
+  int g0 = 0;
+  for (; g0 + 2 <= ngroups; g0 += 2) {
     const int e_next = 32 * (g0 + 2);       // first entry of the next block
     const int nn = ip[e_next + 64];         // the block after it
     consume(0);
     issue(0, nxt, 0, e_next);
-    // (an early exit here for odd group counts measured slower: user half 1.19 -> 1.32 ms; the
-    // idle half-pair only gathers the all-zero row)
+    // (an early exit HERE for odd group counts measured slower in round 4: user half 1.19 -> 1.32 ms - a
+    // branch between the loads and their use drains the gather queue)
     consume(1);
     issue(1, nxt, 1, e_next);
     cur = nxt;
     nxt = nn;
   }
+  // Round 6: an odd group count ends with ONE consume behind the loop (no load follows it, so the branch
+  // costs no drain) instead of a second group of all-zero rows - half a group (60 matrix + ~90 vector
+  // instructions) less per row on average, a whole one for the rows of at most 32 entries.  The loads of
+  // slot 1 that are in flight (zero rows) are simply never used.
+  if (g0 < ngroups) consume(0);
   (void)cur;
 #pragma unroll
   for (int i = 0; i < T; i++) {
@@ -1062,7 +1071,7 @@ __device__ unsigned long long ials_phase_clk[8 * 4096];
 #define IPHASE_BEGIN
 #endif
 
-// BF16X3: the rank update of syrk_gather_bf16x3 (opt-in; UNIT, Cholesky, T == 4 only).
+// BF16X3: the rank update of syrk_gather_bf16x3 (UNIT, Cholesky, T == 4 only; the default there since round 6).
 // RESID: rhs -= (P x)_row + reg x (hpp:459-466: the Gramian and ridge terms of the gradient); lane (g, m)
 // holds the dims T m .. T m + T - 1
 template <int T>

@@ -157,20 +157,32 @@ def test_ials_k64_ml20m_benchmarked_kernels_vs_oracle(X20, X20t, kind):
                                         f"ml20m K=64 {kind} {'user' if side == 0 else 'item'} half, all rows",
                                         test="test_ials_k64_ml20m_benchmarked_kernels_vs_oracle")
         assert np.isfinite(got).all()
-    # the general (non-unit) rank update on the same inputs: with loss = IALSPP (bias 0) the
-    # two code paths perform the same float operations
-    os.environ["IRSPACK_AMD_IALS_UNIT"] = "0"
+    # the general (non-unit) rank update on the same inputs: with loss = IALSPP (bias 0) it performs the
+    # same float operations as the unit-confidence code on the fp32-input matrix instruction
+    # (IRSPACK_AMD_IALS_BF16X3=0; the default Cholesky rank update at K = 64 is the bf16x3 form, checked
+    # above against the oracle and float64 on every row)
+    os.environ["IRSPACK_AMD_IALS_BF16X3"] = "0"
     try:
+        t32 = IALSTrainer(mc, X20)
+        os.environ["IRSPACK_AMD_IALS_UNIT"] = "0"
         g = IALSTrainer(mc, X20)
     finally:
-        del os.environ["IRSPACK_AMD_IALS_UNIT"]
+        os.environ.pop("IRSPACK_AMD_IALS_UNIT", None)
+        del os.environ["IRSPACK_AMD_IALS_BF16X3"]
     for side in (0, 1):
-        t.user, t.item = user0, item0
+        t32.user, t32.item = user0, item0
         g.user, g.item = user0, item0
-        half_step(t, side, sc)
+        half_step(t32, side, sc)
         half_step(g, side, sc)
-        a, b = (t.user, g.user) if side == 0 else (t.item, g.item)
+        a, b = (t32.user, g.user) if side == 0 else (t32.item, g.item)
         assert row_rel_err(a, b) < 1e-6, (kind, side)
+        if kind == "CHOLESKY":  # ... and the fp32-input path against the same oracle rows, as before round 6
+            Xs, tgt0, oth0 = (X20, user0, item0) if side == 0 else (X20t, item0, user0)
+            rows, _ = row_sample(Xs, 20_000, seed=90 + side)
+            want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
+            assert_rows_match(kind, a[rows], want, Xs, rows, tgt0, oth0,
+                              f"ml20m K=64 CHOLESKY fp32-input MFMA (BF16X3=0) {'user' if side == 0 else 'item'} half, sample",
+                              test="test_ials_k64_ml20m_benchmarked_kernels_vs_oracle")
 
 
 @pytest.mark.parametrize("name,normalize", [("cosine", True), ("cosine", False), ("jaccard", False)])
@@ -433,15 +445,16 @@ def test_ials_k128_c4_full_matrix_vs_oracle(XC4, kind):
 
 
 def test_ials_k64_bf16x3_rank_update_is_fp32_accurate(X20, X20t, monkeypatch):
-    """Opt-in IRSPACK_AMD_IALS_BF16X3=1: the rank update on the bf16 matrix cores from exact
-    three-way splits of the fp32 factors (syrk_gather_bf16x3).  Same bar as the fp32 path
-    (per row 1e-4 against the oracle on all split rows + the longest + 2,000 random ones), and
-    against the float64 normal equations its error must stay within 2x the fp32 path's."""
+    """The default rank update of binary interactions at K = 64 (Cholesky): the bf16 matrix cores on exact
+    three-way splits of the fp32 factors (syrk_gather_bf16x3) - beside the fp32-input matrix instruction
+    (IRSPACK_AMD_IALS_BF16X3=0).  Same bar as every Cholesky path (per row against the oracle and float64 on
+    all split rows + the longest + 2,000 random ones), and against the float64 normal equations its error
+    must stay within 2x the fp32-input path's (achieved: smaller - the products are exact)."""
     K, kind = 64, "CHOLESKY"
     mc, sc, omc, osc = configs(K, kind)
+    b = IALSTrainer(mc, X20)  # (default: bf16x3)
+    monkeypatch.setenv("IRSPACK_AMD_IALS_BF16X3", "0")
     t = IALSTrainer(mc, X20)
-    monkeypatch.setenv("IRSPACK_AMD_IALS_BF16X3", "1")
-    b = IALSTrainer(mc, X20)
     monkeypatch.delenv("IRSPACK_AMD_IALS_BF16X3")
     t.step(sc)
     user0, item0 = t.user, t.item
@@ -451,6 +464,7 @@ def test_ials_k64_bf16x3_rank_update_is_fp32_accurate(X20, X20t, monkeypatch):
             half_step(tr, side, sc)
         got32 = t.user if side == 0 else t.item
         got16 = b.user if side == 0 else b.item
+        assert not np.array_equal(got32, got16)  # (two different rank updates really ran)
         rows, split = row_sample(Xs, 2000, seed=20 + side)
         want = oracle_rows(tgt0, Xs, rows, oth0, omc, osc)
         assert_rows_match(kind, got16[rows], want, Xs, rows, tgt0, oth0,

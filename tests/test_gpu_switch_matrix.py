@@ -35,12 +35,12 @@ IALS_SWITCHES = {
     "pp_direct_off": {"IRSPACK_AMD_IALSPP_DIRECT": "0"},
     "pp_chain_off": {"IRSPACK_AMD_IALSPP_CHAIN": "0"},
     "pp_fork_off": {"IRSPACK_AMD_IALSPP_FORK": "0"},
-    "bf16x3_on": {"IRSPACK_AMD_IALS_BF16X3": "1"},
+    "bf16x3_off": {"IRSPACK_AMD_IALS_BF16X3": "0"},
     "chunk_small": {"IRSPACK_AMD_IALS_CHUNK": "256", "IRSPACK_AMD_IALS_CHUNK_LONG": "512"},
 }
 IALS_PAIRS = [("unit_off", "short_off"), ("wave128_off", "wg16_off"), ("eig_off", "short_off"),
               ("mf_off", "wg16_off"), ("unit_off", "chunk_small"), ("pp_direct_off", "pp_chain_off"),
-              ("pp_chain_off", "pp_fork_off"), ("short2_off", "eig_off"), ("unit_off", "bf16x3_on"),
+              ("pp_chain_off", "pp_fork_off"), ("short2_off", "eig_off"), ("unit_off", "bf16x3_off"),
               ("mf_off", "wave128_off")]
 IALS_CASES = [("default",)] + [(k,) for k in IALS_SWITCHES] + IALS_PAIRS
 
