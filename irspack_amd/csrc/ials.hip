@@ -1512,6 +1512,8 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
           t->prof.launch(name, ials_solve_kernel<TT, 0, 0, true, false, true>, grid, block, 0, t->stream, p);
         else if (pp_direct)
           t->prof.launch(name, ials_solve_kernel<TT, 0, 0, false, false, true>, grid, block, 0, t->stream, p);
+        else if (cg && unit && t->opt_bf16x3 && TT == 4)
+          t->prof.launch(name, ials_solve_kernel<4, 1, 0, true, true>, grid, block, 0, t->stream, p);
         else if (cg && unit)
           t->prof.launch(name, ials_solve_kernel<TT, 1, 0, true>, grid, block, 0, t->stream, p);
         else if (cg)
@@ -1529,6 +1531,8 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
         if (pp_direct)
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 0, 1, false, false, true>, grid, block, 0,
                          t->stream, p);
+        else if (cg && unit && t->opt_bf16x3 && TT == 4)  // (the bf16x3 chunks left lower-form partials)
+          t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<4, 1, 1, false, true>, grid, block, 0, t->stream, p);
         else if (cg)
           t->prof.launch(kNames[cg][1][pidx], ials_solve_kernel<TT, 1, 1>, grid, block, 0, t->stream, p);
         else

@@ -601,7 +601,9 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
 //             (Eigen::LLT + solve, hpp:316-324)
 //   SOLVER 1: conjugate gradient on the explicit matrix (same iterates as the
 //             matrix-free loop of hpp:199-264: A x = P x + reg x + sum c (v.x) v)
-template <int T, int SOLVER>
+// LOWER_ACC: slot tix(i, j), i <= j, holds the tile (row block j, column block i) - what the bf16x3 rank
+// update accumulates - instead of its transpose; the matrix is symmetric, only the staging indices swap.
+template <int T, int SOLVER, bool LOWER_ACC = false>
 __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
                                           float reg, float *sm, float *xrow, int K,
                                           int nnz, int max_cg_steps, int warm_start,
@@ -648,7 +650,7 @@ __device__ __forceinline__ void solve_row(f32x4 (&acc)[Geo<T>::NT], const float 
       for (int j = i; j < T; j++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int row = T * (4 * g + r) + i, col = T * m + j;
+          const int row = T * (4 * g + r) + (LOWER_ACC ? j : i), col = T * m + (LOWER_ACC ? i : j);
           if (rows_here) sm[(row - pass * ROWS) * LD + col] = acc[t][r];
           if (i != j && cols_here) sm[(col - pass * ROWS) * LD + row] = acc[t][r];
         }
@@ -1096,12 +1098,15 @@ template <int T> __device__ __forceinline__ void resid_add_step(float *xrow, con
 // current row, solution = the step; SOLVER 0, T <= 4.
 template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false, bool RESID = false>
 __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? (RESID && MODE == 0 ? (UNIT ? 3 : 4) : SOLVE_MIN_WAVES_PER_SIMD_K64) : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
-  static_assert(!BF16X3 || (UNIT && SOLVER == 0 && T == 4 && MODE == 0), "bf16x3: unit-confidence Cholesky at K <= 64");
+  // bf16x3: unit confidences, K <= 64 padded to 64; Cholesky (whose split rows' second pass is the plain MODE 1
+  // kernel: both work on lower tiles) and, round 6, CG on the explicit system (MODE 1 with BF16X3 = "the
+  // partials and the Gramian are lower-form tiles")
+  static_assert(!BF16X3 || (T == 4 && (MODE == 1 ? SOLVER == 1 : UNIT)), "bf16x3: unit confidences at K <= 64");
   static_assert(!RESID || (SOLVER == 0 && T <= 4 && !BF16X3), "the gradient form: Cholesky at K <= 64");
   constexpr int WAVES = SOLVE_WAVES;
   using G = Geo<T>;
   // Cholesky: lower-form tiles + the 16-row block solve of ials_chol16.hpp
-  constexpr bool LOWER = SOLVER == 0;
+  constexpr bool LOWER = SOLVER == 0 || BF16X3;
   constexpr int RING = (T > 4 && SOLVER == 0) ? 4 : 8;  // gathered sub-steps in flight
   constexpr int LDS_PER_WAVE = SOLVER == 0 ? Chol16Geo<T>::LDS_FLOATS
                                            : (T == 8 ? CholGeo<T>::SPILL_CG_FLOATS : G::CG_LDS_FLOATS);
@@ -1164,7 +1169,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
                          p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
                          p.max_cg_steps, p.warm_start, p.err_flag);
     else
-      solve_row<T, SOLVER>(acc, bsum, p.reg[task.row], sm,
+      solve_row<T, SOLVER, LOWER>(acc, bsum, p.reg[task.row], sm,
                            p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
                            p.max_cg_steps, p.warm_start, p.err_flag);
   } else {
@@ -1214,7 +1219,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
                          p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
                          p.max_cg_steps, p.warm_start, p.err_flag);
     else
-      solve_row<T, SOLVER>(acc, bsum, p.reg[sr.row], sm,
+      solve_row<T, SOLVER, LOWER>(acc, bsum, p.reg[sr.row], sm,
                            p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
                            p.max_cg_steps, p.warm_start, p.err_flag);
   }
