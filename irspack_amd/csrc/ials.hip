@@ -91,6 +91,7 @@ struct Side {
   int32_t n_tasks = 0, n_split = 0, n_slots = 0, n_long = 0;
   // tasks at the end of the (longest-first) list with <= SHORT_MAX (n_short) / <= 16 entries
   int32_t n_short = 0, n_short16 = 0, n_short8 = 0;
+  int64_t long_entries = 0;  // stored entries of the tasks [0, n_tasks - n_short)
   // matrix-free CG at 128 < K <= 256 (ials_mf_kernels.hpp): rows_by_len is cut into the
   // level-synchronous rows (more than MF_NCAP entries, chunked) and the resident classes of
   // MF_CAPS; mf_class[c] = first index of class c in rows_by_len, [MF_CLASSES] = end
@@ -225,6 +226,8 @@ struct Side {
       if (tk[n_tasks - 1 - n_short].end - tk[n_tasks - 1 - n_short].begin <= 8) n_short8++;
       n_short++;
     }
+    long_entries = 0;  // entries of the tasks in front of the short ones (the rank-update kernels' work)
+    for (int32_t i = 0; i < n_tasks - n_short; i++) long_entries += tk[i].end - tk[i].begin;
     n_slots = slots;
     if (share) {
       indptr.borrow(share->indptr);
@@ -1481,10 +1484,24 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     p.partials = t->split_partial.ptr;
     if (n_regular > 0) {
       t->prof.begin(kNames[cg][0][pidx], t->stream);
-      if (cg && unit)
+      // (unit confidences: the bf16x3 rank update of ials_kernels.hpp, round 6 also at T = 8 - 216 bf16 matrix
+      // instructions of 16 cycles per 32 entries instead of 288 fp32-input ones of 32)
+      // The bf16x3 kernels hold ~410-440 registers (one wave per SIMD, like the CG kernels always did); the
+      // fp32-input Cholesky kernel holds 236 (two).  Under Cholesky the second wave is worth more than the
+      // faster rank update when rows are short - ML-20M user half, 144 entries per task: 4.8 ms fp32-input,
+      // 5.3 ms bf16x3; item half, 544 per task: 3.1 -> 2.5 ms - so the choice goes by the mean task length.
+      // (`unit` also requires a gathered table below 4 GB - the fp32-input UNIT kernels address it with
+      // 32-bit byte offsets; the T = 8 bf16x3 gather uses 64-bit row addresses and has no such limit)
+      const bool x3_any = sd.unit && t->opt_unit && other == t->factor[1 - pidx].ptr && t->opt_bf16x3;
+      const bool x3 = x3_any && (cg || sd.long_entries >= int64_t(320) * std::max(n_regular, 1));
+      if (cg && x3)
+        hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0, true, true>), dim3(n_regular), dim3(64), 0, t->stream, p);
+      else if (cg && unit)
         hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0, true>), dim3(n_regular), dim3(64), 0, t->stream, p);
       else if (cg)
         hipLaunchKernelGGL((ials_solve_kernel<8, 1, 0>), dim3(n_regular), dim3(64), 0, t->stream, p);
+      else if (x3)
+        hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0, true, true>), dim3(n_regular), dim3(64), 0, t->stream, p);
       else if (unit)
         hipLaunchKernelGGL((ials_solve_kernel<8, 0, 0, true>), dim3(n_regular), dim3(64), 0, t->stream, p);
       else
@@ -1494,7 +1511,9 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
     if (with_split && sd.n_split > 0) {
       fold_partials(G::PARTIAL_FLOATS);
       t->prof.begin(kNames[cg][1][pidx], t->stream);
-      if (cg)
+      if (cg && sd.unit && t->opt_unit && other == t->factor[1 - pidx].ptr && t->opt_bf16x3)  // (lower-form partials)
+        hipLaunchKernelGGL((ials_solve_kernel<8, 1, 1, false, true>), dim3(sd.n_split), dim3(64), 0, t->stream, p);
+      else if (cg)
         hipLaunchKernelGGL((ials_solve_kernel<8, 1, 1>), dim3(sd.n_split), dim3(64), 0, t->stream, p);
       else
         hipLaunchKernelGGL((ials_solve_kernel<8, 0, 1>), dim3(sd.n_split), dim3(64), 0, t->stream, p);

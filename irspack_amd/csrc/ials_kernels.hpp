@@ -506,15 +506,16 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
                                                    const int32_t *__restrict__ indices, int begin,
                                                    int end, float bias, f32x4 (&acc)[Geo<T>::NT],
                                                    float (&bsum)[T], unsigned zero_row) {
-  static_assert(T == 4, "dims per lane = one 16 B load");
+  static_assert(T == 4 || T == 8, "dims per lane = one or two 16 B loads");
   constexpr int KP = Geo<T>::KP;
+  constexpr int V4 = T / 4;  // 16-byte loads per lane and entry
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
   const int n = end - begin;
   const int ngroups = (n + 31) >> 5;
   const uint32_t lane_off = static_cast<uint32_t>(T * m * sizeof(float));
   const int32_t *ip = indices + begin + lane;
-  f32x4 raw[2][8];  // two groups in flight
+  f32x4 raw[2][8][V4];  // two groups in flight
   // entries 32 gi + 8 g + kk of the 64-entry index block held one per lane in blk_idx
   auto issue = [&](int slot, int blk_idx, int gi, int entry0) {
 #pragma unroll
@@ -522,8 +523,18 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
       const int src = 4 * (32 * gi + 8 * g + kk);
       unsigned idx = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, blk_idx));
       idx = entry0 + 32 * gi + 8 * g + kk < n ? idx : zero_row;
-      const uint32_t off = idx * static_cast<uint32_t>(KP * sizeof(float)) + lane_off;
-      raw[slot][kk] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(other) + off);
+      if constexpr (T == 8) {
+        // (64-bit row addresses: configs[3] gathers a 5.1 GB user table at K = 128 - one more vector
+        // instruction per entry beside ~70 of splitting)
+        const float *rp = other + (static_cast<size_t>(idx) * KP + T * m);
+#pragma unroll
+        for (int v = 0; v < V4; v++) raw[slot][kk][v] = *reinterpret_cast<const f32x4 *>(rp + 4 * v);
+      } else {
+        const uint32_t off = idx * static_cast<uint32_t>(KP * sizeof(float)) + lane_off;
+#pragma unroll
+        for (int v = 0; v < V4; v++)
+          raw[slot][kk][v] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(other) + off + 16 * v);
+      }
     }
   };
   auto consume = [&](int slot) {
@@ -532,7 +543,7 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
     for (int d = 0; d < T; d++) {
 #pragma unroll
       for (int pp = 0; pp < 4; pp++) {
-        const float x0 = raw[slot][2 * pp][d], x1 = raw[slot][2 * pp + 1][d];
+        const float x0 = raw[slot][2 * pp][d >> 2][d & 3], x1 = raw[slot][2 * pp + 1][d >> 2][d & 3];
         bsum[d] += x0 + x1;
         const unsigned h = pack_bf16(x0, x1);
         const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
@@ -945,7 +956,9 @@ __device__ __forceinline__ void solve_row_cholesky(f32x4 (&acc)[Geo<T>::NT], con
 // row-wise (b128), tiles left of it column-wise.  Everything runs in the virtual basis
 // k = 16 I + m'  <->  latent dim T m' + I, which is a permutation and leaves CG's iterates
 // unchanged.
-template <int T>
+// LOWER_ACC: slot tix(i, j) holds the tile (row block j, column block i) (the bf16x3 rank update): it is
+// the transpose of the upper tile, so it is staged transposed.
+template <int T, bool LOWER_ACC = false>
 __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const float (&b4)[T],
                                                 float reg, float *sm, float *xrow, int K, int nnz,
                                                 int max_cg_steps, int warm_start,
@@ -967,7 +980,10 @@ __device__ __forceinline__ void solve_row_cg128(f32x4 (&acc)[Geo<T>::NT], const 
 #pragma unroll
     for (int j = i; j < T; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) sm[C::tix(i, j) * C::TS_CG + (4 * g + r) * C::RS_CG + m] = acc[C::tix(i, j)][r];
+      for (int r = 0; r < 4; r++) {
+        if constexpr (LOWER_ACC) sm[C::tix(i, j) * C::TS_CG + m * C::RS_CG + (4 * g + r)] = acc[C::tix(i, j)][r];
+        else sm[C::tix(i, j) * C::TS_CG + (4 * g + r) * C::RS_CG + m] = acc[C::tix(i, j)][r];
+      }
     if (g == 0) bbuf[16 * i + m] = b4[i];
   }
   __threadfence_block();
@@ -1097,11 +1113,12 @@ template <int T> __device__ __forceinline__ void resid_add_step(float *xrow, con
 // RESID: the one-block iALS++ sweep (see syrk_gather_impl): right-hand side = negative gradient at the
 // current row, solution = the step; SOLVER 0, T <= 4.
 template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false, bool RESID = false>
-__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <= 4 ? (RESID && MODE == 0 ? (UNIT ? 3 : 4) : SOLVE_MIN_WAVES_PER_SIMD_K64) : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
+__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && (SOLVER == 1 || BF16X3)) ? 1 : (T <= 4 ? (RESID && MODE == 0 ? (UNIT ? 3 : 4) : SOLVE_MIN_WAVES_PER_SIMD_K64) : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
   // bf16x3: unit confidences, K <= 64 padded to 64; Cholesky (whose split rows' second pass is the plain MODE 1
   // kernel: both work on lower tiles) and, round 6, CG on the explicit system (MODE 1 with BF16X3 = "the
   // partials and the Gramian are lower-form tiles")
-  static_assert(!BF16X3 || (T == 4 && (MODE == 1 ? SOLVER == 1 : UNIT)), "bf16x3: unit confidences at K <= 64");
+  static_assert(!BF16X3 || ((T == 4 || T == 8) && (MODE == 1 ? SOLVER == 1 : UNIT)),
+                "bf16x3: unit confidences at 48 < K <= 64 and 64 < K <= 128");
   static_assert(!RESID || (SOLVER == 0 && T <= 4 && !BF16X3), "the gradient form: Cholesky at K <= 64");
   constexpr int WAVES = SOLVE_WAVES;
   using G = Geo<T>;
@@ -1165,7 +1182,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
       if constexpr (RESID) resid_add_step<T>(p.target + static_cast<size_t>(task.row) * G::KP, xr);
     }
     else if constexpr (T == 8)
-      solve_row_cg128<T>(acc, bsum, p.reg[task.row], sm,
+      solve_row_cg128<T, LOWER>(acc, bsum, p.reg[task.row], sm,
                          p.target + static_cast<size_t>(task.row) * G::KP, p.K, nnz_cg,
                          p.max_cg_steps, p.warm_start, p.err_flag);
     else
@@ -1215,7 +1232,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && SOLVER == 1) ? 1 : (T <
       if constexpr (RESID) resid_add_step<T>(p.target + static_cast<size_t>(sr.row) * G::KP, xr);
     }
     else if constexpr (T == 8)
-      solve_row_cg128<T>(acc, bsum, p.reg[sr.row], sm,
+      solve_row_cg128<T, LOWER>(acc, bsum, p.reg[sr.row], sm,
                          p.target + static_cast<size_t>(sr.row) * G::KP, p.K, sr.nnz,
                          p.max_cg_steps, p.warm_start, p.err_flag);
     else

@@ -66,7 +66,8 @@ def matrices():
 
 @pytest.mark.parametrize("case", IALS_CASES, ids=lambda c: "+".join(c))
 @pytest.mark.parametrize("K,kind,data", [(64, "CHOLESKY", "binary"), (64, "CG", "weighted"), (48, "IALSPP", "binary"),
-                                         (128, "CHOLESKY", "weighted"), (128, "CG", "binary"), (128, "IALSPP", "weighted"),
+                                         (128, "CHOLESKY", "weighted"), (128, "CHOLESKY", "binary"), (128, "CG", "binary"),
+                                         (128, "IALSPP", "weighted"),
                                          (200, "CHOLESKY", "binary"), (200, "CG", "weighted")])
 def test_ials_switches_alone_and_in_pairs(matrices, monkeypatch, case, K, kind, data):
     for name in case:
