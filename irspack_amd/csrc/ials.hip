@@ -909,7 +909,7 @@ void launch_ialspp(irs_ials_trainer *t, Side &sd, const float *other, float *tar
 //   IRSPACK_AMD_IALS_UNIT=0     keeps binary interactions on the general rank-update code
 //   IRSPACK_AMD_IALS_SHORT=0    sends the short rows of a CG step through the general kernels
 //   IRSPACK_AMD_IALS_WG16=0     Cholesky at K > 64 on the first-generation kernels (4-row panels)
-//   IRSPACK_AMD_IALS_BF16X3=0   binary interactions, Cholesky, 48 < K <= 64: the rank update back on the
+//   IRSPACK_AMD_IALS_BF16X3=0   binary interactions, Cholesky and CG, 48 < K <= 128: the rank update back on the
 //                               fp32-input matrix instruction.  Default (round 6): the bf16 matrix cores
 //                               on exact three-way splits of the fp32 values, six fp32-exact partial
 //                               products per product, fp32 accumulate (syrk_gather_bf16x3, ials_kernels.hpp)
