@@ -691,6 +691,30 @@ def knn_leg(X, ceilings):
         del rec
     out["learn"] = learn
     out["learn_wall_s"] = learn["NONE"]["learn_wall_s"]
+    # ... and the model EVALUATED: Evaluator(test).get_score(model) for the item-kNN model fitted on the 80 %
+    # training entries, nDCG@20 over all users on the 20 % hold-out.  The model scores as X_train[u] @ W: the
+    # fused path forms that block on the device (scipy's per-entry order and rounding: the host product bit for
+    # bit), masks and ranks it there; `block_loop` is the reference-shaped loop (the model's own
+    # get_score_block through scipy, 128 users at a time, uploaded and ranked) on the first 4096 users.
+    from irspack_amd.evaluation import Evaluator
+
+    gt, train = holdout(X)
+    rec = CosineKNNRecommender(train, shrinkage=0.0, normalize=True, top_k=100).learn()
+    ev = Evaluator(gt, cutoff=20, target_metric="ndcg")
+    ws = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ndcg = ev.get_score(rec)["ndcg"]
+        ws.append(time.perf_counter() - t0)
+    n_loop = min(4096, U)
+    ev_loop = Evaluator(gt[:n_loop], cutoff=20, target_metric="ndcg", fused=False)
+    t0 = time.perf_counter()
+    ndcg_loop = ev_loop.get_score(rec)["ndcg"]
+    loop_s = time.perf_counter() - t0
+    out["evaluate"] = {"workload": f"nDCG@20 of the cosine item-kNN model (top_k = 100) over {U} users, 20 % hold-out",
+                       "wall_s": min(ws), "wall_s_three_calls": ws, "users_per_s": U / min(ws), "ndcg@20": ndcg,
+                       "block_loop": {"users": n_loop, "wall_s": loop_s, "users_per_s": n_loop / loop_s,
+                                      "ndcg@20_first_users": ndcg_loop}}
     return out
 
 

@@ -394,6 +394,25 @@ irs_status irs_eval_get_metrics_masked(irs_evaluator *e, int32_t is_f64, const v
                                        const int64_t *cutoffs, int64_t offset,
                                        int64_t n_threads, int32_t recall_with_cutoff,
                                        irs_metrics *out, int64_t *item_cnt);
+/* Evaluator.get_score(model) for a SIMILARITY model (evaluation/evaluator.py:400-441 with
+ * BaseSimilarityRecommender.get_score_block, recommenders/base.py:406-429: score = X_train[u] @ W), without
+ * the host in the loop: users begin .. end of the model are scored on the device - x_* are the profiles
+ * X [n_model_users, n_profile_cols] as CSR float64, w_* is W [n_profile_cols, n_items] BY ROWS (CSR): the
+ * training matrix and the learnt item-item weights for item-kNN / P3alpha / RP3beta, the learnt user-user
+ * weights and the training matrix for user-kNN (base.py:432-453) - with the per-entry order and rounding of
+ * scipy's row-by-row sparse product (the block is the host product bit for bit), masked (mask_* as in irs_eval_get_metrics_masked: the rows begin .. end only, NULL = no mask) and
+ * ranked once per cutoff; out[c] / item_cnt[c * n_items ..] receive the metrics of cutoffs[c].  `offset`:
+ * ground-truth row of user `begin`. */
+irs_status irs_eval_get_metrics_similarity(irs_evaluator *e, int64_t begin, int64_t end,
+                                           int64_t n_model_users, int64_t n_profile_cols,
+                                           const int64_t *x_indptr,
+                                           const int32_t *x_indices, const double *x_data,
+                                           const int64_t *w_indptr, const int32_t *w_indices,
+                                           const double *w_data, const int64_t *mask_indptr,
+                                           const int32_t *mask_indices, int32_t n_cutoffs,
+                                           const int64_t *cutoffs, int64_t offset,
+                                           int32_t recall_with_cutoff, irs_metrics *out,
+                                           int64_t *item_cnt);
 /* Fused device path used by the Evaluator counterpart when the model is an
  * iALS trainer of this library: scores = user[begin:end] @ item^T (hpp:942-984)
  * are produced, masked (evaluator.py:417-432, mask = CSR rows given here, set

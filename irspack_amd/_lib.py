@@ -146,6 +146,7 @@ EXPORTED_SYMBOLS = [
     "irs_eval_destroy",
     "irs_eval_get_metrics",
     "irs_eval_get_metrics_masked",
+    "irs_eval_get_metrics_similarity",
     "irs_eval_get_metrics_ials",
     "irs_eval_cache_mask",
     "irs_eval_last_stats",

@@ -299,6 +299,43 @@ class EvaluatorCore:
         )
         return Metrics._from_struct(self.n_items, st, cnt)
 
+    def get_metrics_similarity(self, X: sps.csr_matrix, W: Any, begin: int, end: int,
+                               mask: Optional["MaskRows"], mask_begin: int, cutoffs: Sequence[int],
+                               offset: int, recall_with_cutoff: bool = False) -> List[Metrics]:
+        """Device path for SIMILARITY models (not in the reference): users ``[begin, end)`` of the
+        profile matrix ``X`` (the training matrix for item-kNN / P3alpha / RP3beta with ``W`` item x item;
+        the user-user weights for user-kNN with ``W`` = the training matrix) are scored as ``X[u] @ W`` on the device - entry by entry in the order
+        and with the rounding of scipy's sparse product, so the block is ``X[begin:end].dot(W)`` bit
+        for bit -, rows ``mask_begin ..`` of ``mask`` are set to ``-inf`` and the block is ranked
+        once per cutoff: what ``Evaluator`` does per 128-user block with
+        ``model.get_score_block`` (evaluator.py:417-438), without the scores crossing PCIe.
+        ``offset``: ground-truth row of user ``begin``.  One ``Metrics`` per cutoff."""
+        if offset < 0 or any(int(c) < 0 for c in cutoffs):
+            raise TypeError("cutoff / offset must be non-negative (size_t).")
+        Xc, xp, xi, xd = _lib.csr_arrays(X, np.float64)
+        Wc, wp, wi, wd = _lib.csr_arrays(W, np.float64)  # (a CSC matrix is regrouped into rows here)
+        if Wc.shape != (Xc.shape[1], self.n_items):
+            raise ValueError("W must be X.shape[1] x n_items.")
+        rows, nc = end - begin, len(cutoffs)
+        cut = np.asarray([int(c) for c in cutoffs], dtype=np.int64)
+        sts = (MetricsStruct * max(nc, 1))()
+        cnt = np.zeros((max(nc, 1), self.n_items), dtype=np.int64)
+        mp, mi = (None, None) if mask is None else mask.rows(mask_begin, mask_begin + rows)
+        one_i, one_d = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.float64)
+        check(
+            lib().irs_eval_get_metrics_similarity(
+                self._h, C.c_int64(begin), C.c_int64(end), C.c_int64(Xc.shape[0]), C.c_int64(Xc.shape[1]),
+                ptr(xp, C.c_int64),
+                ptr(xi if xi.size else one_i, C.c_int32), ptr(xd if xd.size else one_d, C.c_double),
+                ptr(wp, C.c_int64), ptr(wi if wi.size else one_i, C.c_int32),
+                ptr(wd if wd.size else one_d, C.c_double),
+                None if mp is None else ptr(mp, C.c_int64), None if mi is None else ptr(mi, C.c_int32),
+                C.c_int32(nc), ptr(cut, C.c_int64), C.c_int64(offset),
+                C.c_int32(1 if recall_with_cutoff else 0), sts, ptr(cnt, C.c_int64),
+            )
+        )
+        return [Metrics._from_struct(self.n_items, sts[i], cnt[i]) for i in range(nc)]
+
     def last_call_stats(self) -> dict:
         """What the last ``get_metrics_ials`` call did on the device (measurement only):
         which path ran, how many 64 x 64 score tiles it computed of how many, and the rows it

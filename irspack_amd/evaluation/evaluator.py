@@ -240,6 +240,38 @@ class Evaluator:
             return None
         return trainer if getattr(trainer, "_device", None) == self.core._device else None
 
+    def _similarity_weights(self, model: Any) -> Optional[Any]:
+        """``(profiles, W by rows)`` when the model scores as ``profiles[u] @ W`` with sparse float64
+        operands and nothing overrides its block scores: item-similarity models (``X_train[u] @ W``,
+        base.py:406-429) and user-similarity models (``U[u] @ X_train``, base.py:432-453).  The row form of
+        a CSC operand is kept per model."""
+        from ..recommenders.base import BaseSimilarityRecommender, BaseUserSimilarityRecommender
+
+        if not self.fused:
+            return None
+        if isinstance(model, BaseSimilarityRecommender):
+            if type(model).get_score_block is not BaseSimilarityRecommender.get_score_block:
+                return None  # (a subclass that scores differently goes through its own get_score_block)
+            profiles, W = model.X_train_all, getattr(model, "_W", None)
+        elif isinstance(model, BaseUserSimilarityRecommender):
+            if type(model).get_score_block is not BaseUserSimilarityRecommender.get_score_block:
+                return None
+            profiles, W = getattr(model, "U_", None), model.X_train_all
+        else:
+            return None
+        if W is None or profiles is None or not sps.issparse(W) or not sps.issparse(profiles) or \
+                W.dtype != np.float64 or profiles.dtype != np.float64:
+            return None
+        held = getattr(self, "_sim_rows_held", None)
+        if held is None or held[0] is not W or held[1] is not profiles:
+            rows = []
+            for M in (profiles, W):
+                Mr = M if sps.isspmatrix_csr(M) else sps.csr_matrix(M)
+                Mr.sort_indices()
+                rows.append(Mr)
+            held = self._sim_rows_held = (W, profiles, rows[0], rows[1])
+        return held[2], held[3]
+
     def _window_of_training_matrix(self, model: Any, first: int, last: int) -> Any:
         """rows [first, last) of the model's training matrix as the fused path's mask: the whole
         matrix as it is (no copy, its device copy is reused), a slice kept between calls otherwise
@@ -265,6 +297,18 @@ class Evaluator:
             return [self._with_coverage(self.core.get_metrics_ials(trainer, first, last, mask, c, 0,
                                                                    self.recall_with_cutoff))
                     for c in cutoffs]
+        sim = self._similarity_weights(model)
+        if sim is not None:
+            profiles, W = sim
+            # score = X_train[u] @ W on the device (the host product bit for bit), masked and ranked there:
+            # what the block loop below does per `mb_size` users through scipy and PCIe
+            if self.masked_interactions is None:
+                mask, mask_begin = self._mask_rows(model.X_train_all), first
+            else:
+                mask, mask_begin = self._mask_rows(self.masked_interactions), 0
+            ranked = self.core.get_metrics_similarity(profiles, W, first, last, mask, mask_begin,
+                                                      cutoffs, 0, self.recall_with_cutoff)
+            return [self._with_coverage(m) for m in ranked]
         # blocks are numbered by MODEL user: the ground truth starts at `offset`; an explicit mask is
         # indexed like the ground truth, the training matrix like the model
         if self.masked_interactions is None:

@@ -356,3 +356,91 @@ def test_ials_recommender_cold_paths_through_the_evaluator():
     for (raw, cnt), c in zip(want, [5, 10]):
         assert got[f"ndcg@{c}"] == pytest.approx(raw[4] / max(raw[0], 1), rel=1e-9)
         assert got[f"appeared_item@{c}"] == float((cnt > 0).sum())
+
+
+# ---------------------------------------------------------------- similarity models on the device (round 6)
+def _knn_problem(seed, U=1500, I=700, density=0.03, weighted=False):
+    rns = np.random.RandomState(seed)
+    X = sps.random(U, I, density=density, format="csr", random_state=rns, dtype=np.float64)
+    X.data = rns.uniform(0.5, 3.0, X.nnz) if weighted else np.ones_like(X.data)
+    lil = X.tolil()
+    for r in (0, 7, U - 1):  # users without a profile: every score is 0, ties by item index
+        lil.rows[r], lil.data[r] = [], []
+    X = sps.csr_matrix(lil)
+    X.sort_indices()
+    gt = sps.csr_matrix((rns.rand(U, I) >= 0.985).astype(np.float64))
+    return X, gt
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("kind", ["cosine", "p3alpha", "user_cosine"])
+def test_similarity_models_are_scored_on_the_device(kind, weighted):
+    """``Evaluator.get_scores(model)`` for a similarity model (score = X_train[u] @ W, base.py:406-429):
+    the fused path computes the score block on the device - per column the updates `x * w` in the order of
+    the user's stored profile, product and sum rounded separately: scipy's `csr_matmat` order, so the block is
+    `X[b:e].dot(W)` bit for bit - masks and ranks it there.  Against (a) the block loop through the host
+    (`fused=False`: the model's own `get_score_block`, uploaded and ranked per 128 users) and (b) the oracle's
+    evaluator fed the model's `get_score_remove_seen_block`: counters and item histogram equal, float64
+    sums to 1e-12; several cutoffs, an offset window, an explicit mask, users without a profile, stored zeros
+    in the training matrix (not masked: `mask.nonzero()`)."""
+    from irspack_amd.recommenders import knn as KN
+    from irspack_amd.recommenders.user_knn import CosineUserKNNRecommender
+
+    X, gt = _knn_problem(3 if weighted else 4, weighted=weighted)
+    if weighted:
+        X.data[::11] = 0.0  # stored zeros: part of the profile's pattern, not of the mask
+    if kind == "cosine":
+        model = KN.CosineKNNRecommender(X, shrinkage=1.0, normalize=True, top_k=20, feature_weighting="TF_IDF").learn()
+    elif kind == "p3alpha":
+        model = KN.P3alphaRecommender(X, alpha=0.8, top_k=15).learn()
+    else:
+        model = CosineUserKNNRecommender(X, shrinkage=0.5, top_k=25).learn()
+    cutoffs = [1, 5, 20, 65]
+    keys = ("hit", "recall", "ndcg", "map", "precision")
+    for offset, n in ((0, X.shape[0]), (300, 700)):
+        g = gt[offset:offset + n]
+        for masked in (None, sps.csr_matrix((np.random.RandomState(9).rand(n, X.shape[1]) > 0.9).astype(np.float64))):
+            fused = Evaluator(g, offset=offset, cutoff=10, masked_interactions=masked)
+            plain = Evaluator(g, offset=offset, cutoff=10, masked_interactions=masked, fused=False)
+            got, want = fused.get_scores(model, cutoffs), plain.get_scores(model, cutoffs)
+            assert fused._similarity_weights(model) is not None and plain._similarity_weights(model) is None
+            for c in cutoffs:
+                for k in ("appeared_item", "catalog_coverage"):
+                    assert got[f"{k}@{c}"] == want[f"{k}@{c}"], (k, c, offset)
+                for k in keys + ("entropy", "gini_index"):
+                    assert got[f"{k}@{c}"] == pytest.approx(want[f"{k}@{c}"], rel=1e-12, abs=1e-15), (k, c, offset)
+    # and against the oracle's evaluator on the model's own host scores, all users, no explicit mask
+    ocore = O.EvaluatorCore(gt, [])
+    core = EvaluatorCore(gt, [])
+    profiles, Wr = (model.U, model.X_train_all) if kind == "user_cosine" else (model.X_train_all, sps.csr_matrix(model.W))
+    Wr.sort_indices()
+    got = core.get_metrics_similarity(profiles, Wr, 0, X.shape[0], MaskRows(model.X_train_all, X.shape[1]), 0,
+                                      cutoffs, 0, False)
+    for c, m in zip(cutoffs, got):
+        raw, cnt = np.zeros(7), np.zeros(X.shape[1], dtype=np.int64)
+        for b in range(0, X.shape[0], 256):
+            om = ocore.get_metrics_f64(np.ascontiguousarray(model.get_score_remove_seen_block(b, min(b + 256, X.shape[0]))),
+                                       c, b, 1, False)
+            raw += om.raw()
+            cnt += om.item_cnt()
+        np.testing.assert_array_equal(m.item_cnt, cnt)
+        assert m.valid_user == int(raw[0]) and m.total_user == int(raw[1])
+        for got_v, want_v in ((m.hit, raw[2]), (m.recall, raw[3]), (m.ndcg, raw[4]), (m.precision, raw[5]), (m.map, raw[6])):
+            assert got_v == pytest.approx(want_v, rel=1e-12, abs=1e-15)
+
+
+def test_similarity_path_argument_errors():
+    X, gt = _knn_problem(5, U=200, I=90)
+    core = EvaluatorCore(gt, [])
+    W = sps.identity(90, format="csr", dtype=np.float64)
+    with pytest.raises(ValueError, match="n_items"):
+        core.get_metrics_similarity(X, sps.identity(91, format="csr", dtype=np.float64), 0, 200, None, 0, [5], 0)
+    with pytest.raises(ValueError, match="n_items"):
+        core.get_metrics_similarity(X, sps.csr_matrix((90, 89), dtype=np.float64), 0, 200, None, 0, [5], 0)
+    with pytest.raises(ValueError, match="out of bounds"):
+        core.get_metrics_similarity(X, W, 0, 201, None, 0, [5], 0)
+    with pytest.raises(ValueError, match="cutoff"):
+        core.get_metrics_similarity(X, W, 0, 200, None, 0, [0], 0)
+    # identity W: the scores are the profile itself; unmasked, every user's own items lead the list
+    m = core.get_metrics_similarity(X, W, 0, 200, None, 0, [3], 0)[0]
+    assert m.total_user == 200
