@@ -336,10 +336,6 @@ irs_status irs_comm_create(const void *id256, int32_t rank, int32_t world, int32
     std::memcpy(ids, id256, sizeof(ids));
     IRS_RCCL(api.CommInitRank(&c->rows, world, ids[0], rank));
     IRS_RCCL(api.CommInitRank(&c->gram, world, ids[1], rank));
-    if (const char *e = std::getenv("IRSPACK_AMD_SHARD_EXCHANGE")) {
-      if (e[0] == 'b') c->exchange = IRS_EXCHANGE_BROADCAST;
-      if (e[0] == 'm') c->exchange = IRS_EXCHANGE_MESH;
-    }
     *out = c.release();
   });
 }

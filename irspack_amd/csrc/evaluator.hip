@@ -1657,11 +1657,6 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
     e->stats.tiles_total += total;
     e->stats.tiles_scored += scored;
   }
-  static const bool debug = std::getenv("IRSPACK_AMD_EVAL_DEBUG") != nullptr;
-  if (debug)
-    fprintf(stderr, "eval emit: flags %d, hard rows %d (after the first sample %d) of %lld, tiles scored %.4f\n",
-            bad[0], bad[1], bad[2], static_cast<long long>(rows),
-            static_cast<double>(e->stats.tiles_scored) / static_cast<double>(e->stats.tiles_total));
   // non-finite scores (the two-pass path defines the order of NaN), or so many hard rows that
   // one by one is the slower way: the caller runs the two-pass path
   if (bad[0] || bad[1] > 1024) return false;

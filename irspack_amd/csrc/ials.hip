@@ -69,14 +69,7 @@ static int chunk_size() {
   return v;
 }
 
-static int max_chunks() {
-  static int v = [] {
-    const char *e = std::getenv("IRSPACK_AMD_IALS_MAX_CHUNKS");
-    int c = e ? std::atoi(e) : 256;
-    return std::max(c, 1);
-  }();
-  return v;
-}
+static int max_chunks() { return 256; }
 
 // One CSR orientation resident on the device, with its longest-first task list.
 struct Side {
@@ -979,12 +972,8 @@ bool eig_begin(irs_ials_trainer *t, Side &sd, int pidx, bool cg) {
   // Cholesky saves a dense KP^3 / 3 factorisation per short row, CG only its products with P, and
   // the table product competes with the long rows' kernels beside it.  configs[3], item side
   // (0.8 M short rows, 10^7 gathered rows) on this path: Cholesky epoch 60.2 -> 52.1 ms, CG epoch
-  // 48.8 -> 50.9 ms.  IRSPACK_AMD_IALS_EIG_RATIO overrides both thresholds.
-  static const double ratio_env = [] {
-    const char *e = std::getenv("IRSPACK_AMD_IALS_EIG_RATIO");
-    return e ? std::atof(e) : 0.0;
-  }();
-  const double ratio = ratio_env > 0.0 ? ratio_env : (cg ? 64.0 : 8.0);
+  // 48.8 -> 50.9 ms.
+  const double ratio = cg ? 64.0 : 8.0;
   if (static_cast<double>(sd.n_short) * KP < ratio * static_cast<double>(sd.n_other)) return false;
   if (!t->stream2) {
     IRS_HIP(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
@@ -1025,9 +1014,6 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
   IRS_HIP(hipMemcpyAsync(t->eig_stats_host, t->eig_stats.ptr, 3 * sizeof(float), hipMemcpyDeviceToHost, s2));
   IRS_HIP(hipStreamSynchronize(s2));
   const float *st = t->eig_stats_host;
-  if (env_flag("IRSPACK_AMD_EIG_DEBUG", false))
-    std::fprintf(stderr, "eig: side %d lambda [%g, %g] sweeps %g reg_min %g n_short %d\n", pidx, st[1], st[0],
-                 st[2], sd.reg_min, sd.n_short);
   // M = P + reg_r I must be well conditioned for EVERY row: float32 carries Q and 1 / (lambda + reg)
   const double lo = std::max(0.0, static_cast<double>(st[1])) + sd.reg_min;
   const double hi = static_cast<double>(st[0]) + sd.reg_min;
@@ -1091,7 +1077,7 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
                          : (pidx == 0 ? "ials_short_cholesky_user" : "ials_short_cholesky_item");
   // the list is longest first: [17..32 entries | 9..16 entries | <= 8 entries]
   const int32_t n32 = sd.n_short - sd.n_short16;
-  static const bool rows8 = env_flag("IRSPACK_AMD_IALS_EIG8", true);  // A/B: the 8-entry forms
+  constexpr bool rows8 = true;  // (the 8-entry forms: four waves per SIMD for the tail of the list)
   const int32_t n16 = sd.n_short - (rows8 ? sd.n_short8 : 0);         // rows before the <= 8 class
   for (int32_t b0 = 0; b0 < sd.n_short; b0 += B) {
     const int32_t m = std::min(B, sd.n_short - b0);
@@ -1113,7 +1099,7 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
       q.xt = xt + static_cast<size_t>(off) * KP;
       hipLaunchKernelGGL(kernel, dim3(ceil_div(cnt, rows_per_block)), dim3(256), lds, sb, q);
     };
-    static const bool rows16 = env_flag("IRSPACK_AMD_IALS_EIG16", true);  // A/B: one row per wave everywhere
+    constexpr bool rows16 = true;  // (four rows of <= 16 entries per wave)
     if (cg) {
       t->prof.begin("eig_rotate", sb);
       rotate(target, tasks, xt, nullptr, t->eig_Qrows.ptr, m);  // x~0 = Q^T x0
@@ -1139,7 +1125,7 @@ bool eig_finish(irs_ials_trainer *t, Side &sd, const float *other, float *target
       // 17..32 entries: the MFMA kernel (one row per wave) by default; the 32-lanes-per-row form of
       // the register kernel is slower for Cholesky (its n x n factorisation is n^2 / 2 lane
       // broadcasts: configs[3] epoch 69 -> 77 ms) although it is the faster one for CG (68 -> 63)
-      static const bool rows32 = env_flag("IRSPACK_AMD_IALS_EIG32", false);
+      constexpr bool rows32 = false;
       if (KP == 128) {
         if (rows16 && rows32) part(ials_wb_eig16_kernel<128, 32>, 0, m2, 8, 0);
         else part(ials_wb_short_kernel<128, 2>, 0, m2, 4, lds2);

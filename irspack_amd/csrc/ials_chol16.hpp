@@ -189,7 +189,7 @@ __device__ __forceinline__ void solve_row_cholesky16(f32x4 (&acc)[Geo<T>::NT], c
                                                      float reg, float *sm, float *xrow, int K,
                                                      int32_t *err_flag) {
   using C = Chol16Geo<T>;
-  constexpr int KP = C::KP, WS = C::WS;
+  constexpr int WS = C::WS;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, m = lane & 15;
   float *pan = sm + C::PAN, *wt = sm + C::WT, *scr = sm + C::SCR, *zx = sm + C::ZX;
