@@ -1513,7 +1513,9 @@ void launch_solve(irs_ials_trainer *t, Side &sd, const float *other, float *targ
       if (n_regular > 0) {
         const dim3 grid(ceil_div(n_regular, SOLVE_WAVES)), block(64 * SOLVE_WAVES);
         const char *name = kNames[cg][0][pidx];
-        if (pp_direct && unit)
+        if (pp_direct && unit && t->opt_bf16x3 && TT == 4)  // (the gradient form on the bf16x3 rank update, round 6)
+          t->prof.launch(name, ials_solve_kernel<4, 0, 0, true, true, true>, grid, block, 0, t->stream, p);
+        else if (pp_direct && unit)
           t->prof.launch(name, ials_solve_kernel<TT, 0, 0, true, false, true>, grid, block, 0, t->stream, p);
         else if (pp_direct)
           t->prof.launch(name, ials_solve_kernel<TT, 0, 0, false, false, true>, grid, block, 0, t->stream, p);

@@ -501,11 +501,15 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_b
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2_t));
 }
 
-template <int T>
+// RESID (the one-block iALS++ sweep, see syrk_gather_impl): the right-hand side is the negative gradient at
+// the current row `xr`, built from the predictions d_q = v_q . x - from the gathered fp32 values, before
+// they are split: sum_q ((bias + 1) - d_q) v_q; the 16 lanes of a group share the group's eight entries, so
+// a prediction is T multiply-adds and one 16-lane DPP sum.
+template <int T, bool RESID = false>
 __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ other,
                                                    const int32_t *__restrict__ indices, int begin,
                                                    int end, float bias, f32x4 (&acc)[Geo<T>::NT],
-                                                   float (&bsum)[T], unsigned zero_row) {
+                                                   float (&bsum)[T], unsigned zero_row, const float (&xr)[T]) {
   static_assert(T == 4 || T == 8, "dims per lane = one or two 16 B loads");
   constexpr int KP = Geo<T>::KP;
   constexpr int V4 = T / 4;  // 16-byte loads per lane and entry
@@ -539,12 +543,23 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
   };
   auto consume = [&](int slot) {
     u32x4_t hi[T], mid[T], lo[T];
+    float w8[RESID ? 8 : 1];
+    if constexpr (RESID) {
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        float d = 0.f;  // the prediction v_q . x (hpp:455-457); a zero row (past the row's end) predicts 0 and adds 0
+#pragma unroll
+        for (int dd = 0; dd < T; dd++) d = fmaf(raw[slot][kk][dd >> 2][dd & 3], xr[dd], d);
+        w8[kk] = (bias + 1.0f) - row16_sum(d);
+      }
+    }
 #pragma unroll
     for (int d = 0; d < T; d++) {
 #pragma unroll
       for (int pp = 0; pp < 4; pp++) {
         const float x0 = raw[slot][2 * pp][d >> 2][d & 3], x1 = raw[slot][2 * pp + 1][d >> 2][d & 3];
-        bsum[d] += x0 + x1;
+        if constexpr (RESID) bsum[d] = fmaf(w8[2 * pp + 1], x1, fmaf(w8[2 * pp], x0, bsum[d]));
+        else bsum[d] += x0 + x1;
         const unsigned h = pack_bf16(x0, x1);
         const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
         const unsigned mi = pack_bf16(r0, r1);
@@ -601,7 +616,7 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
   for (int i = 0; i < T; i++) {
     bsum[i] += __shfl_xor(bsum[i], 16, 64);
     bsum[i] += __shfl_xor(bsum[i], 32, 64);
-    bsum[i] *= bias + 1.0f;
+    if constexpr (!RESID) bsum[i] *= bias + 1.0f;
   }
 }
 
@@ -1119,7 +1134,7 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && (SOLVER == 1 || BF16X3)
   // partials and the Gramian are lower-form tiles")
   static_assert(!BF16X3 || ((T == 4 || T == 8) && (MODE == 1 ? SOLVER == 1 : UNIT)),
                 "bf16x3: unit confidences at 48 < K <= 64 and 64 < K <= 128");
-  static_assert(!RESID || (SOLVER == 0 && T <= 4 && !BF16X3), "the gradient form: Cholesky at K <= 64");
+  static_assert(!RESID || (SOLVER == 0 && T <= 4), "the gradient form: Cholesky at K <= 64");
   constexpr int WAVES = SOLVE_WAVES;
   using G = Geo<T>;
   // Cholesky: lower-form tiles + the 16-row block solve of ials_chol16.hpp
@@ -1155,8 +1170,8 @@ __global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && (SOLVER == 1 || BF16X3)
     float xr[T] = {};
     if constexpr (RESID) load_dims<T>(p.target + static_cast<size_t>(task.row) * G::KP + T * (lane & 15), xr);
     if constexpr (BF16X3)
-      syrk_gather_bf16x3<T>(p.other, p.indices, task.begin, task.end, p.bias, acc, bsum,
-                            static_cast<unsigned>(p.zero_row));
+      syrk_gather_bf16x3<T, RESID>(p.other, p.indices, task.begin, task.end, p.bias, acc, bsum,
+                                   static_cast<unsigned>(p.zero_row), xr);
     else
       syrk_gather_impl<T, 1, 0, RING, UNIT, LOWER, RESID>(p.other, p.indices, p.data, task.begin, task.end, p.bias,
                                                           acc, bsum, static_cast<unsigned>(p.zero_row), xr);
