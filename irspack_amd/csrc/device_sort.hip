@@ -67,7 +67,8 @@ static void transpose_csr_device_impl(const int32_t *indptr, const int32_t *indi
   auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
   const size_t o_cnt = 0, o_keys = o_cnt + up(static_cast<size_t>(cols) * 4), o_perm = o_keys + up(n * 4),
                o_sort = o_perm + up(n * 4);
-  tmp.alloc(o_sort + sort_bytes);
+  // (a caller's view that is large enough - scratch carved out of an arena - is used as it is)
+  if (!tmp.ptr || tmp.count < o_sort + sort_bytes) tmp.alloc(o_sort + sort_bytes);
   int32_t *d_cnt = reinterpret_cast<int32_t *>(tmp.ptr + o_cnt);
   int32_t *d_keys = reinterpret_cast<int32_t *>(tmp.ptr + o_keys);
   int32_t *d_perm = reinterpret_cast<int32_t *>(tmp.ptr + o_perm);

@@ -2955,37 +2955,68 @@ irs_status irs_knn_fetch_csc(irs_knn_computer *c, int64_t zero_diagonal_row0, in
     check_arg(nnz < (int64_t(1) << 31), "nnz must be below 2^31.");
     IRS_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;  // (idle: the compute call that made the result has returned)
+    // Scratch out of the compute call's arena: its merged-row buffers (out_idx / out_val, sized like the result)
+    // and the target's column indices (t_idx: tens of MB) are dead once the call has returned - five hipMalloc /
+    // hipFree pairs per learn() were 4 of this call's 13 ms.
+    irs_knn_computer::Scratch &sc = c->scratch;
+    const bool arena = sc.out_idx.ptr && sc.out_idx.count >= static_cast<size_t>(nnz) &&
+                       sc.out_val.count >= static_cast<size_t>(nnz) && sc.t_idx.ptr;
+    DeviceBuffer<int32_t> own_tidx, d_rp, d_cp;
+    DeviceBuffer<double> own_tval;
+    DeviceBuffer<char> tmp;
+    int32_t *t_idx = nullptr;
+    double *t_val = nullptr;
+    if (arena) {
+      t_idx = sc.out_idx.ptr;
+      t_val = sc.out_val.ptr;
+      tmp.view(sc.t_idx.ptr, sc.t_idx.count * sizeof(int32_t));
+    } else {
+      own_tidx.alloc(static_cast<size_t>(nnz));
+      own_tval.alloc(static_cast<size_t>(nnz));
+      t_idx = own_tidx.ptr;
+      t_val = own_tval.ptr;
+    }
     std::vector<int32_t> rp(static_cast<size_t>(n) + 1);
     for (int64_t i = 0; i <= n; i++) rp[i] = static_cast<int32_t>(c->res_ptr[i]);
-    DeviceBuffer<int32_t> d_rp, d_tidx, d_cp;
-    DeviceBuffer<double> d_tval;
-    DeviceBuffer<char> tmp;
     d_rp.upload(rp, s);
-    d_tidx.alloc(static_cast<size_t>(nnz));
-    d_tval.alloc(static_cast<size_t>(nnz));
     std::vector<int32_t> t_count;
-    transpose_csr_device(d_rp.ptr, c->res_idx.ptr, static_cast<const double *>(c->res_val.ptr), n, N, nnz, d_tidx.ptr,
-                         d_tval.ptr, t_count, tmp, s);
+    transpose_csr_device(d_rp.ptr, c->res_idx.ptr, static_cast<const double *>(c->res_val.ptr), n, N, nnz, t_idx, t_val,
+                         t_count, tmp, s);
     for (int64_t j = 0; j < N; j++) col_ptr[j + 1] = col_ptr[j] + t_count[j];
     if (zero_diagonal_row0 >= 0) {
       std::vector<int32_t> cp(static_cast<size_t>(N) + 1);
       for (int64_t j = 0; j <= N; j++) cp[j] = static_cast<int32_t>(col_ptr[j]);
       d_cp.upload(cp, s);
       hipLaunchKernelGGL(knn_zero_diagonal_csc_kernel, dim3(static_cast<unsigned>(ceil_div(N, 256))), dim3(256), 0, s,
-                         static_cast<const int32_t *>(d_cp.ptr), static_cast<const int32_t *>(d_tidx.ptr), N,
-                         zero_diagonal_row0, d_tval.ptr);
+                         static_cast<const int32_t *>(d_cp.ptr), static_cast<const int32_t *>(t_idx), N,
+                         zero_diagonal_row0, t_val);
       IRS_HIP(hipGetLastError());
       IRS_HIP(hipStreamSynchronize(s));  // (cp goes out of scope)
     }
-    // into the caller's pageable arrays: a few copies side by side (see irs_knn_weight)
+    // To the caller's (pageable, usually untouched) arrays: through the computer's page-locked staging buffer
+    // when it has one of the size (one copy at the link's rate + a threaded host copy; the staged CSR copy of the
+    // result is gone afterwards), else a few device-to-host copies side by side (see irs_knn_weight).
+    const size_t need = static_cast<size_t>(nnz) * (sizeof(double) + sizeof(int32_t));
+    if (c->stage && c->stage_bytes >= need) {
+      c->staged = false;
+      char *sv = c->stage, *si = c->stage + static_cast<size_t>(nnz) * sizeof(double);
+      IRS_HIP(hipMemcpyAsync(sv, t_val, static_cast<size_t>(nnz) * sizeof(double), hipMemcpyDeviceToHost, s));
+      IRS_HIP(hipMemcpyAsync(si, t_idx, static_cast<size_t>(nnz) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      IRS_HIP(hipStreamSynchronize(s));
+      parallel_ranges(nnz, [&](int64_t lo, int64_t hi) {
+        std::memcpy(data + lo, reinterpret_cast<const double *>(sv) + lo, static_cast<size_t>(hi - lo) * sizeof(double));
+        std::memcpy(row_idx + lo, reinterpret_cast<const int32_t *>(si) + lo, static_cast<size_t>(hi - lo) * sizeof(int32_t));
+      }, 8, 200000);
+      return;
+    }
     const int n_copy = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(4, nnz / (int64_t(1) << 20))));
     std::atomic<int> failed(0);
     run_on_threads(n_copy, [&](int k) {
       const int64_t q0 = nnz * k / n_copy, q1 = nnz * (k + 1) / n_copy;
       if (q1 <= q0) return;
       if (hipSetDevice(c->device) != hipSuccess ||
-          hipMemcpy(data + q0, d_tval.ptr + q0, static_cast<size_t>(q1 - q0) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
-          hipMemcpy(row_idx + q0, d_tidx.ptr + q0, static_cast<size_t>(q1 - q0) * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+          hipMemcpy(data + q0, t_val + q0, static_cast<size_t>(q1 - q0) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(row_idx + q0, t_idx + q0, static_cast<size_t>(q1 - q0) * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
         failed.store(1);
     });
     if (failed.load()) throw std::runtime_error("copying the result to the host failed.");
