@@ -400,6 +400,54 @@ def test_ials_k320_ml20m_general_size_kernels_vs_oracle(X20, X20t, kind):
                           test="test_ials_k320_ml20m_general_size_kernels_vs_oracle")
 
 
+@pytest.mark.parametrize("scheme", ["NONE", "TF_IDF", "BM_25"])
+def test_knn_recommender_learn_ml20m_vs_oracle(X20, X20t, scheme):
+    """`CosineKNNRecommender(X, feature_weighting=...).learn()` END TO END at benchmark size - what bench.py's
+    `knn.learn` legs time: X.T handed over as the CSC view it is, the weighting fused into the construction
+    (binary interactions: row factor x column scale), the target's columns regrouped inside the
+    call, the result regrouped to CSC with its diagonal zeroed on the device - against the oracle's pipeline
+    (util.hpp weighting -> KNNComputer on X_w^T -> top-100 of X^T -> remove_diagonal) on EVERY one of the 26,744
+    rows: same row lengths; unweighted: indices bit-exact, values 1e-12; weighted: indices equal except between
+    candidates whose values agree to 1e-11 (ties in exact arithmetic: DESIGN 3.4; achieved: every index equal),
+    values to 1e-11 - the ORACLE's sum of n individually rounded weights, added one by one in float64, carries
+    up to n 2^-53 of rounding (n up to 116,199 co-occurrences here: 1.3e-11; achieved 2.0e-12), where the device
+    value is count x idf_j rounded once (tf-idf) or an exact fixed-point sum (BM25)."""
+    from irspack_amd.recommenders.knn import CosineKNNRecommender
+
+    X64 = sps.csr_matrix(X20, dtype=np.float64)
+    rec = CosineKNNRecommender(X64, shrinkage=0.0, normalize=True, top_k=100, feature_weighting=scheme).learn()
+    got = sps.csr_matrix(rec.W)  # rows = target items (W = S with its diagonal zeroed)
+    got.sort_indices()
+    Xw = {"NONE": lambda m: m, "TF_IDF": O.tf_idf_weight, "BM_25": lambda m: O.okapi_BM_25_weight(m, 1.2, 0.75)}[scheme](X64)
+    Xwt = sps.csr_matrix(Xw.T)
+    Xwt.sort_indices()
+    Xt = sps.csr_matrix(X20t, dtype=np.float64)
+    want = O.remove_diagonal(O.KNNComputer("cosine", Xwt, 0.0, normalize=True, n_threads=CORES, max_chunk_size=4)
+                             .compute_similarity(Xt, 100))
+    want = sps.csr_matrix(want)
+    want.sort_indices()
+    assert np.array_equal(got.indptr, want.indptr)
+    n_diff_rows, worst = 0, 0.0
+    for r in range(got.shape[0]):
+        sl = slice(got.indptr[r], got.indptr[r + 1])
+        gi, wi, gv, wv = got.indices[sl], want.indices[sl], got.data[sl], want.data[sl]
+        if np.array_equal(gi, wi):
+            err = np.abs(gv - wv) / np.maximum(np.abs(wv), 1e-300)
+            worst = max(worst, float(err.max(initial=0.0)))
+            continue
+        n_diff_rows += 1
+        assert scheme != "NONE", r  # counts: bit-exact top-k sets
+        np.testing.assert_allclose(np.sort(gv), np.sort(wv), rtol=1e-11, atol=0)
+        allv = np.concatenate([gv, wv])
+        for j in np.setxor1d(gi, wi):
+            v = gv[gi == j][0] if j in gi else wv[wi == j][0]
+            assert np.sum(np.abs(allv - v) <= 1e-11 * max(abs(v), 1e-300)) >= 3, (r, int(j), float(v))
+    record_parity("test_knn_recommender_learn_ml20m_vs_oracle", f"ml20m CosineKNNRecommender.learn() weighting={scheme}, all rows",
+                  n_rows=int(got.shape[0]), rows_with_tie_order_differences=int(n_diff_rows),
+                  worst_value_rel_err=worst, indices_bit_exact=bool(n_diff_rows == 0))
+    assert worst <= (1e-12 if scheme == "NONE" else 1e-11)
+
+
 @pytest.fixture(scope="module")
 def XC4():
     """BASELINE configs[3], the FULL matrix: 10 M users x 1 M items, 95 M stored entries
