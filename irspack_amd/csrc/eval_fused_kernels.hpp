@@ -99,6 +99,7 @@ struct EmitParams {
   // + wg_desc[b].z - 1 (at most four) of user tile wg_desc[b].x - one 16-byte load instead of
   // a chain of three (only workgroups with a live tile are launched)
   const int4 *wg_desc;
+  const int32_t *n_wg;  // length of the work list (device side), or null: one entry per workgroup of the grid
   // rows the path cannot finish (no threshold from the sample, candidate list overflow): set
   // to 1 here, ranked one by one from their full score rows afterwards
   int32_t *hard;
@@ -177,13 +178,185 @@ __global__ __launch_bounds__(256) void sample_tau_kernel(const float *__restrict
   }
 }
 
+// The sample pass in ONE launch (round 6; bounded variant, 512 sample items, K <= 128): scores, mask and
+// the cutoff-th best per user without the [users, 512] score block in memory (three launches per 32,768
+// users before: user_scores_kernel, mask_entries_perm_kernel, sample_tau_kernel - 0.58 of the call's 1.5 ms).
+// A 512-thread workgroup stays resident and walks tiles of 16 users.  Wave w holds the operands of the
+// sample items 64 w .. 64 w + 63 in REGISTERS for the whole launch; per tile it scores 16 users x its 64
+// items (the MFMA sequence of user_scores_kernel: same bits), writes them to the tile's LDS slab (two
+// slabs, so one barrier per tile), and after the barrier owns the users 2 w, 2 w + 1 of the tile: lane l
+// takes the scores l, l + 64, ..., the user's mask entries that fall into the sample were marked in a
+// 512-byte LDS row by the same wave before the MFMAs (mask CSR -> sorted position through `iinv`), and the
+// cutoff-th largest is found EXACTLY by a bit-by-bit search on order-preserving keys (32 steps of eight
+// compares + ballot counts on the scalar unit) - the value sample_tau_kernel finds by popping heads.
+struct SampleParams {
+  const float *user;        // factors of the call's side; row r of the call = user + (begin + r) * KP
+  const float *sample;      // [512, KP]: the sample items, sorted position order
+  int64_t begin, rows;
+  const int64_t *mask_ptr;  // mask CSR of the call's rows, or null
+  const int32_t *mask_idx;
+  const int32_t *iinv;      // item id -> sorted position
+  int32_t cutoff;
+  float *tau;               // [rows]
+  int32_t *hard;            // [rows]
+  int32_t *bad_flag;        // bit 0: non-finite score
+};
+constexpr int SF_ITEMS = 512, SF_USERS = 16, SF_SROW = 516;  // (516: rows 4 apart land 16 banks apart)
+constexpr size_t SF_LDS_BYTES = 2 * SF_USERS * SF_SROW * sizeof(float) + 8 * 2 * SF_ITEMS;
+
+__device__ __forceinline__ uint32_t sf_key(float v) {  // order-preserving: a < b <=> key(a) < key(b)
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+template <int KP>
+__global__ __launch_bounds__(512, KP <= 64 ? 4 : 2) void sample_tau_fused_kernel(SampleParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+  float *slab = reinterpret_cast<float *>(sf_smem);
+  const int wid = wave_index_in_block(), ln = threadIdx.x & 63;
+  const int g = ln >> 4, m = ln & 15;
+  unsigned char *mk = sf_smem + 2 * SF_USERS * SF_SROW * sizeof(float) + wid * (2 * SF_ITEMS);
+  constexpr int NJ = KP / 16;
+  const float NEG_INF = -std::numeric_limits<float>::infinity();
+  // B operands: item 64 wid + 16 bb + m, dims 16 j + 4 g .. + 3
+  fz_f32x4 bv[4][NJ];
+#pragma unroll
+  for (int bb = 0; bb < 4; bb++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+      bv[bb][j] = *reinterpret_cast<const fz_f32x4 *>(p.sample + static_cast<size_t>(64 * wid + 16 * bb + m) * KP + 16 * j + 4 * g);
+  const int64_t n_tiles = (p.rows + SF_USERS - 1) / SF_USERS;
+  int buf = 0;
+  int64_t nq[3] = {0, 0, 0};  // mask row bounds of this wave's two users in the NEXT tile
+  if (p.mask_ptr) {
+    const int64_t nr = static_cast<int64_t>(blockIdx.x) * SF_USERS + 2 * wid;
+#pragma unroll
+    for (int u = 0; u < 3; u++) nq[u] = p.mask_ptr[min(nr + u, p.rows)];
+  }
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+    const int64_t r0 = tile * SF_USERS;
+    // A operands: user r0 + m, dims 16 j + 4 g .. + 3 (the eight waves load the same 16 rows)
+    fz_f32x4 av[NJ];
+    {
+      const float *up = p.user + (p.begin + min(r0 + m, p.rows - 1)) * KP + 4 * g;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) av[j] = *reinterpret_cast<const fz_f32x4 *>(up + 16 * j);
+    }
+    // this wave's two users: mark the sample positions their mask holds.  The walk is a chain of dependent
+    // loads (row bounds -> item ids -> sorted positions -> LDS byte); the bounds were fetched one tile
+    // ahead, and the first MK_AHEAD x 64 entries of both rows are requested HERE, before the MFMAs, with
+    // clamped addresses (no load under a branch), so the chain costs two round trips per tile, not eight.
+    constexpr int MK_AHEAD = 3;
+    int32_t mid[2][MK_AHEAD];
+    int64_t mq0[2] = {0, 0}, mq1[2] = {0, 0};
+    if (p.mask_ptr) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        mq0[u] = nq[u];
+        mq1[u] = nq[u + 1];
+      }
+      // (the next tile's bounds: rows past the end repeat the last pointer = empty rows)
+      const int64_t nr = (tile + gridDim.x) * SF_USERS + 2 * wid;
+#pragma unroll
+      for (int u = 0; u < 3; u++) nq[u] = p.mask_ptr[min(nr + u, p.rows)];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int k = 0; k < MK_AHEAD; k++) {
+          const int64_t q = mq0[u] + 64 * k + ln;
+          mid[u][k] = p.mask_idx[max(min(q, mq1[u] - 1), static_cast<int64_t>(0))];
+        }
+    }
+    fz_f32x4 acc[4];
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) acc[bb] = fz_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int bb = 0; bb < 4; bb++)
+          acc[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][c], bv[bb][j][c], acc[bb], 0, 0, 0);
+    float *S = slab + buf * (SF_USERS * SF_SROW);
+    // acc[bb][r] of lane (g, m): user 4 g + r, item 64 wid + 16 bb + m
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) S[(4 * g + r) * SF_SROW + 64 * wid + 16 * bb + m] = acc[bb][r];
+    if (p.mask_ptr) {
+      reinterpret_cast<uint64_t *>(mk)[ln] = 0ull;
+      reinterpret_cast<uint64_t *>(mk)[64 + ln] = 0ull;
+      int32_t pos[2][MK_AHEAD];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int k = 0; k < MK_AHEAD; k++)  // (an id fetched past the row's end is not an address)
+          pos[u][k] = p.iinv[mq0[u] + 64 * k + ln < mq1[u] ? mid[u][k] : 0];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+#pragma unroll
+        for (int k = 0; k < MK_AHEAD; k++)
+          if (mq0[u] + 64 * k + ln < mq1[u] && pos[u][k] < SF_ITEMS) mk[SF_ITEMS * u + pos[u][k]] = 1;
+        // rows longer than MK_AHEAD x 64 entries (wave-uniform trip count)
+        for (int64_t q = mq0[u] + 64 * MK_AHEAD + ln; q - ln < mq1[u]; q += 64) {
+          const int32_t ps = p.iinv[p.mask_idx[min(q, mq1[u] - 1)]];
+          if (q < mq1[u] && ps < SF_ITEMS) mk[SF_ITEMS * u + ps] = 1;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the two users of this wave: lane l holds the scores l + 64 q
+    uint32_t key[2][8];
+    int n_rank[2];
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const float *srow = S + (2 * wid + u) * SF_SROW + ln;
+      n_rank[u] = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        float v = srow[64 * q];
+        if (p.mask_ptr && mk[SF_ITEMS * u + 64 * q + ln]) v = NEG_INF;
+        bad |= v != v || v == std::numeric_limits<float>::infinity();
+        n_rank[u] += __popcll(__ballot(v != NEG_INF));
+        key[u][q] = sf_key(v);
+      }
+    }
+    if (__any(bad && r0 + 2 * wid < p.rows)) {
+      if (ln == 0) atomicOr(p.bad_flag, 1);
+    }
+    // the cutoff-th largest key, bit by bit from the top (both users in step: independent chains)
+    uint32_t t[2] = {0u, 0u};
+    for (int bit = 31; bit >= 0; bit--) {
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint32_t cand = t[u] | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) cnt += __popcll(__ballot(key[u][q] >= cand));
+        if (cnt >= p.cutoff) t[u] = cand;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int64_t row = r0 + 2 * wid + u;
+      if (row < p.rows && ln == 0) {
+        const bool ok = n_rank[u] >= p.cutoff;
+        const uint32_t b = (t[u] & 0x80000000u) ? (t[u] & 0x7fffffffu) : ~t[u];
+        p.hard[row] = ok ? 0 : 1;
+        // too few rankable sample items for a threshold: +inf (as sample_tau_kernel)
+        p.tau[row] = ok ? __uint_as_float(b) : std::numeric_limits<float>::infinity();
+      }
+    }
+  }
+}
+
 // BOUNDED: users and items are addressed through the two sort permutations (tile rows = 64
 // users of similar pruning radius, tile columns = 64 items of similar norm), tiles at or beyond
 // the user tile's limit leave at once, and the mask is probed per passing score (the bitmap is
 // indexed by item id, not by sorted position).
 template <int KP, bool BOUNDED>
-__global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
+__device__ __forceinline__ void score_emit_body(const EmitParams &p, unsigned char *em_smem, const int64_t bidx) {
   const int wid = wave_index_in_block(), ln = threadIdx.x & 63;
   const int g = ln >> 4, m = ln & 15;
   float *S = reinterpret_cast<float *>(em_smem) + wid * (64 * FZ_SROW);
@@ -191,12 +364,12 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
   const int64_t item_tiles = (p.n_items + 63) / 64;
   int64_t ut, it;
   if constexpr (BOUNDED) {
-    const int4 d = p.wg_desc[blockIdx.x];
+    const int4 d = p.wg_desc[bidx];
     ut = d.x;
     it = static_cast<int64_t>(d.y) + wid;
     if (wid >= d.z) return;
   } else {
-    const int64_t w = static_cast<int64_t>(blockIdx.x) * 4 + wid;
+    const int64_t w = bidx * 4 + wid;
     ut = w / item_tiles;
     it = w % item_tiles;
     if (ut * 64 >= p.rows) return;
@@ -337,6 +510,17 @@ __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
       base++;
     }
   }
+}
+
+// The bounded variant walks the work list with a grid stride: its length (`n_wg`, written by wg_scan_kernel)
+// stays on the device, the host launches a grid that covers any list of the call's size class and the
+// workgroups past the end leave at once - no read-back between the scan and this launch (42 us of an
+// ML-20M call's 1.3 ms).  The waves of a workgroup are independent (no barrier): each walks on its own.
+template <int KP, bool BOUNDED>
+__global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
+  const int64_t n = (BOUNDED && p.n_wg) ? static_cast<int64_t>(*p.n_wg) : static_cast<int64_t>(gridDim.x);
+  for (int64_t b = blockIdx.x; b < n; b += gridDim.x) score_emit_body<KP, BOUNDED>(p, em_smem, b);
 }
 
 

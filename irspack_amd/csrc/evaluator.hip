@@ -1049,8 +1049,42 @@ __global__ __launch_bounds__(1024) void item_hist_kernel(const int32_t *__restri
     if (ids[i] >= 0 && cnt[i] > 0) atomicAdd(&item_cnt[ids[i]], static_cast<unsigned long long>(cnt[i]));
 }
 
-inline void launch_item_hist(const int32_t *rec, int64_t n, unsigned long long *item_cnt, hipStream_t s) {
+// Catalogues whose counters fit one CU's LDS (n_items <= 36,864; ML-20M: 26,744): a direct table per
+// workgroup - one LDS atomic per entry, no tags, no collisions (the hashed table above sends every
+// collision to a hot global address: 109 us for the 2.8 M entries of an ML-20M call, this form 12).
+constexpr int64_t HIST_DIRECT_MAX = 36864;
+__global__ __launch_bounds__(1024) void item_hist_direct_kernel(const int32_t *__restrict__ rec, int64_t n,
+                                                                int32_t n_items,
+                                                                unsigned long long *__restrict__ item_cnt) {
+  extern __shared__ uint32_t hist_cnt[];
+  for (int i = threadIdx.x; i < n_items; i += 1024) hist_cnt[i] = 0u;
+  __syncthreads();
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b = per * blockIdx.x, e = min(b + per, n);
+  for (int64_t i = b + threadIdx.x; i < e; i += 1024) {
+    const int32_t it = rec[i];
+    if (it >= 0 && it < n_items) atomicAdd(&hist_cnt[it], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_items; i += 1024) {
+    const uint32_t c = hist_cnt[i];
+    if (c) atomicAdd(&item_cnt[i], static_cast<unsigned long long>(c));
+  }
+}
+
+inline void launch_item_hist(const int32_t *rec, int64_t n, unsigned long long *item_cnt, hipStream_t s,
+                             int64_t n_items = 0) {
   if (n <= 0) return;
+  if (n_items > 0 && n_items <= HIST_DIRECT_MAX && n >= 65536) {
+    const size_t lds = static_cast<size_t>(n_items) * sizeof(uint32_t);
+    IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(item_hist_direct_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(HIST_DIRECT_MAX * sizeof(uint32_t))));
+    const int64_t grid = std::min<int64_t>(128, (n + 16383) / 16384);
+    hipLaunchKernelGGL(item_hist_direct_kernel, dim3(static_cast<unsigned>(grid)), dim3(1024), lds, s, rec, n,
+                       static_cast<int32_t>(n_items), item_cnt);
+    return;
+  }
   const int64_t grid = std::min<int64_t>(1024, (n + 16383) / 16384);
   hipLaunchKernelGGL(item_hist_kernel, dim3(static_cast<unsigned>(grid)), dim3(1024), 0, s, rec, n, item_cnt);
 }
@@ -1336,7 +1370,7 @@ void rank_block(irs_evaluator *e, const void *d_scores, int64_t rows, int64_t cu
   p.rec_out = e->rec_out.ptr;
   p.item_cnt = e->item_cnt.ptr;
   launch_rank<T>(p, e->n_items, s, e->todo.ptr);
-  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s);
+  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s, e->n_items);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(1024), 0, s, e->row_out.ptr, rows,
                      e->metrics.ptr);
   IRS_HIP(hipGetLastError());
@@ -1375,6 +1409,24 @@ bool ensure_mask_bitmap(irs_evaluator *e, int64_t rows, int64_t words, const int
 // IRSPACK_AMD_EVAL_EMIT=0 switches the threshold-filtered path off (A/B against the two-pass one).
 bool emit_enabled() {
   const char *e = std::getenv("IRSPACK_AMD_EVAL_EMIT");
+  return e ? std::atoi(e) != 0 : true;
+}
+
+int device_cu_count(int device) {
+  static std::atomic<int> cached[64] = {};
+  const int slot = device >= 0 && device < 64 ? device : 0;
+  int n = cached[slot].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    IRS_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+    n = std::max(n, 1);
+    cached[slot].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+// IRSPACK_AMD_EVAL_SAMPLE_FUSED=0: the sample pass as three launches per 32,768 users (round 5).
+bool sample_fused_enabled() {
+  const char *e = std::getenv("IRSPACK_AMD_EVAL_SAMPLE_FUSED");
   return e ? std::atoi(e) != 0 : true;
 }
 
@@ -1492,7 +1544,37 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
     e->fused_scores.alloc(std::max(static_cast<size_t>(std::min(SB, rows)) * n_sample,
                                    static_cast<size_t>(HCAP) * EM_SAMPLE2));
     const int32_t *no_list = nullptr;
-    for (int64_t b = 0; b < rows; b += SB) {
+    // the whole pass in one launch (sample_tau_fused_kernel); IRSPACK_AMD_EVAL_SAMPLE_FUSED=0: the three
+    // launches per block of users below (A/B)
+    const bool fused_sample = bounded && n_sample == SF_ITEMS && (KP == 16 || KP == 32 || KP == 64 || KP == 128) &&
+                              sample_fused_enabled();
+    if (fused_sample) {
+      SampleParams sp{};
+      sp.user = user;
+      sp.sample = e->sample_item.ptr;
+      sp.begin = begin;
+      sp.rows = rows;
+      sp.mask_ptr = d_mptr;
+      sp.mask_idx = d_midx;
+      sp.iinv = e->iinv.ptr;
+      sp.cutoff = static_cast<int32_t>(cutoff);
+      sp.tau = e->tau.ptr;
+      sp.hard = e->hard.ptr;
+      sp.bad_flag = e->bad_flag.ptr;
+      auto launch = [&](auto kernel, int per_cu) {
+        IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(SF_LDS_BYTES)));
+        const int64_t grid = std::min<int64_t>(ceil_div(rows, SF_USERS), int64_t(per_cu) * device_cu_count(dev));
+        hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(512), SF_LDS_BYTES, s, sp);
+      };
+      switch (KP) {
+        case 16: launch(sample_tau_fused_kernel<16>, 2); break;
+        case 32: launch(sample_tau_fused_kernel<32>, 2); break;
+        case 64: launch(sample_tau_fused_kernel<64>, 2); break;
+        default: launch(sample_tau_fused_kernel<128>, 1); break;
+      }
+    }
+    for (int64_t b = fused_sample ? rows : 0; b < rows; b += SB) {
       const int64_t m = std::min(SB, rows - b);
       if (irs_ials_scores_prefix_device_(t, begin + b, begin + b + m, n_sample,
                                          bounded ? e->sample_item.ptr : nullptr, nullptr,
@@ -1556,6 +1638,7 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
   f.bad_flag = e->bad_flag.ptr;
   f.iperm = f.uperm = f.limit_tiles = nullptr;
   f.wg_desc = nullptr;
+  f.n_wg = nullptr;
   f.hard = e->hard.ptr;
   int32_t n_wg = 0;
   if (bounded) {
@@ -1583,9 +1666,19 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
     e->wg_prefix.alloc(n_ut + 1);
     hipLaunchKernelGGL(wg_scan_kernel, dim3(1), dim3(1024), 0, s, e->limit_tiles.ptr, n_ut,
                        e->wg_prefix.ptr, e->bad_flag.ptr + 3);
-    IRS_HIP(hipMemcpyAsync(&n_wg, e->bad_flag.ptr + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    IRS_HIP(hipStreamSynchronize(s));
-    e->wg_desc.alloc(std::max<int64_t>(n_wg, 1));
+    // at most ceil(item tiles / 4) entries per user tile.  Up to 2^24 entries (64 MB) the list is sized for
+    // that bound and its length stays on the device (score_emit_kernel walks it with a grid stride);
+    // beyond, the length comes back first
+    const int64_t wg_bound = n_ut * ceil_div(ceil_div(ni, 64), 4);
+    if (wg_bound <= (int64_t(1) << 24)) {
+      n_wg = static_cast<int32_t>(std::min<int64_t>(wg_bound, 32768));  // the grid
+      e->wg_desc.alloc(std::max<int64_t>(wg_bound, 1));
+      f.n_wg = e->bad_flag.ptr + 3;
+    } else {
+      IRS_HIP(hipMemcpyAsync(&n_wg, e->bad_flag.ptr + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      IRS_HIP(hipStreamSynchronize(s));
+      e->wg_desc.alloc(std::max<int64_t>(n_wg, 1));
+    }
     hipLaunchKernelGGL(wg_fill_kernel, dim3(ceil_div(n_ut, 4)), dim3(256), 0, s, e->wg_prefix.ptr,
                        e->limit_tiles.ptr, n_ut, e->wg_desc.ptr);
     f.wg_desc = e->wg_desc.ptr;
@@ -1682,11 +1775,13 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
       q.scores = e->fused_scores.ptr;
       q.rows = m;
       q.row_map = list;
-      launch_rank<float>(q, ni, s, e->todo.ptr);
+      // (no `todo` scratch = the general kernel for every row: a few dozen rows leave the one-wave-per-row
+      // kernel latency bound - 51 us for 76 rows of an ML-20M call, the 1024-thread form takes 12)
+      launch_rank<float>(q, ni, s, n_hard >= 2048 ? e->todo.ptr : nullptr);
     }
     IRS_HIP(hipGetLastError());
   }
-  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s);
+  launch_item_hist(e->rec_out.ptr, rows * cutoff, e->item_cnt.ptr, s, e->n_items);
   if (rows >= 32768) {  // two levels: 4096-row chunks, then the chunks in order
     const int64_t chunk = 4096;
     const int nb = static_cast<int>(ceil_div(rows, chunk));

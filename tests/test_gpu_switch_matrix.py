@@ -134,6 +134,7 @@ EVAL_SWITCHES = {
     "bound_off": {"IRSPACK_AMD_EVAL_BOUND": "0"},
     "wave_off": {"IRSPACK_AMD_EVAL_WAVE": "0"},
     "sample_64": {"IRSPACK_AMD_EVAL_SAMPLE": "64"},
+    "sample_unfused": {"IRSPACK_AMD_EVAL_SAMPLE_FUSED": "0"},
     "pass_rows_256": {"IRSPACK_AMD_EVAL_PASS_ROWS": "256"},
     "block_512": {"IRSPACK_AMD_EVAL_BLOCK": "512"},
 }
