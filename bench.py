@@ -533,8 +533,11 @@ def evaluator_leg(X, trainer, K, ceilings):
     st = ev.last_call_stats()
     dense_flops = 2.0 * U * I * K
     flops = 2.0 * K * (64.0 * 64.0 * st["tiles_scored"] + float(U) * st["sample_items"])
-    # HBM side of what runs: the sample score block (written, masked, read) and the candidate lists
-    byts = 2.0 * U * st["sample_items"] * 4 + 2.0 * U * 20 * 8
+    # HBM side of what runs: the sample pass and the candidate lists.  One-launch sample pass (K <= 128, 512
+    # sample items): the user factors and the mask's item ids, read once; otherwise the [users, sample] score
+    # block (written, masked, read)
+    fused_sample = K <= 128 and st["sample_items"] == 512 and os.environ.get("IRSPACK_AMD_EVAL_SAMPLE_FUSED", "1") != "0"
+    byts = (U * K * 4.0 + mask.nnz * 4.0 if fused_sample else 2.0 * U * st["sample_items"] * 4) + 2.0 * U * 20 * 8
     # Three clocks of the same call: the Python wall (fingerprint of the 80 MB mask + ctypes + the C
     # call), the C call alone (host clock inside the library), and the DEVICE span (HIP events on the
     # launch stream, first kernel -> last kernel done).  The roofline is priced on the device span: the
@@ -557,12 +560,12 @@ def evaluator_leg(X, trainer, K, ceilings):
         "tiles_scored_frac": st["tiles_scored"] / max(1, st["tiles_total"]),
         "roofline": both_terms(flops, byts, span_s, ceilings, bound=None,
                                scope="device span of the call (HIP events, first kernel -> last kernel done; "
-                                     "includes the gaps in which the host reads the hard-row list back); "
+                                     "includes the gap in which the host reads the flags / hard-row count back); "
                                      "after pruning the call is launch / latency bound",
                                executed_gflop=flops / 1e9, dense_gflop=dense_flops / 1e9,
                                dense_equivalent_tflops=dense_flops / span_s / 1e12,
                                dense_equivalent_tflops_python_wall=dense_flops / wall / 1e12,
-                               sample_block_gbyte_write_plus_read=byts / 1e9),
+                               sample_pass_and_lists_gbyte=byts / 1e9, sample_pass="one launch" if fused_sample else "score block in HBM"),
     }
 
 
