@@ -95,10 +95,11 @@ struct EmitParams {
   // bounded variant (below): sorted position -> item id / row of the call, and per 64-user
   // tile the number of leading item tiles that can still hold a candidate
   const int32_t *iperm, *uperm, *limit_tiles;
-  // the work list of the bounded variant: one entry per live (user tile, item tile) pair, user tile
-  // by user tile (tile_limit_kernel / wg_scan_kernel / wg_fill_kernel); its length stays on the device
-  const int2 *tile_list;
-  const int32_t *n_tiles;  // device side
+  // the work list of the bounded variant: workgroup b scores the item tiles wg_desc[b].y ..
+  // + wg_desc[b].z - 1 (at most four) of user tile wg_desc[b].x - one 16-byte load instead of
+  // a chain of three (only workgroups with a live tile are launched)
+  const int4 *wg_desc;
+  const int32_t *n_wg;  // length of the work list (device side), or null: one entry per workgroup of the grid
   // rows the path cannot finish (no threshold from the sample, candidate list overflow): set
   // to 1 here, ranked one by one from their full score rows afterwards
   int32_t *hard;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(512, KP <= 64 ? 4 : 2) void sample_tau_fused_kernel
 // the user tile's limit leave at once, and the mask is probed per passing score (the bitmap is
 // indexed by item id, not by sorted position).
 template <int KP, bool BOUNDED>
-__device__ __forceinline__ void score_emit_body(const EmitParams &p, unsigned char *em_smem, const int64_t q) {
+__device__ __forceinline__ void score_emit_body(const EmitParams &p, unsigned char *em_smem, const int64_t bidx) {
   const int wid = wave_index_in_block(), ln = threadIdx.x & 63;
   const int g = ln >> 4, m = ln & 15;
   float *S = reinterpret_cast<float *>(em_smem) + wid * (64 * FZ_SROW);
@@ -363,12 +364,15 @@ __device__ __forceinline__ void score_emit_body(const EmitParams &p, unsigned ch
   const int64_t item_tiles = (p.n_items + 63) / 64;
   int64_t ut, it;
   if constexpr (BOUNDED) {
-    const int2 d = p.tile_list[q];
+    const int4 d = p.wg_desc[bidx];
     ut = d.x;
-    it = d.y;
+    it = static_cast<int64_t>(d.y) + wid;
+    if (wid >= d.z) return;
   } else {
-    ut = q / item_tiles;
-    it = q % item_tiles;
+    const int64_t w = bidx * 4 + wid;
+    ut = w / item_tiles;
+    it = w % item_tiles;
+    if (ut * 64 >= p.rows) return;
   }
   // lane l as user l: threshold and mask word of this tile (requested now, used after the MFMAs)
   const int64_t my_pos = ut * 64 + ln;
@@ -508,19 +512,15 @@ __device__ __forceinline__ void score_emit_body(const EmitParams &p, unsigned ch
   }
 }
 
-// Every WAVE walks the list of tiles with a grid stride (the four waves of a workgroup take four
-// consecutive entries = mostly the same 64 users; no barrier anywhere, each wave walks on its own): a few
-// thousand resident waves stay busy until the list ends, where round 5 launched one workgroup per four
-// item tiles of a user tile - slots of a workgroup without a tile, and the slots of finished waves, stood
-// empty until its last wave was done (1.1 waves per SIMD resident on average of the 2 that fit,
-// `SQ_WAVE_CYCLES`).  The bounded list's length (written by wg_scan_kernel) is read HERE, on the device -
-// no read-back between the scan and this launch (42 us of an ML-20M call's 1.3 ms).
+// The bounded variant walks the work list with a grid stride: its length (`n_wg`, written by wg_scan_kernel)
+// stays on the device, the host launches a grid that covers any list of the call's size class and the
+// workgroups past the end leave at once - no read-back between the scan and this launch (42 us of an
+// ML-20M call's 1.3 ms).  The waves of a workgroup are independent (no barrier): each walks on its own.
 template <int KP, bool BOUNDED>
 __global__ __launch_bounds__(256, 2) void score_emit_kernel(EmitParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char em_smem[];
-  const int64_t n = BOUNDED ? static_cast<int64_t>(*p.n_tiles) : ((p.rows + 63) / 64) * ((p.n_items + 63) / 64);
-  for (int64_t q = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block(); q < n; q += static_cast<int64_t>(gridDim.x) * 4)
-    score_emit_body<KP, BOUNDED>(p, em_smem, q);
+  const int64_t n = (BOUNDED && p.n_wg) ? static_cast<int64_t>(*p.n_wg) : static_cast<int64_t>(gridDim.x);
+  for (int64_t b = blockIdx.x; b < n; b += gridDim.x) score_emit_body<KP, BOUNDED>(p, em_smem, b);
 }
 
 
@@ -647,8 +647,8 @@ __global__ void prune_radius_kernel(float *__restrict__ tau, const float *__rest
   radius[r] = rad;
 }
 
-// wg_prefix[ut] = exclusive prefix sum of limit_tiles[ut] (the live item tiles of user tile ut),
-// wg_prefix[n_ut] = their number, also written to *total.  One workgroup.
+// wg_prefix[ut] = exclusive prefix sum of ceil(limit_tiles[ut] / 4) (workgroups of four item
+// tiles), wg_prefix[n_ut] = their number, also written to *total.  One workgroup.
 __global__ __launch_bounds__(1024) void wg_scan_kernel(const int32_t *__restrict__ limit_tiles,
                                                        int64_t n_ut, int32_t *__restrict__ wg_prefix,
                                                        int32_t *__restrict__ total) {
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(1024) void wg_scan_kernel(const int32_t *__restrict
   const int64_t per = (n_ut + 1023) / 1024;
   const int64_t b = per * tid, e = min(b + per, n_ut);
   int32_t sum = 0;
-  for (int64_t i = b; i < e; i++) sum += limit_tiles[i];
+  for (int64_t i = b; i < e; i++) sum += (limit_tiles[i] + 3) / 4;
   part[tid] = sum;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(1024) void wg_scan_kernel(const int32_t *__restrict
   int32_t run = part[tid] - sum;
   for (int64_t i = b; i < e; i++) {
     wg_prefix[i] = run;
-    run += limit_tiles[i];
+    run += (limit_tiles[i] + 3) / 4;
   }
   if (tid == 1023) {
     wg_prefix[n_ut] = part[1023];
@@ -677,13 +677,18 @@ __global__ __launch_bounds__(1024) void wg_scan_kernel(const int32_t *__restrict
   }
 }
 
-// tile_list[wg_prefix[ut] + j] = (ut, j) for the live item tiles j of user tile ut (one wave per user tile)
-__global__ __launch_bounds__(256) void wg_fill_kernel(const int32_t *__restrict__ wg_prefix, int64_t n_ut,
-                                                      int2 *__restrict__ tile_list) {
+// wg_desc[b] = (ut, first item tile, live tiles of the workgroup) for the workgroups b of user
+// tile ut (one wave per user tile)
+__global__ __launch_bounds__(256) void wg_fill_kernel(const int32_t *__restrict__ wg_prefix,
+                                                      const int32_t *__restrict__ limit_tiles,
+                                                      int64_t n_ut, int4 *__restrict__ wg_desc) {
   const int64_t ut = static_cast<int64_t>(blockIdx.x) * 4 + wave_index_in_block();
   if (ut >= n_ut) return;
-  const int32_t b = wg_prefix[ut], e = wg_prefix[ut + 1];
-  for (int32_t i = b + (threadIdx.x & 63); i < e; i += 64) tile_list[i] = int2{static_cast<int32_t>(ut), i - b};
+  const int32_t b = wg_prefix[ut], e = wg_prefix[ut + 1], lim = limit_tiles[ut];
+  for (int32_t i = b + (threadIdx.x & 63); i < e; i += 64) {
+    const int32_t it0 = 4 * (i - b);
+    wg_desc[i] = int4{static_cast<int32_t>(ut), it0, min(4, lim - it0), 0};
+  }
 }
 
 // list[0 .. min(*count, cap)) = hard rows that have ground truth (any order); *count = all of them

@@ -1248,7 +1248,7 @@ struct irs_evaluator {
   // bounded variant of the emit path: norms, the two sort permutations, per-tile limits
   DeviceBuffer<float> inorm, inorm_sorted, unorm, radius, radius_sorted, sample_item, hard_user;
   DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_prefix;
-  DeviceBuffer<int2> tile_list;
+  DeviceBuffer<int4> wg_desc;
   DeviceBuffer<char> sort_tmp;
   DeviceBuffer<unsigned long long> tiles_scored;
   DeviceBuffer<RowPartial> row_partials;  // chunk sums of the two-level reduction
@@ -1637,10 +1637,10 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
   f.cand_cnt = e->cand_cnt.ptr;
   f.bad_flag = e->bad_flag.ptr;
   f.iperm = f.uperm = f.limit_tiles = nullptr;
-  f.tile_list = nullptr;
-  f.n_tiles = nullptr;
+  f.wg_desc = nullptr;
+  f.n_wg = nullptr;
   f.hard = e->hard.ptr;
-  int64_t n_list = 0;
+  int32_t n_wg = 0;
   if (bounded) {
     // users in order of increasing pruning radius, and what each 64-user tile still needs
     e->unorm.alloc(rows);
@@ -1660,37 +1660,36 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
     f.iperm = e->iperm.ptr;
     f.uperm = e->uperm.ptr;
     f.limit_tiles = e->limit_tiles.ptr;
-    // the work list: the live (user tile, item tile) pairs, user tile by user tile
+    // the work list: only workgroups with a live tile are launched (the others would still
+    // queue for a workgroup slot and its LDS just to leave); its length comes back to the host
     const int64_t n_ut = ceil_div(rows, 64);
     e->wg_prefix.alloc(n_ut + 1);
     hipLaunchKernelGGL(wg_scan_kernel, dim3(1), dim3(1024), 0, s, e->limit_tiles.ptr, n_ut,
                        e->wg_prefix.ptr, e->bad_flag.ptr + 3);
-    // up to 2^24 pairs (128 MB) the list is sized for EVERY pair and its length stays on the device
-    // (score_emit_kernel reads it there); beyond, the length comes back first
-    const int64_t pair_bound = n_ut * ceil_div(ni, 64);
-    if (pair_bound <= (int64_t(1) << 24)) {
-      n_list = pair_bound;
+    // at most ceil(item tiles / 4) entries per user tile.  Up to 2^24 entries (64 MB) the list is sized for
+    // that bound and its length stays on the device (score_emit_kernel walks it with a grid stride);
+    // beyond, the length comes back first
+    const int64_t wg_bound = n_ut * ceil_div(ceil_div(ni, 64), 4);
+    if (wg_bound <= (int64_t(1) << 24)) {
+      n_wg = static_cast<int32_t>(std::min<int64_t>(wg_bound, 32768));  // the grid
+      e->wg_desc.alloc(std::max<int64_t>(wg_bound, 1));
+      f.n_wg = e->bad_flag.ptr + 3;
     } else {
-      int32_t n_dev = 0;
-      IRS_HIP(hipMemcpyAsync(&n_dev, e->bad_flag.ptr + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      IRS_HIP(hipMemcpyAsync(&n_wg, e->bad_flag.ptr + 3, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       IRS_HIP(hipStreamSynchronize(s));
-      n_list = n_dev;
+      e->wg_desc.alloc(std::max<int64_t>(n_wg, 1));
     }
-    e->tile_list.alloc(std::max<int64_t>(n_list, 1));
-    hipLaunchKernelGGL(wg_fill_kernel, dim3(ceil_div(n_ut, 4)), dim3(256), 0, s, e->wg_prefix.ptr, n_ut,
-                       e->tile_list.ptr);
-    f.tile_list = e->tile_list.ptr;
-    f.n_tiles = e->bad_flag.ptr + 3;
+    hipLaunchKernelGGL(wg_fill_kernel, dim3(ceil_div(n_ut, 4)), dim3(256), 0, s, e->wg_prefix.ptr,
+                       e->limit_tiles.ptr, n_ut, e->wg_desc.ptr);
+    f.wg_desc = e->wg_desc.ptr;
   }
-  if (!bounded || n_list > 0) {
-    // resident workgroups (two per CU: 69 KB of LDS each) x 4 for an even tail; every wave walks the list
-    const int64_t tiles = bounded ? n_list : ceil_div(rows, 64) * ceil_div(ni, 64);
-    const int64_t grid = std::min<int64_t>(ceil_div(tiles, 4), int64_t(8) * device_cu_count(dev));
+  if (!bounded || n_wg > 0) {
+    const int64_t tiles = bounded ? int64_t(n_wg) * 4 : ceil_div(rows, 64) * ceil_div(ni, 64);
     const size_t lds = 4 * 64 * FZ_SROW * sizeof(float) + 4 * 64 * sizeof(int32_t);
     auto launch = [&](auto kernel) {
       IRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(grid)), dim3(256), lds, s, f);
+      hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>(ceil_div(tiles, 4))), dim3(256), lds, s, f);
     };
 #define IRS_EMIT_CASE(KK)                                        \
   case KK:                                                       \

@@ -403,11 +403,6 @@ def test_norm_bound_pruning_keeps_the_lists(K, monkeypatch):
     assert st["path"] == "emit_bounded" and st["tiles_scored"] < 0.5 * st["tiles_total"], st
     assert st["hard_rows"] >= 5, st  # 5, 6 (overflow), 10, 11, 700 (no threshold)
     compare(a, want)
-    monkeypatch.setenv("IRSPACK_AMD_EVAL_BOUND", "0")
-    b = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)
-    assert core.last_call_stats()["path"] == "emit"
-    compare(b, want)
-    np.testing.assert_array_equal(a.item_cnt, b.item_cnt)
     # the sample pass as three launches per block of users (round 5) instead of the one fused launch: the
     # thresholds are the same numbers, so the pruning statistics are too
     monkeypatch.setenv("IRSPACK_AMD_EVAL_SAMPLE_FUSED", "0")
@@ -417,6 +412,11 @@ def test_norm_bound_pruning_keeps_the_lists(K, monkeypatch):
     compare(unfused, want)
     np.testing.assert_array_equal(a.item_cnt, unfused.item_cnt)
     monkeypatch.delenv("IRSPACK_AMD_EVAL_SAMPLE_FUSED")
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_BOUND", "0")
+    b = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)
+    assert core.last_call_stats()["path"] == "emit"
+    compare(b, want)
+    np.testing.assert_array_equal(a.item_cnt, b.item_cnt)
     # the same call in passes of 256 users (what a call over millions of users, or a catalogue
     # of a million items, does to keep its scratch bounded)
     monkeypatch.setenv("IRSPACK_AMD_EVAL_BOUND", "1")
