@@ -525,8 +525,10 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
 #pragma unroll
     for (int kk = 0; kk < 8; kk++) {
       const int src = 4 * (32 * gi + 8 * g + kk);
-      unsigned idx = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, blk_idx));
-      idx = entry0 + 32 * gi + 8 * g + kk < n ? idx : zero_row;
+      // (entries past the row's end were replaced by the zero row when their block was LOADED: one
+      // compare + select per lane and 64-entry block instead of one per gathered entry - 15 vector
+      // instructions less per 32-entry group)
+      const unsigned idx = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(src, blk_idx));
       if constexpr (T == 8) {
         // (64-bit row addresses: configs[3] gathers a 5.1 GB user table at K = 128 - one more vector
         // instruction per entry beside ~70 of splitting)
@@ -590,13 +592,17 @@ __device__ __forceinline__ void syrk_gather_bf16x3(const float *__restrict__ oth
   };
   // index blocks of 64 entries, one per lane, two blocks ahead (padded arrays: every load is
   // unconditional, the loop is one basic block)
+  const int zr = static_cast<int>(zero_row);
   int cur = ip[0], nxt = ip[64];
+  cur = lane < n ? cur : zr;
+  nxt = 64 + lane < n ? nxt : zr;
   issue(0, cur, 0, 0);
   issue(1, cur, 1, 0);
   int g0 = 0;
   for (; g0 + 2 <= ngroups; g0 += 2) {
     const int e_next = 32 * (g0 + 2);       // first entry of the next block
-    const int nn = ip[e_next + 64];         // the block after it
+    int nn = ip[e_next + 64];               // the block after it
+    nn = e_next + 64 + lane < n ? nn : zr;
     consume(0);
     issue(0, nxt, 0, e_next);
     // (an early exit HERE for odd group counts measured slower in round 4: user half 1.19 -> 1.32 ms - a
@@ -1128,7 +1134,7 @@ template <int T> __device__ __forceinline__ void resid_add_step(float *xrow, con
 // RESID: the one-block iALS++ sweep (see syrk_gather_impl): right-hand side = negative gradient at the
 // current row, solution = the step; SOLVER 0, T <= 4.
 template <int T, int SOLVER, int MODE, bool UNIT = false, bool BF16X3 = false, bool RESID = false>
-__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && (SOLVER == 1 || BF16X3)) ? 1 : (T <= 4 ? (RESID && MODE == 0 ? (UNIT ? 3 : 4) : SOLVE_MIN_WAVES_PER_SIMD_K64) : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
+__global__ __launch_bounds__(64 * SOLVE_WAVES, (T > 4 && (SOLVER == 1 || BF16X3)) ? 1 : (T <= 4 ? (RESID && MODE == 0 ? (UNIT ? 3 : 4) : (BF16X3 && MODE == 0 ? 3 : SOLVE_MIN_WAVES_PER_SIMD_K64)) : SOLVE_MIN_WAVES_PER_SIMD)) void ials_solve_kernel(SolveParams p) {
   // bf16x3: unit confidences, K <= 64 padded to 64; Cholesky (whose split rows' second pass is the plain MODE 1
   // kernel: both work on lower tiles) and, round 6, CG on the explicit system (MODE 1 with BF16X3 = "the
   // partials and the Gramian are lower-form tiles")
