@@ -783,8 +783,8 @@ def knn_sharded_leg(X, device, barrier):
     """configs[2] over N ranks (EVERY rank calls this): the target rows of the item-item product are
     split into contiguous ranges of equal multiply-add count (sharding.similarity_row_bounds - the row
     split of knn.hpp:54-71 with ranks in the place of threads), every rank holds the whole computer and
-    runs ``compute_similarity(rows=...)`` on its range; the CSR blocks are exchanged as host objects
-    and stacked on every rank.  No data-path collective.  ``item_pairs_per_s`` = I^2 / (max over ranks
+    runs ``compute_similarity(rows=...)`` on its range; the CSR blocks are exchanged by two tensor
+    all-gathers and laid end to end on every rank.  No collective inside the compute.  ``item_pairs_per_s`` = I^2 / (max over ranks
     of the wall of compute + exchange, between barriers); the compute-only maximum beside it."""
     import scipy.sparse as sps
     import torch.distributed as dist
@@ -827,7 +827,8 @@ def knn_sharded_leg(X, device, barrier):
         "row_bounds": [int(b) for b in bounds], "balance": "equal multiply-add count per rank",
         "kernel_ms_rank0": comp.last_kernel_ms, "macs_rank0": comp.last_macs,
         "out_nnz": int(S.nnz), "scaling": "strong",
-        "exchange": "all_gather_object of the CSR blocks (host objects; every rank ends with the whole result)",
+        "exchange": "two tensor all-gathers (lengths, then one padded byte buffer per rank: row lengths, column ids, "
+                    "values); every rank ends with the whole result",
     }
 
 
