@@ -326,15 +326,33 @@ __global__ __launch_bounds__(512, KP <= 64 ? 4 : 2) void sample_tau_fused_kernel
       if (ln == 0) atomicOr(p.bad_flag, 1);
     }
     // the cutoff-th largest key, bit by bit from the top (both users in step: independent chains)
+    // (a prefix that exactly `cutoff` keys reach ends the search early: the answer is the smallest of them -
+    // with distinct scores that happens after ~14 of the 32 bits)
     uint32_t t[2] = {0u, 0u};
+    bool exact_set[2] = {false, false};
     for (int bit = 31; bit >= 0; bit--) {
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const uint32_t cand = t[u] | (1u << bit);
-        int cnt = 0;
+        if (!exact_set[u]) {  // (wave-uniform)
+          const uint32_t cand = t[u] | (1u << bit);
+          int cnt = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) cnt += __popcll(__ballot(key[u][q] >= cand));
-        if (cnt >= p.cutoff) t[u] = cand;
+          for (int q = 0; q < 8; q++) cnt += __popcll(__ballot(key[u][q] >= cand));
+          if (cnt >= p.cutoff) t[u] = cand;
+          exact_set[u] = cnt == p.cutoff;
+        }
+      }
+      if (exact_set[0] && exact_set[1]) break;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (exact_set[u]) {
+        uint32_t mn = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 8; q++) mn = min(mn, key[u][q] >= t[u] ? key[u][q] : 0xffffffffu);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mn = min(mn, static_cast<uint32_t>(__shfl_xor(static_cast<int>(mn), o, 64)));
+        t[u] = mn;
       }
     }
 #pragma unroll
