@@ -288,6 +288,12 @@ def _rccl_world1_worker(rank, port, out_dir):
     local.synchronize()
     torch.cuda.synchronize()
     ok = bool(torch.equal(user, before)) and bool(torch.isfinite(local.gramian_view(1)).all())
+    # the byte exchange of sharded_similarity on RCCL's device tensors (empty and odd-sized buffers)
+    from irspack_amd.sharding import _all_gather_bytes
+    for n in (0, 1, 12345):
+        buf = (np.arange(n) % 251).astype(np.uint8)
+        got = _all_gather_bytes(buf)
+        ok = ok and len(got) == 1 and np.array_equal(got[0], buf)
     with open(os.path.join(out_dir, "rccl1.txt"), "w") as fh:
         fh.write("ok" if ok else "mismatch")
     dist.destroy_process_group()
