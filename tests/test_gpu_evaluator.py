@@ -437,6 +437,56 @@ def test_norm_bound_pruning_keeps_the_lists(K, monkeypatch):
     compare(part, ocore.get_metrics_f32(scores[3:1203], cutoff, 3, 4, True))
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_one_launch_sample_pass_against_the_three_launch_form_and_the_oracle(seed, monkeypatch):
+    """Random shapes for the sample pass in one launch (sample_tau_fused_kernel): user counts that are not
+    multiples of its 16-user tiles, K = 16 .. 128, cutoffs 1 .. 32, masks from empty to covering most of the
+    sample (users without a threshold), duplicated scores (ties at the cutoff).  The thresholds must be the
+    numbers of the three-launch form - same pruning statistics, same hard rows - and the metrics the
+    oracle's on the full masked score block."""
+    from irspack_amd.recommenders._ials_core import (IALSModelConfigBuilder,
+                                                      IALSSolverConfigBuilder, IALSTrainer)
+
+    rng2 = np.random.default_rng(100 + seed)
+    U = int(rng2.integers(1, 700))
+    I = int(rng2.integers(8192, 9500))
+    K = int(rng2.choice([16, 32, 64, 128]))
+    cutoff = int(rng2.choice([1, 5, 20, 32]))
+    mc = IALSModelConfigBuilder().set_K(K).build()
+    sc = IALSSolverConfigBuilder().build()
+    t = IALSTrainer(mc, sps.csr_matrix((U, I), dtype=np.float32))
+    pop = ((1.0 + np.arange(I)) ** -0.6).astype(np.float32)
+    rng2.shuffle(pop)
+    item = rng2.standard_normal((I, K)).astype(np.float32) * pop[:, None]
+    user = rng2.standard_normal((U, K)).astype(np.float32)
+    if seed % 2:  # few distinct user rows and duplicated item rows: scores tie, also at the cutoff
+        user = user[rng2.integers(0, max(1, U // 7 + 1), U)]
+        item[rng2.integers(0, I, I // 3)] = item[rng2.integers(0, I, I // 3)]
+    t.user, t.item = user, item
+    density = [0.0, 0.002, 0.02, 0.1][seed % 4]
+    mask = sps.random(U, I, density=density, format="lil", random_state=rng2, dtype=np.float32)
+    top = np.argsort(-np.linalg.norm(item.astype(np.float64), axis=1))
+    for u in rng2.integers(0, U, 3):  # these users have seen most of the sample
+        mask[int(u), top[:int(rng2.integers(490, 4000))]] = 1.0
+    mask = sps.csr_matrix(mask)
+    mask.data[:] = 1.0
+    gt = sps.csr_matrix(sps.random(U, I, density=0.004, format="csr", random_state=rng2, dtype=np.float64))
+    gt.data[:] = 1.0
+    core, ocore = EvaluatorCore(gt, []), O.EvaluatorCore(gt, [])
+    scores = t.user_scores(0, U, sc)
+    scores[mask.nonzero()] = -np.inf
+    want = ocore.get_metrics_f32(scores, cutoff, 0, 4, False)
+    a = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)
+    st = core.last_call_stats()
+    assert st["path"] == "emit_bounded", st
+    compare(a, want)
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_SAMPLE_FUSED", "0")
+    b = core.get_metrics_ials(t, 0, U, mask, cutoff, 0, False)
+    stb = core.last_call_stats()
+    assert (stb["path"], stb["hard_rows"], stb["tiles_scored"]) == (st["path"], st["hard_rows"], st["tiles_scored"])
+    compare(b, want)
+
+
 @pytest.mark.parametrize("rows", [1, 5, 64, 65, 130])
 def test_bounded_path_on_a_handful_of_users(rows):
     """User blocks smaller than, equal to and just above one 64-user tile (the second-chance
