@@ -1128,9 +1128,11 @@ __global__ void mask_block_kernel(T *scores, int64_t rows, int64_t n_items,
 // order in which scipy's csr_matmat accumulates `sums[j] += x * w` for a result row, so the block is the
 // host product bit for bit (a column gets at most one update per profile entry - W's rows hold distinct
 // columns - and LDS operations of one wave execute in order: no atomics, no barriers, no dependence on
-// arrival order).  Every tile re-scans the profile's rows of W (a few hundred 8-byte loads per lane for a
-// 144-item profile with 100 neighbours per item) - cheap next to writing the dense block.
-constexpr int SIM_TILE = 4096;  // columns per wave: 32 KB of LDS
+// arrival order).  When W's rows hold strictly increasing columns (every recommender of this package) a
+// table made per call (sim_tile_ptr_kernel) gives each (row of W, tile) its range of entries, so a tile
+// reads a row's entries INSIDE it - one strip, sixteen rows in flight; otherwise every tile re-scans the
+// whole rows (two strips, eight rows in flight).
+constexpr int SIM_TILE = 2048;  // columns per wave: 16 KB of LDS, ten waves per CU (4096: 65 ms for the ML-20M model, 2048: 59, 1024: 66)
 
 __device__ __forceinline__ int64_t readlane_i64(int64_t v, int src) {
   const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), src);
@@ -1141,11 +1143,31 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __longlong_as_double(readlane_i64(__double_as_longlong(v), src));
 }
 
+// tptr[i * (n_tiles + 1) + t] = first entry of row i of W (columns increasing) whose column is >= t * SIM_TILE
+__global__ __launch_bounds__(256) void sim_tile_ptr_kernel(const int64_t *__restrict__ w_ptr,
+                                                           const int32_t *__restrict__ w_idx, int64_t n_rows,
+                                                           int32_t n_tiles, int32_t *__restrict__ tptr) {
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= n_rows * (n_tiles + 1)) return;
+  const int64_t i = id / (n_tiles + 1);
+  const int32_t t = static_cast<int32_t>(id % (n_tiles + 1));
+  int64_t lo = w_ptr[i], hi = w_ptr[i + 1];
+  const int64_t bound = static_cast<int64_t>(t) * SIM_TILE;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (w_idx[mid] < bound) lo = mid + 1;
+    else hi = mid;
+  }
+  tptr[id] = static_cast<int32_t>(lo);
+}
+
+template <bool TILED>  // TILED: w_tptr given - a row's entries inside the tile are one strip (a second one is not fetched)
 __global__ __launch_bounds__(64) void sim_score_kernel(const int64_t *__restrict__ x_ptr, const int32_t *__restrict__ x_idx,
                                                        const double *__restrict__ x_val,  // null: all ones
                                                        const int64_t *__restrict__ w_ptr, const int32_t *__restrict__ w_idx,
                                                        const double *__restrict__ w_val, int64_t w_last, int64_t row0,
-                                                       int64_t n_items, int32_t n_tiles, double *__restrict__ out) {
+                                                       int64_t n_items, int32_t n_tiles, double *__restrict__ out,
+                                                       const int32_t *__restrict__ w_tptr) {
   __shared__ double acc[SIM_TILE];
   const int lane = threadIdx.x;
   const int64_t unit = blockIdx.x;
@@ -1162,12 +1184,22 @@ __global__ __launch_bounds__(64) void sim_score_kernel(const int64_t *__restrict
   // 64 profile entries are fetched at once (one per lane, with their row bounds), and the first 128 entries of
   // the rows of D consecutive profile entries are in flight while an earlier row is added - one exposed round
   // trip per 64 profile entries instead of three per entry (195 -> ~40 ms for the ML-20M model).
-  constexpr int D = 8;
+  constexpr int D = TILED ? 16 : 8;  // rows in flight (TILED: one strip per row, twice the rows)
   for (int64_t q0 = qb; q0 < qe; q0 += 64) {
     const int64_t q = min(q0 + lane, qe - 1);
     const int32_t i_l = x_idx[q];
     const double x_l = x_val ? x_val[q] : 1.0;
-    const int64_t eb_l = w_ptr[i_l], ee_l = w_ptr[i_l + 1];
+    // (rows of W with increasing columns: only the row's entries INSIDE this tile, from the table
+    // sim_tile_ptr_kernel made - a seventh of a row on the ML-20M shape, one strip instead of two)
+    int64_t eb_l, ee_l;
+    if constexpr (TILED) {
+      const int32_t *tp = w_tptr + static_cast<int64_t>(i_l) * (n_tiles + 1) + tile;
+      eb_l = tp[0];
+      ee_l = tp[1];
+    } else {
+      eb_l = w_ptr[i_l];
+      ee_l = w_ptr[i_l + 1];
+    }
     const int n = static_cast<int>(min<int64_t>(64, qe - q0));
     int32_t ja[D], jb[D];
     double wa[D], wb[D];
@@ -1177,9 +1209,12 @@ __global__ __launch_bounds__(64) void sim_score_kernel(const int64_t *__restrict
       const int64_t e0 = min(eb + lane, w_last), e1 = min(eb + 64 + lane, w_last);
       ja[slot] = w_idx[e0];
       wa[slot] = w_val[e0];
-      jb[slot] = w_idx[e1];
-      wb[slot] = w_val[e1];
+      if constexpr (!TILED) {
+        jb[slot] = w_idx[e1];
+        wb[slot] = w_val[e1];
+      }
       (void)ee;
+      (void)e1;
     };
 #pragma unroll
     for (int d = 0; d < D; d++) fetch(d, min(d, n - 1));
@@ -1190,12 +1225,15 @@ __global__ __launch_bounds__(64) void sim_score_kernel(const int64_t *__restrict
         if (k < n) {  // (wave-uniform)
           const int64_t eb = readlane_i64(eb_l, k), ee = readlane_i64(ee_l, k);
           const double x = readlane_f64(x_l, k);
-          const int32_t j0 = ja[d], j1 = jb[d];
-          const double w0 = wa[d], w1 = wb[d];
+          const int32_t j0 = ja[d], j1 = TILED ? 0 : jb[d];
+          const double w0 = wa[d], w1 = TILED ? 0.0 : wb[d];
           if (k + D < n) fetch(d, k + D);  // (the slot's registers were copied: its next row starts now)
           if (eb + lane < ee) add(j0, x, w0);
-          if (eb + 64 + lane < ee) add(j1, x, w1);
-          for (int64_t e = eb + 128 + lane; e < ee; e += 64) add(w_idx[e], x, w_val[e]);  // (rows above 128 entries)
+          if constexpr (!TILED) {
+            if (eb + 64 + lane < ee) add(j1, x, w1);
+          }
+          // (rows above 128 entries; TILED: more than 64 of a row's entries inside one tile)
+          for (int64_t e = eb + (TILED ? 64 : 128) + lane; e < ee; e += 64) add(w_idx[e], x, w_val[e]);
         }
       }
     }
@@ -2040,6 +2078,16 @@ irs_status irs_eval_get_metrics_similarity(irs_evaluator *e, int64_t begin, int6
       if (hi > lo && (mn < 0 || mx >= ni)) bad.store(1);
     });
     check_arg(bad.load() == 0, "column index out of range.");
+    // rows of W with strictly increasing columns (what every recommender of this package stores) are cut
+    // into per-tile ranges on the device; any other W takes the whole-row walk
+    std::atomic<int> w_unsorted{0};
+    parallel_ranges(np_, [&](int64_t lo, int64_t hi) {
+      int any = 0;
+      for (int64_t r = lo; r < hi; r++)
+        for (int64_t q = w_indptr[r] + 1; q < w_indptr[r + 1]; q++) any |= w_indices[q] <= w_indices[q - 1];
+      if (any) w_unsorted.store(1);
+    });
+    const bool w_tiled = w_unsorted.load() == 0 && w_nnz < (int64_t(1) << 31);
     IRS_HIP(hipSetDevice(e->device));
     hipStream_t s = nullptr;
     // uploads: the profile rows (values only when they are not all ones), W by rows, the mask rows
@@ -2074,14 +2122,23 @@ irs_status irs_eval_get_metrics_similarity(irs_evaluator *e, int64_t begin, int6
     std::vector<int64_t> cnt_block(static_cast<size_t>(ni));
     std::fill(item_cnt, item_cnt + static_cast<int64_t>(std::max(n_cutoffs, 0)) * ni, int64_t(0));
     if (rows > 0) e->score_buf.alloc(static_cast<size_t>(per) * ni * 8);
+    DeviceBuffer<int32_t> d_wt;
+    if (w_tiled && rows > 0 && np_ > 0) {
+      const int64_t n_tp = np_ * (n_tiles + 1);
+      d_wt.alloc(static_cast<size_t>(n_tp));
+      hipLaunchKernelGGL(sim_tile_ptr_kernel, dim3(static_cast<unsigned>(ceil_div(n_tp, 256))), dim3(256), 0, s,
+                         static_cast<const int64_t *>(d_wp.ptr), static_cast<const int32_t *>(d_wi.ptr), np_, n_tiles,
+                         d_wt.ptr);
+    }
     for (int64_t b = 0; b < rows; b += per) {
       const int64_t m = std::min(per, rows - b);
       double *scores = reinterpret_cast<double *>(e->score_buf.ptr);
-      hipLaunchKernelGGL(sim_score_kernel, dim3(static_cast<unsigned>(m * n_tiles)), dim3(64), 0, s,
+      hipLaunchKernelGGL(d_wt.ptr ? sim_score_kernel<true> : sim_score_kernel<false>, dim3(static_cast<unsigned>(m * n_tiles)), dim3(64), 0, s,
                          static_cast<const int64_t *>(d_xp.ptr), static_cast<const int32_t *>(d_xi.ptr),
                          x_not_ones.load() ? static_cast<const double *>(d_xv.ptr) : static_cast<const double *>(nullptr),
                          static_cast<const int64_t *>(d_wp.ptr), static_cast<const int32_t *>(d_wi.ptr),
-                         static_cast<const double *>(d_wv.ptr), std::max<int64_t>(w_nnz - 1, 0), b, ni, n_tiles, scores);
+                         static_cast<const double *>(d_wv.ptr), std::max<int64_t>(w_nnz - 1, 0), b, ni, n_tiles, scores,
+                         static_cast<const int32_t *>(d_wt.ptr));
       if (m_nnz > 0)
         hipLaunchKernelGGL(mask_block_kernel<double>, dim3(static_cast<unsigned>(m)), dim3(64), 0, s, scores, m, ni,
                            static_cast<const int64_t *>(d_mp.ptr) + b, static_cast<const int32_t *>(d_mi.ptr));

@@ -429,6 +429,28 @@ def test_similarity_models_are_scored_on_the_device(kind, weighted):
             assert got_v == pytest.approx(want_v, rel=1e-12, abs=1e-15)
 
 
+def test_similarity_path_with_unsorted_rows_of_w():
+    """W whose rows are NOT in column order (a C-ABI caller may hand that over; `_lib.csr_arrays` would sort
+    it, so the flag scipy caches is set by hand): the library sees it, skips the per-tile ranges and every
+    tile walks the whole rows - the same float64 block, so the same metrics as the sorted W."""
+    X, gt = _knn_problem(11, U=900, I=2500, density=0.02, weighted=True)
+    rns = np.random.RandomState(5)
+    W = sps.random(2500, 2500, density=0.01, format="csr", random_state=rns, dtype=np.float64)
+    W.sort_indices()
+    core = EvaluatorCore(gt, [])
+    want = core.get_metrics_similarity(X, W, 0, 900, None, 0, [5, 20], 0)
+    Wu = W.copy()
+    for r in range(Wu.shape[0]):  # reverse every row's entries
+        b, e = Wu.indptr[r], Wu.indptr[r + 1]
+        Wu.indices[b:e] = Wu.indices[b:e][::-1].copy()
+        Wu.data[b:e] = Wu.data[b:e][::-1].copy()
+    Wu.has_sorted_indices = True  # (a lie, on purpose: csr_arrays then passes the arrays as they are)
+    got = core.get_metrics_similarity(X, Wu, 0, 900, None, 0, [5, 20], 0)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a.item_cnt, b.item_cnt)
+        assert (a.valid_user, a.total_user, a.hit, a.ndcg, a.map) == (b.valid_user, b.total_user, b.hit, b.ndcg, b.map)
+
+
 def test_similarity_path_argument_errors():
     X, gt = _knn_problem(5, U=200, I=90)
     core = EvaluatorCore(gt, [])
