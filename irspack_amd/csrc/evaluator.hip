@@ -2114,8 +2114,13 @@ irs_status irs_eval_get_metrics_similarity(irs_evaluator *e, int64_t begin, int6
       d_mp.upload(mp, s);
       d_mi.upload(mask_indices, static_cast<size_t>(m_nnz), s);
     }
-    // blocks of users whose dense float64 scores fit ~1 GB; every cutoff ranks the same block
-    const int64_t per = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t(1) << 30) / std::max<int64_t>(8 * ni, 1)));
+    // blocks of users whose dense float64 scores fit 4 GB; every cutoff ranks the same block.  (A block ends
+    // with a read-back of its metrics and item counts: ~0.7 ms of launches, synchronisation and host merge.
+    // All 138,493 users of the ML-20M shape, 29.6 GB of scores: 1 GB blocks 59.8 ms, 2 GB 50.1, 4 GB 44.5,
+    // 8 GB 42.6, one block 40.5 - against 90 / 190 / 310 ms for the first call's allocation at 1 / 4 / 8 GB.)
+    int64_t per = std::max<int64_t>(1, std::min<int64_t>(rows, (int64_t(1) << 32) / std::max<int64_t>(8 * ni, 1)));
+    if (const char *v = std::getenv("IRSPACK_AMD_EVAL_SIM_BLOCK_ROWS"))  // (tests: several blocks on a small call)
+      per = std::max<int64_t>(1, std::min<int64_t>(per, std::atoll(v)));
     const int32_t n_tiles = static_cast<int32_t>(ceil_div(std::max<int64_t>(ni, 1), SIM_TILE));
     std::vector<irs_metrics> total(static_cast<size_t>(std::max(n_cutoffs, 1)));
     std::memset(total.data(), 0, total.size() * sizeof(irs_metrics));

@@ -429,6 +429,25 @@ def test_similarity_models_are_scored_on_the_device(kind, weighted):
             assert got_v == pytest.approx(want_v, rel=1e-12, abs=1e-15)
 
 
+def test_similarity_path_in_several_score_blocks(monkeypatch):
+    """The call walks the users in blocks of 4 GB of float64 scores (20,074 users at 26,744 items); here 37
+    users per block: counters and histogram of the one-block call, float64 sums merged block by block
+    (Metrics::merge order) to 1e-12."""
+    X, gt = _knn_problem(13, U=700, I=1200, density=0.02, weighted=True)
+    rns = np.random.RandomState(6)
+    W = sps.random(1200, 1200, density=0.02, format="csr", random_state=rns, dtype=np.float64)
+    W.sort_indices()
+    core = EvaluatorCore(gt, [])
+    want = core.get_metrics_similarity(X, W, 3, 650, None, 0, [5, 20], 3)
+    monkeypatch.setenv("IRSPACK_AMD_EVAL_SIM_BLOCK_ROWS", "37")
+    got = core.get_metrics_similarity(X, W, 3, 650, None, 0, [5, 20], 3)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a.item_cnt, b.item_cnt)
+        assert (a.valid_user, a.total_user) == (b.valid_user, b.total_user)
+        np.testing.assert_allclose([a.hit, a.recall, a.ndcg, a.precision, a.map],
+                                   [b.hit, b.recall, b.ndcg, b.precision, b.map], rtol=1e-12)
+
+
 def test_similarity_path_with_unsorted_rows_of_w():
     """W whose rows are NOT in column order (a C-ABI caller may hand that over; `_lib.csr_arrays` would sort
     it, so the flag scipy caches is set by hand): the library sees it, skips the per-tile ranges and every
