@@ -2209,8 +2209,9 @@ irs_status irs_eval_get_metrics_similarity(irs_evaluator *e, int64_t begin, int6
         // Metrics::merge of the block into the cutoff's totals, block after block (evaluator.cpp:76-85)
         hipLaunchKernelGGL(metrics_fold_kernel, dim3(1), dim3(64), 0, s, static_cast<const irs_metrics *>(e->metrics.ptr),
                            tot_m.ptr + c);
-        hipLaunchKernelGGL(counts_fold_kernel, dim3(static_cast<unsigned>(ceil_div(ni, 256))), dim3(256), 0, s,
-                           static_cast<const unsigned long long *>(e->item_cnt.ptr), ni, tot_cnt.ptr + static_cast<size_t>(c) * ni);
+        if (ni > 0)
+          hipLaunchKernelGGL(counts_fold_kernel, dim3(static_cast<unsigned>(ceil_div(ni, 256))), dim3(256), 0, s,
+                             static_cast<const unsigned long long *>(e->item_cnt.ptr), ni, tot_cnt.ptr + static_cast<size_t>(c) * ni);
       }
     }
     if (e->span_open) IRS_HIP(hipEventRecord(e->ev_last, s));
