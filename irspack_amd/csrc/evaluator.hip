@@ -1291,7 +1291,7 @@ struct irs_evaluator {
   DeviceBuffer<int32_t> iota, iperm, iinv, uperm, limit_tiles, hard, hard_list, wg_prefix;
   DeviceBuffer<int4> wg_desc;
   DeviceBuffer<char> sort_tmp;
-  DeviceBuffer<unsigned long long> tiles_scored;
+  int32_t *flags_host = nullptr;  // page-locked: the emit path's flags / hard-row count / scored tiles, one copy per pass
   DeviceBuffer<RowPartial> row_partials;  // chunk sums of the two-level reduction
   DeviceBuffer<int32_t> mask_row;         // row of every mask entry (built with the bitmap)
   std::vector<int64_t> mask_ptr_host;     // host copy of the mask's row pointers
@@ -1561,13 +1561,15 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
     n_masked = e->mask_count.ptr;
   }
   // [0] flags, [1] hard rows at the end, [2] hard rows after the sample pass, [3] workgroups
-  e->bad_flag.alloc(4);
-  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, 4 * sizeof(int32_t), s));
+  // ([4..5]: the scored-tile count, 64 bits - one block, so that the call's single read-back is ONE copy, into
+  // page-locked memory: two pageable copies and their staging cost ~50 us of a 1.2 ms call)
+  e->bad_flag.alloc(8);
+  IRS_HIP(hipMemsetAsync(e->bad_flag.ptr, 0, 8 * sizeof(int32_t), s));
+  unsigned long long *const tiles_scored_dev = reinterpret_cast<unsigned long long *>(e->bad_flag.ptr + 4);
+  if (!e->flags_host) IRS_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->flags_host), 8 * sizeof(int32_t), hipHostMallocDefault));
   e->hard.alloc(rows);
   e->hard_list.alloc(rows);
   IRS_HIP(hipMemsetAsync(e->hard.ptr, 0, rows * sizeof(int32_t), s));
-  e->tiles_scored.alloc(1);
-  IRS_HIP(hipMemsetAsync(e->tiles_scored.ptr, 0, sizeof(unsigned long long), s));
   // ---- 0. bounded variant: items in order of decreasing norm (the sample is then the items
   //         of largest norm, which hold most of every user's final list)
   const float norm_c = 1.0f + (KP + 16) * 2.5e-7f;
@@ -1715,7 +1717,7 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
                    e->sort_tmp, s);
     hipLaunchKernelGGL(tile_limit_kernel, dim3(ceil_div(ceil_div(rows, 64), 256)), dim3(256), 0, s,
                        e->radius_sorted.ptr, rows, e->inorm_sorted.ptr, ni, e->limit_tiles.ptr,
-                       e->tiles_scored.ptr);
+                       tiles_scored_dev);
     f.iperm = e->iperm.ptr;
     f.uperm = e->uperm.ptr;
     f.limit_tiles = e->limit_tiles.ptr;
@@ -1796,11 +1798,11 @@ bool emit_block(irs_evaluator *e, irs_ials_trainer *t, int64_t begin, int64_t ro
                      e->gt_ptr.ptr, offset, rows, e->hard_list.ptr, e->bad_flag.ptr + 1,
                      static_cast<int32_t>(rows));
   IRS_HIP(hipGetLastError());
-  int32_t bad[3] = {0, 0, 0};
-  unsigned long long tiles_scored = 0;
-  IRS_HIP(hipMemcpyAsync(bad, e->bad_flag.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
-  IRS_HIP(hipMemcpyAsync(&tiles_scored, e->tiles_scored.ptr, sizeof(tiles_scored), hipMemcpyDeviceToHost, s));
+  IRS_HIP(hipMemcpyAsync(e->flags_host, e->bad_flag.ptr, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   IRS_HIP(hipStreamSynchronize(s));
+  const int32_t bad[3] = {e->flags_host[0], e->flags_host[1], e->flags_host[2]};
+  unsigned long long tiles_scored = 0;
+  std::memcpy(&tiles_scored, e->flags_host + 4, sizeof(tiles_scored));
   {
     const int64_t total = ceil_div(rows, 64) * ceil_div(ni, 64);
     const int64_t scored = bounded ? static_cast<int64_t>(tiles_scored) : total;
@@ -1972,6 +1974,7 @@ irs_status irs_eval_destroy(irs_evaluator *e) {
       (void)hipSetDevice(e->device);
       if (e->ev_first) (void)hipEventDestroy(e->ev_first);
       if (e->ev_last) (void)hipEventDestroy(e->ev_last);
+      if (e->flags_host) (void)hipHostFree(e->flags_host);
       delete e;
     }
   });
