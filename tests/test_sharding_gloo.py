@@ -229,6 +229,14 @@ def _knn_eval_worker(rank, world, port, out_dir):
         return _RawMetrics(X.shape[1], m.raw(), m.item_cnt())
 
     total = sharded_metrics(evaluate, X.shape[0], _RawMetrics(X.shape[1]))
+    # the byte exchange under it: buffers of different lengths, one of them empty; and a rank without rows
+    from irspack_amd.sharding import _all_gather_bytes
+    mine = (np.arange(0 if rank == 1 else 1000 + rank) % 251).astype(np.uint8)
+    parts = _all_gather_bytes(mine)
+    assert [p.size for p in parts] == [1000, 0] and np.array_equal(parts[rank], mine)
+    S_uneven = sharded_similarity(lambda b, e: comp.compute_similarity(Xt[b:e], 7), Xt.shape[0],
+                                  bounds=[0, Xt.shape[0], Xt.shape[0]])
+    assert (S_uneven != S).nnz == 0 and np.array_equal(S_uneven.indptr, S.indptr)
     with open(os.path.join(out_dir, f"knn_eval{rank}.pkl"), "wb") as fh:
         pickle.dump((S, total.raw, total.cnt), fh)
     dist.barrier()
