@@ -490,23 +490,27 @@ __device__ __forceinline__ void score_emit_body(const EmitParams &p, unsigned ch
   if (!my_valid) pm = 0ull;
   if (!__any(pm != 0ull)) return;
   if constexpr (BOUNDED) {
-    if (p.mask_bits) {  // two independent probes per trip: bit (item id) of the user's bitmap row
+    if (p.mask_bits) {  // four independent probes per trip: bit (item id) of the user's bitmap row
       const uint64_t *mrow = p.mask_bits + my_row * p.words;
       uint64_t left = pm;
       while (__any(left != 0ull)) {
-        int j0 = -1, j1 = -1;
-        if (left != 0ull) {
-          j0 = __ffsll(static_cast<long long>(left)) - 1;
-          left &= left - 1;
+        int j[4];
+        int32_t id[4];
+        uint64_t w[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          j[t] = -1;
+          if (left != 0ull) {
+            j[t] = __ffsll(static_cast<long long>(left)) - 1;
+            left &= left - 1;
+          }
+          id[t] = j[t] >= 0 ? IDS[j[t]] : 0;
         }
-        if (left != 0ull) {
-          j1 = __ffsll(static_cast<long long>(left)) - 1;
-          left &= left - 1;
-        }
-        const int32_t id0 = j0 >= 0 ? IDS[j0] : 0, id1 = j1 >= 0 ? IDS[j1] : 0;
-        const uint64_t w0 = j0 >= 0 ? mrow[id0 >> 6] : 0ull, w1 = j1 >= 0 ? mrow[id1 >> 6] : 0ull;
-        if (j0 >= 0 && ((w0 >> (id0 & 63)) & 1ull)) pm &= ~(1ull << j0);
-        if (j1 >= 0 && ((w1 >> (id1 & 63)) & 1ull)) pm &= ~(1ull << j1);
+#pragma unroll
+        for (int t = 0; t < 4; t++) w[t] = j[t] >= 0 ? mrow[id[t] >> 6] : 0ull;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+          if (j[t] >= 0 && ((w[t] >> (id[t] & 63)) & 1ull)) pm &= ~(1ull << j[t]);
       }
       if (!__any(pm != 0ull)) return;
     }
